@@ -1,0 +1,294 @@
+"""ctypes binding of the CPU oracle (oracle/qex_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (qex_amd) never imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libqexoracle.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or (
+        os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "qex_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libqexoracle.so"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        vp, ci, cd = C.c_void_p, C.c_int, C.c_double
+        L.qo_layout_new.restype = vp
+        L.qo_layout_new.argtypes = [C.POINTER(ci)]
+        L.qo_layout_free.argtypes = [vp]
+        L.qo_vol.argtypes = [vp]
+        L.qo_index.argtypes = [vp, C.POINTER(ci)]
+        L.qo_coord.argtypes = [vp, ci, C.POINTER(ci)]
+        L.qo_neighbor.argtypes = [vp, ci, ci, ci]
+        L.qo_rngfield_new.restype = vp
+        L.qo_rngfield_new.argtypes = [vp, ci, C.c_uint64]
+        L.qo_rngfield_free.argtypes = [vp]
+        L.qo_milc6_test.argtypes = [C.c_uint32, C.c_uint32, ci, vp, vp]
+        L.qo_mrg32k3a_test.argtypes = [C.c_uint64, C.c_uint64, ci, vp]
+        for f in ("qo_vector_gaussian", "qo_gauge_gaussian", "qo_gauge_random", "qo_gauge_random_tah"):
+            getattr(L, f).argtypes = [vp, vp, vp]
+        L.qo_gauge_warm.argtypes = [vp, vp, cd, vp]
+        L.qo_gauge_unit.argtypes = [vp, vp]
+        for f in ("qo_projectU", "qo_projectSU", "qo_projectTAH", "qo_exp"):
+            getattr(L, f).argtypes = [vp, vp]
+        L.qo_setBC.argtypes = [vp, vp]
+        L.qo_stagPhase.argtypes = [vp, vp, C.POINTER(ci)]
+        L.qo_plaq.argtypes = [vp, vp, vp]
+        L.qo_gauge_force.argtypes = [vp, vp, vp]
+        L.qo_gauge_deriv.argtypes = [vp, vp, vp, cd]
+        L.qo_wflow.argtypes = [vp, vp, ci, cd]
+        L.qo_norm2.restype = cd
+        L.qo_norm2.argtypes = [vp, vp, ci]
+        L.qo_redot.restype = cd
+        L.qo_redot.argtypes = [vp, vp, vp, ci]
+        L.qo_stagD2.argtypes = [vp, vp, vp, vp, vp, ci, cd, cd]
+        L.qo_stagD.argtypes = [vp, vp, vp, vp, vp, ci, cd, cd, cd]
+        L.qo_D.argtypes = [vp, vp, vp, vp, vp, cd]
+        L.qo_Ddag.argtypes = [vp, vp, vp, vp, vp, cd]
+        L.qo_stagD2xx.argtypes = [vp, vp, vp, vp, vp, cd, ci]
+        L.qo_eoReconstruct.argtypes = [vp, vp, vp, vp, vp, cd]
+        L.qo_solveXX.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp, ci, vp]
+        L.qo_solve.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, vp]
+        L.qo_solveXX_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp, ci]
+        L.qo_solve_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+RNG_MILC6, RNG_MRG32K3A = 0, 1
+EVEN, ODD, ALL = 0, 1, 2
+
+
+class Layout:
+    """V=1 MILC even-odd layout (src/layout/qlayout.nim:110-131)."""
+
+    def __init__(self, lat):
+        self.lat = [int(v) for v in lat]
+        self._h = C.c_void_p(lib().qo_layout_new((C.c_int * 4)(*self.lat)))
+        self.vol = int(np.prod(self.lat))
+
+    def __del__(self):
+        try:
+            lib().qo_layout_free(self._h)
+        except Exception:
+            pass
+
+    def index(self, x):
+        return lib().qo_index(self._h, (C.c_int * 4)(*x))
+
+    def coord(self, idx):
+        c = (C.c_int * 4)()
+        lib().qo_coord(self._h, idx, c)
+        return list(c)
+
+    def neighbor(self, idx, mu, ln):
+        return lib().qo_neighbor(self._h, idx, mu, ln)
+
+    def new_vector(self):
+        return np.zeros((self.vol, 3, 2))
+
+    def new_gauge(self):
+        return np.zeros((self.vol, 4, 3, 3, 2))
+
+
+class RngField:
+    def __init__(self, lo, kind=RNG_MILC6, seed=17 ** 7):
+        self.lo = lo
+        self._h = C.c_void_p(lib().qo_rngfield_new(lo._h, kind, seed))
+
+    def __del__(self):
+        try:
+            lib().qo_rngfield_free(self._h)
+        except Exception:
+            pass
+
+
+def gauge_random(lo, rf=None, seed=17 ** 7):
+    rf = rf or RngField(lo, RNG_MILC6, seed)
+    g = lo.new_gauge()
+    lib().qo_gauge_random(lo._h, rf._h, _p(g))
+    return g
+
+
+def gauge_warm(lo, s, rf):
+    g = lo.new_gauge()
+    lib().qo_gauge_warm(lo._h, rf._h, s, _p(g))
+    return g
+
+
+def gauge_unit(lo):
+    g = lo.new_gauge()
+    lib().qo_gauge_unit(lo._h, _p(g))
+    return g
+
+
+def gauge_random_tah(lo, rf):
+    g = lo.new_gauge()
+    lib().qo_gauge_random_tah(lo._h, rf._h, _p(g))
+    return g
+
+
+def vector_gaussian(lo, rf):
+    v = lo.new_vector()
+    lib().qo_vector_gaussian(lo._h, rf._h, _p(v))
+    return v
+
+
+def setBC(lo, g):
+    lib().qo_setBC(lo._h, _p(g))
+
+
+def stagPhase(lo, g, phases=(8, 9, 11, 0)):
+    lib().qo_stagPhase(lo._h, _p(g), (C.c_int * 4)(*phases))
+
+
+def rephase(lo, g):
+    """Staggered.rephase (stagD.nim:72-80): setBC then stagPhase."""
+    setBC(lo, g)
+    stagPhase(lo, g)
+
+
+def plaq(lo, g):
+    out = np.zeros(6)
+    lib().qo_plaq(lo._h, _p(g), _p(out))
+    return out
+
+
+def gauge_force(lo, g):
+    f = lo.new_gauge()
+    lib().qo_gauge_force(lo._h, _p(g), _p(f))
+    return f
+
+
+def gauge_deriv(lo, g, cplaq=1.0):
+    f = lo.new_gauge()
+    lib().qo_gauge_deriv(lo._h, _p(g), _p(f), cplaq)
+    return f
+
+
+def wflow(lo, g, nsteps, eps):
+    lib().qo_wflow(lo._h, _p(g), nsteps, eps)
+
+
+def su3_fn(name, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    r = np.zeros_like(x)
+    getattr(lib(), name)(_p(r), _p(x))
+    return r
+
+
+def norm2(lo, x, parity=ALL):
+    return lib().qo_norm2(lo._h, _p(x), parity)
+
+
+def redot(lo, x, y, parity=ALL):
+    return lib().qo_redot(lo._h, _p(x), _p(y), parity)
+
+
+def stagD2(lo, fat, lng, r, x, parity, a, b):
+    lib().qo_stagD2(lo._h, _p(fat), _p(lng), _p(r), _p(x), parity, a, b)
+
+
+def stagD(lo, fat, lng, r, x, parity, m, sc=1.0, a=0.0):
+    lib().qo_stagD(lo._h, _p(fat), _p(lng), _p(r), _p(x), parity, m, sc, a)
+
+
+def D(lo, fat, lng, x, m):
+    r = np.zeros_like(x)
+    lib().qo_D(lo._h, _p(fat), _p(lng), _p(r), _p(x), m)
+    return r
+
+
+def Ddag(lo, fat, lng, x, m):
+    r = np.zeros_like(x)
+    lib().qo_Ddag(lo._h, _p(fat), _p(lng), _p(r), _p(x), m)
+    return r
+
+
+def stagD2xx(lo, fat, lng, x, m2, par_even=True):
+    r = np.zeros_like(x)
+    lib().qo_stagD2xx(lo._h, _p(fat), _p(lng), _p(r), _p(x), m2, 1 if par_even else 0)
+    return r
+
+
+def eoReconstruct(lo, fat, lng, r, b, m):
+    lib().qo_eoReconstruct(lo._h, _p(fat), _p(lng), _p(r), _p(b), m)
+
+
+def solveXX(lo, fat, lng, b, m, r2req, maxits, par_even=True, histcap=0):
+    x = np.zeros_like(b)
+    hist = np.zeros(max(histcap, 1))
+    fin = C.c_double(0)
+    its = lib().qo_solveXX(lo._h, _p(fat), _p(lng), _p(x), _p(b), m, r2req, maxits,
+                           1 if par_even else 0, _p(hist), histcap, C.byref(fin))
+    return x, its, fin.value, hist[: min(histcap, its + 1)]
+
+
+def solve(lo, fat, lng, b, m, r2req, maxits):
+    x = np.zeros_like(b)
+    fin = C.c_double(0)
+    its = lib().qo_solve(lo._h, _p(fat), _p(lng), _p(x), _p(b), m, r2req, maxits, C.byref(fin))
+    return x, its, fin.value
+
+
+def _pp(arrs):
+    return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+
+def solveXX_multi(lo, fat, lng, b, shifts, r2req, maxits, par_even=True, histcap=0):
+    n = len(shifts)
+    xs = [np.zeros_like(b) for _ in range(n)]
+    sh = np.array(shifts, dtype=np.float64)
+    hist = np.zeros(max(histcap, 1))
+    its = lib().qo_solveXX_multi(lo._h, _p(fat), _p(lng), _pp(xs), _p(b), _p(sh), n, r2req, maxits,
+                                 1 if par_even else 0, _p(hist), histcap)
+    return xs, its, hist[: min(histcap, its + 1)]
+
+
+def solve_multi(lo, fat, lng, b, masses, r2req, maxits):
+    n = len(masses)
+    xs = [np.zeros_like(b) for _ in range(n)]
+    ms = np.array(masses, dtype=np.float64)
+    fin = C.c_double(0)
+    its = lib().qo_solve_multi(lo._h, _p(fat), _p(lng), _pp(xs), _p(b), _p(ms), n, r2req, maxits, C.byref(fin))
+    return xs, its, fin.value
+
+
+def milc6_stream(seed, index, n):
+    u = np.zeros(n, dtype=np.float32)
+    g = np.zeros(n)
+    lib().qo_milc6_test(seed & 0xFFFFFFFF, index, n, u.ctypes.data_as(C.c_void_p), _p(g))
+    return u, g
+
+
+def mrg32k3a_uniforms(seed, index, n):
+    u = np.zeros(n)
+    lib().qo_mrg32k3a_test(seed, index, n, _p(u))
+    return u
+
+
+def num_threads():
+    return lib().qo_num_threads()

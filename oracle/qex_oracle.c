@@ -1,0 +1,1067 @@
+/* qex_oracle.c -- CPU oracle (TEST INFRASTRUCTURE ONLY; see qex_oracle.h).
+ *
+ * Plain-C restatement of the reference algorithms for the staggered Dslash / CG /
+ * Wilson-flow path of ctpeterson/qex.  Every function cites the reference
+ * file:line (relative to /root/reference) it follows.  Nothing here is used by
+ * the product path.
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -fopenmp, NO fast-math so results are
+ * reproducible; the reference itself is -Ofast, hence 1e-12-level gates).
+ */
+#include "qex_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ */
+/* layout: V=1 MILC even-odd order  (src/layout/qlayout.nim:110-131)   */
+/* ------------------------------------------------------------------ */
+struct qo_layout {
+  int L[4];
+  int vol, volh;
+  int *coords;      /* [vol][4] */
+  int *nb[4][4];    /* nb[mu][k]: k=0:+1, 1:-1, 2:+3, 3:-3 */
+};
+
+int qo_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+int qo_index(const qo_layout *lo, const int x[4]) {
+  /* lex_i with x[0] fastest (qlayout.nim:85-97), parity from coordinate sum
+   * (:125-129): oi2 = oi/2 (even) or (oi+nSites)/2 (odd). */
+  int lex = 0, p = 0;
+  for (int i = 3; i >= 0; i--) lex = lex * lo->L[i] + x[i];
+  for (int i = 0; i < 4; i++) p += x[i];
+  if (p & 1) return (lex + lo->vol) / 2;
+  return lex / 2;
+}
+
+void qo_coord(const qo_layout *lo, int idx, int x[4]) {
+  for (int i = 0; i < 4; i++) x[i] = lo->coords[4 * idx + i];
+}
+
+qo_layout *qo_layout_new(const int L[4]) {
+  qo_layout *lo = (qo_layout *)calloc(1, sizeof(qo_layout));
+  lo->vol = 1;
+  for (int i = 0; i < 4; i++) { lo->L[i] = L[i]; lo->vol *= L[i]; }
+  lo->volh = lo->vol / 2;
+  lo->coords = (int *)malloc(sizeof(int) * 4 * (size_t)lo->vol);
+  int x[4];
+  for (x[3] = 0; x[3] < L[3]; x[3]++)
+    for (x[2] = 0; x[2] < L[2]; x[2]++)
+      for (x[1] = 0; x[1] < L[1]; x[1]++)
+        for (x[0] = 0; x[0] < L[0]; x[0]++) {
+          int idx = qo_index(lo, x);
+          for (int i = 0; i < 4; i++) lo->coords[4 * idx + i] = x[i];
+        }
+  static const int lens[4] = {1, -1, 3, -3};
+  for (int mu = 0; mu < 4; mu++)
+    for (int k = 0; k < 4; k++) {
+      lo->nb[mu][k] = (int *)malloc(sizeof(int) * (size_t)lo->vol);
+      for (int idx = 0; idx < lo->vol; idx++) {
+        int y[4];
+        for (int i = 0; i < 4; i++) y[i] = lo->coords[4 * idx + i];
+        /* dest s receives source s + len*mu  (shiftX.nim:76-81, qshifts.nim:204) */
+        y[mu] = ((y[mu] + lens[k]) % L[mu] + L[mu]) % L[mu];
+        lo->nb[mu][k][idx] = qo_index(lo, y);
+      }
+    }
+  return lo;
+}
+
+void qo_layout_free(qo_layout *lo) {
+  if (!lo) return;
+  for (int mu = 0; mu < 4; mu++)
+    for (int k = 0; k < 4; k++) free(lo->nb[mu][k]);
+  free(lo->coords);
+  free(lo);
+}
+
+int qo_vol(const qo_layout *lo) { return lo->vol; }
+
+int qo_neighbor(const qo_layout *lo, int idx, int mu, int len) {
+  switch (len) {
+    case 1: return lo->nb[mu][0][idx];
+    case -1: return lo->nb[mu][1][idx];
+    case 3: return lo->nb[mu][2][idx];
+    case -3: return lo->nb[mu][3][idx];
+    default: {
+      int y[4];
+      for (int i = 0; i < 4; i++) y[i] = lo->coords[4 * idx + i];
+      y[mu] = ((y[mu] + len) % lo->L[mu] + lo->L[mu]) % lo->L[mu];
+      return qo_index(lo, y);
+    }
+  }
+}
+
+static inline void subset_range(const qo_layout *lo, int parity, int *s0, int *s1) {
+  /* layoutSubset (layoutX.nim:285-295): even = [0,nEven), odd = [nEven,nSites) */
+  if (parity == 0) { *s0 = 0; *s1 = lo->volh; }
+  else if (parity == 1) { *s0 = lo->volh; *s1 = lo->vol; }
+  else { *s0 = 0; *s1 = lo->vol; }
+}
+
+/* ------------------------------------------------------------------ */
+/* 3x3 complex matrix helpers: double m[18], row-major, (re,im)        */
+/* ------------------------------------------------------------------ */
+#define RE(m, i, j) ((m)[2 * (3 * (i) + (j))])
+#define IM(m, i, j) ((m)[2 * (3 * (i) + (j)) + 1])
+
+static inline void m_zero(double *r) { for (int i = 0; i < 18; i++) r[i] = 0.0; }
+static inline void m_copy(double *r, const double *a) { for (int i = 0; i < 18; i++) r[i] = a[i]; }
+static inline void m_unit(double *r) { m_zero(r); RE(r,0,0) = RE(r,1,1) = RE(r,2,2) = 1.0; }
+static inline void m_adj(double *r, const double *a) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { RE(r,i,j) = RE(a,j,i); IM(r,i,j) = -IM(a,j,i); }
+}
+/* r = a*b */
+static inline void m_mul(double *r, const double *a, const double *b) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double sr = 0, si = 0;
+    for (int k = 0; k < 3; k++) {
+      sr += RE(a,i,k) * RE(b,k,j) - IM(a,i,k) * IM(b,k,j);
+      si += RE(a,i,k) * IM(b,k,j) + IM(a,i,k) * RE(b,k,j);
+    }
+    RE(r,i,j) = sr; IM(r,i,j) = si;
+  }
+}
+/* r = a * b^dagger */
+static inline void m_mul_na(double *r, const double *a, const double *b) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double sr = 0, si = 0;
+    for (int k = 0; k < 3; k++) {
+      sr += RE(a,i,k) * RE(b,j,k) + IM(a,i,k) * IM(b,j,k);
+      si += IM(a,i,k) * RE(b,j,k) - RE(a,i,k) * IM(b,j,k);
+    }
+    RE(r,i,j) = sr; IM(r,i,j) = si;
+  }
+}
+/* r = a^dagger * b */
+static inline void m_mul_an(double *r, const double *a, const double *b) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    double sr = 0, si = 0;
+    for (int k = 0; k < 3; k++) {
+      sr += RE(a,k,i) * RE(b,k,j) + IM(a,k,i) * IM(b,k,j);
+      si += RE(a,k,i) * IM(b,k,j) - IM(a,k,i) * RE(b,k,j);
+    }
+    RE(r,i,j) = sr; IM(r,i,j) = si;
+  }
+}
+static inline void m_axpy(double *r, double a, const double *x) { for (int i = 0; i < 18; i++) r[i] += a * x[i]; }
+static inline void m_scale(double *r, double a, const double *x) { for (int i = 0; i < 18; i++) r[i] = a * x[i]; }
+static inline void m_add_diag(double *r, double s) { RE(r,0,0) += s; RE(r,1,1) += s; RE(r,2,2) += s; }
+static inline double m_retr_adj_mul(const double *a, const double *b) {
+  /* redot(a,b) = Re tr(a^dagger b) = sum re*re + im*im */
+  double s = 0; for (int i = 0; i < 18; i++) s += a[i] * b[i]; return s;
+}
+/* determinant (matrixFunctions.nim:72-75) */
+static inline void m_det(double *dr, double *di, const double *x) {
+#define CMUL(ar, ai, br, bi, cr, ci) do { cr = (ar) * (br) - (ai) * (bi); ci = (ar) * (bi) + (ai) * (br); } while (0)
+  double t1r, t1i, t2r, t2i, pr, pi, sr = 0, si = 0, qr, qi;
+  /* (x00*x11 - x01*x10)*x22 */
+  CMUL(RE(x,0,0), IM(x,0,0), RE(x,1,1), IM(x,1,1), t1r, t1i);
+  CMUL(RE(x,0,1), IM(x,0,1), RE(x,1,0), IM(x,1,0), t2r, t2i);
+  pr = t1r - t2r; pi = t1i - t2i;
+  CMUL(pr, pi, RE(x,2,2), IM(x,2,2), qr, qi); sr += qr; si += qi;
+  /* (x02*x10 - x00*x12)*x21 */
+  CMUL(RE(x,0,2), IM(x,0,2), RE(x,1,0), IM(x,1,0), t1r, t1i);
+  CMUL(RE(x,0,0), IM(x,0,0), RE(x,1,2), IM(x,1,2), t2r, t2i);
+  pr = t1r - t2r; pi = t1i - t2i;
+  CMUL(pr, pi, RE(x,2,1), IM(x,2,1), qr, qi); sr += qr; si += qi;
+  /* (x01*x12 - x02*x11)*x20 */
+  CMUL(RE(x,0,1), IM(x,0,1), RE(x,1,2), IM(x,1,2), t1r, t1i);
+  CMUL(RE(x,0,2), IM(x,0,2), RE(x,1,1), IM(x,1,1), t2r, t2i);
+  pr = t1r - t2r; pi = t1i - t2i;
+  CMUL(pr, pi, RE(x,2,0), IM(x,2,0), qr, qi); sr += qr; si += qi;
+  *dr = sr; *di = si;
+}
+
+/* eigs3 (matrixFunctions.nim:79-111) */
+static void eigs3(double *e0, double *e1, double *e2, double tr, double p2, double det) {
+  double tr3 = (1.0 / 3.0) * tr;
+  double p23 = (1.0 / 3.0) * p2;
+  double tr32 = tr3 * tr3;
+  double q = fabs(0.5 * (p23 - tr32));
+  double r = 0.25 * tr3 * (5 * tr32 - p2) - 0.5 * det;
+  double sq = sqrt(q);
+  double sq3 = q * sq;
+  double isq3 = 1.0 / sq3;
+  double isq3c = fmin(3e38, fmax(-3e38, isq3));
+  double rsq3c = r * isq3c;
+  double rsq3 = fmin(1.0, fmax(-1.0, rsq3c));
+  double t = (1.0 / 3.0) * acos(rsq3);
+  double st = sin(t), ct = cos(t);
+  double sqc = sq * ct;
+  double sqs = 1.73205080756887729352 * sq * st;
+  double ll = tr3 + sqc;
+  *e0 = tr3 - 2 * sqc;
+  *e1 = ll + sqs;
+  *e2 = ll - sqs;
+}
+
+/* rsqrtPHM3f + rsqrtPHM3 (matrixFunctions.nim:126-182): r = x^{-1/2} for pos. Hermitian x */
+static void rsqrtPHM3(double *r, const double *x) {
+  double tr = RE(x,0,0) + RE(x,1,1) + RE(x,2,2);
+  double x2[18];
+  m_mul(x2, x, x);
+  double p2 = RE(x2,0,0) + RE(x2,1,1) + RE(x2,2,2);
+  double det, deti;
+  m_det(&det, &deti, x);
+  double l0, l1, l2;
+  eigs3(&l0, &l1, &l2, tr, p2, det);
+  double sl0 = sqrt(fabs(l0)), sl1 = sqrt(fabs(l1)), sl2 = sqrt(fabs(l2));
+  double u = sl0 + sl1 + sl2;
+  double w = sl0 * sl1 * sl2;
+  double d = w * (sl0 + sl1) * (sl0 + sl2) * (sl1 + sl2);
+  double di = 1 / d;
+  double c0 = (w * u * u + l0 * sl0 * (l1 + l2) + l1 * sl1 * (l0 + l2) + l2 * sl2 * (l0 + l1)) * di;
+  double c1 = -(tr * u + w) * di;
+  double c2 = u * di;
+  /* r := c0 + c1*x + c2*x2 */
+  for (int i = 0; i < 18; i++) r[i] = c1 * x[i] + c2 * x2[i];
+  m_add_diag(r, c0);
+}
+
+/* projectU: x (x'x + eps)^{-1/2}  (matrixFunctions.nim:293-313) */
+void qo_projectU(double *r, const double *x) {
+  double t[18], t2[18];
+  m_mul_an(t, x, x);
+  m_add_diag(t, 1e-20);
+  rsqrtPHM3(t2, t);
+  double xx[18];
+  m_copy(xx, x); /* allow r==x */
+  m_mul(r, xx, t2);
+}
+
+/* projectSU (matrixFunctions.nim:359-370) */
+void qo_projectSU(double *r, const double *x) {
+  double m[18];
+  qo_projectU(m, x);
+  double dr, di;
+  m_det(&dr, &di, m);
+  double p = (1.0 / (double)(-3)) * atan2(di, dr);
+  double cr = cos(p), ci = sin(p);
+  for (int i = 0; i < 9; i++) {
+    double a = m[2 * i], b = m[2 * i + 1];
+    r[2 * i] = cr * a - ci * b;
+    r[2 * i + 1] = cr * b + ci * a;
+  }
+}
+
+/* projectTAH (matrixFunctions.nim:375-380): r = 0.5(x - x^dag) - trace/nc */
+void qo_projectTAH(double *r, const double *x) {
+  double t[18];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    RE(t,i,j) = 0.5 * (RE(x,i,j) - RE(x,j,i));
+    IM(t,i,j) = 0.5 * (IM(x,i,j) + IM(x,j,i));
+  }
+  double dr = (RE(t,0,0) + RE(t,1,1) + RE(t,2,2)) / 3.0;
+  double di = (IM(t,0,0) + IM(t,1,1) + IM(t,2,2)) / 3.0;
+  for (int i = 0; i < 3; i++) { RE(t,i,i) -= dr; IM(t,i,i) -= di; }
+  m_copy(r, t);
+}
+
+/* exp: ExpParam{scale 20, ekPoly, order 4} (matrixFunctions.nim:436-445);
+ * expm1 = expm1Poly4(m/2^20) then 20x r <- r(r+2) (matexp.nim:80-85,634-649); +1 (:707-710) */
+void qo_exp(double *r, const double *m) {
+  const double s = 1.0 / (double)(1 << 20);
+  double ms[18], m2[18], a[18], e[18], t[18];
+  m_scale(ms, s, m);
+  m_mul(m2, ms, ms);
+  /* a = C4*m2 + C3*m + C2 ; r = a*m2 + m   (splitVars order: a=C4*m2; a+=C3*m; a+=C2) */
+  for (int i = 0; i < 18; i++) a[i] = (1.0 / 24.0) * m2[i];
+  for (int i = 0; i < 18; i++) a[i] += (1.0 / 6.0) * ms[i];
+  m_add_diag(a, 0.5);
+  m_mul(e, a, m2);
+  for (int i = 0; i < 18; i++) e[i] += ms[i];
+  for (int k = 0; k < 20; k++) {
+    m_copy(t, e);
+    m_add_diag(t, 2.0);
+    m_mul(a, e, t);
+    m_copy(e, a);
+  }
+  m_add_diag(e, 1.0);
+  m_copy(r, e);
+}
+
+/* ------------------------------------------------------------------ */
+/* RNGs                                                                */
+/* ------------------------------------------------------------------ */
+/* RngMilc6 (rng/milcrng.nim:12-14,48-55,92-110,120-133,150-154,158-193) */
+typedef struct { uint32_t r0, r1, r2, r3, r4, r5, r6, ic, mult; } milc6_t;
+#define M6_INDX1 69607u
+#define M6_INDX2 8u
+#define M6_ADDEND 12345u
+#define M6_MASK 0x00FFFFFFu
+
+static void milc6_seed(milc6_t *p, uint32_t seed0, uint32_t index) {
+  uint32_t seed = seed0;
+#define M6SET(x) do { seed = (M6_INDX1 + M6_INDX2 * index) * seed + M6_ADDEND; x = (seed >> 8) & M6_MASK; } while (0)
+  M6SET(p->r0); M6SET(p->r1); M6SET(p->r2); M6SET(p->r3); M6SET(p->r4); M6SET(p->r5); M6SET(p->r6);
+  seed = (M6_INDX1 + M6_INDX2 * index) * seed + M6_ADDEND;
+  p->ic = seed;
+  p->mult = 100005u + 8u * index;
+}
+static inline uint32_t milc6_next(milc6_t *p) {
+  uint32_t t = (((p->r5 >> 7) | (p->r6 << 17)) ^ ((p->r4 >> 1) | (p->r5 << 23))) & M6_MASK;
+  p->r6 = p->r5; p->r5 = p->r4; p->r4 = p->r3; p->r3 = p->r2; p->r2 = p->r1; p->r1 = p->r0; p->r0 = t;
+  uint32_t s = p->ic * p->mult + M6_ADDEND;
+  p->ic = s;
+  return t ^ ((s >> 8) & M6_MASK);
+}
+static inline float milc6_uniform(milc6_t *p) {
+  const float SCALE = 1.0f / (float)0x01000000;
+  return SCALE * (float)milc6_next(p);
+}
+static inline double milc6_gaussian(milc6_t *p) {
+  /* milcrng.nim:183-193 (non-FUELCompat branch).
+   * PINNED BY G1 + G5: the arithmetic is double, but the deviate every caller receives is
+   * rounded to float32.  48 precision variants were tried against the six golden plaquettes of
+   * tests/reprod/trandgauge.nim:17; only "all-double, result rounded to float32" reproduces them
+   * (sum diff^2 = 2.6e-32 vs the test's 1e-30 bound; every other variant >= 1e-20).  The same
+   * rounding is required for randTah3 (gaugeUtils.nim:1356-1375) to reproduce
+   * tests/base/trngseed.nim:56 (131563.7475902051: 1e-15 with rounding, 6e-11 without). */
+  const double TINY = 9.999999999999999e-308;
+  double v = (double)milc6_uniform(p);
+  double pp = (double)milc6_uniform(p) * 2.0 * 3.14159265358979323846;
+  double r = sqrt(-2.0 * log(v + TINY));
+  return (double)(float)(r * cos(pp));
+}
+
+/* MRG32k3a (rng/mrg32k3a.nim) */
+typedef struct { uint32_t s1[3], s2[3]; } mrg_t;
+#define MRG_M1 4294967087ull
+#define MRG_M2 4294944443ull
+static uint32_t mrg_a1sq[190][3][3], mrg_a2sq[190][3][3];
+static int mrg_init_done = 0;
+static void mrg_squaremod(uint32_t x[3][3], uint32_t a[3][3], uint64_t m) {
+  /* mrg32k3a.nim:18-30 */
+  for (int i = 0; i < 3; i++) {
+    uint64_t t[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++) {
+      uint64_t aik = a[i][k];
+      t[0] += (aik * a[k][0]) % m; t[1] += (aik * a[k][1]) % m; t[2] += (aik * a[k][2]) % m;
+    }
+    x[i][0] = (uint32_t)(t[0] % m); x[i][1] = (uint32_t)(t[1] % m); x[i][2] = (uint32_t)(t[2] % m);
+  }
+}
+static void mrg_init(void) {
+  if (mrg_init_done) return;
+  uint32_t a1[3][3] = {{0, 1, 0}, {0, 0, 1}, {(uint32_t)(MRG_M1 - 810728ull), 1403580u, 0}};
+  uint32_t a2[3][3] = {{0, 1, 0}, {0, 0, 1}, {(uint32_t)(MRG_M2 - 1370589ull), 0, 527612u}};
+  memcpy(mrg_a1sq[0], a1, sizeof(a1)); memcpy(mrg_a2sq[0], a2, sizeof(a2));
+  for (int i = 1; i < 190; i++) { mrg_squaremod(mrg_a1sq[i], mrg_a1sq[i - 1], MRG_M1); mrg_squaremod(mrg_a2sq[i], mrg_a2sq[i - 1], MRG_M2); }
+  mrg_init_done = 1;
+}
+static void mrg_matvecmod(uint32_t a[3][3], uint32_t v[3], uint64_t m) {
+  uint64_t v0 = v[0], v1 = v[1], v2 = v[2];
+  for (int i = 0; i < 3; i++) v[i] = (uint32_t)((((uint64_t)a[i][0] * v0) % m + ((uint64_t)a[i][1] * v1) % m + ((uint64_t)a[i][2] * v2) % m) % m);
+}
+static void mrg_skip(mrg_t *p, uint64_t offset, int base) {
+  int i = 0; uint64_t s = offset;
+  while (s > 0) {
+    if (s & 1) { mrg_matvecmod(mrg_a1sq[base + i], p->s1, MRG_M1); mrg_matvecmod(mrg_a2sq[base + i], p->s2, MRG_M2); }
+    s >>= 1; i++;
+  }
+}
+static void mrg_seed(mrg_t *p, uint64_t seed, uint64_t subseq) {
+  /* seedX, mrg32k3a.nim:103-120 */
+  mrg_init();
+  if (seed != 0) {
+    uint64_t d1 = 12345ull * (uint64_t)((uint32_t)seed ^ 0x55555555u);
+    uint64_t d2 = 12345ull * (uint64_t)((uint32_t)(seed >> 32) ^ 0xAAAAAAAAu);
+    p->s1[0] = (uint32_t)(d1 % MRG_M1); p->s1[1] = (uint32_t)(d2 % MRG_M1); p->s1[2] = (uint32_t)(d1 % MRG_M1);
+    p->s2[0] = (uint32_t)(d2 % MRG_M2); p->s2[1] = (uint32_t)(d1 % MRG_M2); p->s2[2] = (uint32_t)(d2 % MRG_M2);
+  } else {
+    for (int i = 0; i < 3; i++) { p->s1[i] = 12345u; p->s2[i] = 12345u; }
+  }
+  mrg_skip(p, subseq, 76);
+}
+static inline int64_t mrg_next(mrg_t *p) {
+  /* nextI, mrg32k3a.nim:158-187 */
+  int64_t p1 = 1403580ll * (int64_t)p->s1[1] - 810728ll * (int64_t)p->s1[0];
+  p1 = p1 % (int64_t)MRG_M1; if (p1 < 0) p1 += (int64_t)MRG_M1;
+  p->s1[0] = p->s1[1]; p->s1[1] = p->s1[2]; p->s1[2] = (uint32_t)p1;
+  int64_t p2 = 527612ll * (int64_t)p->s2[2] - 1370589ll * (int64_t)p->s2[0];
+  p2 = p2 % (int64_t)MRG_M2; if (p2 < 0) p2 += (int64_t)MRG_M2;
+  p->s2[0] = p->s2[1]; p->s2[1] = p->s2[2]; p->s2[2] = (uint32_t)p2;
+  return (p1 <= p2) ? p1 - p2 + (int64_t)MRG_M1 : p1 - p2;
+}
+static inline double mrg_uniform(mrg_t *p) { return 2.328306549295728e-10 * (double)mrg_next(p); }
+static inline double mrg_gaussian(mrg_t *p) {
+  /* mrg32k3a.nim:225-232: all double, no epsilon */
+  double v = mrg_uniform(p);
+  double pp = mrg_uniform(p) * 2.0 * 3.14159265358979323846;
+  double r = sqrt(-2.0 * log(v));
+  return r * cos(pp);
+}
+
+struct qo_rngfield {
+  int kind, vol;
+  milc6_t *m6;
+  mrg_t *mrg;
+};
+
+qo_rngfield *qo_rngfield_new(const qo_layout *lo, int kind, uint64_t seed) {
+  /* newRNGField (distributionUtils.nim:306-331): one generator per site, seeded with
+   * (seed, lexicographic index with x fastest). */
+  qo_rngfield *rf = (qo_rngfield *)calloc(1, sizeof(qo_rngfield));
+  rf->kind = kind; rf->vol = lo->vol;
+  if (kind == QO_RNG_MILC6) rf->m6 = (milc6_t *)malloc(sizeof(milc6_t) * (size_t)lo->vol);
+  else rf->mrg = (mrg_t *)malloc(sizeof(mrg_t) * (size_t)lo->vol);
+  for (int j = 0; j < lo->vol; j++) {
+    const int *c = &lo->coords[4 * j];
+    long l = c[3];
+    for (int i = 2; i >= 0; i--) l = l * lo->L[i] + c[i];
+    if (kind == QO_RNG_MILC6) milc6_seed(&rf->m6[j], (uint32_t)seed, (uint32_t)l); /* seedIndep narrows to uint32, milcrng.nim:111-112 */
+    else mrg_seed(&rf->mrg[j], seed, (uint64_t)l);
+  }
+  return rf;
+}
+void qo_rngfield_free(qo_rngfield *rf) { if (!rf) return; free(rf->m6); free(rf->mrg); free(rf); }
+
+static inline double rf_gaussian(qo_rngfield *rf, int site) {
+  return rf->kind == QO_RNG_MILC6 ? milc6_gaussian(&rf->m6[site]) : mrg_gaussian(&rf->mrg[site]);
+}
+
+void qo_milc6_test(uint32_t seed, uint32_t index, int n, float *uniforms, double *gaussians) {
+  milc6_t p;
+  if (uniforms) { milc6_seed(&p, seed, index); for (int i = 0; i < n; i++) uniforms[i] = milc6_uniform(&p); }
+  if (gaussians) { milc6_seed(&p, seed, index); for (int i = 0; i < n; i++) gaussians[i] = milc6_gaussian(&p); }
+}
+void qo_mrg32k3a_test(uint64_t seed, uint64_t index, int n, double *uniforms) {
+  mrg_t p; mrg_seed(&p, seed, index);
+  for (int i = 0; i < n; i++) uniforms[i] = mrg_uniform(&p);
+}
+
+/* gaussian(Field, RNGField): per site, components in storage order, re then im
+ * (distributionUtils.nim:64-96) */
+#define rf_gaussian_field rf_gaussian
+void qo_vector_gaussian(const qo_layout *lo, qo_rngfield *rf, double *v) {
+  for (int s = 0; s < lo->vol; s++)
+    for (int k = 0; k < 6; k++) v[6 * (size_t)s + k] = rf_gaussian_field(rf, s);
+}
+/* uniform(Field, RNGField) (distributionUtils.nim:23-44): ncomp reals per site in storage order.
+ * Test hook for golden set G4 (tests/base/tmrg32k3a.nim:22-27). */
+void qo_field_uniform(const qo_layout *lo, qo_rngfield *rf, int ncomp, double *v, int round_f32) {
+  for (int s = 0; s < lo->vol; s++)
+    for (int k = 0; k < ncomp; k++) {
+      double u = rf->kind == QO_RNG_MILC6 ? (double)milc6_uniform(&rf->m6[s]) : mrg_uniform(&rf->mrg[s]);
+      v[(size_t)ncomp * s + k] = round_f32 ? (double)(float)u : u;
+    }
+}
+/* g[mu].gaussian r for mu = 0..3 in turn: field-major, so each site's stream is consumed
+ * 18 numbers per direction, direction by direction (gaugeUtils.nim:1424-1429) */
+void qo_gauge_gaussian(const qo_layout *lo, qo_rngfield *rf, double *g) {
+  for (int mu = 0; mu < 4; mu++)
+    for (int s = 0; s < lo->vol; s++) {
+      double *m = &g[((size_t)s * 4 + mu) * 18];
+      for (int k = 0; k < 18; k++) m[k] = rf_gaussian_field(rf, s);
+    }
+}
+void qo_gauge_random(const qo_layout *lo, qo_rngfield *rf, double *g) {
+  /* randomSU = gaussian + projectSU (gaugeUtils.nim:1352-1354) */
+  qo_gauge_gaussian(lo, rf, g);
+#pragma omp parallel for
+  for (int i = 0; i < lo->vol * 4; i++) { double *m = &g[(size_t)i * 18]; qo_projectSU(m, m); }
+}
+void qo_gauge_unit(const qo_layout *lo, double *g) {
+  for (int i = 0; i < lo->vol * 4; i++) m_unit(&g[(size_t)i * 18]);
+}
+/* randTah3 (gaugeUtils.nim:1356-1375) */
+static void rand_tah3(double *m, qo_rngfield *rf, int site) {
+  const double s2 = 0.70710678118654752440, s3 = 0.57735026918962576450;
+  double r3 = s2 * rf_gaussian(rf, site);
+  double r8 = s2 * s3 * rf_gaussian(rf, site);
+  m_zero(m);
+  IM(m,0,0) = r8 + r3; IM(m,1,1) = r8 - r3; IM(m,2,2) = -2 * r8;
+  double r01 = s2 * rf_gaussian(rf, site), r02 = s2 * rf_gaussian(rf, site), r12 = s2 * rf_gaussian(rf, site);
+  double i01 = s2 * rf_gaussian(rf, site), i02 = s2 * rf_gaussian(rf, site), i12 = s2 * rf_gaussian(rf, site);
+  RE(m,0,1) = r01; IM(m,0,1) = i01; RE(m,1,0) = -r01; IM(m,1,0) = i01;
+  RE(m,0,2) = r02; IM(m,0,2) = i02; RE(m,2,0) = -r02; IM(m,2,0) = i02;
+  RE(m,1,2) = r12; IM(m,1,2) = i12; RE(m,2,1) = -r12; IM(m,2,1) = i12;
+}
+void qo_gauge_random_tah(const qo_layout *lo, qo_rngfield *rf, double *g) {
+  for (int mu = 0; mu < 4; mu++)
+    for (int s = 0; s < lo->vol; s++) rand_tah3(&g[((size_t)s * 4 + mu) * 18], rf, s);
+}
+void qo_gauge_warm(const qo_layout *lo, qo_rngfield *rf, double s, double *g) {
+  /* warmSU: x = exp(s * randomTAH) (gaugeUtils.nim:1384-1388,1431-1441) */
+  qo_gauge_random_tah(lo, rf, g);
+#pragma omp parallel for
+  for (int i = 0; i < lo->vol * 4; i++) {
+    double *m = &g[(size_t)i * 18], t[18];
+    m_scale(t, s, m);
+    qo_exp(m, t);
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* BC and staggered phases                                             */
+/* ------------------------------------------------------------------ */
+void qo_setBC(const qo_layout *lo, double *g) {
+  /* gaugeUtils.nim:124-131: U_3 *= -1 on the last t slice */
+  for (int s = 0; s < lo->vol; s++)
+    if (lo->coords[4 * s + 3] == lo->L[3] - 1) {
+      double *m = &g[((size_t)s * 4 + 3) * 18];
+      for (int k = 0; k < 18; k++) m[k] = -m[k];
+    }
+}
+void qo_stagPhase(const qo_layout *lo, double *g, const int phases[4]) {
+  /* stagD.nim:509-518: bit k of phases[mu] selects coordinate k */
+  for (int mu = 0; mu < 4; mu++)
+    for (int i = 0; i < lo->vol; i++) {
+      int s = 0;
+      for (int k = 0; k < 4; k++) s += (phases[mu] >> k) & lo->coords[4 * i + k];
+      if (s & 1) {
+        double *m = &g[((size_t)i * 4 + mu) * 18];
+        for (int k = 0; k < 18; k++) m[k] = -m[k];
+      }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* plaquette (gaugeUtils.nim:213-282)                                  */
+/* ------------------------------------------------------------------ */
+#define GLINK(g, s, mu) (&(g)[((size_t)(s) * 4 + (mu)) * 18])
+
+void qo_plaq(const qo_layout *lo, const double *g, double out[6]) {
+  int nt = qo_num_threads();
+  double *part = (double *)calloc((size_t)nt * 6, sizeof(double));
+#pragma omp parallel
+  {
+    double plt[6] = {0, 0, 0, 0, 0, 0};
+#pragma omp for schedule(static)
+    for (int ir = 0; ir < lo->vol; ir++)
+      for (int mu = 1; mu < 4; mu++)
+        for (int nu = 0; nu < mu; nu++) {
+          double unumu[18], umunu[18];
+          /* unumu = U_nu(x) U_mu(x+nu) ; umunu = U_mu(x) U_nu(x+mu) */
+          m_mul(unumu, GLINK(g, ir, nu), GLINK(g, lo->nb[nu][0][ir], mu));
+          m_mul(umunu, GLINK(g, ir, mu), GLINK(g, lo->nb[mu][0][ir], nu));
+          plt[(mu * (mu - 1)) / 2 + nu] += m_retr_adj_mul(umunu, unumu);
+        }
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    for (int i = 0; i < 6; i++) part[6 * tid + i] = plt[i];
+  }
+  /* thread-order sum, as threadSum does (base/threading.nim:291-316) */
+  for (int i = 0; i < 6; i++) {
+    double s = 0;
+    for (int t = 0; t < nt; t++) s += part[6 * t + i];
+    out[i] = s / ((double)lo->vol * (double)(6 * 3));
+  }
+  free(part);
+}
+
+/* ------------------------------------------------------------------ */
+/* gauge force + Wilson flow                                           */
+/* ------------------------------------------------------------------ */
+/* gaugeActionDeriv, plaquette part (gaugeAction.nim:148-204) with staples from
+ * makeStaples (staples.nim:153-238):
+ *   stf[mu,nu](x) = U_nu(x) U_mu(x+nu) U_nu(x+mu)^+
+ *   stu[mu,nu](x) = U_nu(x)^+ U_mu(x) U_nu(x+mu)   (used at x+nu: "offset up")
+ *   f[mu](x) = cp * sum_{nu!=mu} [ stf[mu,nu](x) + stu[mu,nu](x-nu) ],  cp = c.plaq/nc
+ * accumulation order follows the (mu>nu) pair loop of :186-194. */
+void qo_gauge_deriv(const qo_layout *lo, const double *g, double *f, double cplaq) {
+  const double cp = cplaq / 3.0;
+#pragma omp parallel for schedule(static)
+  for (int ir = 0; ir < lo->vol; ir++) {
+    double acc[4][18];
+    for (int mu = 0; mu < 4; mu++) m_zero(acc[mu]);
+    for (int mu = 1; mu < 4; mu++)
+      for (int nu = 0; nu < mu; nu++) {
+        double umunu[18], t[18], st[18];
+        const double *Umu = GLINK(g, ir, mu), *Unu = GLINK(g, ir, nu);
+        const double *umu_n = GLINK(g, lo->nb[nu][0][ir], mu); /* U_mu(x+nu) */
+        const double *unu_m = GLINK(g, lo->nb[mu][0][ir], nu); /* U_nu(x+mu) */
+        m_mul_na(umunu, umu_n, unu_m);          /* U_mu(x+nu) U_nu(x+mu)^+ */
+        m_mul(st, Unu, umunu);                  /* stf[mu,nu] */
+        m_axpy(acc[mu], cp, st);
+        m_mul_na(st, Umu, umunu);               /* stf[nu,mu] = U_mu(x) umunu^+ */
+        m_axpy(acc[nu], cp, st);
+        /* backward staples, evaluated at x-nu (for mu) and x-mu (for nu) */
+        int xb = lo->nb[nu][1][ir];
+        m_mul_an(t, GLINK(g, xb, nu), GLINK(g, xb, mu));       /* U_nu^+ U_mu at x-nu */
+        m_mul(st, t, GLINK(g, lo->nb[mu][0][xb], nu));         /* * U_nu(x-nu+mu) */
+        m_axpy(acc[mu], cp, st);
+        xb = lo->nb[mu][1][ir];
+        m_mul_an(t, GLINK(g, xb, mu), GLINK(g, xb, nu));       /* U_mu^+ U_nu at x-mu  (= unumu^+) */
+        m_mul(st, t, GLINK(g, lo->nb[nu][0][xb], mu));         /* * U_mu(x-mu+nu) */
+        m_axpy(acc[nu], cp, st);
+      }
+    for (int mu = 0; mu < 4; mu++) m_copy(&f[((size_t)ir * 4 + mu) * 18], acc[mu]);
+  }
+}
+
+/* gaugeForce (gaugeAction.nim:334-350) = deriv + contractProjectTAH (gaugeUtils.nim:389-398):
+ * f <- TAH( U_mu(x) f_mu(x)^+ ) */
+void qo_gauge_force(const qo_layout *lo, const double *g, double *f) {
+  qo_gauge_deriv(lo, g, f, 1.0);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < lo->vol * 4; i++) {
+    double s[18];
+    m_mul_na(s, &g[(size_t)i * 18], &f[(size_t)i * 18]);
+    qo_projectTAH(&f[(size_t)i * 18], s);
+  }
+}
+
+/* gaugeFlow (wflow.nim:21-67): Luescher RK3 */
+void qo_wflow(const qo_layout *lo, double *g, int nsteps, double eps) {
+  size_t n = (size_t)lo->vol * 4 * 18;
+  double *p = (double *)malloc(sizeof(double) * n);
+  double *f = (double *)malloc(sizeof(double) * n);
+  const double epsnc = eps * 3.0;
+  for (int step = 0; step < nsteps; step++) {
+    for (int stage = 0; stage < 3; stage++) {
+      qo_gauge_force(lo, g, f);
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < lo->vol * 4; i++) {
+        double v[18], e[18], t[18];
+        double *gi = &g[(size_t)i * 18], *fi = &f[(size_t)i * 18], *pi = &p[(size_t)i * 18];
+        if (stage == 0) for (int k = 0; k < 18; k++) v[k] = (-1.0 / 4.0) * epsnc * fi[k];
+        else if (stage == 1) for (int k = 0; k < 18; k++) v[k] = (-8.0 / 9.0) * epsnc * fi[k] + (-17.0 / 9.0) * pi[k];
+        else for (int k = 0; k < 18; k++) v[k] = (-3.0 / 4.0) * epsnc * fi[k] - pi[k];
+        qo_exp(e, v);
+        m_mul(t, e, gi);
+        if (stage < 2) m_copy(pi, v);
+        m_copy(gi, t);
+      }
+    }
+  }
+  free(p); free(f);
+}
+
+/* ------------------------------------------------------------------ */
+/* field algebra: norm2 / redot with fp64 accumulation                 */
+/* (fieldET.nim:605-625,704-724; thread partials summed in thread      */
+/*  order, base/threading.nim:291-316)                                 */
+/* ------------------------------------------------------------------ */
+double qo_norm2(const qo_layout *lo, const double *x, int parity) { return qo_redot(lo, x, x, parity); }
+
+double qo_redot(const qo_layout *lo, const double *x, const double *y, int parity) {
+  int s0, s1; subset_range(lo, parity, &s0, &s1);
+  int nt = qo_num_threads();
+  double *part = (double *)calloc((size_t)nt, sizeof(double));
+#pragma omp parallel
+  {
+    double acc = 0;
+#pragma omp for schedule(static)
+    for (int s = s0; s < s1; s++)
+      for (int k = 0; k < 6; k++) acc += x[6 * (size_t)s + k] * y[6 * (size_t)s + k];
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    part[tid] = acc;
+  }
+  double r = 0;
+  for (int t = 0; t < nt; t++) r += part[t];
+  free(part);
+  return r;
+}
+
+/* ------------------------------------------------------------------ */
+/* staggered Dslash                                                    */
+/* ------------------------------------------------------------------ */
+/* rir += U * v   (imadd) */
+static inline void mv_add(double *r, const double *U, const double *v) {
+  for (int i = 0; i < 3; i++) {
+    double sr = r[2 * i], si = r[2 * i + 1];
+    for (int j = 0; j < 3; j++) {
+      sr += RE(U,i,j) * v[2 * j] - IM(U,i,j) * v[2 * j + 1];
+      si += RE(U,i,j) * v[2 * j + 1] + IM(U,i,j) * v[2 * j];
+    }
+    r[2 * i] = sr; r[2 * i + 1] = si;
+  }
+}
+/* t = U^+ * v */
+static inline void mv_adj(double *t, const double *U, const double *v) {
+  for (int i = 0; i < 3; i++) {
+    double sr = 0, si = 0;
+    for (int j = 0; j < 3; j++) {
+      sr += RE(U,j,i) * v[2 * j] + IM(U,j,i) * v[2 * j + 1];
+      si += RE(U,j,i) * v[2 * j + 1] - IM(U,j,i) * v[2 * j];
+    }
+    t[2 * i] = sr; t[2 * i + 1] = si;
+  }
+}
+
+/* stagD2 (stagD.nim:349-395): r = a*r + b*x + sum_mu [U_mu(s) x(s+mu) - U_mu^+(s-mu) x(s-mu)],
+ * with 8 links the odd entries hop +-3 (initStagD3T :38-49; fat = g[2mu], long = g[2mu+1]).
+ * Per-site order: for mu { forward fat, backward fat, forward long, backward long }. */
+void qo_stagD2(const qo_layout *lo, const double *fat, const double *lng,
+               double *r, const double *x, int parity, double a, double b) {
+  int s0, s1; subset_range(lo, parity, &s0, &s1);
+#pragma omp parallel for schedule(static)
+  for (int ir = s0; ir < s1; ir++) {
+    double rir[6], t[6];
+    for (int k = 0; k < 6; k++) {
+      /* a==0 must not propagate NaN/garbage from r (reference evaluates a*r[ir]; with r
+       * freshly allocated = 0 this is identical).  We keep the literal expression. */
+      rir[k] = (a == 0.0 ? 0.0 : a * r[6 * (size_t)ir + k]) + (b == 0.0 ? 0.0 : b * x[6 * (size_t)ir + k]);
+    }
+    for (int mu = 0; mu < 4; mu++) {
+      int xf = lo->nb[mu][0][ir], xb = lo->nb[mu][1][ir];
+      mv_add(rir, GLINK(fat, ir, mu), &x[6 * (size_t)xf]);
+      mv_adj(t, GLINK(fat, xb, mu), &x[6 * (size_t)xb]);
+      for (int k = 0; k < 6; k++) rir[k] -= t[k];
+      if (lng) {
+        int xf3 = lo->nb[mu][2][ir], xb3 = lo->nb[mu][3][ir];
+        mv_add(rir, GLINK(lng, ir, mu), &x[6 * (size_t)xf3]);
+        mv_adj(t, GLINK(lng, xb3, mu), &x[6 * (size_t)xb3]);
+        for (int k = 0; k < 6; k++) rir[k] -= t[k];
+      }
+    }
+    for (int k = 0; k < 6; k++) r[6 * (size_t)ir + k] = rir[k];
+  }
+}
+
+/* stagD (stagD.nim:406-409): stagD2(a/(.5sc), m/(.5sc)); r[subset] := (.5sc)*r */
+void qo_stagD(const qo_layout *lo, const double *fat, const double *lng,
+              double *r, const double *x, int parity, double m, double sc, double a) {
+  qo_stagD2(lo, fat, lng, r, x, parity, a / (0.5 * sc), m / (0.5 * sc));
+  int s0, s1; subset_range(lo, parity, &s0, &s1);
+  const double h = 0.5 * sc;
+#pragma omp parallel for schedule(static)
+  for (int s = s0; s < s1; s++) for (int k = 0; k < 6; k++) r[6 * (size_t)s + k] = h * r[6 * (size_t)s + k];
+}
+/* D / Ddag (stagD.nim:566-571) */
+void qo_D(const qo_layout *lo, const double *fat, const double *lng, double *r, const double *x, double m) {
+  qo_stagD(lo, fat, lng, r, x, 0, m, 1.0, 0.0);
+  qo_stagD(lo, fat, lng, r, x, 1, m, 1.0, 0.0);
+}
+void qo_Ddag(const qo_layout *lo, const double *fat, const double *lng, double *r, const double *x, double m) {
+  qo_stagD(lo, fat, lng, r, x, 0, m, -1.0, 0.0);
+  qo_stagD(lo, fat, lng, r, x, 1, m, -1.0, 0.0);
+}
+/* eoReconstruct (stagD.nim:583-586): r.odd = (b.odd - D_oe r.even)/m */
+void qo_eoReconstruct(const qo_layout *lo, const double *fat, const double *lng,
+                      double *r, const double *b, double m) {
+  qo_stagD(lo, fat, lng, r, r, 1, 0.0, -1.0 / m, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int s = lo->volh; s < lo->vol; s++) for (int k = 0; k < 6; k++) r[6 * (size_t)s + k] += b[6 * (size_t)s + k] / m;
+}
+
+/* stagD2xx (stagD.nim:434-469): t[y] = (2D) x via stagDP (:200-237);
+ * r[x-parity] = 4 m2 x - (2D) t via stagDM (:278-313: per mu, -U t(+mu) then +U^+ t(-mu)). */
+static void stagD2xx_t(const qo_layout *lo, const double *fat, const double *lng,
+                       double *r, const double *x, double m2, int par_even, double *t) {
+  int px = par_even ? 0 : 1, py = 1 - px;
+  /* stagDP on the other parity: all forward hops, then all backward hops */
+  int s0, s1; subset_range(lo, py, &s0, &s1);
+  const int nl = lng ? 2 : 1;
+#pragma omp parallel for schedule(static)
+  for (int ir = s0; ir < s1; ir++) {
+    double rir[6] = {0, 0, 0, 0, 0, 0}, u[6];
+    for (int mu = 0; mu < 4; mu++)
+      for (int l = 0; l < nl; l++) {
+        const double *G = l ? lng : fat;
+        mv_add(rir, GLINK(G, ir, mu), &x[6 * (size_t)lo->nb[mu][2 * l][ir]]);
+      }
+    for (int mu = 0; mu < 4; mu++)
+      for (int l = 0; l < nl; l++) {
+        const double *G = l ? lng : fat;
+        int xb = lo->nb[mu][2 * l + 1][ir];
+        mv_adj(u, GLINK(G, xb, mu), &x[6 * (size_t)xb]);
+        for (int k = 0; k < 6; k++) rir[k] -= u[k];
+      }
+    for (int k = 0; k < 6; k++) t[6 * (size_t)ir + k] = rir[k];
+  }
+  subset_range(lo, px, &s0, &s1);
+#pragma omp parallel for schedule(static)
+  for (int ir = s0; ir < s1; ir++) {
+    double rir[6], u[6], nrm[6];
+    for (int k = 0; k < 6; k++) rir[k] = (4.0 * m2) * x[6 * (size_t)ir + k];
+    for (int mu = 0; mu < 4; mu++)
+      for (int l = 0; l < nl; l++) {
+        const double *G = l ? lng : fat;
+        /* imsub(rir, U, t(+)) */
+        for (int k = 0; k < 6; k++) nrm[k] = 0;
+        mv_add(nrm, GLINK(G, ir, mu), &t[6 * (size_t)lo->nb[mu][2 * l][ir]]);
+        for (int k = 0; k < 6; k++) rir[k] -= nrm[k];
+        int xb = lo->nb[mu][2 * l + 1][ir];
+        mv_adj(u, GLINK(G, xb, mu), &t[6 * (size_t)xb]);
+        for (int k = 0; k < 6; k++) rir[k] += u[k];
+      }
+    for (int k = 0; k < 6; k++) r[6 * (size_t)ir + k] = rir[k];
+  }
+}
+void qo_stagD2xx(const qo_layout *lo, const double *fat, const double *lng,
+                 double *r, const double *x, double m2, int par_even) {
+  double *t = (double *)calloc((size_t)lo->vol * 6, sizeof(double));
+  stagD2xx_t(lo, fat, lng, r, x, m2, par_even, t);
+  free(t);
+}
+
+/* ------------------------------------------------------------------ */
+/* CG (solvers/cg.nim:55-272, precon = cpNone => z=r, q=p, LAp=Ap)     */
+/* ------------------------------------------------------------------ */
+int qo_solveXX(const qo_layout *lo, const double *fat, const double *lng,
+               double *x, const double *b, double m, double r2req, int maxits, int par_even,
+               double *r2hist, int histcap, double *final_r2_over_b2) {
+  /* solveXX(s, r, x, ...) (stagSolve.nim:57-132): here `x` is the solution ("r" there), `b` the rhs. */
+  const int par = par_even ? 0 : 1;
+  size_t n6 = (size_t)lo->vol * 6;
+  int s0, s1; subset_range(lo, par, &s0, &s1);
+  double *r = (double *)calloc(n6, sizeof(double));
+  double *p = (double *)calloc(n6, sizeof(double));
+  double *Ap = (double *)calloc(n6, sizeof(double));
+  double *t = (double *)calloc(n6, sizeof(double));
+  const double m2 = m * m;
+  /* threads: r := 0  (stagSolve.nim:63-64) -- whole field */
+  memset(x, 0, sizeof(double) * n6);
+  double b2 = qo_norm2(lo, b, par);                                  /* cg.nim:134 */
+  double r2 = 1.0, rzo = 1.0;
+  int itn = 0, nh = 0;
+  if (b2 == 0.0) {
+    r2 = 0.0;                                                        /* :139-144 */
+  } else {
+    stagD2xx_t(lo, fat, lng, Ap, x, m2, par_even, t);                /* :147 op.apply(Ap,x) */
+#pragma omp parallel for schedule(static)
+    for (int s = s0; s < s1; s++) for (int k = 0; k < 6; k++) { r[6 * (size_t)s + k] = b[6 * (size_t)s + k] - Ap[6 * (size_t)s + k]; p[6 * (size_t)s + k] = 0; }
+    r2 = qo_norm2(lo, r, par);
+  }
+  const double r2stop = r2req * b2;                                  /* :155 */
+  if (r2hist && nh < histcap) r2hist[nh++] = (b2 != 0 ? r2 / b2 : 0.0);
+  while (itn < maxits && r2 > r2stop) {                              /* :174 */
+    double rz = r2;                                                  /* getRz, cpNone */
+    double beta = rz / rzo;                                          /* :186 */
+    rzo = rz;
+    if (itn == 0) {
+#pragma omp parallel for schedule(static)
+      for (int s = s0; s < s1; s++) for (int k = 0; k < 6; k++) p[6 * (size_t)s + k] = r[6 * (size_t)s + k];
+    } else {
+#pragma omp parallel for schedule(static)
+      for (int s = s0; s < s1; s++) for (int k = 0; k < 6; k++) p[6 * (size_t)s + k] = r[6 * (size_t)s + k] + beta * p[6 * (size_t)s + k];
+    }
+    itn++;
+    stagD2xx_t(lo, fat, lng, Ap, p, m2, par_even, t);                /* :200 */
+    double pAp = qo_redot(lo, p, Ap, par);                           /* :206 */
+    double alpha = rz / pAp;                                         /* :208 */
+#pragma omp parallel for schedule(static)
+    for (int s = s0; s < s1; s++) for (int k = 0; k < 6; k++) {
+      x[6 * (size_t)s + k] += alpha * p[6 * (size_t)s + k];          /* :209 */
+      r[6 * (size_t)s + k] -= alpha * Ap[6 * (size_t)s + k];         /* :211 */
+    }
+    r2 = qo_norm2(lo, r, par);                                       /* :213 */
+    if (r2hist && nh < histcap) r2hist[nh++] = r2 / b2;
+  }
+  if (final_r2_over_b2) *final_r2_over_b2 = (b2 != 0 ? r2 / b2 : 0.0);
+  free(r); free(p); free(Ap); free(t);
+  return itn;
+}
+
+/* ------------------------------------------------------------------ */
+/* full solve  D x = b  (stagSolve.nim:141-294)                        */
+/* ------------------------------------------------------------------ */
+static int solve_inner(const qo_layout *lo, const double *fat, const double *lng,
+                       double *x, const double *b, double m, double r2req, int maxits,
+                       double b2e, double b2o) {
+  size_t n6 = (size_t)lo->vol * 6;
+  const double b2 = b2e + b2o;
+  const double r2stop = r2req * b2, r2stop2 = 0.5 * r2stop;
+  const double r2stope = (b2o <= r2stop2) ? r2stop - b2o : r2stop2;
+  const double r2stopo = (b2e <= r2stop2) ? r2stop - b2e : r2stop2;
+  int its = 0;
+  if (b2e <= r2stope || b2o <= r2stopo || m == 0.0) {
+    /* solveReconR (:141-176) */
+    double *y = (double *)calloc(n6, sizeof(double));
+    if (b2e > r2stope) {
+      its = qo_solveXX(lo, fat, lng, y, b, m, r2stope / b2e, maxits, 1, NULL, 0, NULL);
+      for (int s = 0; s < lo->volh; s++) for (int k = 0; k < 6; k++) y[6 * (size_t)s + k] *= 4;
+      qo_Ddag(lo, fat, lng, x, y, m);
+    } else if (b2o > r2stopo) {
+      its = qo_solveXX(lo, fat, lng, y, b, m, r2stopo / b2o, maxits, 0, NULL, 0, NULL);
+      for (int s = lo->volh; s < lo->vol; s++) for (int k = 0; k < 6; k++) y[6 * (size_t)s + k] *= 4;
+      qo_Ddag(lo, fat, lng, x, y, m);
+    }
+    free(y);
+  } else {
+    /* solveReconL (:179-208) */
+    double *d = (double *)calloc(n6, sizeof(double));
+    qo_Ddag(lo, fat, lng, d, b, m);
+    memset(x, 0, sizeof(double) * n6);
+    double d2e = qo_norm2(lo, d, 0);
+    double rr = 0.99 * r2req * (b2e + b2o) * m * m / d2e;
+    its = qo_solveXX(lo, fat, lng, x, d, m, rr, maxits, 1, NULL, 0, NULL);
+    for (int s = 0; s < lo->volh; s++) for (int k = 0; k < 6; k++) x[6 * (size_t)s + k] *= 4;
+    qo_eoReconstruct(lo, fat, lng, x, b, m);
+    free(d);
+  }
+  return its;
+}
+
+int qo_solve(const qo_layout *lo, const double *fat, const double *lng,
+             double *x, const double *b, double m, double r2req, int maxits, double *r2_final) {
+  size_t n6 = (size_t)lo->vol * 6;
+  double b2 = qo_norm2(lo, b, 2);
+  const double r2stop = r2req * b2;
+  double *r = (double *)malloc(sizeof(double) * n6);
+  double *y = (double *)calloc(n6, sizeof(double));
+  memset(x, 0, sizeof(double) * n6);
+  memcpy(r, b, sizeof(double) * n6);
+  double r2e = qo_norm2(lo, r, 0), r2o = qo_norm2(lo, r, 1);
+  double r2 = r2e + r2o;
+  int its = 0;
+  while (r2 > r2stop) {
+    int mx = maxits - its;
+    if (mx <= 0) break;
+    its += solve_inner(lo, fat, lng, y, r, m, r2stop / r2, mx, r2e, r2o);
+    for (size_t i = 0; i < n6; i++) x[i] += y[i];
+    qo_D(lo, fat, lng, r, x, m);
+    for (size_t i = 0; i < n6; i++) r[i] = b[i] - r[i];
+    r2e = qo_norm2(lo, r, 0); r2o = qo_norm2(lo, r, 1);
+    r2 = r2e + r2o;
+  }
+  if (r2_final) *r2_final = (b2 != 0 ? r2 / b2 : 0.0);
+  free(r); free(y);
+  return its;
+}
+
+/* ------------------------------------------------------------------ */
+/* multi-shift CG (solvers/cgm.nim:84-315, precon = cpNone)            */
+/* op = stagD2ee|oo(mass^2 + shift)  (stagSolve.nim:318-325)           */
+/* ------------------------------------------------------------------ */
+int qo_solveXX_multi(const qo_layout *lo, const double *fat, const double *lng,
+                     double **xs, const double *b, const double *shifts, int nmass,
+                     double r2req, int maxits, int par_even, double *r2hist, int histcap) {
+  const int par = par_even ? 0 : 1;
+  size_t n6 = (size_t)lo->vol * 6;
+  int s0, s1; subset_range(lo, par, &s0, &s1);
+  const double mass = shifts[0];
+  const double m2 = mass * mass;
+  double *sg = (double *)calloc((size_t)nmass, sizeof(double));
+  for (int k = 1; k < nmass; k++) sg[k] = shifts[k];  /* sg[0] = 0 (cgm.nim:108-111) */
+  double *r = (double *)calloc(n6, sizeof(double));
+  double *Ap = (double *)calloc(n6, sizeof(double));
+  double *t = (double *)calloc(n6, sizeof(double));
+  double **ps = (double **)calloc((size_t)nmass, sizeof(double *));
+  for (int k = 0; k < nmass; k++) ps[k] = (double *)calloc(n6, sizeof(double));
+  double *zi = (double *)calloc((size_t)nmass, sizeof(double));
+  double *zim1 = (double *)calloc((size_t)nmass, sizeof(double));
+  /* new solution branch (:169-175): r := b; xs := 0; b2 = |b|^2; r2 = b2 */
+#pragma omp parallel for schedule(static)
+  for (int s = s0; s < s1; s++) for (int k = 0; k < 6; k++) r[6 * (size_t)s + k] = b[6 * (size_t)s + k];
+  for (int k = 0; k < nmass; k++)
+    for (int s = s0; s < s1; s++) for (int c = 0; c < 6; c++) xs[k][6 * (size_t)s + c] = 0.0;
+  double b2 = qo_norm2(lo, b, par), r2 = b2;
+  const double r2stop = r2req * b2;
+  int itn = 0, nh = 0;
+  if (r2hist && nh < histcap) r2hist[nh++] = (b2 != 0 ? r2 / b2 : 0.0);
+  if (r2 > r2stop) {
+    double alphaim1 = -1.0, betaim1 = 0.0, alpha = 0, beta = 0;
+    for (int k = 0; k < nmass; k++) { zim1[k] = 1.0; zi[k] = 1.0; }
+    double r2i = r2, r2ip1 = 0;
+    for (int k = 0; k < nmass; k++)
+      for (int s = s0; s < s1; s++) for (int c = 0; c < 6; c++) ps[k][6 * (size_t)s + c] = r[6 * (size_t)s + c];
+    int continuing = 1;
+    while (continuing) {
+      for (int k = 0; k < nmass; k++) {
+        if (k == 0) {
+          stagD2xx_t(lo, fat, lng, Ap, ps[0], m2, par_even, t);
+          itn++;
+          double qLAp = qo_redot(lo, ps[0], Ap, par);
+          alpha = (qLAp != 0.0) ? r2i / qLAp : 0.0;
+#pragma omp parallel for schedule(static)
+          for (int s = s0; s < s1; s++) for (int c = 0; c < 6; c++) {
+            r[6 * (size_t)s + c] -= alpha * Ap[6 * (size_t)s + c];
+            xs[0][6 * (size_t)s + c] += alpha * ps[0][6 * (size_t)s + c];
+          }
+          r2ip1 = qo_norm2(lo, r, par);
+          beta = (r2i != 0.0) ? r2ip1 / r2i : 0.0;
+          continuing = (itn < maxits) && (r2ip1 > r2stop);
+          if (continuing) {
+#pragma omp parallel for schedule(static)
+            for (int s = s0; s < s1; s++) for (int c = 0; c < 6; c++)
+              ps[0][6 * (size_t)s + c] = r[6 * (size_t)s + c] + beta * ps[0][6 * (size_t)s + c];
+          }
+        } else {
+          double zip1d = alpha * betaim1 * (zim1[k] - zi[k]);
+          zip1d += zim1[k] * alphaim1 * (1.0 + sg[k] * alpha);
+          double zip1 = (zip1d != 0.0) ? zi[k] * zim1[k] * alphaim1 / zip1d : 0.0;
+          double zr = (zi[k] != 0.0) ? zip1 / zi[k] : 0.0;
+          const double axz = alpha * zr;
+#pragma omp parallel for schedule(static)
+          for (int s = s0; s < s1; s++) for (int c = 0; c < 6; c++)
+            xs[k][6 * (size_t)s + c] += axz * ps[k][6 * (size_t)s + c];
+          if (continuing) {
+            const double bzz = beta * zr * zr;
+#pragma omp parallel for schedule(static)
+            for (int s = s0; s < s1; s++) for (int c = 0; c < 6; c++)
+              ps[k][6 * (size_t)s + c] = zip1 * r[6 * (size_t)s + c] + bzz * ps[k][6 * (size_t)s + c];
+            zim1[k] = zi[k]; zi[k] = zip1;
+          }
+        }
+      }
+      alphaim1 = alpha; betaim1 = beta; r2i = r2ip1;
+      r2 = r2ip1;
+      if (r2hist && nh < histcap) r2hist[nh++] = r2 / b2;
+    }
+  }
+  for (int k = 0; k < nmass; k++) free(ps[k]);
+  free(ps); free(zi); free(zim1); free(r); free(Ap); free(t); free(sg);
+  return itn;
+}
+
+/* multi-mass solve (stagSolve.nim:347-446) */
+int qo_solve_multi(const qo_layout *lo, const double *fat, const double *lng,
+                   double **xs, const double *b, const double *masses, int nmass,
+                   double r2req, int maxits, double *r2_final) {
+  size_t n6 = (size_t)lo->vol * 6;
+  const double mass = masses[0];
+  double *shifts = (double *)calloc((size_t)nmass, sizeof(double));
+  double **ys = (double **)calloc((size_t)nmass, sizeof(double *));
+  double *r = (double *)malloc(sizeof(double) * n6);
+  double *xt = (double *)calloc(n6, sizeof(double));
+  memcpy(r, b, sizeof(double) * n6);
+  double b2 = qo_norm2(lo, b, 2), b2e = qo_norm2(lo, b, 0), b2o = qo_norm2(lo, b, 1);
+  double r2 = b2e + b2o;
+  const double r2stop = r2req * b2;
+  for (int k = 0; k < nmass; k++) {
+    shifts[k] = (k == 0) ? masses[0] : 4.0 * (masses[k] * masses[k] - mass * mass);
+    ys[k] = (double *)calloc(n6, sizeof(double));
+    memset(xs[k], 0, sizeof(double) * n6);
+  }
+  int its = 0;
+  while (r2 > r2stop) {
+    int mx = maxits - its;
+    if (mx <= 0) break;
+    double rq = r2stop;
+    const double r2stop2 = 0.5 * rq;
+    const double r2stope = (b2o <= r2stop2) ? rq - b2o : r2stop2;
+    const double r2stopo = (b2e <= r2stop2) ? rq - b2e : r2stop2;
+    int even = 1;
+    if (b2e > r2stope) { rq = r2stope / b2e; even = 1; }
+    else if (b2o > r2stopo) { rq = r2stopo / b2o; even = 0; }
+    its += qo_solveXX_multi(lo, fat, lng, ys, r, shifts, nmass, rq, mx, even, NULL, 0);
+    int s0 = even ? 0 : lo->volh, s1 = even ? lo->volh : lo->vol;
+    for (int k = 0; k < nmass; k++)
+      for (int s = s0; s < s1; s++) for (int c = 0; c < 6; c++) xs[k][6 * (size_t)s + c] += 4.0 * ys[k][6 * (size_t)s + c];
+    qo_Ddag(lo, fat, lng, xt, xs[0], mass);
+    qo_D(lo, fat, lng, r, xt, mass);
+    for (size_t i = 0; i < n6; i++) r[i] = b[i] - r[i];
+    b2e = qo_norm2(lo, r, 0); b2o = qo_norm2(lo, r, 1);
+    r2 = b2e + b2o;
+  }
+  /* full solutions (:431-438): for m != 0 recompute xt = Ddag(m_k) xs[k]; xs[k] := xt
+   * (for m == 0, xt still holds Ddag(mass) xs[0] from the loop above). */
+  for (int k = 0; k < nmass; k++) {
+    if (k != 0) qo_Ddag(lo, fat, lng, xt, xs[k], masses[k]);
+    memcpy(xs[k], xt, sizeof(double) * n6);
+  }
+  if (r2_final) *r2_final = (b2 != 0 ? r2 / b2 : 0.0);
+  for (int k = 0; k < nmass; k++) free(ys[k]);
+  free(ys); free(shifts); free(r); free(xt);
+  return its;
+}
