@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- staggered Dslash + CG on a 32^4 SU(3) fp64 lattice (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one iteration of the even/odd CG hot loop (src/solvers/cg.nim:174-214):
+    p = r + beta p ; Ap = 4(m^2 - D_eo D_oe) p (two one-parity Dslash sweeps) ; <p,Ap> ;
+    x += alpha p ; r -= alpha Ap ; |r|^2
+on gauge links and vectors already resident in HBM.  The timed region is exactly K iterations
+(r2req = 0 so the solver cannot stop early) between barrier + device synchronisation on both
+sides; the time is the max over ranks.  `value` is the CG throughput in GFLOP/s with QEX's own
+flop count, (4*nd*72+60) = 1212 flop per even site per iteration (src/physics/stagSolve.nim:92),
+over the whole job; CG iterations/s and the Dslash GFLOP/s (570 flop/site) are reported next to
+it, and the dominant kernel (the one-parity Dslash sweep) is priced against the HBM roofline from
+hipEvent timings taken inside the timed region on the library's own stream.
+
+N > 1: the 32^4 lattice is split along t over the N GPUs (strong scaling), faces exchanged with
+RCCL send/recv overlapped with the interior sweep.  Launch with torch.distributed.run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+B_SWEEP1 = 1248                # bytes/site, stagDP sweep: 8 links*144 + read 48 + write 48
+B_SWEEP2 = 1296                # stagDM sweep: + 48 for the 4m^2 x term (which also feeds <p,Ap>)
+FLOP_DSLASH = 570              # 8*66 + 7*6 per site; QEX's own convention is 582
+FLOP_CG = 1212                 # per even site per iteration, stagSolve.nim:92
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--lat", type=int, nargs=4, default=[32, 32, 32, 32])
+    ap.add_argument("--mass", type=float, default=0.1)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    N = args.gpus
+    if world != N:
+        if world == 1 and N > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    if N > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # control plane only
+
+    import qex_amd as q
+
+    lat = list(args.lat)
+    if lat[3] % N or (lat[3] // N) % 2:
+        raise SystemExit("t extent must split into even slabs")
+    lt = lat[3] // N
+    lat_loc = lat[:3] + [lt]
+    lo = q.Layout(lat_loc)
+    V = int(np.prod(lat))
+    Vh_loc = lo.vol // 2
+
+    # synthetic inputs (no network, no stored configurations): random SU(3) links with antiperiodic
+    # t boundary + staggered phases, gaussian source.
+    g = q.synthetic_random_su3(lo, seed=987654321 + rank)
+    q.rephase(lo, g, t_offset=rank * lt, t_global=lat[3])
+    b = q.synthetic_gaussian_vector(lo, seed=4321 + rank)
+
+    ctx = q.Context(lat_loc, device=local_rank, rank_geom=(1, 1, 1, N), rank_coord=(0, 0, 0, rank))
+    if N > 1:
+        uid = [q.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], N, rank)
+    s = q.newStag(ctx, g)
+    bid = ctx.field_new(b)
+    xid = ctx.field_new()
+
+    def barrier():
+        if N > 1:
+            dist.barrier()
+
+    # warmup
+    ctx.dev_solve_xx(xid, bid, args.mass, 0.0, max(args.warmup, 1), True)
+    ctx.sync()
+    torch.cuda.synchronize()
+
+    ctx.timers_enable(True)
+    ctx.timers_reset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    its, fin, _ = ctx.dev_solve_xx(xid, bid, args.mass, 0.0, args.steps, True)
+    ctx.sync()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    ctx.timers_enable(False)
+    assert its == args.steps, (its, args.steps)
+    dt = t1 - t0
+    if N > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+
+    n_int, ms_int = ctx.timer("dslash")
+    n_bnd, ms_bnd = ctx.timer("dslash_bnd")
+    n_blas, ms_blas = ctx.timer("blas")
+    n_red, ms_red = ctx.timer("reduce")
+    # dominant kernel: the one-parity Dslash sweep.  Per launch it processes the sites of that launch
+    # (all Vh_loc without sharding; the interior range when the faces are split off).
+    if N == 1:
+        sites_per_launch = Vh_loc
+    else:
+        F = lat_loc[0] // 2 * lat_loc[1] * lat_loc[2]
+        sites_per_launch = max(Vh_loc - 2 * F, 0)
+    avg_ms = ms_int / max(n_int, 1)
+    b_alg = 0.5 * (B_SWEEP1 + B_SWEEP2) * sites_per_launch
+    achieved_gbs = b_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # whole sweep incl. boundary launches, for the Dslash GFLOP/s figure
+    sweep_ms = (ms_int + ms_bnd) / max(n_int, 1)
+    dslash_gflops = FLOP_DSLASH * Vh_loc * N / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+
+    out = None
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = FLOP_CG * (V // 2) * args.steps / dt / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "dslash_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch_32x4")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "staggered Dslash GFLOP/s + CG iters/s, 32^4 SU(3) fp64, 1/2/4/8 MI355X",
+            "value": round(value, 2),
+            "unit": "GFLOP/s",
+            "n_gpus": N,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%dx%dx%dx%d SU(3) even/odd staggered CG (2 Dslash sweeps + BLAS per step), mass %g, "
+                            "t split over %d GPU(s)" % (lat[0], lat[1], lat[2], lat[3], args.mass, N),
+                "lattice": lat, "mass": args.mass, "parallelism": "t-shard x%d" % N,
+            },
+            "cg_iters_per_s": round(args.steps / dt, 2),
+            "dslash_gflops": round(dslash_gflops, 1),
+            "dslash_gflops_qex582": round(dslash_gflops * 582.0 / 570.0, 1),
+            "dslash_us_per_sweep": round(sweep_ms * 1e3, 2),
+            "kernel_ms": {"dslash": round(ms_int, 3), "dslash_bnd": round(ms_bnd, 3), "blas": round(ms_blas, 3),
+                          "reduce": round(ms_red, 3), "wall": round(dt * 1e3, 3)},
+            "roofline": {
+                "bound": "hbm", "kernel": "k_dslash (one-parity sweep)",
+                "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "launches": n_int, "avg_us": round(avg_ms * 1e3, 2),
+                "alg_bytes_per_launch": int(b_alg), "traffic": traffic,
+            },
+        }
+        if N == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(lat_loc, g, b, args.mass, args.cpu_seconds)
+    barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if N > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(lat, g, b, mass, budget_s):
+    """The oracle's CG (plain C + OpenMP restatement of cg.nim / stagD.nim) on the same links and
+    source, on the GPU box's host cores.  kind = "port": the reference itself is Nim and cannot be
+    built here.  Bounded sample: calibrate on 2 iterations, then run ~budget_s worth."""
+    from oracle import oracle as o
+
+    lo = o.Layout(lat)
+    t0 = time.perf_counter()
+    o.solveXX(lo, g, None, b, mass, 0.0, 2, True)
+    per = (time.perf_counter() - t0) / 2.0
+    n = int(max(3, min(400, budget_s / max(per, 1e-6))))
+    t0 = time.perf_counter()
+    _, its, _, _ = o.solveXX(lo, g, None, b, mass, 0.0, n, True)
+    dt = time.perf_counter() - t0
+    vh = lo.vol // 2
+    return {
+        "value": round(FLOP_CG * vh * its / dt / 1e9, 3), "unit": "GFLOP/s", "cores": o.num_threads(),
+        "kind": "port", "cg_iters_per_s": round(its / dt, 3),
+        "sample": "%d CG iterations of the same %dx%dx%dx%d workload (same links/source), C+OpenMP oracle" % (
+            its, lat[0], lat[1], lat[2], lat[3]),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/* qexhip.h -- C ABI of libqexhip.so: MI355X-native staggered Dslash + CG (+ Wilson flow)
+ * behind QEX's stagD / stagSolve operator API.
+ *
+ * This is the drop-in boundary.  Every entry point names the reference interface it
+ * replaces (file:line relative to ctpeterson/qex @ 2025-02-23).  The precedent for the
+ * whole boundary is QEX's own QUDA bridge, src/quda/qudaWrapperImpl.nim:165-261
+ * (qudaSolveXX): host fields are handed over site-major in the V=1 layout, one C call
+ * does the solve, the solution is copied back.  INTEGRATION.md shows the Nim binding.
+ *
+ * Conventions
+ *   - all pointers are HOST pointers to fp64 data unless a name says `dev`;
+ *   - site order: V=1 MILC even-odd order of the rank-local lattice
+ *       lex = x0 + L0*(x1 + L1*(x2 + L2*x3)); idx = lex/2 + ((x0+x1+x2+x3)&1)*vol/2
+ *     (src/layout/qlayout.nim:110-131 with innerGeom = 1);
+ *   - colour vector: double[vol][3][2]; gauge field: double[vol][4][3][3][2]
+ *     ([site][mu][row][col][re,im], QUDA_MILC_GAUGE_ORDER as in qudaWrapperImpl.nim:216-240);
+ *   - links passed to qexhip_stag_set_links already carry boundary conditions and
+ *     staggered phases (Staggered.g, src/physics/stagD.nim:19-22,72-80); they are general
+ *     3x3 complex matrices (smeared links are not unitary);
+ *   - parity: 0 = "even", 1 = "odd", 2 = "all" (src/layout/layoutX.nim:285-295);
+ *   - return value: 0 = ok, <0 = error, message from qexhip_last_error().  Not converging
+ *     within maxits is NOT an error (src/solvers/cg.nim:174): iters == maxits is returned.
+ *   - threading: entry points are called from one host thread (the master thread outside
+ *     any `threads:` block, src/physics/stagSolve.nim:63,78); one context per GPU/rank.
+ */
+#ifndef QEXHIP_H
+#define QEXHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qexhip_ctx *qexhip_handle;
+
+#define QEXHIP_OK 0
+#define QEXHIP_ERR_ARG (-1)
+#define QEXHIP_ERR_HIP (-2)
+#define QEXHIP_ERR_STATE (-3)
+#define QEXHIP_ERR_COMM (-4)
+
+#define QEXHIP_EVEN 0
+#define QEXHIP_ODD 1
+#define QEXHIP_ALL 2
+
+/* ---------------- context ----------------
+ * Replaces qudaInit/qudaSetup (src/quda/qudaWrapperImpl.nim:70-123): bind one GPU, record the
+ * rank-local lattice and the rank grid (src/layout/layoutX.nim:70-125).  Only a split of the
+ * outermost dimension is supported: rankGeom = {1,1,1,N} (BASELINE.json north_star). */
+int qexhip_init(qexhip_handle *h, int device, const int latLocal[4],
+                const int rankGeom[4], const int rankCoord[4]);
+int qexhip_finalize(qexhip_handle h);
+const char *qexhip_last_error(void);
+/* wait for all work queued on the context's streams */
+int qexhip_sync(qexhip_handle h);
+/* library / device description, for logs */
+int qexhip_device_info(qexhip_handle h, char *buf, int buflen);
+
+/* ---------------- communicator (RCCL over xGMI) ----------------
+ * Replaces the QMP send/recv pairs of the shifts (src/layout/qshifts.nim:51-131) and
+ * threadRankSum's QMP_sum (src/comms/commsUtils.nim:195-204, commsQmp.nim:127-128).
+ * Rank 0 obtains an id, the host broadcasts it (QMP_broadcast in QEX), every rank calls init. */
+#define QEXHIP_UNIQUE_ID_BYTES 128
+int qexhip_comm_unique_id(char id[QEXHIP_UNIQUE_ID_BYTES]);
+int qexhip_comm_init(qexhip_handle h, const char id[QEXHIP_UNIQUE_ID_BYTES], int nranks, int rank);
+/* test hook: with one rank, route the t-direction hops through the halo path
+ * (pack -> RCCL self send/recv -> boundary sweep) instead of the periodic wrap. */
+int qexhip_comm_force_halo(qexhip_handle h, int on);
+
+/* ---------------- staggered operator ----------------
+ * Staggered.g  (src/physics/stagD.nim:19-22; newStag :522-541, newStag3 :543-564).
+ * fat: 4 links per site; lng: NULL (plain) or 4 three-hop links per site (Naik). */
+int qexhip_stag_set_links(qexhip_handle h, const double *fat, const double *lng);
+
+/* stagD2 (src/physics/stagD.nim:349-395):
+ *   r[parity] = a*r + b*x + sum_mu [ U_mu(s) x(s+mu) - U_mu^+(s-mu) x(s-mu) ]  (= a r + b x + 2D x) */
+int qexhip_stag_dslash(qexhip_handle h, double *r, const double *x, int parity, double a, double b);
+
+/* stagD (src/physics/stagD.nim:406-409) on both parities = Staggered.D (sc=+1, :566-568) and
+ * Staggered.Ddag (sc=-1, :569-571):  r = m*x + sc*D*x */
+int qexhip_stag_D(qexhip_handle h, double *r, const double *x, double m, double sc);
+
+/* stagD2ee / stagD2oo (src/physics/stagD.nim:434-469): r[par] = 4 m2 x - (2D_eo)(2D_oe) x */
+int qexhip_stag_op_xx(qexhip_handle h, double *r, const double *x, double m2, int par_even);
+
+/* eoReconstruct (src/physics/stagD.nim:583-586): r.odd = (b.odd - D_oe r.even)/m, r.even kept */
+int qexhip_stag_eo_reconstruct(qexhip_handle h, double *r, const double *b, double m);
+
+/* ---------------- solvers ----------------
+ * solveEE / solveOO = solveXX (src/physics/stagSolve.nim:57-138), the backend seam next to
+ * sbQuda (:105-118 -> qudaSolveEE/OO, src/quda/qudaWrapperImpl.nim:263-267).
+ * On `par_even ? even : odd` sites solve  4(m^2 - D_eo D_oe) x = b  from x = 0 with the CG of
+ * src/solvers/cg.nim:55-272; stop when |r|^2 <= r2req*|b_par|^2 or after maxits iterations.
+ * x is zeroed on both parities first (stagSolve.nim:63-64).
+ *   iters          <- sp.iterations (cg.nim:271)
+ *   r2_over_b2     <- final recursive |r|^2/|b|^2
+ *   hist[k]        <- |r|^2/|b|^2 after iteration k (k = 0 initial), the values of the
+ *                     "CG iteration: k  r2/b2:" log lines (cg.nim:172,215-217); at most histcap. */
+int qexhip_stag_solve_xx(qexhip_handle h, double *x, const double *b, double mass, double r2req,
+                         int maxits, int par_even, int *iters, double *r2_over_b2,
+                         double *hist, int histcap);
+
+/* Staggered.solve (src/physics/stagSolve.nim:224-294): full-lattice D x = b by even-odd
+ * preconditioning with the outer true-residual restart loop, x starts from 0.
+ *   iters <- total CG iterations, r2_final <- |b - D x|^2/|b|^2 (sp.r2) */
+int qexhip_stag_solve(qexhip_handle h, double *x, const double *b, double mass, double r2req,
+                      int maxits, int *iters, double *r2_final);
+
+/* multi-shift solveXX (src/physics/stagSolve.nim:296-345 + src/solvers/cgm.nim:84-315).
+ * shifts[0] = base mass, shifts[k>0] = sigma_k added to m0^2; xs[k] full-volume vectors. */
+int qexhip_stag_solve_xx_multi(qexhip_handle h, double *const *xs, const double *b,
+                               const double *shifts, int nmass, double r2req, int maxits,
+                               int par_even, int *iters, double *hist, int histcap);
+/* Staggered.solve(xs, b, ms, sp) (src/physics/stagSolve.nim:347-446) */
+int qexhip_stag_solve_multi(qexhip_handle h, double *const *xs, const double *b,
+                            const double *masses, int nmass, double r2req, int maxits,
+                            int *iters, double *r2_final);
+
+/* ---------------- field algebra hooks ----------------
+ * norm2 / redot with fp64 accumulation (src/field/fieldET.nim:605-625,704-724) and the
+ * elementwise updates CG uses (fieldET.nim:547-598).  On host vectors; for tests. */
+int qexhip_norm2(qexhip_handle h, const double *x, int parity, double *out);
+int qexhip_redot(qexhip_handle h, const double *x, const double *y, int parity, double *out);
+/* y[parity] += a*x */
+int qexhip_axpy(qexhip_handle h, double a, const double *x, double *y, int parity);
+/* y[parity] = x + a*y */
+int qexhip_xpay(qexhip_handle h, const double *x, double a, double *y, int parity);
+
+/* ---------------- device-resident fields ----------------
+ * QEX re-uploads per call through the QUDA seam; these keep vectors in HBM between calls
+ * (the "set once per trajectory" extension of SURVEY.md 8b "Ownership"). Fields are
+ * full-volume colour vectors identified by small integer ids. */
+int qexhip_field_new(qexhip_handle h, int *id);
+int qexhip_field_free(qexhip_handle h, int id);
+int qexhip_field_upload(qexhip_handle h, int id, const double *host);
+int qexhip_field_download(qexhip_handle h, int id, double *host);
+int qexhip_field_zero(qexhip_handle h, int id);
+/* asynchronous on the context stream; qexhip_sync() to wait */
+int qexhip_dev_dslash(qexhip_handle h, int r_id, int x_id, int parity, double a, double b);
+int qexhip_dev_op_xx(qexhip_handle h, int r_id, int x_id, double m2, int par_even);
+/* solveXX on resident fields; blocks until finished. */
+int qexhip_dev_solve_xx(qexhip_handle h, int x_id, int b_id, double mass, double r2req,
+                        int maxits, int par_even, int *iters, double *r2_over_b2,
+                        double *hist, int histcap);
+
+/* ---------------- gauge field, plaquette, Wilson flow ----------------
+ * qexhip_gauge_set/get: the `g` of src/gauge/wflow.nim:21 (unphased links, periodic). */
+int qexhip_gauge_set(qexhip_handle h, const double *g);
+int qexhip_gauge_get(qexhip_handle h, double *g);
+/* plaq (src/gauge/gaugeUtils.nim:213-282): six values, index mu(mu-1)/2+nu, each /(V*6*nc) */
+int qexhip_plaq(qexhip_handle h, double out[6]);
+/* gaugeForce with GaugeActionCoeffs(plaq: cplaq) (src/gauge/gaugeAction.nim:334-350):
+ * f_mu(x) = TAH( U_mu(x) * [ (cplaq/nc) sum_staples ]^+ ), written to host f */
+int qexhip_gauge_force(qexhip_handle h, double *f, double cplaq);
+/* gaugeFlow(steps, eps) (src/gauge/wflow.nim:21-67): RK3 Wilson flow of the resident gauge field */
+int qexhip_wflow(qexhip_handle h, int nsteps, double eps);
+
+/* ---------------- kernel timers ----------------
+ * hipEvent pairs around launches of the named kernel class on the context stream
+ * (the tic/toc hooks of src/physics/stagD.nim:354-395, src/solvers/cg.nim:175-241).
+ * names: "dslash" (one-parity sweep), "blas", "reduce", "staple", "expupdate", "plaq". */
+int qexhip_timers_enable(qexhip_handle h, int on);
+int qexhip_timers_reset(qexhip_handle h);
+int qexhip_timers_get(qexhip_handle h, const char *name, long *count, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

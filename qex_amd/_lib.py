@@ -1,0 +1,82 @@
+"""ctypes loader for libqexhip.so (the C ABI of include/qexhip.h).
+
+There is no CPU fallback: if the shared library is missing, or no GPU is visible when a
+context is created, this raises.  The library is built in-tree by `make -C qex_amd`
+(see __graft_entry__.build()).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqexhip.so")
+_lib = None
+
+# every symbol include/qexhip.h declares: (name, restype, argtypes)
+_vp, _ci, _cd = C.c_void_p, C.c_int, C.c_double
+_pi, _pd = C.POINTER(C.c_int), C.POINTER(C.c_double)
+SYMBOLS = [
+    ("qexhip_init", _ci, [C.POINTER(_vp), _ci, _pi, _pi, _pi]),
+    ("qexhip_finalize", _ci, [_vp]),
+    ("qexhip_last_error", C.c_char_p, []),
+    ("qexhip_sync", _ci, [_vp]),
+    ("qexhip_device_info", _ci, [_vp, C.c_char_p, _ci]),
+    ("qexhip_comm_unique_id", _ci, [C.c_char_p]),
+    ("qexhip_comm_init", _ci, [_vp, C.c_char_p, _ci, _ci]),
+    ("qexhip_comm_force_halo", _ci, [_vp, _ci]),
+    ("qexhip_stag_set_links", _ci, [_vp, _vp, _vp]),
+    ("qexhip_stag_dslash", _ci, [_vp, _vp, _vp, _ci, _cd, _cd]),
+    ("qexhip_stag_D", _ci, [_vp, _vp, _vp, _cd, _cd]),
+    ("qexhip_stag_op_xx", _ci, [_vp, _vp, _vp, _cd, _ci]),
+    ("qexhip_stag_eo_reconstruct", _ci, [_vp, _vp, _vp, _cd]),
+    ("qexhip_stag_solve_xx", _ci, [_vp, _vp, _vp, _cd, _cd, _ci, _ci, _pi, _pd, _vp, _ci]),
+    ("qexhip_stag_solve", _ci, [_vp, _vp, _vp, _cd, _cd, _ci, _pi, _pd]),
+    ("qexhip_stag_solve_xx_multi", _ci, [_vp, _vp, _vp, _vp, _ci, _cd, _ci, _ci, _pi, _vp, _ci]),
+    ("qexhip_stag_solve_multi", _ci, [_vp, _vp, _vp, _vp, _ci, _cd, _ci, _pi, _pd]),
+    ("qexhip_norm2", _ci, [_vp, _vp, _ci, _pd]),
+    ("qexhip_redot", _ci, [_vp, _vp, _vp, _ci, _pd]),
+    ("qexhip_axpy", _ci, [_vp, _cd, _vp, _vp, _ci]),
+    ("qexhip_xpay", _ci, [_vp, _vp, _cd, _vp, _ci]),
+    ("qexhip_field_new", _ci, [_vp, _pi]),
+    ("qexhip_field_free", _ci, [_vp, _ci]),
+    ("qexhip_field_upload", _ci, [_vp, _ci, _vp]),
+    ("qexhip_field_download", _ci, [_vp, _ci, _vp]),
+    ("qexhip_field_zero", _ci, [_vp, _ci]),
+    ("qexhip_dev_dslash", _ci, [_vp, _ci, _ci, _ci, _cd, _cd]),
+    ("qexhip_dev_op_xx", _ci, [_vp, _ci, _ci, _cd, _ci]),
+    ("qexhip_dev_solve_xx", _ci, [_vp, _ci, _ci, _cd, _cd, _ci, _ci, _pi, _pd, _vp, _ci]),
+    ("qexhip_gauge_set", _ci, [_vp, _vp]),
+    ("qexhip_gauge_get", _ci, [_vp, _vp]),
+    ("qexhip_plaq", _ci, [_vp, _vp]),
+    ("qexhip_gauge_force", _ci, [_vp, _vp, _cd]),
+    ("qexhip_wflow", _ci, [_vp, _ci, _cd]),
+    ("qexhip_timers_enable", _ci, [_vp, _ci]),
+    ("qexhip_timers_reset", _ci, [_vp]),
+    ("qexhip_timers_get", _ci, [_vp, C.c_char_p, C.POINTER(C.c_long), _pd]),
+]
+
+
+class QexHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QexHipError(
+                f"{LIB_PATH} not found: build it with `make -C {_HERE}` "
+                "(__graft_entry__.build()).  qex_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)  # AttributeError if the symbol is missing
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().qexhip_last_error()
+        raise QexHipError(f"libqexhip error {rc}: {msg.decode() if msg else ''}")

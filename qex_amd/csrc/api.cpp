@@ -1,0 +1,394 @@
+// api.cpp -- the extern "C" boundary declared in include/qexhip.h.
+// Host-pointer entry points upload into work fields, run the device path, download the result:
+// the same choreography as qudaSolveXX (src/quda/qudaWrapperImpl.nim:165-261).
+#include "qexhip_internal.h"
+#include "../../include/qexhip.h"
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+
+static thread_local char g_err[1024] = "";
+
+void qexhip_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char *qexhip_last_error(void) { return g_err; }
+
+// ---- timers ----
+ScopedTimer::ScopedTimer(qexhip_ctx *c_, const char *name, hipStream_t st_) : c(c_), st(st_) {
+  if (!c->timers_on) return;
+  s = &c->timers[name];
+  if (s->used + 2 > s->ev.size()) {
+    size_t old = s->ev.size();
+    s->ev.resize(old + 512);
+    for (size_t i = old; i < s->ev.size(); i++) (void)hipEventCreate(&s->ev[i]);
+  }
+  (void)hipEventRecord(s->ev[s->used], st);
+}
+ScopedTimer::~ScopedTimer() {
+  if (!s) return;
+  (void)hipEventRecord(s->ev[s->used + 1], st);
+  s->used += 2;
+}
+int timers_collect(qexhip_ctx *c) {
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto &kv : c->timers) {
+    TimerSlot &s = kv.second;
+    for (size_t i = 0; i + 1 < s.used; i += 2) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, s.ev[i], s.ev[i + 1]) == hipSuccess) { s.total_ms += ms; s.count++; }
+    }
+    s.used = 0;
+  }
+  return 0;
+}
+
+extern "C" int qexhip_timers_enable(qexhip_handle c, int on) { if (!c) return QEXHIP_ERR_ARG; c->timers_on = on; return 0; }
+extern "C" int qexhip_timers_reset(qexhip_handle c) {
+  if (!c) return QEXHIP_ERR_ARG;
+  CHK(timers_collect(c));
+  for (auto &kv : c->timers) { kv.second.count = 0; kv.second.total_ms = 0; }
+  return 0;
+}
+extern "C" int qexhip_timers_get(qexhip_handle c, const char *name, long *count, double *total_ms) {
+  if (!c || !name) return QEXHIP_ERR_ARG;
+  CHK(timers_collect(c));
+  auto it = c->timers.find(name);
+  if (count) *count = (it == c->timers.end()) ? 0 : it->second.count;
+  if (total_ms) *total_ms = (it == c->timers.end()) ? 0.0 : it->second.total_ms;
+  return 0;
+}
+
+// ---- context ----
+extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], const int rankGeom[4],
+                           const int rankCoord[4]) {
+  if (!h || !latLocal) return QEXHIP_ERR_ARG;
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) { qexhip_set_error("no HIP device visible: libqexhip has no CPU fallback"); return QEXHIP_ERR_HIP; }
+  if (device < 0 || device >= ndev) { qexhip_set_error("device %d out of range (%d visible)", device, ndev); return QEXHIP_ERR_ARG; }
+  qexhip_ctx *c = new qexhip_ctx();
+  c->device = device;
+  for (int i = 0; i < 4; i++) {
+    c->rankGeom[i] = rankGeom ? rankGeom[i] : 1;
+    c->rankCoord[i] = rankCoord ? rankCoord[i] : 0;
+  }
+  for (int i = 0; i < 3; i++)
+    if (c->rankGeom[i] != 1) { qexhip_set_error("only rankGeom = {1,1,1,N} (split along t) is supported"); delete c; return QEXHIP_ERR_ARG; }
+  const int halo = c->rankGeom[3] > 1;
+  if (geom_init(c->g, latLocal, 1, halo)) { delete c; return QEXHIP_ERR_ARG; }
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
+  c->npartials = 3 * 2048 + 64;
+  HIPCHK(hipMalloc((void **)&c->partials, sizeof(double) * c->npartials));
+  HIPCHK(hipMalloc((void **)&c->dscal, sizeof(double) * 64));
+  HIPCHK(hipMemset(c->dscal, 0, sizeof(double) * 64));
+  HIPCHK(hipMalloc((void **)&c->cg, sizeof(CgScal)));
+  HIPCHK(hipMemset(c->cg, 0, sizeof(CgScal)));
+  HIPCHK(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
+  c->nranks = 1;  // until qexhip_comm_init
+  c->rank = 0;
+  *h = c;
+  return 0;
+}
+
+extern "C" int qexhip_finalize(qexhip_handle c) {
+  if (!c) return QEXHIP_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (auto &kv : c->fields) (void)hipFree(kv.second.d);
+  c->fields.clear();
+  for (auto &kv : c->timers) for (auto e : kv.second.ev) (void)hipEventDestroy(e);
+  gauge_free(c);
+  comm_destroy(c);
+  if (c->W) (void)hipFree(c->W);
+  if (c->stage) (void)hipFree(c->stage);
+  if (c->partials) (void)hipFree(c->partials);
+  if (c->dscal) (void)hipFree(c->dscal);
+  if (c->cg) (void)hipFree(c->cg);
+  if (c->hist) (void)hipFree(c->hist);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  (void)hipEventDestroy(c->ev_ready);
+  (void)hipEventDestroy(c->ev_halo);
+  (void)hipStreamDestroy(c->stream);
+  (void)hipStreamDestroy(c->cstream);
+  delete c;
+  return 0;
+}
+
+extern "C" int qexhip_sync(qexhip_handle c) {
+  if (!c) return QEXHIP_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(c->cstream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int qexhip_device_info(qexhip_handle c, char *buf, int buflen) {
+  if (!c || !buf) return QEXHIP_ERR_ARG;
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, c->device));
+  snprintf(buf, buflen, "%s (%s) CUs=%d mem=%.0fGiB local=%dx%dx%dx%d ranks=%d halo=%d", p.name, p.gcnArchName,
+           p.multiProcessorCount, p.totalGlobalMem / 1073741824.0, c->g.X[0], c->g.X[1], c->g.X[2], c->g.X[3],
+           c->rankGeom[3], c->g.halo);
+  return 0;
+}
+
+static int drop_fields_for_regeom(qexhip_ctx *c) {
+  // geometry (ghost zones) changed: user fields keep their ids but are re-allocated empty
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto &kv : c->fields) {
+    HIPCHK(hipFree(kv.second.d));
+    kv.second.d = nullptr;
+    CHK(field_alloc(c, kv.second));
+  }
+  return 0;
+}
+
+extern "C" int qexhip_comm_force_halo(qexhip_handle c, int on) {
+  if (!c) return QEXHIP_ERR_ARG;
+  if (c->rankGeom[3] > 1) return 0;  // already on
+  c->force_halo = on;
+  int depth = c->g.depth ? c->g.depth : 1;
+  if (geom_init(c->g, c->g.X, depth, on ? 1 : 0)) return QEXHIP_ERR_ARG;
+  if (c->W) { HIPCHK(hipFree(c->W)); c->W = nullptr; c->ndir = 0; }
+  return drop_fields_for_regeom(c);
+}
+
+// ---- staggered operator ----
+extern "C" int qexhip_stag_set_links(qexhip_handle c, const double *fat, const double *lng) {
+  if (!c || !fat) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  if (c->rankGeom[3] > 1 && !c->comm) { qexhip_set_error("rankGeom[3] = %d but qexhip_comm_init was not called", c->rankGeom[3]); return QEXHIP_ERR_STATE; }
+  if (c->g.halo) {
+    int depth = lng ? 3 : 1;
+    if (c->g.X[3] < depth) { qexhip_set_error("local t extent %d < hop length %d", c->g.X[3], depth); return QEXHIP_ERR_ARG; }
+    c->g.depth = depth;  // ghost tiles were allocated for depth 3
+  }
+  return links_upload(c, fat, lng);
+}
+
+static int host_in(qexhip_ctx *c, int slot, const double *host, DevField **f) {
+  CHK(get_work(c, slot, f));
+  return field_upload(c, **f, host);
+}
+
+extern "C" int qexhip_stag_dslash(qexhip_handle c, double *r, const double *x, int parity, double a, double b) {
+  if (!c || !r || !x || parity < 0 || parity > 2) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx, *fr;
+  CHK(host_in(c, WK_IN, x, &fx));
+  CHK(host_in(c, WK_OUT, r, &fr));  // r is read when a != 0, and the untouched parity is preserved
+  for (int p = (parity == 2 ? 0 : parity); p <= (parity == 2 ? 1 : parity); p++) {
+    DslashOpts o;
+    o.ca = a; o.cb = b; o.rin = fr; o.xs = fx;
+    CHK(dslash_sweep(c, *fr, *fx, p, o));
+  }
+  return field_download(c, *fr, r);
+}
+
+extern "C" int qexhip_stag_D(qexhip_handle c, double *r, const double *x, double m, double sc) {
+  if (!c || !r || !x || sc == 0.0) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx, *fr;
+  CHK(host_in(c, WK_IN, x, &fx));
+  CHK(get_work(c, WK_OUT, &fr));
+  CHK(op_D(c, *fr, *fx, m, sc));
+  return field_download(c, *fr, r);
+}
+
+extern "C" int qexhip_stag_op_xx(qexhip_handle c, double *r, const double *x, double m2, int par_even) {
+  if (!c || !r || !x) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx, *fr;
+  CHK(host_in(c, WK_IN, x, &fx));
+  CHK(host_in(c, WK_OUT, r, &fr));
+  CHK(op_xx(c, *fr, *fx, m2, par_even, 0, nullptr));
+  return field_download(c, *fr, r);
+}
+
+int op_eo_reconstruct_pub(qexhip_ctx *c, DevField &r, DevField &b, double m);
+extern "C" int qexhip_stag_eo_reconstruct(qexhip_handle c, double *r, const double *b, double m) {
+  if (!c || !r || !b || m == 0.0) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fb, *fr;
+  CHK(host_in(c, WK_IN, b, &fb));
+  CHK(host_in(c, WK_OUT, r, &fr));
+  CHK(op_eo_reconstruct_pub(c, *fr, *fb, m));
+  return field_download(c, *fr, r);
+}
+
+// ---- solvers ----
+extern "C" int qexhip_stag_solve_xx(qexhip_handle c, double *x, const double *b, double mass, double r2req,
+                                    int maxits, int par_even, int *iters, double *r2_over_b2, double *hist,
+                                    int histcap) {
+  if (!c || !x || !b) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fb, *fx;
+  CHK(host_in(c, WK_IN, b, &fb));
+  CHK(get_work(c, WK_OUT, &fx));
+  CHK(solve_xx_dev(c, *fx, *fb, mass, r2req, maxits, par_even, iters, r2_over_b2, hist, histcap));
+  return field_download(c, *fx, x);
+}
+
+extern "C" int qexhip_stag_solve(qexhip_handle c, double *x, const double *b, double mass, double r2req,
+                                 int maxits, int *iters, double *r2_final) {
+  if (!c || !x || !b) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fb, *fx;
+  CHK(host_in(c, WK_IN, b, &fb));
+  CHK(get_work(c, WK_OUT, &fx));
+  CHK(solve_full_dev(c, *fx, *fb, mass, r2req, maxits, iters, r2_final));
+  return field_download(c, *fx, x);
+}
+
+static int multi_common(qexhip_ctx *c, double *const *xs, const double *b, const double *vals, int nmass,
+                        double r2req, int maxits, int par_even, int full, int *iters, double *out, double *hist,
+                        int histcap) {
+  if (!c || !xs || !b || !vals || nmass < 1) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fb;
+  CHK(host_in(c, WK_IN, b, &fb));
+  std::vector<DevField> xf(nmass);
+  std::vector<DevField *> xp(nmass);
+  for (int k = 0; k < nmass; k++) { CHK(field_alloc(c, xf[k])); xp[k] = &xf[k]; }
+  int rc;
+  if (full) rc = solve_multi_dev(c, xp, *fb, vals, nmass, r2req, maxits, iters, out);
+  else rc = solve_xx_multi_dev(c, xp, *fb, vals, nmass, r2req, maxits, par_even, iters, hist, histcap);
+  if (rc == 0) for (int k = 0; k < nmass && rc == 0; k++) rc = field_download(c, xf[k], xs[k]);
+  (void)hipStreamSynchronize(c->stream);
+  for (int k = 0; k < nmass; k++) (void)hipFree(xf[k].d);
+  return rc;
+}
+
+extern "C" int qexhip_stag_solve_xx_multi(qexhip_handle c, double *const *xs, const double *b, const double *shifts,
+                                          int nmass, double r2req, int maxits, int par_even, int *iters,
+                                          double *hist, int histcap) {
+  return multi_common(c, xs, b, shifts, nmass, r2req, maxits, par_even, 0, iters, nullptr, hist, histcap);
+}
+extern "C" int qexhip_stag_solve_multi(qexhip_handle c, double *const *xs, const double *b, const double *masses,
+                                       int nmass, double r2req, int maxits, int *iters, double *r2_final) {
+  return multi_common(c, xs, b, masses, nmass, r2req, maxits, 1, 1, iters, r2_final, nullptr, 0);
+}
+
+// ---- field algebra hooks ----
+extern "C" int qexhip_norm2(qexhip_handle c, const double *x, int parity, double *out) {
+  if (!c || !x || !out) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx;
+  CHK(host_in(c, WK_IN, x, &fx));
+  CHK(blas_norm2(c, *fx, parity, &c->dscal[8]));
+  return read_scalars(c, &c->dscal[8], 1, out);
+}
+extern "C" int qexhip_redot(qexhip_handle c, const double *x, const double *y, int parity, double *out) {
+  if (!c || !x || !y || !out) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx, *fy;
+  CHK(host_in(c, WK_IN, x, &fx));
+  CHK(host_in(c, WK_IN2, y, &fy));
+  CHK(blas_redot(c, *fx, *fy, parity, &c->dscal[8]));
+  return read_scalars(c, &c->dscal[8], 1, out);
+}
+extern "C" int qexhip_axpy(qexhip_handle c, double a, const double *x, double *y, int parity) {
+  if (!c || !x || !y) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx, *fy;
+  CHK(host_in(c, WK_IN, x, &fx));
+  CHK(host_in(c, WK_OUT, y, &fy));
+  CHK(blas_axpy(c, a, *fx, *fy, parity));
+  return field_download(c, *fy, y);
+}
+extern "C" int qexhip_xpay(qexhip_handle c, const double *x, double a, double *y, int parity) {
+  if (!c || !x || !y) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx, *fy;
+  CHK(host_in(c, WK_IN, x, &fx));
+  CHK(host_in(c, WK_OUT, y, &fy));
+  CHK(blas_xpay(c, *fx, a, *fy, parity));
+  return field_download(c, *fy, y);
+}
+
+// ---- device-resident fields ----
+static int find_field(qexhip_ctx *c, int id, DevField **f) {
+  auto it = c->fields.find(id);
+  if (id <= 0 || it == c->fields.end()) { qexhip_set_error("unknown field id %d", id); return QEXHIP_ERR_ARG; }
+  *f = &it->second;
+  return 0;
+}
+extern "C" int qexhip_field_new(qexhip_handle c, int *id) {
+  if (!c || !id) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField f;
+  CHK(field_alloc(c, f));
+  *id = c->next_field++;
+  c->fields[*id] = f;
+  return 0;
+}
+extern "C" int qexhip_field_free(qexhip_handle c, int id) {
+  if (!c) return QEXHIP_ERR_ARG;
+  DevField *f;
+  CHK(find_field(c, id, &f));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(f->d));
+  c->fields.erase(id);
+  return 0;
+}
+extern "C" int qexhip_field_upload(qexhip_handle c, int id, const double *host) {
+  if (!c || !host) return QEXHIP_ERR_ARG;
+  DevField *f;
+  CHK(find_field(c, id, &f));
+  CHK(field_upload(c, *f, host));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+extern "C" int qexhip_field_download(qexhip_handle c, int id, double *host) {
+  if (!c || !host) return QEXHIP_ERR_ARG;
+  DevField *f;
+  CHK(find_field(c, id, &f));
+  return field_download(c, *f, host);
+}
+extern "C" int qexhip_field_zero(qexhip_handle c, int id) {
+  if (!c) return QEXHIP_ERR_ARG;
+  DevField *f;
+  CHK(find_field(c, id, &f));
+  return blas_zero(c, *f, 2);
+}
+extern "C" int qexhip_dev_dslash(qexhip_handle c, int r_id, int x_id, int parity, double a, double b) {
+  if (!c || parity < 0 || parity > 2) return QEXHIP_ERR_ARG;
+  DevField *fr, *fx;
+  CHK(find_field(c, r_id, &fr));
+  CHK(find_field(c, x_id, &fx));
+  for (int p = (parity == 2 ? 0 : parity); p <= (parity == 2 ? 1 : parity); p++) {
+    DslashOpts o;
+    o.ca = a; o.cb = b; o.rin = fr; o.xs = fx;
+    CHK(dslash_sweep(c, *fr, *fx, p, o));
+  }
+  return 0;
+}
+extern "C" int qexhip_dev_op_xx(qexhip_handle c, int r_id, int x_id, double m2, int par_even) {
+  if (!c) return QEXHIP_ERR_ARG;
+  DevField *fr, *fx;
+  CHK(find_field(c, r_id, &fr));
+  CHK(find_field(c, x_id, &fx));
+  return op_xx(c, *fr, *fx, m2, par_even, 0, nullptr);
+}
+extern "C" int qexhip_dev_solve_xx(qexhip_handle c, int x_id, int b_id, double mass, double r2req, int maxits,
+                                   int par_even, int *iters, double *r2_over_b2, double *hist, int histcap) {
+  if (!c) return QEXHIP_ERR_ARG;
+  DevField *fx, *fb;
+  CHK(find_field(c, x_id, &fx));
+  CHK(find_field(c, b_id, &fb));
+  return solve_xx_dev(c, *fx, *fb, mass, r2req, maxits, par_even, iters, r2_over_b2, hist, histcap);
+}
+
+// ---- gauge / flow ----
+extern "C" int qexhip_gauge_set(qexhip_handle c, const double *g) { if (!c || !g) return QEXHIP_ERR_ARG; return gauge_set(c, g); }
+extern "C" int qexhip_gauge_get(qexhip_handle c, double *g) { if (!c || !g) return QEXHIP_ERR_ARG; return gauge_get(c, g); }
+extern "C" int qexhip_plaq(qexhip_handle c, double out[6]) { if (!c || !out) return QEXHIP_ERR_ARG; return gauge_plaq(c, out); }
+extern "C" int qexhip_gauge_force(qexhip_handle c, double *f, double cplaq) { if (!c || !f) return QEXHIP_ERR_ARG; return gauge_force(c, f, cplaq); }
+extern "C" int qexhip_wflow(qexhip_handle c, int nsteps, double eps) { if (!c || nsteps < 0) return QEXHIP_ERR_ARG; return gauge_wflow(c, nsteps, eps); }

@@ -1,0 +1,240 @@
+// blas.hip -- streaming field algebra + reductions of the CG (kernels K4/K5 of SURVEY.md 2.3).
+//
+// Restates the expression-template assignments x := y, x += a*y, ... (src/field/fieldET.nim:547-598)
+// and norm2P / redotP (:605-625, :704-724; always accumulated in fp64).  A one-parity vector is a
+// dense array of ntile*192 double2 (padding lanes of the last tile are zero and stay zero), so
+// every kernel is a grid-stride loop with 16-byte accesses.  The CG scalars live in a CgScal on
+// the device: alpha/beta are formed by every lane from the same two doubles (IEEE division, so
+// all lanes agree), which keeps the host out of the iteration loop.
+#include "qexhip_internal.h"
+#include "reduce.h"
+
+static inline int grid_for(size_t n2) {
+  size_t nb = (n2 + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+static inline size_t body2(const qexhip_ctx *c) { return (size_t)c->g.ntile * 192; }
+
+// parity 0/1: one half body; 2: both halves (two launches keep ghost tiles untouched)
+#define FOR_PAR(par, p) for (int p = ((par) == 2 ? 0 : (par)); p <= ((par) == 2 ? 1 : (par)); p++)
+
+__global__ void __launch_bounds__(256) k_zero(double2 *y, size_t n) {
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = make_double2(0, 0);
+}
+__global__ void __launch_bounds__(256) k_copy(double2 *y, const double2 *x, size_t n) {
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = x[i];
+}
+__global__ void __launch_bounds__(256) k_axpy(double a, const double2 *x, double2 *y, size_t n) {
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    double2 xv = x[i], yv = y[i];
+    yv.x += a * xv.x; yv.y += a * xv.y;
+    y[i] = yv;
+  }
+}
+__global__ void __launch_bounds__(256) k_xpay(const double2 *x, double a, double2 *y, size_t n) {
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    double2 xv = x[i], yv = y[i];
+    yv.x = xv.x + a * yv.x; yv.y = xv.y + a * yv.y;
+    y[i] = yv;
+  }
+}
+__global__ void __launch_bounds__(256) k_scale(double a, double2 *y, size_t n) {
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    double2 yv = y[i];
+    yv.x *= a; yv.y *= a;
+    y[i] = yv;
+  }
+}
+__global__ void __launch_bounds__(256) k_axpby(double a, const double2 *x, double b, const double2 *y, double2 *z, size_t n) {
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    double2 xv = x[i], yv = y[i];
+    z[i] = make_double2(a * xv.x + b * yv.x, a * xv.y + b * yv.y);
+  }
+}
+__global__ void __launch_bounds__(256) k_redot(const double2 *x, const double2 *y, size_t n, double *partials) {
+  double acc = 0;
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    double2 xv = x[i], yv = y[i];
+    acc += xv.x * yv.x + xv.y * yv.y;
+  }
+  double r = block_sum_256(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+// fixed-order final sum of the workgroup partials (deterministic)
+__global__ void __launch_bounds__(256) k_reduce_final(const double *partials, int n, double *out, const int *done) {
+  if (done && *done) return;
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  double r = block_sum_256(acc);
+  if (threadIdx.x == 0) *out = r;
+}
+
+int blas_zero(qexhip_ctx *c, DevField &f, int parity) {
+  size_t n = body2(c);
+  FOR_PAR(parity, p) k_zero<<<grid_for(n), 256, 0, c->stream>>>(f.par(p), n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int blas_copy(qexhip_ctx *c, DevField &dst, const DevField &src, int parity) {
+  size_t n = body2(c);
+  FOR_PAR(parity, p) k_copy<<<grid_for(n), 256, 0, c->stream>>>(dst.par(p), src.par(p), n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int blas_axpy(qexhip_ctx *c, double a, const DevField &x, DevField &y, int parity) {
+  size_t n = body2(c);
+  ScopedTimer tm(c, "blas", c->stream);
+  FOR_PAR(parity, p) k_axpy<<<grid_for(n), 256, 0, c->stream>>>(a, x.par(p), y.par(p), n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int blas_xpay(qexhip_ctx *c, const DevField &x, double a, DevField &y, int parity) {
+  size_t n = body2(c);
+  ScopedTimer tm(c, "blas", c->stream);
+  FOR_PAR(parity, p) k_xpay<<<grid_for(n), 256, 0, c->stream>>>(x.par(p), a, y.par(p), n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int blas_scale(qexhip_ctx *c, double a, DevField &y, int parity) {
+  size_t n = body2(c);
+  FOR_PAR(parity, p) k_scale<<<grid_for(n), 256, 0, c->stream>>>(a, y.par(p), n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int blas_axpby(qexhip_ctx *c, double a, const DevField &x, double b, const DevField &y, DevField &z, int parity) {
+  size_t n = body2(c);
+  FOR_PAR(parity, p) k_axpby<<<grid_for(n), 256, 0, c->stream>>>(a, x.par(p), b, y.par(p), z.par(p), n);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int reduce_partials(qexhip_ctx *c, int n, double *dev_out) {
+  {
+    ScopedTimer tm(c, "reduce", c->stream);
+    k_reduce_final<<<1, 256, 0, c->stream>>>(c->partials, n, dev_out, nullptr);
+    HIPCHK(hipGetLastError());
+  }
+  if (c->nranks > 1) CHK(comm_allreduce(c, dev_out, 1));
+  return 0;
+}
+
+int blas_redot(qexhip_ctx *c, const DevField &x, const DevField &y, int parity, double *dev_out) {
+  size_t n = body2(c);
+  int nb = grid_for(n);
+  int tot = 0;
+  {
+    ScopedTimer tm(c, "blas", c->stream);
+    FOR_PAR(parity, p) {
+      k_redot<<<nb, 256, 0, c->stream>>>(x.par(p), y.par(p), n, c->partials + tot);
+      tot += nb;
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return reduce_partials(c, tot, dev_out);
+}
+int blas_norm2(qexhip_ctx *c, const DevField &x, int parity, double *dev_out) {
+  return blas_redot(c, x, x, parity, dev_out);
+}
+
+int read_scalars(qexhip_ctx *c, const double *dev, int n, double *host) {
+  HIPCHK(hipMemcpyAsync(c->pinned, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) host[i] = ((double *)c->pinned)[i];
+  return 0;
+}
+
+// ---------------- CG-specific fused kernels (src/solvers/cg.nim:174-214) ----------------
+// q := z (itn 0) | q := z + beta*q, beta = rz/rzo   (cg.nim:186-193; cpNone: z=r, q=p)
+__global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, size_t n, const CgScal *s) {
+  if (s->done) return;
+  const bool first = (s->itn == 0);
+  const double beta = s->r2 / s->rzo;
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    double2 rv = r[i];
+    if (first) p[i] = rv;
+    else {
+      double2 pv = p[i];
+      p[i] = make_double2(rv.x + beta * pv.x, rv.y + beta * pv.y);
+    }
+  }
+}
+// alpha = rz/qLAp; x += alpha*p; r -= alpha*Ap; partial |r|^2   (cg.nim:208-213)
+__global__ void __launch_bounds__(256) k_cg_update(double2 *x, double2 *r, const double2 *p, const double2 *Ap,
+                                                  size_t n, const CgScal *s, double *partials) {
+  if (s->done) return;
+  const double alpha = s->r2 / s->pAp;
+  double acc = 0;
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    double2 pv = p[i], xv = x[i], rv = r[i], av = Ap[i];
+    xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+    rv.x -= alpha * av.x; rv.y -= alpha * av.y;
+    x[i] = xv; r[i] = rv;
+    acc += rv.x * rv.x + rv.y * rv.y;
+  }
+  double t = block_sum_256(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+// r2stop = r2req*b2; loop condition `itn<maxits and r2>r2stop` (cg.nim:155,174)
+__global__ void k_cg_init(CgScal *s, const double *dscal, double r2req, int maxits, double *hist, int histcap) {
+  s->b2 = dscal[0];
+  s->r2 = dscal[1];
+  s->rzo = 1.0;    // CgState.reset: rzold = 1.0 (cg.nim:21-27)
+  s->pAp = 0.0;
+  s->r2stop = r2req * s->b2;
+  s->itn = 0;
+  s->maxits = maxits;
+  s->done = !(0 < maxits && s->r2 > s->r2stop);
+  if (histcap > 0) hist[0] = (s->b2 != 0.0) ? s->r2 / s->b2 : 0.0;
+}
+// end of iteration: rzo = rz; ++itn; r2 = |r|^2; history; loop condition
+__global__ void k_cg_finish(CgScal *s, double *hist, int histcap) {
+  if (s->done) return;
+  s->rzo = s->r2;
+  s->r2 = s->tmp;
+  s->itn += 1;
+  if (s->itn < histcap) hist[s->itn] = s->r2 / s->b2;
+  if (!(s->itn < s->maxits && s->r2 > s->r2stop)) s->done = 1;
+}
+__global__ void __launch_bounds__(256) k_reduce_cg(const double *partials, int n, double *out, const CgScal *s) {
+  if (s->done) return;
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  double r = block_sum_256(acc);
+  if (threadIdx.x == 0) *out = r;
+}
+
+int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity) {
+  size_t n = body2(c);
+  ScopedTimer tm(c, "blas", c->stream);
+  k_cg_xpay<<<grid_for(n), 256, 0, c->stream>>>(p.par(parity), r.par(parity), n, c->cg);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity) {
+  size_t n = body2(c);
+  int nb = grid_for(n);
+  {
+    ScopedTimer tm(c, "blas", c->stream);
+    k_cg_update<<<nb, 256, 0, c->stream>>>(x.par(parity), r.par(parity), p.par(parity), Ap.par(parity), n, c->cg, c->partials);
+    HIPCHK(hipGetLastError());
+  }
+  {
+    ScopedTimer tm(c, "reduce", c->stream);
+    k_reduce_cg<<<1, 256, 0, c->stream>>>(c->partials, nb, &c->cg->tmp, c->cg);
+    HIPCHK(hipGetLastError());
+  }
+  if (c->nranks > 1) CHK(comm_allreduce(c, &c->cg->tmp, 1));
+  return 0;
+}
+int cg_init(qexhip_ctx *c, double r2req, int maxits) {
+  k_cg_init<<<1, 1, 0, c->stream>>>(c->cg, c->dscal, r2req, maxits, c->hist, c->histcap);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int cg_finish(qexhip_ctx *c) {
+  k_cg_finish<<<1, 1, 0, c->stream>>>(c->cg, c->hist, c->histcap);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

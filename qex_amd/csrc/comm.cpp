@@ -1,0 +1,108 @@
+// comm.cpp -- RCCL (over xGMI) communicator: t-face halo exchange and scalar all-reduce.
+//
+// Replaces (a) the persistent QMP send/recv pairs behind startSB/boundarySB2
+// (src/layout/shifts.nim:67-94,254-285; src/layout/qshifts.nim:51-131) and (b) the
+// QMP_sum_double_array at the end of threadRankSum (src/comms/commsUtils.nim:195-204,
+// src/comms/commsQmp.nim:127-128).  The lattice is split along t only (rankGeom {1,1,1,N}),
+// so every rank talks to two ring neighbours; faces are contiguous tile ranges of the field
+// (qexhip_internal.h), so there is no pack or unpack kernel: RCCL sends straight out of the
+// field and receives straight into the ghost tiles.
+#include "qexhip_internal.h"
+#include "../../include/qexhip.h"
+#include <rccl/rccl.h>
+#include <cstring>
+
+#define NCCLCHK(expr)                                                                      \
+  do {                                                                                     \
+    ncclResult_t r_ = (expr);                                                              \
+    if (r_ != ncclSuccess) {                                                               \
+      qexhip_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(r_)); \
+      return QEXHIP_ERR_COMM;                                                              \
+    }                                                                                      \
+  } while (0)
+
+extern "C" int qexhip_comm_unique_id(char id[QEXHIP_UNIQUE_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) <= QEXHIP_UNIQUE_ID_BYTES, "id size");
+  ncclUniqueId u;
+  NCCLCHK(ncclGetUniqueId(&u));
+  memset(id, 0, QEXHIP_UNIQUE_ID_BYTES);
+  memcpy(id, &u, sizeof(u));
+  return 0;
+}
+
+extern "C" int qexhip_comm_init(qexhip_handle c, const char id[QEXHIP_UNIQUE_ID_BYTES], int nranks, int rank) {
+  if (!c) return QEXHIP_ERR_ARG;
+  if (nranks != c->rankGeom[3] || rank != c->rankCoord[3]) {
+    qexhip_set_error("comm_init: nranks/rank (%d/%d) must equal rankGeom[3]/rankCoord[3] (%d/%d)", nranks, rank,
+                     c->rankGeom[3], c->rankCoord[3]);
+    return QEXHIP_ERR_ARG;
+  }
+  if (c->comm) { qexhip_set_error("communicator already initialised"); return QEXHIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(c->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  ncclComm_t comm;
+  NCCLCHK(ncclCommInitRank(&comm, nranks, u, rank));
+  c->comm = comm;
+  c->nranks = nranks;
+  c->rank = rank;
+  return 0;
+}
+
+void comm_destroy(qexhip_ctx *c) {
+  if (c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+}
+
+static inline int upper(const qexhip_ctx *c) { return (c->rank + 1) % c->nranks; }
+static inline int lower(const qexhip_ctx *c) { return (c->rank - 1 + c->nranks) % c->nranks; }
+
+// Exchange the t-faces of one parity half of f.  Runs on the comm stream after ev_ready (the
+// producer of f on the compute stream); records ev_halo.  Message order is the same on every
+// rank -- sends {bottom->lower, top->upper}, receives {ghost_hi<-upper, ghost_lo<-lower} -- so
+// that with two ranks (upper == lower) or one rank (self) the k-th send pairs with the k-th recv.
+int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity) {
+  const Geom &g = c->g;
+  const size_t face2 = (size_t)g.depth * g.F * 3;  // double2 per face
+  const size_t nd = face2 * 2;                     // doubles
+  double2 *base = f.par(parity);
+  double2 *bottom = base;                                       // t = 0 .. depth-1
+  double2 *top = base + (size_t)(g.ntile) * 192 - face2;        // t = Xt-depth .. Xt-1
+  double2 *ghost_hi = base + (size_t)g.ntile * 192;
+  double2 *ghost_lo = ghost_hi + face2;
+  HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+  if (c->comm) {
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    NCCLCHK(ncclGroupStart());
+    NCCLCHK(ncclSend(bottom, nd, ncclDouble, lower(c), comm, c->cstream));
+    NCCLCHK(ncclSend(top, nd, ncclDouble, upper(c), comm, c->cstream));
+    NCCLCHK(ncclRecv(ghost_hi, nd, ncclDouble, upper(c), comm, c->cstream));
+    NCCLCHK(ncclRecv(ghost_lo, nd, ncclDouble, lower(c), comm, c->cstream));
+    NCCLCHK(ncclGroupEnd());
+  } else {
+    // single rank, no communicator: periodic wrap by device-to-device copies
+    HIPCHK(hipMemcpyAsync(ghost_hi, bottom, nd * sizeof(double), hipMemcpyDeviceToDevice, c->cstream));
+    HIPCHK(hipMemcpyAsync(ghost_lo, top, nd * sizeof(double), hipMemcpyDeviceToDevice, c->cstream));
+  }
+  HIPCHK(hipEventRecord(c->ev_halo, c->cstream));
+  return 0;
+}
+
+// send `bytes` to the upper neighbour, receive the same amount from the lower one (stream-ordered)
+int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st) {
+  if (c->comm) {
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    NCCLCHK(ncclGroupStart());
+    NCCLCHK(ncclSend(send_up, bytes, ncclChar, upper(c), comm, st));
+    NCCLCHK(ncclRecv(recv_from_down, bytes, ncclChar, lower(c), comm, st));
+    NCCLCHK(ncclGroupEnd());
+  } else {
+    HIPCHK(hipMemcpyAsync(recv_from_down, send_up, bytes, hipMemcpyDeviceToDevice, st));
+  }
+  return 0;
+}
+
+int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
+  if (c->nranks <= 1 || !c->comm) return 0;
+  NCCLCHK(ncclAllReduce(dptr, dptr, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
+  return 0;
+}

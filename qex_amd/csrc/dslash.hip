@@ -1,0 +1,188 @@
+// dslash.hip -- one-parity staggered Dslash sweep (kernels K1/K2/K3 of SURVEY.md 2.3).
+//
+// Restates stagD2 (src/physics/stagD.nim:349-395), stagDP (:200-237) and stagDM (:278-313):
+//   out(s) = ca*rin(s) + cb*xs(s) +/- sum_mu [ U_mu(s) in(s+mu) - U_mu(s-mu)^+ in(s-mu) ]
+// (+ the 3-hop terms with 16 links, initStagD3T :38-49).  One lane per output site, one
+// wavefront per 64-site tile: the wavefront streams its contiguous block of links (72 KiB /
+// 144 KiB) with 16-byte loads, neighbour vectors come from the opposite-parity field with
+// unit-stride (x), row-stride (y), plane-stride (z) or slice-stride (t) access, all coalesced.
+// HBM-bound: 1248 B and 570 flop per site (1-hop), no MFMA on purpose.
+#include "qexhip_internal.h"
+#include "site_index.h"
+#include "reduce.h"
+
+struct DslashArgs {
+  Geom g;
+  const double2 *W;      // links of the output parity
+  const double2 *in;     // hop source (opposite parity half)
+  double2 *out;          // output parity half
+  const double2 *rin;    // a-term
+  const double2 *xs;     // b-term / dot partner
+  double ca, cb;
+  double sgn;            // +1 (stagDP / stagD2) or -1 (stagDM)
+  double post;           // final scale, the `r := (0.5*sc)*r` of stagD (stagD.nim:409)
+  int parity, c0, c1;
+  double *partials;
+  const int *done;
+  int swz;               // number of workgroups if XCD swizzle is on, else 0
+};
+
+__device__ __forceinline__ void mv3(double2 acc[3], const double2 U[9], const double2 v[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      acc[i].x += U[3 * i + j].x * v[j].x;
+      acc[i].x -= U[3 * i + j].y * v[j].y;
+      acc[i].y += U[3 * i + j].x * v[j].y;
+      acc[i].y += U[3 * i + j].y * v[j].x;
+    }
+  }
+}
+
+template <int NDIR, bool HALO, bool INIT, bool DOT>
+__global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
+  if (A.done && *A.done) return;
+  int bid = blockIdx.x;
+  if (A.swz) {
+    // XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs; give every XCD a
+    // contiguous run of tiles (= a contiguous t-range) so that y/z/t neighbours share its L2.
+    int per = A.swz >> 3;
+    bid = (bid & 7) * per + (bid >> 3);
+  }
+  int c = A.c0 + bid * 256 + threadIdx.x;
+  double dotv = 0;
+  if (c < A.c1) {
+    const Geom &g = A.g;
+    SiteXYZT s = site_coord(g, c, A.parity);
+    double2 acc[3];
+    double2 xsv[3];
+    if (INIT || DOT) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) xsv[k] = A.xs[vec_off(c, k)];
+    }
+    if (INIT) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        acc[k].x = A.cb * xsv[k].x;
+        acc[k].y = A.cb * xsv[k].y;
+      }
+      if (A.ca != 0.0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          double2 r = A.rin[vec_off(c, k)];
+          acc[k].x += A.ca * r.x;
+          acc[k].y += A.ca * r.y;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; k++) acc[k] = make_double2(0.0, 0.0);
+    }
+    const double2 *w = A.W + (size_t)(c >> 6) * (NDIR * 576) + (c & 63);
+#pragma unroll
+    for (int d = 0; d < NDIR; d++) {
+      const int mu = (d >> 1) & 3;
+      const int hop = (d >= 8 ? 3 : 1) * ((d & 1) ? -1 : 1);
+      int pos = nbr_pos<HALO>(g, c, s, mu, hop);
+      double2 U[9], v[3];
+#pragma unroll
+      for (int k = 0; k < 9; k++) U[k] = w[(size_t)d * 576 + k * 64];
+      const double sg = (d & 1) ? -A.sgn : A.sgn;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        double2 t = A.in[vec_off(pos, k)];
+        v[k] = make_double2(sg * t.x, sg * t.y);
+      }
+      mv3(acc, U, v);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      acc[k].x *= A.post; acc[k].y *= A.post;
+      A.out[vec_off(c, k)] = acc[k];
+    }
+    if (DOT) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) dotv += xsv[k].x * acc[k].x + xsv[k].y * acc[k].y;
+    }
+  }
+  if (DOT) {
+    double r = block_sum_256(dotv);
+    if (threadIdx.x == 0) A.partials[blockIdx.x] = r;
+  }
+}
+
+template <int NDIR, bool HALO>
+static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool dot, int part_off) {
+  if (c1 <= c0) return 0;
+  A.c0 = c0; A.c1 = c1;
+  int nb = (c1 - c0 + 255) / 256;
+  A.swz = (nb >= 64 && (nb & 7) == 0) ? nb : 0;
+  double *psave = A.partials;
+  A.partials = psave ? psave + part_off : nullptr;
+  dim3 grid(nb), block(256);
+  if (init && dot) k_dslash<NDIR, HALO, true, true><<<grid, block, 0, c->stream>>>(A);
+  else if (init) k_dslash<NDIR, HALO, true, false><<<grid, block, 0, c->stream>>>(A);
+  else if (dot) k_dslash<NDIR, HALO, false, true><<<grid, block, 0, c->stream>>>(A);
+  else k_dslash<NDIR, HALO, false, false><<<grid, block, 0, c->stream>>>(A);
+  A.partials = psave;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const DslashOpts &o) {
+  const Geom &g = c->g;
+  if (!c->W) { qexhip_set_error("staggered links not set (qexhip_stag_set_links)"); return -3; }
+  DslashArgs A;
+  A.g = g;
+  A.W = c->W + (size_t)parity * g.ntile * c->ndir * 576;
+  A.in = in.par(1 - parity);
+  A.out = out.par(parity);
+  A.rin = o.rin ? o.rin->par(parity) : nullptr;
+  A.xs = o.xs ? o.xs->par(parity) : nullptr;
+  A.ca = o.ca; A.cb = o.cb;
+  A.sgn = o.neg ? -1.0 : 1.0;
+  A.post = o.post;
+  A.parity = parity;
+  A.partials = c->partials;
+  A.done = o.done;
+  const bool init = (o.ca != 0.0 || o.cb != 0.0);
+  if ((init || o.dot) && !A.xs) { qexhip_set_error("dslash_sweep: b-term/dot needs xs"); return -1; }
+  if (o.ca != 0.0 && !A.rin) { qexhip_set_error("dslash_sweep: a-term needs rin"); return -1; }
+  int nparts = 0;
+  if (!g.halo) {
+    ScopedTimer tm(c, "dslash", c->stream);
+    if (c->ndir == 8) CHK((launch<8, false>(c, A, 0, g.Vh, init, o.dot, 0)));
+    else CHK((launch<16, false>(c, A, 0, g.Vh, init, o.dot, 0)));
+    nparts = (g.Vh + 255) / 256;
+  } else {
+    // halo: exchange faces of `in` on the comm stream, interior sweep meanwhile, then boundary
+    HIPCHK(hipEventRecord(c->ev_ready, c->stream));
+    CHK(comm_halo_exchange(c, in, 1 - parity));
+    int lo_end = g.depth * g.F; if (lo_end > g.Vh) lo_end = g.Vh;
+    int hi_beg = g.Vh - g.depth * g.F; if (hi_beg < lo_end) hi_beg = lo_end;
+    int nb_int = (hi_beg - lo_end + 255) / 256, nb_lo = (lo_end + 255) / 256;
+    {
+      ScopedTimer tm(c, "dslash", c->stream);
+      if (c->ndir == 8) CHK((launch<8, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
+      else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
+    }
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    {
+      ScopedTimer tm(c, "dslash_bnd", c->stream);
+      if (c->ndir == 8) {
+        CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int)));
+        CHK((launch<8, true>(c, A, hi_beg, g.Vh, init, o.dot, nb_int + nb_lo)));
+      } else {
+        CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int)));
+        CHK((launch<16, true>(c, A, hi_beg, g.Vh, init, o.dot, nb_int + nb_lo)));
+      }
+    }
+    nparts = nb_int + nb_lo + (g.Vh - hi_beg + 255) / 256;
+  }
+  if (o.dot) {
+    if (nparts > c->npartials) { qexhip_set_error("internal: partial buffer too small"); return -3; }
+    CHK(reduce_partials(c, nparts, o.dot_out));
+  }
+  return 0;
+}

@@ -1,0 +1,246 @@
+// gauge.hip -- plaquette, staple force and Wilson-flow step (kernels K8/K9/K10 of SURVEY.md 2.3).
+//
+// Restates (file:line in ctpeterson/qex):
+//   plaq                       src/gauge/gaugeUtils.nim:213-282
+//   makeStaples                src/gauge/staples.nim:153-238
+//   gaugeActionDeriv (plaq)    src/gauge/gaugeAction.nim:148-204
+//   contractProjectTAH         src/gauge/gaugeUtils.nim:389-398
+//   gaugeFlow (RK3)            src/gauge/wflow.nim:21-67
+// Layout: natural links G[parity][tile][mu][9][64] double2 (one 16-byte load per lane and entry).
+// Single GPU (BASELINE.json config 3); the staggered path above is the sharded one.
+#include "qexhip_internal.h"
+#include "reduce.h"
+#include "su3.h"
+
+struct GaugeNat {
+  double2 *U = nullptr, *F = nullptr, *P = nullptr;
+  size_t n2 = 0;  // double2 elements per field
+};
+
+__device__ __forceinline__ void coords_of(const Geom &g, int c, int p, int x[4]) {
+  unsigned r = (unsigned)c;
+  int xh = r % (unsigned)g.Xh; r /= (unsigned)g.Xh;
+  x[1] = r % (unsigned)g.X[1]; r /= (unsigned)g.X[1];
+  x[2] = r % (unsigned)g.X[2];
+  x[3] = r / (unsigned)g.X[2];
+  x[0] = 2 * xh + ((x[1] + x[2] + x[3] + p) & 1);
+}
+__device__ __forceinline__ size_t link_off(const Geom &g, const int x[4], int mu) {
+  int lex = x[0] + g.X[0] * (x[1] + g.X[1] * (x[2] + g.X[2] * x[3]));
+  int p = (x[0] + x[1] + x[2] + x[3]) & 1;
+  int c = lex >> 1;
+  return (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+}
+__device__ __forceinline__ void shifted(const Geom &g, const int x[4], int mu, int d, int y[4]) {
+  y[0] = x[0]; y[1] = x[1]; y[2] = x[2]; y[3] = x[3];
+  int v = y[mu] + d;
+  y[mu] = v >= g.X[mu] ? v - g.X[mu] : (v < 0 ? v + g.X[mu] : v);
+}
+
+// host [idx][mu][9] <-> tiles
+__global__ void __launch_bounds__(256) k_gauge_to_tiles(Geom g, const double2 *__restrict__ host, double2 *G) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  int p = i >= g.Vh, c = i - p * g.Vh;
+  for (int mu = 0; mu < 4; mu++) {
+    double2 *w = G + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    for (int k = 0; k < 9; k++) w[k * 64] = host[((size_t)i * 4 + mu) * 9 + k];
+  }
+}
+__global__ void __launch_bounds__(256) k_gauge_from_tiles(Geom g, double2 *__restrict__ host, const double2 *G) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  int p = i >= g.Vh, c = i - p * g.Vh;
+  for (int mu = 0; mu < 4; mu++) {
+    const double2 *w = G + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    for (int k = 0; k < 9; k++) host[((size_t)i * 4 + mu) * 9 + k] = w[k * 64];
+  }
+}
+
+// plaquette: per site six Re tr[(U_mu(x)U_nu(x+mu))^+ (U_nu(x)U_mu(x+nu))], ip = mu(mu-1)/2+nu
+__global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict__ G, double *partials) {
+  double pl[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < g.V; i += gridDim.x * 256) {
+    int p = i >= g.Vh, c = i - p * g.Vh;
+    int x[4], y[4];
+    coords_of(g, c, p, x);
+    M3 U[4];
+#pragma unroll
+    for (int mu = 0; mu < 4; mu++) U[mu] = m3_load(G + link_off(g, x, mu), 64);
+#pragma unroll
+    for (int mu = 1; mu < 4; mu++) {
+#pragma unroll
+      for (int nu = 0; nu < mu; nu++) {
+        shifted(g, x, nu, 1, y);
+        M3 unumu = m3_mul(U[nu], m3_load(G + link_off(g, y, mu), 64));
+        shifted(g, x, mu, 1, y);
+        M3 umunu = m3_mul(U[mu], m3_load(G + link_off(g, y, nu), 64));
+        pl[(mu * (mu - 1)) / 2 + nu] += m3_redot(umunu, unumu);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    double r = block_sum_256(pl[k]);
+    if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = r;
+  }
+}
+__global__ void __launch_bounds__(256) k_plaq_final(const double *partials, int nb, double norm, double *out) {
+  for (int k = 0; k < 6; k++) {
+    double acc = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += partials[(size_t)k * nb + i];
+    double r = block_sum_256(acc);
+    if (threadIdx.x == 0) out[k] = r / norm;
+  }
+}
+
+// force: one lane per (mu, site).  F_mu(x) = TAH( U_mu(x) [cp * sum_nu (fwd + bwd staples)]^+ )
+__global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict__ G, double2 *F, double cp) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= 4 * g.V) return;
+  int mu = j / g.V, i = j - mu * g.V;
+  int p = i >= g.Vh, c = i - p * g.Vh;
+  int x[4], xpm[4], y[4], z[4];
+  coords_of(g, c, p, x);
+  shifted(g, x, mu, 1, xpm);
+  M3 acc = m3_zero();
+#pragma unroll 1
+  for (int nu = 0; nu < 4; nu++) {
+    if (nu == mu) continue;
+    // forward: U_nu(x) U_mu(x+nu) U_nu(x+mu)^+          (stf[mu,nu], staples.nim:181-183)
+    shifted(g, x, nu, 1, y);
+    M3 t = m3_mul_na(m3_load(G + link_off(g, y, mu), 64), m3_load(G + link_off(g, xpm, nu), 64));
+    M3 s = m3_mul(m3_load(G + link_off(g, x, nu), 64), t);
+    m3_axpy(acc, cp, s);
+    // backward: U_nu(x-nu)^+ U_mu(x-nu) U_nu(x-nu+mu)   (stu[mu,nu] shifted down, staples.nim:184-186)
+    shifted(g, x, nu, -1, y);
+    shifted(g, y, mu, 1, z);
+    t = m3_mul_an(m3_load(G + link_off(g, y, nu), 64), m3_load(G + link_off(g, y, mu), 64));
+    s = m3_mul(t, m3_load(G + link_off(g, z, nu), 64));
+    m3_axpy(acc, cp, s);
+  }
+  size_t o = link_off(g, x, mu);
+  M3 f = m3_tah(m3_mul_na(m3_load(G + o, 64), acc));
+  m3_store(F + o, 64, f);
+}
+
+// RK3 stage: v = cf*F + cp*P ; U <- exp(v) U ; P <- v   (wflow.nim:36-62)
+__global__ void __launch_bounds__(256) k_exp_update(size_t nlinks_tiles, double2 *G, const double2 *F, double2 *P,
+                                                   double cf, double cpm, int store_p) {
+  size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;  // (tile-of-links, lane)
+  size_t tile = j >> 6;
+  if (tile >= nlinks_tiles) return;
+  size_t o = tile * 576 + (j & 63);
+  M3 f = m3_load(F + o, 64);
+  M3 v;
+  if (cpm != 0.0) {
+    M3 pm = m3_load(P + o, 64);
+#pragma unroll
+    for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x + cpm * pm.e[k].x, cf * f.e[k].y + cpm * pm.e[k].y);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x, cf * f.e[k].y);
+  }
+  M3 e = m3_exp(v);
+  M3 u = m3_load(G + o, 64);
+  m3_store(G + o, 64, m3_mul(e, u));
+  if (store_p) m3_store(P + o, 64, v);
+}
+
+static int gn_alloc(qexhip_ctx *c) {
+  if (c->gn) return 0;
+  if (c->g.halo) { qexhip_set_error("gauge/flow kernels are single-GPU (no t sharding)"); return -3; }
+  c->gn = new GaugeNat();
+  c->gn->n2 = (size_t)2 * c->g.ntile * 4 * 576;
+  size_t bytes = c->gn->n2 * sizeof(double2);
+  HIPCHK(hipMalloc((void **)&c->gn->U, bytes));
+  HIPCHK(hipMemsetAsync(c->gn->U, 0, bytes, c->stream));
+  return 0;
+}
+static int gn_alloc_fp(qexhip_ctx *c) {
+  size_t bytes = c->gn->n2 * sizeof(double2);
+  if (!c->gn->F) { HIPCHK(hipMalloc((void **)&c->gn->F, bytes)); HIPCHK(hipMemsetAsync(c->gn->F, 0, bytes, c->stream)); }
+  if (!c->gn->P) { HIPCHK(hipMalloc((void **)&c->gn->P, bytes)); HIPCHK(hipMemsetAsync(c->gn->P, 0, bytes, c->stream)); }
+  return 0;
+}
+void gauge_free(qexhip_ctx *c) {
+  if (!c->gn) return;
+  if (c->gn->U) (void)hipFree(c->gn->U);
+  if (c->gn->F) (void)hipFree(c->gn->F);
+  if (c->gn->P) (void)hipFree(c->gn->P);
+  delete c->gn;
+  c->gn = nullptr;
+}
+
+int gauge_set(qexhip_ctx *c, const double *g) {
+  HIPCHK(hipSetDevice(c->device));
+  CHK(gn_alloc(c));
+  size_t bytes = (size_t)c->g.V * 72 * sizeof(double);
+  CHK(ensure_stage(c, bytes));
+  HIPCHK(hipMemcpyAsync(c->stage, g, bytes, hipMemcpyHostToDevice, c->stream));
+  k_gauge_to_tiles<<<(c->g.V + 255) / 256, 256, 0, c->stream>>>(c->g, (const double2 *)c->stage, c->gn->U);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+static int download_nat(qexhip_ctx *c, const double2 *G, double *host) {
+  size_t bytes = (size_t)c->g.V * 72 * sizeof(double);
+  CHK(ensure_stage(c, bytes));
+  k_gauge_from_tiles<<<(c->g.V + 255) / 256, 256, 0, c->stream>>>(c->g, (double2 *)c->stage, G);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(host, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int gauge_get(qexhip_ctx *c, double *g) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  return download_nat(c, c->gn->U, g);
+}
+
+int gauge_plaq(qexhip_ctx *c, double out[6]) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  int nb = (c->g.V + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  {
+    ScopedTimer tm(c, "plaq", c->stream);
+    k_plaq<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->partials);
+    HIPCHK(hipGetLastError());
+  }
+  // pl[i]/(physVol*np*nc)  (gaugeUtils.nim:277)
+  k_plaq_final<<<1, 256, 0, c->stream>>>(c->partials, nb, (double)c->g.V * 18.0, &c->dscal[16]);
+  HIPCHK(hipGetLastError());
+  return read_scalars(c, &c->dscal[16], 6, out);
+}
+
+static int force_dev(qexhip_ctx *c, double cplaq) {
+  CHK(gn_alloc_fp(c));
+  ScopedTimer tm(c, "staple", c->stream);
+  int n = 4 * c->g.V;
+  k_force<<<(n + 255) / 256, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int gauge_force(qexhip_ctx *c, double *f_host, double cplaq) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  CHK(force_dev(c, cplaq));
+  return download_nat(c, c->gn->F, f_host);
+}
+
+int gauge_wflow(qexhip_ctx *c, int nsteps, double eps) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  CHK(gn_alloc_fp(c));
+  const double epsnc = eps * 3.0;
+  const size_t ltiles = (size_t)2 * c->g.ntile * 4;
+  const int nb = (int)((ltiles * 64 + 255) / 256);
+  const double cf[3] = {(-1.0 / 4.0) * epsnc, (-8.0 / 9.0) * epsnc, (-3.0 / 4.0) * epsnc};
+  const double cpm[3] = {0.0, -17.0 / 9.0, -1.0};
+  for (int s = 0; s < nsteps; s++)
+    for (int st = 0; st < 3; st++) {
+      CHK(force_dev(c, 1.0));
+      ScopedTimer tm(c, "expupdate", c->stream);
+      k_exp_update<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->F, c->gn->P, cf[st], cpm[st], st < 2);
+      HIPCHK(hipGetLastError());
+    }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}

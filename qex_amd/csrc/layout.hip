@@ -1,0 +1,161 @@
+// layout.hip -- geometry, and reorder kernels between the host format (V=1 MILC even-odd order,
+// src/quda/qudaWrapperImpl.nim:198-240 is the reference-side producer of that format) and the
+// tiled device layout described in qexhip_internal.h  (kernel K11 of SURVEY.md 2.3).
+#include "qexhip_internal.h"
+#include "site_index.h"
+
+int geom_init(Geom &g, const int X[4], int depth, int halo) {
+  for (int i = 0; i < 4; i++) {
+    if (X[i] < 2 || (X[i] & 1)) { qexhip_set_error("local lattice extents must be even and >= 2 (got %d in dim %d)", X[i], i); return -1; }
+    g.X[i] = X[i];
+  }
+  g.Xh = X[0] / 2;
+  g.V = X[0] * X[1] * X[2] * X[3];
+  g.Vh = g.V / 2;
+  g.F = g.Xh * X[1] * X[2];
+  g.ntile = (g.Vh + QEXHIP_TILE - 1) / QEXHIP_TILE;
+  g.halo = halo;
+  g.depth = halo ? depth : 0;
+  if (halo) {
+    if (g.F % QEXHIP_TILE) { qexhip_set_error("sharding in t needs X*Y*Z/2 to be a multiple of 64 (got %d)", g.F); return -1; }
+    if (X[3] < 3) { qexhip_set_error("sharding in t needs a local t extent >= 3"); return -1; }
+    g.gtile = 3 * g.F / QEXHIP_TILE;  // room for the 3-hop (Naik) ghost depth; g.depth is the depth in use
+  } else {
+    g.gtile = 0;
+  }
+  g.etile = g.ntile + 2 * g.gtile;
+  return 0;
+}
+
+int ensure_stage(qexhip_ctx *c, size_t bytes) {
+  if (c->stage_bytes >= bytes) return 0;
+  if (c->stage) HIPCHK(hipFree(c->stage));
+  c->stage = nullptr; c->stage_bytes = 0;
+  HIPCHK(hipMalloc((void **)&c->stage, bytes));
+  c->stage_bytes = bytes;
+  return 0;
+}
+
+int field_alloc(qexhip_ctx *c, DevField &f) {
+  f.half = (size_t)c->g.etile * 192;
+  size_t bytes = 2 * f.half * sizeof(double2);
+  HIPCHK(hipMalloc((void **)&f.d, bytes));
+  HIPCHK(hipMemsetAsync(f.d, 0, bytes, c->stream));  // alignedMem.nim:30 zero-initialises fields
+  return 0;
+}
+
+// one thread per (parity, c): host[(p*Vh+c)][3] double2  <->  tile layout
+__global__ void __launch_bounds__(256) k_vec_to_tiles(Geom g, const double2 *__restrict__ host, double2 *dev, size_t half) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  int p = i >= g.Vh, c = i - p * g.Vh;
+  double2 *d = dev + (size_t)p * half;
+  for (int k = 0; k < 3; k++) d[vec_off(c, k)] = host[(size_t)i * 3 + k];
+}
+__global__ void __launch_bounds__(256) k_vec_from_tiles(Geom g, double2 *__restrict__ host, const double2 *dev, size_t half) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  int p = i >= g.Vh, c = i - p * g.Vh;
+  const double2 *d = dev + (size_t)p * half;
+  for (int k = 0; k < 3; k++) host[(size_t)i * 3 + k] = d[vec_off(c, k)];
+}
+
+int field_upload(qexhip_ctx *c, DevField &f, const double *host) {
+  size_t bytes = (size_t)c->g.V * 6 * sizeof(double);
+  CHK(ensure_stage(c, bytes));
+  HIPCHK(hipMemcpyAsync(c->stage, host, bytes, hipMemcpyHostToDevice, c->stream));
+  k_vec_to_tiles<<<(c->g.V + 255) / 256, 256, 0, c->stream>>>(c->g, (const double2 *)c->stage, f.d, f.half);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int field_download(qexhip_ctx *c, const DevField &f, double *host) {
+  size_t bytes = (size_t)c->g.V * 6 * sizeof(double);
+  CHK(ensure_stage(c, bytes));
+  k_vec_from_tiles<<<(c->g.V + 255) / 256, 256, 0, c->stream>>>(c->g, (double2 *)c->stage, f.d, f.half);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(host, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- links ----
+// pack U_3 of the top `depth` t-slices (both parities) for the upper neighbour:
+// buf[p][j][9], j = c - (Vh - depth*F)
+__global__ void __launch_bounds__(256) k_pack_top_links(Geom g, const double2 *__restrict__ hostfmt, double2 *buf) {
+  int n = g.depth * g.F;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * n) return;
+  int p = i / n, j = i - p * n;
+  int c = g.Vh - n + j;
+  const double2 *U = hostfmt + ((size_t)(p * g.Vh + c) * 4 + 3) * 9;
+  for (int k = 0; k < 9; k++) buf[(size_t)i * 9 + k] = U[k];
+}
+
+// W[p][tile][d][k][lane]; hostfmt = [idx][mu][9] double2; ghost = lower neighbour's packed top links
+template <bool HALO>
+__global__ void __launch_bounds__(256) k_links_to_tiles(Geom g, const double2 *__restrict__ hostfmt,
+                                                        const double2 *__restrict__ ghost, double2 *W,
+                                                        int ndir, int dbase, int hop) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  int p = i >= g.Vh, c = i - p * g.Vh;
+  SiteXYZT s = site_coord(g, c, p);
+  double2 *w = W + ((size_t)p * g.ntile + (c >> 6)) * ndir * 576 + (c & 63);
+  for (int mu = 0; mu < 4; mu++) {
+    const double2 *U = hostfmt + ((size_t)i * 4 + mu) * 9;
+    double2 *wf = w + (size_t)(dbase + 2 * mu) * 576;
+    for (int k = 0; k < 9; k++) wf[k * 64] = U[k];
+    // backward: U_mu(s - hop*mu)^+ ; the source site has the opposite parity
+    const double2 *B;
+    if (HALO && mu == 3 && s.t - hop < 0) {
+      int cF = c - s.t * g.F;
+      int j = (s.t - hop + g.depth) * g.F + cF;
+      B = ghost + ((size_t)(1 - p) * g.depth * g.F + j) * 9;
+    } else {
+      int cb = nbr_pos<false>(g, c, s, mu, -hop);
+      B = hostfmt + ((size_t)((1 - p) * g.Vh + cb) * 4 + mu) * 9;
+    }
+    double2 *wb = w + (size_t)(dbase + 2 * mu + 1) * 576;
+    for (int r = 0; r < 3; r++)
+      for (int q = 0; q < 3; q++) {
+        double2 v = B[q * 3 + r];
+        wb[(r * 3 + q) * 64] = make_double2(v.x, -v.y);
+      }
+  }
+}
+
+int links_upload(qexhip_ctx *c, const double *fat, const double *lng) {
+  const Geom &g = c->g;
+  int ndir = lng ? 16 : 8;
+  if (lng) for (int i = 0; i < 4; i++) if (g.X[i] < 4) { qexhip_set_error("Naik links need local extents >= 4"); return -1; }
+  if (lng && g.halo && g.depth < 3) { qexhip_set_error("internal: ghost depth %d < 3 for Naik links", g.depth); return -3; }
+  size_t wbytes = (size_t)2 * g.ntile * ndir * 576 * sizeof(double2);
+  if (c->W && c->ndir != ndir) { HIPCHK(hipFree(c->W)); c->W = nullptr; }
+  if (!c->W) { HIPCHK(hipMalloc((void **)&c->W, wbytes)); }
+  HIPCHK(hipMemsetAsync(c->W, 0, wbytes, c->stream));
+  c->ndir = ndir;
+  size_t gbytes = (size_t)g.V * 72 * sizeof(double);
+  size_t ghost_elems = g.halo ? (size_t)2 * g.depth * g.F * 9 : 0;
+  size_t ghost_bytes = ghost_elems * sizeof(double2);
+  CHK(ensure_stage(c, gbytes + 2 * ghost_bytes + 256));
+  double2 *hostfmt = (double2 *)c->stage;
+  double2 *sendbuf = (double2 *)((char *)c->stage + gbytes);
+  double2 *ghost = (double2 *)((char *)c->stage + gbytes + ghost_bytes);
+  for (int pass = 0; pass < (lng ? 2 : 1); pass++) {
+    const double *src = pass ? lng : fat;
+    HIPCHK(hipMemcpyAsync(hostfmt, src, gbytes, hipMemcpyHostToDevice, c->stream));
+    if (g.halo) {
+      int n = 2 * g.depth * g.F;
+      k_pack_top_links<<<(n + 255) / 256, 256, 0, c->stream>>>(g, hostfmt, sendbuf);
+      HIPCHK(hipGetLastError());
+      CHK(comm_exchange_raw(c, sendbuf, ghost, ghost_bytes, c->stream));
+      k_links_to_tiles<true><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, hostfmt, ghost, c->W, ndir, pass * 8, pass ? 3 : 1);
+    } else {
+      k_links_to_tiles<false><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, hostfmt, nullptr, c->W, ndir, pass * 8, pass ? 3 : 1);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}

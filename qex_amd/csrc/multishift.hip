@@ -1,0 +1,243 @@
+// multishift.hip -- multi-shift CG (kernel K7 of SURVEY.md 2.3) and the multi-mass solve.
+//
+// Restates CgmState.solve (src/solvers/cgm.nim:84-315, precon = cpNone: z = r, q = ps[0],
+// LAp = Ap) driven by Staggered.solveXX(xs,b,ms,..) (src/physics/stagSolve.nim:296-345, op =
+// stagD2ee|oo(mass^2 + shift)) and Staggered.solve(xs,b,ms,sp) (:347-446).  The zeta recurrences
+// (cgm.nim:253-266) run in a one-thread kernel on the device; one streaming kernel then updates
+// every shifted solution and search direction, reading r once.
+#include "qexhip_internal.h"
+#include "reduce.h"
+#include <algorithm>
+#include <cstring>
+
+#define CGM_MAXM 32
+
+struct CgmScal {
+  int nmass, cont;
+  double alpha, beta, alphaim1, betaim1;
+  double sg[CGM_MAXM], zi[CGM_MAXM], zim1[CGM_MAXM], axz[CGM_MAXM], zip1[CGM_MAXM], bzz[CGM_MAXM];
+  double2 *xs[CGM_MAXM], *ps[CGM_MAXM];
+};
+
+// after op.apply and redot: alpha, r -= alpha Ap, x += alpha p   (cgm.nim:226-233)
+__global__ void __launch_bounds__(256) k_cgm_base(double2 *x, double2 *r, const double2 *p, const double2 *Ap,
+                                                 size_t n, const CgScal *s, double *partials) {
+  if (s->done) return;
+  const double alpha = (s->pAp != 0.0) ? s->r2 / s->pAp : 0.0;
+  double acc = 0;
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    double2 pv = p[i], xv = x[i], rv = r[i], av = Ap[i];
+    rv.x -= alpha * av.x; rv.y -= alpha * av.y;
+    xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+    x[i] = xv; r[i] = rv;
+    acc += rv.x * rv.x + rv.y * rv.y;
+  }
+  double t = block_sum_256(acc);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(256) k_cgm_reduce(const double *partials, int n, CgScal *s) {
+  if (s->done) return;
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  double r = block_sum_256(acc);
+  if (threadIdx.x == 0) s->tmp = r;
+}
+// scalar recurrences (cgm.nim:226-266)
+__global__ void k_cgm_scalars(CgScal *s, CgmScal *m, double *hist, int histcap) {
+  if (s->done) return;
+  const double r2i = s->r2, r2ip1 = s->tmp;
+  const double alpha = (s->pAp != 0.0) ? r2i / s->pAp : 0.0;
+  const double beta = (r2i != 0.0) ? r2ip1 / r2i : 0.0;
+  s->itn += 1;
+  const int cont = (s->itn < s->maxits) && (r2ip1 > s->r2stop);
+  m->cont = cont;
+  m->alpha = alpha; m->beta = beta;
+  for (int k = 1; k < m->nmass; k++) {
+    double zip1d = alpha * m->betaim1 * (m->zim1[k] - m->zi[k]);
+    zip1d += m->zim1[k] * m->alphaim1 * (1.0 + m->sg[k] * alpha);
+    const double zip1 = (zip1d != 0.0) ? m->zi[k] * m->zim1[k] * m->alphaim1 / zip1d : 0.0;
+    const double zr = (m->zi[k] != 0.0) ? zip1 / m->zi[k] : 0.0;
+    m->axz[k] = alpha * zr;
+    m->zip1[k] = zip1;
+    m->bzz[k] = beta * zr * zr;
+    if (cont) { m->zim1[k] = m->zi[k]; m->zi[k] = zip1; }
+  }
+  m->alphaim1 = alpha; m->betaim1 = beta;
+  s->r2 = r2ip1;
+  if (s->itn < histcap) hist[s->itn] = r2ip1 / s->b2;
+}
+// q := z + beta*q (if continuing); xs[k] += alpha*zr*ps[k]; ps[k] := zip1*r + beta*zr^2*ps[k]
+__global__ void __launch_bounds__(256) k_cgm_update(const double2 *r, size_t n, const CgScal *s, const CgmScal *m) {
+  if (s->done) return;
+  const int cont = m->cont, nm = m->nmass;
+  const double beta = m->beta;
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const double2 rv = r[i];
+    if (cont) {
+      double2 pv = m->ps[0][i];
+      m->ps[0][i] = make_double2(rv.x + beta * pv.x, rv.y + beta * pv.y);
+    }
+    for (int k = 1; k < nm; k++) {
+      double2 pv = m->ps[k][i], xv = m->xs[k][i];
+      const double axz = m->axz[k];
+      xv.x += axz * pv.x; xv.y += axz * pv.y;
+      m->xs[k][i] = xv;
+      if (cont) {
+        const double z = m->zip1[k], b = m->bzz[k];
+        m->ps[k][i] = make_double2(z * rv.x + b * pv.x, z * rv.y + b * pv.y);
+      }
+    }
+  }
+}
+__global__ void k_cgm_end(CgScal *s, const CgmScal *m) {
+  if (s->done) return;
+  if (!m->cont) s->done = 1;
+}
+__global__ void k_cgm_init(CgScal *s, const double *dscal, double r2req, int maxits, double *hist, int histcap) {
+  s->b2 = dscal[0];
+  s->r2 = dscal[0];  // r := b, r2 = b2 (cgm.nim:169-175)
+  s->rzo = 1.0; s->pAp = 0.0; s->tmp = 0.0;
+  s->r2stop = r2req * s->b2;
+  s->itn = 0; s->maxits = maxits;
+  s->done = !(s->r2 > s->r2stop);
+  if (histcap > 0) hist[0] = (s->b2 != 0.0) ? 1.0 : 0.0;
+}
+
+static CgmScal *g_cgm_dev = nullptr;  // one per process is enough (single context per GPU)
+
+static int read_cg(qexhip_ctx *c, CgScal *host) {
+  HIPCHK(hipMemcpyAsync(c->pinned, c->cg, sizeof(CgScal), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  memcpy(host, c->pinned, sizeof(CgScal));
+  return 0;
+}
+
+int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, const double *shifts,
+                       int nmass, double r2req, int maxits, int par_even, int *iters, double *hist, int histcap) {
+  if (nmass < 1 || nmass > CGM_MAXM) { qexhip_set_error("multishift: 1 <= nmass <= %d", CGM_MAXM); return -1; }
+  const int par = par_even ? 0 : 1;
+  const Geom &g = c->g;
+  const size_t n = (size_t)g.ntile * 192;
+  int nb = (int)std::min<size_t>((n + 255) / 256, 2048);
+  DevField *r, *Ap;
+  CHK(get_work(c, WK_R, &r));
+  CHK(get_work(c, WK_AP, &Ap));
+  if (c->histcap < std::max(histcap, 1)) {
+    if (c->hist) HIPCHK(hipFree(c->hist));
+    c->hist = nullptr;
+    HIPCHK(hipMalloc((void **)&c->hist, sizeof(double) * std::max(histcap, 1)));
+    c->histcap = std::max(histcap, 1);
+  }
+  // search directions ps[k]: one-parity use of full fields
+  std::vector<DevField> ps(nmass);
+  for (int k = 0; k < nmass; k++) CHK(field_alloc(c, ps[k]));
+  if (!g_cgm_dev) HIPCHK(hipMalloc((void **)&g_cgm_dev, sizeof(CgmScal)));
+  CgmScal hm;
+  memset(&hm, 0, sizeof(hm));
+  hm.nmass = nmass; hm.cont = 1;
+  hm.alphaim1 = -1.0; hm.betaim1 = 0.0;
+  for (int k = 0; k < nmass; k++) {
+    hm.sg[k] = (k == 0) ? 0.0 : shifts[k];
+    hm.zi[k] = 1.0; hm.zim1[k] = 1.0;
+    hm.xs[k] = xs[k]->par(par);
+    hm.ps[k] = ps[k].par(par);
+  }
+  HIPCHK(hipMemcpyAsync(g_cgm_dev, &hm, sizeof(hm), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // hm is a stack object
+  const double mass = shifts[0], m2 = mass * mass;
+  CHK(blas_copy(c, *r, b, par));
+  for (int k = 0; k < nmass; k++) {
+    CHK(blas_zero(c, *xs[k], par));
+    CHK(blas_copy(c, ps[k], *r, par));   // q := z ; ps[m] := p (cgm.nim:196-207)
+  }
+  CHK(blas_norm2(c, b, par, &c->dscal[0]));
+  k_cgm_init<<<1, 1, 0, c->stream>>>(c->cg, c->dscal, r2req, maxits, c->hist, c->histcap);
+  HIPCHK(hipGetLastError());
+  CgScal st;
+  CHK(read_cg(c, &st));
+  while (!st.done) {
+    int nn = std::min(16, std::max(1, st.maxits - st.itn));
+    for (int i = 0; i < nn; i++) {
+      CHK(op_xx(c, *Ap, ps[0], m2, par_even, 1, &c->cg->done));
+      k_cgm_base<<<nb, 256, 0, c->stream>>>(xs[0]->par(par), r->par(par), ps[0].par(par), Ap->par(par), n, c->cg, c->partials);
+      k_cgm_reduce<<<1, 256, 0, c->stream>>>(c->partials, nb, c->cg);
+      HIPCHK(hipGetLastError());
+      if (c->nranks > 1) CHK(comm_allreduce(c, &c->cg->tmp, 1));
+      k_cgm_scalars<<<1, 1, 0, c->stream>>>(c->cg, g_cgm_dev, c->hist, c->histcap);
+      k_cgm_update<<<nb, 256, 0, c->stream>>>(r->par(par), n, c->cg, g_cgm_dev);
+      k_cgm_end<<<1, 1, 0, c->stream>>>(c->cg, g_cgm_dev);
+      HIPCHK(hipGetLastError());
+    }
+    CHK(read_cg(c, &st));
+  }
+  if (iters) *iters = st.itn;
+  if (hist && histcap > 0) {
+    int nh = std::min(histcap, st.itn + 1);
+    HIPCHK(hipMemcpyAsync(hist, c->hist, sizeof(double) * nh, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  for (int k = 0; k < nmass; k++) HIPCHK(hipFree(ps[k].d));
+  return 0;
+}
+
+// Staggered.solve(xs, b, ms, sp)  (stagSolve.nim:347-446)
+int solve_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, const double *masses,
+                    int nmass, double r2req, int maxits, int *iters, double *r2_final) {
+  if (nmass < 1 || nmass > CGM_MAXM) { qexhip_set_error("multishift: 1 <= nmass <= %d", CGM_MAXM); return -1; }
+  DevField *r, *xt;
+  CHK(get_work(c, WK_R2, &r));
+  CHK(get_work(c, WK_XT, &xt));
+  const double mass = masses[0];
+  std::vector<double> shifts(nmass);
+  std::vector<DevField> ysf(nmass);
+  std::vector<DevField *> ys(nmass);
+  for (int k = 0; k < nmass; k++) {
+    shifts[k] = (k == 0) ? masses[0] : 4.0 * (masses[k] * masses[k] - mass * mass);
+    CHK(field_alloc(c, ysf[k]));
+    ys[k] = &ysf[k];
+    CHK(blas_zero(c, *xs[k], 2));
+  }
+  CHK(blas_zero(c, *xt, 2));
+  CHK(blas_copy(c, *r, b, 2));
+  CHK(blas_norm2(c, b, 2, &c->dscal[2]));
+  CHK(blas_norm2(c, b, 0, &c->dscal[3]));
+  CHK(blas_norm2(c, b, 1, &c->dscal[4]));
+  double h[3];
+  CHK(read_scalars(c, &c->dscal[2], 3, h));
+  double b2 = h[0], b2e = h[1], b2o = h[2];
+  double r2 = b2e + b2o;
+  const double r2stop = r2req * b2;
+  int its = 0;
+  while (r2 > r2stop) {
+    int mx = maxits - its;
+    if (mx <= 0) break;
+    double rq = r2stop;
+    const double r2stop2 = 0.5 * rq;
+    const double r2stope = (b2o <= r2stop2) ? rq - b2o : r2stop2;
+    const double r2stopo = (b2e <= r2stop2) ? rq - b2e : r2stop2;
+    int even = 1;
+    if (b2e > r2stope) { rq = r2stope / b2e; even = 1; }
+    else if (b2o > r2stopo) { rq = r2stopo / b2o; even = 0; }
+    int n = 0;
+    CHK(solve_xx_multi_dev(c, ys, *r, shifts.data(), nmass, rq, mx, even, &n, nullptr, 0));
+    its += n;
+    for (int k = 0; k < nmass; k++) CHK(blas_axpy(c, 4.0, *ys[k], *xs[k], even ? 0 : 1));
+    CHK(op_D(c, *xt, *xs[0], mass, -1.0));
+    CHK(op_D(c, *r, *xt, mass, 1.0));
+    CHK(blas_axpby(c, 1.0, b, -1.0, *r, *r, 2));
+    CHK(blas_norm2(c, *r, 0, &c->dscal[3]));
+    CHK(blas_norm2(c, *r, 1, &c->dscal[4]));
+    CHK(read_scalars(c, &c->dscal[3], 2, h));
+    b2e = h[0]; b2o = h[1];
+    r2 = b2e + b2o;
+  }
+  for (int k = 0; k < nmass; k++) {
+    if (k != 0) CHK(op_D(c, *xt, *xs[k], masses[k], -1.0));
+    CHK(blas_copy(c, *xs[k], *xt, 2));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < nmass; k++) HIPCHK(hipFree(ysf[k].d));
+  if (iters) *iters = its;
+  if (r2_final) *r2_final = (b2 != 0.0) ? r2 / b2 : 0.0;
+  return 0;
+}

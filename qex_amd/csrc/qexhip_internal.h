@@ -1,0 +1,184 @@
+// qexhip_internal.h -- shared declarations of libqexhip.so (gfx950 only).
+//
+// Device data layout (DESIGN.md "Data layout in HBM"):
+//   * sites of one parity are numbered by the checkerboard index c = lex/2 of the rank-local
+//     lattice (x fastest, t slowest), so a t-slice is the contiguous range [t*F,(t+1)*F);
+//   * sites are grouped in TILES of 64 = one wavefront.  A colour vector of one parity is
+//       double2 v[tile][3][64]           (re,im packed: one 16-byte load per lane and colour)
+//     and the Dslash-ready gauge field of one parity is
+//       double2 W[tile][ndir][9][64]     ndir = 8 (fat) or 16 (fat + Naik)
+//     with dir d = 2*mu (+8 for the 3-hop links): forward link U_mu(s); d = 2*mu+1: the
+//     backward link already shifted and adjointed, U_mu(s-mu)^+.  A wavefront therefore streams
+//     one contiguous 72 KiB (144 KiB) block of links per sweep;
+//   * with the t dimension sharded, `depth` ghost t-slices follow the body tiles:
+//       [ body: Vh sites | ghost_hi: depth*F (upper neighbour's t=0..depth-1) |
+//         ghost_lo: depth*F (lower neighbour's t=Xt-depth..Xt-1) ]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include <map>
+
+#define QEXHIP_TILE 64
+
+struct Geom {
+  int X[4];
+  int Xh;      // X[0]/2
+  int V, Vh;
+  int F;       // sites of one parity per t-slice
+  int ntile;   // body tiles per parity
+  int depth;   // ghost depth in t (0: no ghost zones)
+  int gtile;   // ghost tiles per side per parity
+  int etile;   // tiles per parity incl. ghosts
+  int halo;    // 1: t-hops across the local boundary read the ghost zones
+};
+
+// position (site number within one parity, possibly in a ghost zone) -> double2 offset
+__host__ __device__ inline size_t vec_off(int pos, int colour) {
+  return (size_t)(pos >> 6) * 192 + (size_t)colour * 64 + (size_t)(pos & 63);
+}
+
+struct DevField {  // full-volume colour vector: parity halves, each with its ghost tiles
+  double2 *d = nullptr;
+  size_t half = 0;  // double2 elements per parity half (= etile*192)
+  double2 *par(int p) const { return d + (size_t)p * half; }
+};
+
+// CG scalars resident on the device (no host round trip per iteration)
+struct CgScal {
+  double b2, r2, rzo, pAp, r2stop, tmp;
+  int itn, maxits, done, pad;
+};
+
+struct TimerSlot {
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+  long count = 0;
+  double total_ms = 0;
+};
+
+struct GaugeNat;  // natural-layout gauge field for plaquette / flow (gauge.hip)
+
+struct qexhip_ctx {
+  int device = 0;
+  Geom g{};
+  int rankGeom[4]{1, 1, 1, 1}, rankCoord[4]{0, 0, 0, 0};
+  hipStream_t stream = nullptr, cstream = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
+  // communicator
+  void *comm = nullptr;  // ncclComm_t
+  int nranks = 1, rank = 0;
+  int force_halo = 0;
+  // staggered links
+  double2 *W = nullptr;  // [parity][tile][ndir][9][64]
+  int ndir = 0;
+  // device fields
+  std::map<int, DevField> fields;
+  int next_field = 1;
+  // scratch
+  double *stage = nullptr; size_t stage_bytes = 0;   // host-format staging on device
+  double *partials = nullptr; int npartials = 0;     // block partial sums
+  double *dscal = nullptr;                           // device scalars (reductions)
+  CgScal *cg = nullptr;                              // device CG state
+  double *hist = nullptr; int histcap = 0;           // device residual history
+  void *pinned = nullptr;                            // pinned host scratch (4 KiB)
+  // work vectors (lazily allocated, like the {.global.} temp of stagD.nim:437-442)
+  int wk[12]{0};
+  // timers
+  int timers_on = 0;
+  std::map<std::string, TimerSlot> timers;
+  // natural gauge (flow)
+  GaugeNat *gn = nullptr;
+};
+
+// work-field slots (get_work)
+enum { WK_T = 0, WK_R, WK_P, WK_AP, WK_Y, WK_D, WK_R2, WK_XT, WK_IN, WK_OUT, WK_IN2, WK_N };
+
+// ---- error handling ----
+void qexhip_set_error(const char *fmt, ...);
+#define HIPCHK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      qexhip_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      return -2;                                                                         \
+    }                                                                                    \
+  } while (0)
+#define CHK(expr) do { int r_ = (expr); if (r_ != 0) return r_; } while (0)
+
+// ---- timers ----
+struct ScopedTimer {
+  qexhip_ctx *c; TimerSlot *s = nullptr; hipStream_t st;
+  ScopedTimer(qexhip_ctx *c_, const char *name, hipStream_t st_);
+  ~ScopedTimer();
+};
+int timers_collect(qexhip_ctx *c);
+
+// ---- layout.hip ----
+int geom_init(Geom &g, const int X[4], int depth, int halo);
+int field_alloc(qexhip_ctx *c, DevField &f);
+int field_upload(qexhip_ctx *c, DevField &f, const double *host);      // host MILC order -> tiles
+int field_download(qexhip_ctx *c, const DevField &f, double *host);
+int links_upload(qexhip_ctx *c, const double *fat, const double *lng);
+int ensure_stage(qexhip_ctx *c, size_t bytes);
+
+// ---- comm.cpp ----
+int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity);  // on cstream, after ev_ready; records ev_halo
+int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
+int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st);
+void comm_destroy(qexhip_ctx *c);
+
+// ---- dslash.hip ----
+// out[parity] = ca*rin + cb*xs + sgn * sum_mu [ U x(+) - U^+ x(-) ]; optional dot = Re<xs,out> partials
+struct DslashOpts {
+  double ca = 0, cb = 0;
+  const DevField *rin = nullptr;   // a-term source (same parity as out)
+  const DevField *xs = nullptr;    // b-term source (same parity as out)
+  int neg = 0;                     // 1: subtract the hop sum (stagDM)
+  double post = 1.0;               // out *= post  (stagD's 0.5*sc)
+  int dot = 0;                     // 1: write block partials of Re<xs,out> and reduce into dot_out
+  double *dot_out = nullptr;       // device scalar
+  const int *done = nullptr;       // device flag: skip when set
+};
+int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const DslashOpts &o);
+
+// ---- blas.hip ----
+int blas_zero(qexhip_ctx *c, DevField &f, int parity);
+int blas_copy(qexhip_ctx *c, DevField &dst, const DevField &src, int parity);
+int blas_axpy(qexhip_ctx *c, double a, const DevField &x, DevField &y, int parity);
+int blas_xpay(qexhip_ctx *c, const DevField &x, double a, DevField &y, int parity);
+int blas_scale(qexhip_ctx *c, double a, DevField &y, int parity);
+int blas_axpby(qexhip_ctx *c, double a, const DevField &x, double b, const DevField &y, DevField &z, int parity);  // z = a x + b y
+int blas_norm2(qexhip_ctx *c, const DevField &x, int parity, double *dev_out);   // rank-global
+int blas_redot(qexhip_ctx *c, const DevField &x, const DevField &y, int parity, double *dev_out);
+int reduce_partials(qexhip_ctx *c, int n, double *dev_out);  // sum partials[0..n) -> dev_out (+ allreduce)
+int read_scalars(qexhip_ctx *c, const double *dev, int n, double *host);  // sync readback
+int blas_grid(const qexhip_ctx *c, int parity_count);
+// CG fused kernels
+int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity);
+int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity);
+int cg_init(qexhip_ctx *c, double r2req, int maxits);  // after b2 (dscal[0]) and r2 (dscal[1]) are known
+int cg_finish(qexhip_ctx *c);
+
+// ---- solver.cpp ----
+int get_work(qexhip_ctx *c, int slot, DevField **f);
+int op_xx(qexhip_ctx *c, DevField &r, DevField &x, double m2, int par_even, int dot, const int *done);
+int op_D(qexhip_ctx *c, DevField &r, DevField &x, double m, double sc);
+int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2req, int maxits,
+                 int par_even, int *iters, double *r2_over_b2, double *hist, int histcap);
+int solve_full_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2req, int maxits,
+                   int *iters, double *r2_final);
+int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, const double *shifts,
+                       int nmass, double r2req, int maxits, int par_even, int *iters, double *hist, int histcap);
+int solve_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, const double *masses,
+                    int nmass, double r2req, int maxits, int *iters, double *r2_final);
+
+// ---- gauge.hip ----
+int gauge_set(qexhip_ctx *c, const double *g);
+int gauge_get(qexhip_ctx *c, double *g);
+int gauge_plaq(qexhip_ctx *c, double out[6]);
+int gauge_force(qexhip_ctx *c, double *f_host, double cplaq);
+int gauge_wflow(qexhip_ctx *c, int nsteps, double eps);
+void gauge_free(qexhip_ctx *c);

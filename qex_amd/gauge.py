@@ -1,0 +1,67 @@
+"""Host-side gauge-field helpers that stay on the host in QEX as well: boundary conditions,
+staggered phases, and synthetic configurations for benchmarks.
+
+    setBC      src/gauge/gaugeUtils.nim:124-131   U_3 *= -1 on the last t slice
+    stagPhase  src/physics/stagD.nim:509-520      eta_mu from bit masks [8,9,11,0]
+    rephase    src/physics/stagD.nim:72-80        setBC then stagPhase
+
+These are sign flips on host arrays (numpy); the arithmetic of the hot path is in libqexhip.
+"""
+import numpy as np
+
+
+def unit(lo):
+    g = lo.newGauge()
+    for i in range(3):
+        g[:, :, i, i, 0] = 1.0
+    return g
+
+
+def setBC(lo, g, t_offset=0, t_global=None):
+    """Anti-periodic t boundary.  For a t-slab of a sharded lattice pass the slab's global
+    t offset and the global extent."""
+    T = t_global if t_global is not None else lo.lat[3]
+    last = (lo.coords[:, 3] + t_offset) == T - 1
+    g[last, 3] *= -1.0
+
+
+def stagPhase(lo, g, phases=(8, 9, 11, 0), t_offset=0):
+    x = lo.coords.copy()
+    x[:, 3] += t_offset
+    for mu in range(4):
+        s = np.zeros(lo.vol, dtype=np.int64)
+        for k in range(4):
+            s += (phases[mu] >> k) & x[:, k]
+        g[(s & 1) == 1, mu] *= -1.0
+
+
+def rephase(lo, g, t_offset=0, t_global=None):
+    setBC(lo, g, t_offset, t_global)
+    stagPhase(lo, g, t_offset=t_offset)
+
+
+def synthetic_random_su3(lo, seed=987654321, spread=None):
+    """Synthetic SU(3) configuration for benchmarks (numpy; NOT QEX's RngMilc6 stream -- the
+    oracle reproduces that one for the parity tests).  Haar-like: QR of a complex Gaussian,
+    phases fixed, determinant rotated to 1.  With `spread`, links are exp-like close to unity
+    (a 'warm' start, better conditioned)."""
+    rng = np.random.default_rng(seed)
+    n = lo.vol * 4
+    a = rng.standard_normal((n, 3, 3)) + 1j * rng.standard_normal((n, 3, 3))
+    if spread is not None:
+        a = np.eye(3)[None] + spread * a
+    q, r = np.linalg.qr(a)
+    d = np.diagonal(r, axis1=1, axis2=2)
+    q = q * (d / np.abs(d))[:, None, :]
+    det = np.linalg.det(q)
+    q = q * np.exp(-1j * np.angle(det) / 3.0)[:, None, None]
+    g = np.empty((lo.vol, 4, 3, 3, 2))
+    q = q.reshape(lo.vol, 4, 3, 3)
+    g[..., 0] = q.real
+    g[..., 1] = q.imag
+    return g
+
+
+def synthetic_gaussian_vector(lo, seed=12345):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((lo.vol, 3, 2))

@@ -1,0 +1,297 @@
+"""Host-side mirror of QEX's staggered operator / solver interface over the C ABI.
+
+Same names, argument meaning and error behaviour as the reference so that tests read like
+QEX's own (tests/examples/testStagProp.nim, src/physics/stagSolve.nim:516-680):
+
+    newStag(g) / newStag3(g, g3)      src/physics/stagD.nim:522-564
+    Staggered.D / Ddag                src/physics/stagD.nim:566-571
+    Staggered.eoReconstruct           src/physics/stagD.nim:583-586
+    stagD2 / stagD2ee / stagD2oo      src/physics/stagD.nim:349-395,463-469
+    Staggered.solveEE / solveOO       src/physics/stagSolve.nim:134-138
+    Staggered.solve (single / multi)  src/physics/stagSolve.nim:224-294,347-446
+    SolverParams                      src/solvers/solverBase.nim:10-58
+
+Fields are numpy arrays in the V=1 even-odd host format (qex_amd.layout).  All arithmetic
+happens in libqexhip.so on the GPU; nothing here computes on field data.
+"""
+import ctypes as C
+import time
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+EVEN, ODD, ALL = 0, 1, 2
+_SUBSET = {"even": EVEN, "odd": ODD, "all": ALL}
+
+
+def _p(a):
+    if a is None:
+        return None
+    if a.dtype != np.float64 or not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("fields must be C-contiguous float64 arrays")
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class SolverParams:
+    """solverBase.nim:10-58 (fields the staggered path uses)."""
+
+    def __init__(self, r2req=1e-6, maxits=50000, verbosity=1, usePrevSoln=False):
+        self.r2req = r2req
+        self.maxits = maxits
+        self.verbosity = verbosity
+        self.usePrevSoln = usePrevSoln
+        self.subsetName = "all"
+        self.resetStats()
+
+    def resetStats(self):
+        self.calls = 0
+        self.iterations = 0
+        self.iterationsMax = 0
+        self.seconds = 0.0
+        self.flops = 0.0
+        self.r2 = 0.0
+        self.r2hist = None
+
+    @property
+    def finalIterations(self):
+        return self.iterations
+
+    def getStats(self):
+        gf = 1e-9 * self.flops / self.seconds if self.seconds > 0 else 0.0
+        return f"its: {self.iterations}  secs: {self.seconds:.6g}  Gf/s: {gf:.6g}  r2: {self.r2:.6g}"
+
+
+class Context:
+    """One GPU / one rank (qexhip_init).  rank_geom must be (1,1,1,N)."""
+
+    def __init__(self, lat_local, device=0, rank_geom=(1, 1, 1, 1), rank_coord=(0, 0, 0, 0)):
+        self.lat = [int(v) for v in lat_local]
+        self.vol = int(np.prod(self.lat))
+        self._h = C.c_void_p()
+        i4 = C.c_int * 4
+        check(lib().qexhip_init(C.byref(self._h), device, i4(*self.lat), i4(*rank_geom), i4(*rank_coord)))
+        self.rank_geom = tuple(rank_geom)
+        self.rank_coord = tuple(rank_coord)
+
+    def close(self):
+        if self._h:
+            lib().qexhip_finalize(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        buf = C.create_string_buffer(512)
+        check(lib().qexhip_device_info(self._h, buf, 512))
+        return buf.value.decode()
+
+    def sync(self):
+        check(lib().qexhip_sync(self._h))
+
+    # communicator
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().qexhip_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid, nranks, rank):
+        check(lib().qexhip_comm_init(self._h, uid, nranks, rank))
+
+    def force_halo(self, on=True):
+        check(lib().qexhip_comm_force_halo(self._h, 1 if on else 0))
+
+    # timers
+    def timers_enable(self, on=True):
+        check(lib().qexhip_timers_enable(self._h, 1 if on else 0))
+
+    def timers_reset(self):
+        check(lib().qexhip_timers_reset(self._h))
+
+    def timer(self, name):
+        cnt, ms = C.c_long(0), C.c_double(0)
+        check(lib().qexhip_timers_get(self._h, name.encode(), C.byref(cnt), C.byref(ms)))
+        return cnt.value, ms.value
+
+    # device-resident fields
+    def field_new(self, host=None):
+        fid = C.c_int(0)
+        check(lib().qexhip_field_new(self._h, C.byref(fid)))
+        if host is not None:
+            check(lib().qexhip_field_upload(self._h, fid.value, _p(host)))
+        return fid.value
+
+    def field_free(self, fid):
+        check(lib().qexhip_field_free(self._h, fid))
+
+    def field_upload(self, fid, host):
+        check(lib().qexhip_field_upload(self._h, fid, _p(host)))
+
+    def field_download(self, fid):
+        out = np.zeros((self.vol, 3, 2))
+        check(lib().qexhip_field_download(self._h, fid, _p(out)))
+        return out
+
+    def field_zero(self, fid):
+        check(lib().qexhip_field_zero(self._h, fid))
+
+    def dev_dslash(self, r_id, x_id, parity, a=0.0, b=0.0):
+        check(lib().qexhip_dev_dslash(self._h, r_id, x_id, parity, a, b))
+
+    def dev_op_xx(self, r_id, x_id, m2, par_even=True):
+        check(lib().qexhip_dev_op_xx(self._h, r_id, x_id, m2, 1 if par_even else 0))
+
+    def dev_solve_xx(self, x_id, b_id, mass, r2req, maxits, par_even=True, histcap=0):
+        its, fin = C.c_int(0), C.c_double(0)
+        hist = np.zeros(max(histcap, 1))
+        check(lib().qexhip_dev_solve_xx(self._h, x_id, b_id, mass, r2req, maxits, 1 if par_even else 0,
+                                        C.byref(its), C.byref(fin), _p(hist), histcap))
+        return its.value, fin.value, hist[: min(histcap, its.value + 1)]
+
+    # field algebra hooks (fieldET.nim:605-625,704-724)
+    def norm2(self, x, subset="all"):
+        out = C.c_double(0)
+        check(lib().qexhip_norm2(self._h, _p(x), _SUBSET[subset], C.byref(out)))
+        return out.value
+
+    def redot(self, x, y, subset="all"):
+        out = C.c_double(0)
+        check(lib().qexhip_redot(self._h, _p(x), _p(y), _SUBSET[subset], C.byref(out)))
+        return out.value
+
+    def axpy(self, a, x, y, subset="all"):
+        check(lib().qexhip_axpy(self._h, a, _p(x), _p(y), _SUBSET[subset]))
+
+    def xpay(self, x, a, y, subset="all"):
+        check(lib().qexhip_xpay(self._h, _p(x), a, _p(y), _SUBSET[subset]))
+
+
+class Staggered:
+    """Staggered[G,T] (stagD.nim:19-22): the links `g` carry BC and phases (rephase)."""
+
+    def __init__(self, ctx, g, g3=None):
+        self.ctx = ctx
+        self.g = g
+        self.g3 = g3
+        self.nlinks = 8 if g3 is not None else 4
+        check(lib().qexhip_stag_set_links(ctx._h, _p(g), _p(g3)))
+
+    # r = m*x + D*x  /  r = m*x - D*x
+    def D(self, r, x, m):
+        check(lib().qexhip_stag_D(self.ctx._h, _p(r), _p(x), float(m), 1.0))
+
+    def Ddag(self, r, x, m):
+        check(lib().qexhip_stag_D(self.ctx._h, _p(r), _p(x), float(m), -1.0))
+
+    def eoReconstruct(self, r, b, m):
+        check(lib().qexhip_stag_eo_reconstruct(self.ctx._h, _p(r), _p(b), float(m)))
+
+    def stagD2(self, r, x, subset, a, b):
+        """r[subset] = a*r + b*x + (2D)x  (stagD.nim:349-395)"""
+        check(lib().qexhip_stag_dslash(self.ctx._h, _p(r), _p(x), _SUBSET[subset], float(a), float(b)))
+
+    def stagD2ee(self, r, x, m2):
+        check(lib().qexhip_stag_op_xx(self.ctx._h, _p(r), _p(x), float(m2), 1))
+
+    def stagD2oo(self, r, x, m2):
+        check(lib().qexhip_stag_op_xx(self.ctx._h, _p(r), _p(x), float(m2), 0))
+
+    def _flops(self, its):
+        # (s.g.len*4*72+60)*nEven*iterations  (stagSolve.nim:92)
+        return float((self.nlinks * 4 * 72 + 60) * (self.ctx.vol // 2) * its)
+
+    def solveXX(self, r, x, m, sp, parEven=True, histcap=0):
+        """solveXX(s, r, x, m, sp0, parEven) (stagSolve.nim:57-132): r <- solution, x = rhs."""
+        t0 = time.time()
+        its, fin = C.c_int(0), C.c_double(0)
+        hist = np.zeros(max(histcap, 1))
+        check(lib().qexhip_stag_solve_xx(self.ctx._h, _p(r), _p(x), float(m), float(sp.r2req), int(sp.maxits),
+                                         1 if parEven else 0, C.byref(its), C.byref(fin), _p(hist), histcap))
+        sp.calls += 1
+        sp.iterations += its.value
+        sp.iterationsMax = max(sp.iterationsMax, its.value)
+        sp.seconds += time.time() - t0
+        sp.flops += self._flops(its.value)
+        sp.r2 = fin.value
+        sp.r2hist = hist[: min(histcap, its.value + 1)] if histcap else None
+        if sp.verbosity > 1:
+            print(("solveEE" if parEven else "solveOO") + "(HIP): " + sp.getStats())
+
+    def solveEE(self, r, x, m, sp, histcap=0):
+        self.solveXX(r, x, m, sp, True, histcap)
+
+    def solveOO(self, r, x, m, sp, histcap=0):
+        self.solveXX(r, x, m, sp, False, histcap)
+
+    def solve(self, x, b, m, sp):
+        """Staggered.solve: x (array or list of arrays) <- D(m)^-1 b  (stagSolve.nim:224-294,347-446)"""
+        t0 = time.time()
+        its, fin = C.c_int(0), C.c_double(0)
+        if isinstance(x, (list, tuple)):
+            ms = np.array([float(v) for v in m], dtype=np.float64)
+            ptrs = (C.c_void_p * len(x))(*[a.ctypes.data for a in x])
+            check(lib().qexhip_stag_solve_multi(self.ctx._h, ptrs, _p(b), _p(ms), len(x), float(sp.r2req),
+                                                int(sp.maxits), C.byref(its), C.byref(fin)))
+        else:
+            check(lib().qexhip_stag_solve(self.ctx._h, _p(x), _p(b), float(m), float(sp.r2req), int(sp.maxits),
+                                          C.byref(its), C.byref(fin)))
+        sp.calls += 1
+        sp.iterations += its.value
+        sp.iterationsMax = max(sp.iterationsMax, its.value)
+        sp.seconds += time.time() - t0
+        sp.flops += self._flops(its.value)
+        sp.r2 = fin.value
+        if sp.verbosity > 1:
+            print("stagSolve(HIP): " + sp.getStats())
+
+    def solveXX_multi(self, xs, b, shifts, sp, parEven=True, histcap=0):
+        """Staggered.solveXX(xs, b, ms, sp, subset) (stagSolve.nim:296-345): shifts[0] = base mass."""
+        its = C.c_int(0)
+        sh = np.array([float(v) for v in shifts], dtype=np.float64)
+        hist = np.zeros(max(histcap, 1))
+        ptrs = (C.c_void_p * len(xs))(*[a.ctypes.data for a in xs])
+        check(lib().qexhip_stag_solve_xx_multi(self.ctx._h, ptrs, _p(b), _p(sh), len(xs), float(sp.r2req),
+                                               int(sp.maxits), 1 if parEven else 0, C.byref(its), _p(hist), histcap))
+        sp.iterations += its.value
+        sp.r2hist = hist[: min(histcap, its.value + 1)] if histcap else None
+
+
+def newStag(ctx, g):
+    return Staggered(ctx, g)
+
+
+def newStag3(ctx, g, g3):
+    return Staggered(ctx, g, g3)
+
+
+# ---- gauge observables / Wilson flow (src/gauge/gaugeUtils.nim:213-282, src/gauge/wflow.nim:21-67) ----
+def plaq(ctx, g=None):
+    if g is not None:
+        check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+    out = np.zeros(6)
+    check(lib().qexhip_plaq(ctx._h, _p(out)))
+    return out
+
+
+def gaugeForce(ctx, g, cplaq=1.0):
+    check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+    f = np.zeros_like(g)
+    check(lib().qexhip_gauge_force(ctx._h, _p(f), float(cplaq)))
+    return f
+
+
+def gaugeFlow(ctx, g, steps, eps, measure=None):
+    """g.gaugeFlow(steps, eps): measure (wflow.nim:21-67).  g is modified in place."""
+    check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+    if measure is None:
+        check(lib().qexhip_wflow(ctx._h, int(steps), float(eps)))
+    else:
+        for n in range(1, steps + 1):
+            check(lib().qexhip_wflow(ctx._h, 1, float(eps)))
+            measure(n * eps)
+    check(lib().qexhip_gauge_get(ctx._h, _p(g)))
