@@ -67,8 +67,37 @@ def lib():
         L.qo_solve.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, vp]
         L.qo_solveXX_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp, ci]
         L.qo_solve_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, vp]
+        L.qo_set_num_threads.argtypes = [ci]
+        L.qo_set_num_threads(_cpu_share())
         _lib = L
     return _lib
+
+
+def _cpu_share():
+    """Threads the oracle may use: OMP_NUM_THREADS if set, else the cgroup CPU quota / affinity
+    (a GPU box exposes 128 hardware threads but grants ~16 CPUs; 128 spinning OpenMP threads on a
+    16-CPU share are orders of magnitude slower than 16)."""
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env:
+        try:
+            return max(1, int(env))
+        except ValueError:
+            pass
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 16))
 
 
 def _p(a):

@@ -655,10 +655,16 @@ double qo_redot(const qo_layout *lo, const double *x, const double *y, int parit
   double *part = (double *)calloc((size_t)nt, sizeof(double));
 #pragma omp parallel
   {
-    double acc = 0;
+    /* per-thread SIMD accumulator of V=8 lanes (globals.nim:33-36), then simdSum (lane order),
+     * then thread partials in thread order -- the structure of fieldET.nim:605-625 */
+    double lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma omp for schedule(static)
-    for (int s = s0; s < s1; s++)
-      for (int k = 0; k < 6; k++) acc += x[6 * (size_t)s + k] * y[6 * (size_t)s + k];
+    for (int s = s0; s < s1; s++) {
+      double t = 0;
+      for (int k = 0; k < 6; k++) t += x[6 * (size_t)s + k] * y[6 * (size_t)s + k];
+      lane[s & 7] += t;
+    }
+    double acc = ((lane[0] + lane[1]) + (lane[2] + lane[3])) + ((lane[4] + lane[5]) + (lane[6] + lane[7]));
     int tid = 0;
 #ifdef _OPENMP
     tid = omp_get_thread_num();
@@ -1064,4 +1070,12 @@ int qo_solve_multi(const qo_layout *lo, const double *fat, const double *lng,
   for (int k = 0; k < nmass; k++) free(ys[k]);
   free(ys); free(shifts); free(r); free(xt);
   return its;
+}
+
+void qo_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
 }

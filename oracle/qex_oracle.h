@@ -112,6 +112,7 @@ int qo_solve_multi(const qo_layout *lo, const double *fat, const double *lng,
                    double r2req, int maxits, double *r2_final);
 
 int qo_num_threads(void);
+void qo_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -38,10 +38,12 @@ __device__ __forceinline__ int nbr_pos(const Geom &g, int c, const SiteXYZT &s, 
   } else {
     int tn = s.t + hop;
     if (HALO) {
-      int cF = c - s.t * g.F;
-      if (tn >= g.X[3]) return g.Vh + (tn - g.X[3]) * g.F + cF;               // ghost_hi
-      if (tn < 0) return g.Vh + g.depth * g.F + (tn + g.depth) * g.F + cF;    // ghost_lo
-      return c + hop * g.F;
+      // The ghost zones continue the slice numbering: ghost_hi holds the virtual slices
+      // t = Xt .. Xt+depth-1 (position t*F + cF, no special case), ghost_lo the virtual slices
+      // t = -depth .. -1 stored at t + Xt + 2*depth.  One select, no control flow.  (A three-way
+      // select / branch formulation made hipcc hoist the loads of all directions and spill:
+      // 256 VGPRs + scratch, 1 wave/SIMD.)
+      return c + hop * g.F + (tn < 0 ? (g.X[3] + 2 * g.depth) * g.F : 0);
     } else {
       return c + (wrap(tn, g.X[3]) - s.t) * g.F;
     }
