@@ -58,7 +58,14 @@ def main():
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
+    def device_sync():
+        # All GPU work of this benchmark runs on libqexhip's own HIP streams (system ROCm runtime,
+        # bound with RTLD_DEEPBIND); PyTorch's bundled HIP runtime is a different instance and sees
+        # none of it, so the authoritative synchronisation is ctx.sync().  torch.cuda.synchronize()
+        # is added only if PyTorch's runtime happens to be initialised.
+        ctx.sync()
+        if torch.cuda.is_initialized():
+            torch.cuda.synchronize()
     if N > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # control plane only
@@ -95,17 +102,15 @@ def main():
 
     # warmup
     ctx.dev_solve_xx(xid, bid, args.mass, 0.0, max(args.warmup, 1), True)
-    ctx.sync()
-    torch.cuda.synchronize()
+    device_sync()
 
-    ctx.timers_enable(True)
+    ctx.timers_enable(int(os.environ.get("QEX_BENCH_TIMERS", "2")))  # 2: Dslash sweeps only
     ctx.timers_reset()
     barrier()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     its, fin, _ = ctx.dev_solve_xx(xid, bid, args.mass, 0.0, args.steps, True)
-    ctx.sync()
-    torch.cuda.synchronize()
+    device_sync()
     barrier()
     t1 = time.perf_counter()
     ctx.timers_enable(False)

@@ -162,6 +162,15 @@ int qexhip_timers_enable(qexhip_handle h, int on);
 int qexhip_timers_reset(qexhip_handle h);
 int qexhip_timers_get(qexhip_handle h, const char *name, long *count, double *total_ms);
 
+/* ---------------- index-arithmetic test hooks (pure host functions, no GPU) ----------------
+ * The site order / neighbour sense / ghost-zone positions the kernels use, evaluated on the host
+ * (same inline code): layoutIndexQ with V=1 (src/layout/qlayout.nim:110-131) and the shift sense of
+ * src/layout/shiftX.nim:76-81.  out[8] = {Vh, F, ntile, ghost tiles/side, tiles/parity, depth, halo, X0/2}. */
+int qexhip_debug_geom(const int latLocal[4], int depth, int halo, int out[8]);
+/* position, in the opposite-parity field, of site (c,parity) + hop*mu; ghost positions when halo */
+int qexhip_debug_nbr_pos(const int latLocal[4], int depth, int halo, int c, int parity, int mu, int hop);
+int qexhip_debug_site_coord(const int latLocal[4], int c, int parity, int x[4]);
+
 #ifdef __cplusplus
 }
 #endif

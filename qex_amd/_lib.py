@@ -52,6 +52,9 @@ SYMBOLS = [
     ("qexhip_timers_enable", _ci, [_vp, _ci]),
     ("qexhip_timers_reset", _ci, [_vp]),
     ("qexhip_timers_get", _ci, [_vp, C.c_char_p, C.POINTER(C.c_long), _pd]),
+    ("qexhip_debug_geom", _ci, [_pi, _ci, _ci, _pi]),
+    ("qexhip_debug_nbr_pos", _ci, [_pi, _ci, _ci, _ci, _ci, _ci, _ci]),
+    ("qexhip_debug_site_coord", _ci, [_pi, _ci, _ci, _pi]),
 ]
 
 
@@ -67,7 +70,11 @@ def lib():
                 f"{LIB_PATH} not found: build it with `make -C {_HERE}` "
                 "(__graft_entry__.build()).  qex_amd has no CPU fallback."
             )
-        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        # RTLD_LOCAL | RTLD_DEEPBIND: libqexhip binds to the ROCm runtime it was linked against
+        # (/opt/rocm) and keeps it out of the global namespace.  PyTorch wheels bundle their own
+        # libamdhip64/librccl; mixing the two through symbol interposition (RTLD_GLOBAL) corrupts
+        # the heap at exit ("free(): invalid pointer").
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0))
         for name, res, args in SYMBOLS:
             f = getattr(L, name)  # AttributeError if the symbol is missing
             f.restype = res

@@ -161,10 +161,20 @@ __global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, s
   }
 }
 // alpha = rz/qLAp; x += alpha*p; r -= alpha*Ap; partial |r|^2   (cg.nim:208-213)
+// With ndot > 0 (single rank) every workgroup first sums the <p,Ap> workgroup partials of the
+// preceding Dslash sweep itself -- same fixed order in every workgroup, so all agree bit for bit --
+// which removes the separate reduction launch from the iteration.
 __global__ void __launch_bounds__(256) k_cg_update(double2 *x, double2 *r, const double2 *p, const double2 *Ap,
-                                                  size_t n, const CgScal *s, double *partials) {
+                                                  size_t n, const CgScal *s, double *partials,
+                                                  const double *dotp, int ndot) {
   if (s->done) return;
-  const double alpha = s->r2 / s->pAp;
+  double pAp = s->pAp;
+  if (ndot > 0) {
+    double a = 0;
+    for (int i = threadIdx.x; i < ndot; i += 256) a += dotp[i];
+    pAp = block_sum_256_all(a);
+  }
+  const double alpha = s->r2 / pAp;
   double acc = 0;
   for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     double2 pv = p[i], xv = x[i], rv = r[i], av = Ap[i];
@@ -197,6 +207,20 @@ __global__ void k_cg_finish(CgScal *s, double *hist, int histcap) {
   if (s->itn < histcap) hist[s->itn] = s->r2 / s->b2;
   if (!(s->itn < s->maxits && s->r2 > s->r2stop)) s->done = 1;
 }
+// single rank: final sum of the |r|^2 partials and the end-of-iteration bookkeeping in one launch
+__global__ void __launch_bounds__(256) k_cg_reduce_finish(const double *partials, int n, CgScal *s, double *hist, int histcap) {
+  if (s->done) return;
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  double r = block_sum_256(acc);
+  if (threadIdx.x == 0) {
+    s->rzo = s->r2;
+    s->r2 = r;
+    s->itn += 1;
+    if (s->itn < histcap) hist[s->itn] = s->r2 / s->b2;
+    if (!(s->itn < s->maxits && s->r2 > s->r2stop)) s->done = 1;
+  }
+}
 __global__ void __launch_bounds__(256) k_reduce_cg(const double *partials, int n, double *out, const CgScal *s) {
   if (s->done) return;
   double acc = 0;
@@ -212,29 +236,32 @@ int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity) {
   HIPCHK(hipGetLastError());
   return 0;
 }
-int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity) {
+// ndot > 0: <p,Ap> is still in workgroup partials c->partials[0..ndot) (deferred, single rank);
+// the |r|^2 partials go to the upper part of the buffer.
+int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity, int ndot) {
   size_t n = body2(c);
   int nb = grid_for(n);
+  double *r2p = c->partials + 4096;
   {
     ScopedTimer tm(c, "blas", c->stream);
-    k_cg_update<<<nb, 256, 0, c->stream>>>(x.par(parity), r.par(parity), p.par(parity), Ap.par(parity), n, c->cg, c->partials);
+    k_cg_update<<<nb, 256, 0, c->stream>>>(x.par(parity), r.par(parity), p.par(parity), Ap.par(parity), n, c->cg, r2p,
+                                           c->partials, ndot);
     HIPCHK(hipGetLastError());
   }
-  {
-    ScopedTimer tm(c, "reduce", c->stream);
-    k_reduce_cg<<<1, 256, 0, c->stream>>>(c->partials, nb, &c->cg->tmp, c->cg);
+  ScopedTimer tm(c, "reduce", c->stream);
+  if (c->nranks > 1) {
+    k_reduce_cg<<<1, 256, 0, c->stream>>>(r2p, nb, &c->cg->tmp, c->cg);
     HIPCHK(hipGetLastError());
+    CHK(comm_allreduce(c, &c->cg->tmp, 1));
+    k_cg_finish<<<1, 1, 0, c->stream>>>(c->cg, c->hist, c->histcap);
+  } else {
+    k_cg_reduce_finish<<<1, 256, 0, c->stream>>>(r2p, nb, c->cg, c->hist, c->histcap);
   }
-  if (c->nranks > 1) CHK(comm_allreduce(c, &c->cg->tmp, 1));
+  HIPCHK(hipGetLastError());
   return 0;
 }
 int cg_init(qexhip_ctx *c, double r2req, int maxits) {
   k_cg_init<<<1, 1, 0, c->stream>>>(c->cg, c->dscal, r2req, maxits, c->hist, c->histcap);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-int cg_finish(qexhip_ctx *c) {
-  k_cg_finish<<<1, 1, 0, c->stream>>>(c->cg, c->hist, c->histcap);
   HIPCHK(hipGetLastError());
   return 0;
 }

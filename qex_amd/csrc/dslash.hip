@@ -25,7 +25,10 @@ struct DslashArgs {
   double *partials;
   const int *done;
   int swz;               // number of workgroups if XCD swizzle is on, else 0
+  int ntstore;           // 1: non-temporal stores of the output
 };
+
+typedef double d2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void mv3(double2 acc[3], const double2 U[9], const double2 v[3]) {
 #pragma unroll
@@ -87,7 +90,13 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
       int pos = nbr_pos<HALO>(g, c, s, mu, hop);
       double2 U[9], v[3];
 #pragma unroll
-      for (int k = 0; k < 9; k++) U[k] = w[(size_t)d * 576 + k * 64];
+      for (int k = 0; k < 9; k++) {
+        // links are read exactly once per sweep: stream them past the caches (non-temporal), which
+        // leaves L2 / Infinity Cache to the 8x re-read neighbour vectors.  Measured on MI355X,
+        // 32^4: 120 us -> 108 us per sweep (scratch/tune_dslash.py, profiles/r01_tune_dslash.log).
+        d2v t = __builtin_nontemporal_load((const d2v *)&w[(size_t)d * 576 + k * 64]);
+        U[k] = make_double2(t.x, t.y);
+      }
       const double sg = (d & 1) ? -A.sgn : A.sgn;
 #pragma unroll
       for (int k = 0; k < 3; k++) {
@@ -99,7 +108,12 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       acc[k].x *= A.post; acc[k].y *= A.post;
-      A.out[vec_off(c, k)] = acc[k];
+      if (A.ntstore) {
+        d2v t; t.x = acc[k].x; t.y = acc[k].y;
+        __builtin_nontemporal_store(t, (d2v *)&A.out[vec_off(c, k)]);
+      } else {
+        A.out[vec_off(c, k)] = acc[k];
+      }
     }
     if (DOT) {
 #pragma unroll
@@ -117,7 +131,8 @@ static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool 
   if (c1 <= c0) return 0;
   A.c0 = c0; A.c1 = c1;
   int nb = (c1 - c0 + 255) / 256;
-  A.swz = (nb >= 64 && (nb & 7) == 0) ? nb : 0;
+  A.swz = (c->opt_swz && nb >= 64 && (nb & 7) == 0) ? nb : 0;
+  A.ntstore = c->opt_ntstore;
   double *psave = A.partials;
   A.partials = psave ? psave + part_off : nullptr;
   dim3 grid(nb), block(256);
@@ -181,8 +196,9 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
     nparts = nb_int + nb_lo + (g.Vh - hi_beg + 255) / 256;
   }
   if (o.dot) {
-    if (nparts > c->npartials) { qexhip_set_error("internal: partial buffer too small"); return -3; }
-    CHK(reduce_partials(c, nparts, o.dot_out));
+    if (nparts > 4096) { qexhip_set_error("internal: partial buffer too small"); return -3; }
+    if (o.dot == 2 && o.nparts_out) *o.nparts_out = nparts;
+    else CHK(reduce_partials(c, nparts, o.dot_out));
   }
   return 0;
 }

@@ -1,0 +1,175 @@
+// dslash_tune.hip -- experimental variants of the one-parity sweep, for on-GPU A/B timing only.
+// Not part of the solver path: qexhip_tune_dslash() runs a variant on scratch fields and returns
+// the average launch time measured with hipEvents (interleave variants in ONE process:
+// cdna_hip_programming.md 5.4 rule 24).  The winner is folded back into dslash.hip by hand.
+#include "qexhip_internal.h"
+#include "site_index.h"
+#include "../../include/qexhip.h"
+
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+struct TuneArgs {
+  Geom g;
+  const double2 *W, *in;
+  double2 *out;
+  int parity, swz;
+};
+
+__device__ __forceinline__ void mv3t(double2 acc[3], const double2 U[9], const double2 v[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      acc[i].x += U[3 * i + j].x * v[j].x;
+      acc[i].x -= U[3 * i + j].y * v[j].y;
+      acc[i].y += U[3 * i + j].x * v[j].y;
+      acc[i].y += U[3 * i + j].y * v[j].x;
+    }
+  }
+}
+
+// VAR bit0: non-temporal link loads; bit1: scheduling fence per direction pair;
+//     bit2: non-temporal output stores; bit3: fence per single direction
+template <int VAR, int BS, int MINW>
+__global__ void __launch_bounds__(BS, MINW) k_tune(TuneArgs A) {
+  int bid = blockIdx.x;
+  if (A.swz) {
+    int per = A.swz >> 3;
+    bid = (bid & 7) * per + (bid >> 3);
+  }
+  int c = bid * BS + threadIdx.x;
+  if (c >= A.g.Vh) return;
+  const Geom &g = A.g;
+  SiteXYZT s = site_coord(g, c, A.parity);
+  double2 acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) acc[k] = make_double2(0.0, 0.0);
+  const double2 *w = A.W + (size_t)(c >> 6) * (8 * 576) + (c & 63);
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    const int mu = (d >> 1) & 3;
+    const int hop = (d & 1) ? -1 : 1;
+    int pos = nbr_pos<false>(g, c, s, mu, hop);
+    double2 U[9], v[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      if (VAR & 1) {
+        d2v t = __builtin_nontemporal_load((const d2v *)&w[(size_t)d * 576 + k * 64]);
+        U[k] = make_double2(t.x, t.y);
+      } else {
+        U[k] = w[(size_t)d * 576 + k * 64];
+      }
+    }
+    const double sg = (d & 1) ? -1.0 : 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double2 t = A.in[vec_off(pos, k)];
+      v[k] = make_double2(sg * t.x, sg * t.y);
+    }
+    mv3t(acc, U, v);
+    if ((VAR & 2) && (d & 1)) __builtin_amdgcn_sched_barrier(0);
+    if (VAR & 8) __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (VAR & 4) {
+      d2v t; t.x = acc[k].x; t.y = acc[k].y;
+      __builtin_nontemporal_store(t, (d2v *)&A.out[vec_off(c, k)]);
+    } else {
+      A.out[vec_off(c, k)] = acc[k];
+    }
+  }
+}
+
+template <int VAR, int BS, int MINW>
+static void launch_tune(TuneArgs &A, int swz_on, hipStream_t st) {
+  int nb = (A.g.Vh + BS - 1) / BS;
+  A.swz = (swz_on && nb >= 64 && (nb & 7) == 0) ? nb : 0;
+  k_tune<VAR, BS, MINW><<<nb, BS, 0, st>>>(A);
+}
+
+// variant ids: see table in tests/../scratch/tune_dslash.py
+extern "C" int qexhip_tune_dslash(qexhip_handle c, int variant, int swz, int nrep, double *avg_us) {
+  if (!c || !c->W || c->ndir != 8 || c->g.halo) { qexhip_set_error("tune: needs plain links, no halo"); return -1; }
+  DevField *fin, *fout;
+  CHK(get_work(c, WK_IN, &fin));
+  CHK(get_work(c, WK_OUT, &fout));
+  TuneArgs A;
+  A.g = c->g;
+  A.W = c->W;  // parity 0
+  A.in = fin->par(1);
+  A.out = fout->par(0);
+  A.parity = 0;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  auto run = [&]() {
+    switch (variant) {
+      case 0: launch_tune<0, 256, 1>(A, swz, c->stream); break;
+      case 1: launch_tune<1, 256, 1>(A, swz, c->stream); break;
+      case 2: launch_tune<2, 256, 1>(A, swz, c->stream); break;
+      case 3: launch_tune<3, 256, 1>(A, swz, c->stream); break;
+      case 4: launch_tune<4, 256, 1>(A, swz, c->stream); break;
+      case 5: launch_tune<5, 256, 1>(A, swz, c->stream); break;
+      case 6: launch_tune<0, 128, 1>(A, swz, c->stream); break;
+      case 7: launch_tune<0, 512, 1>(A, swz, c->stream); break;
+      case 8: launch_tune<0, 64, 1>(A, swz, c->stream); break;
+      case 9: launch_tune<8, 256, 1>(A, swz, c->stream); break;
+      case 10: launch_tune<9, 256, 1>(A, swz, c->stream); break;
+      case 11: launch_tune<0, 256, 4>(A, swz, c->stream); break;
+      case 12: launch_tune<2, 256, 3>(A, swz, c->stream); break;
+      case 13: launch_tune<7, 256, 1>(A, swz, c->stream); break;
+      default: break;
+    }
+  };
+  for (int i = 0; i < 3; i++) run();
+  HIPCHK(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < nrep; i++) run();
+  HIPCHK(hipEventRecord(e1, c->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *avg_us = 1e3 * ms / nrep;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return 0;
+}
+
+// plain device-to-device streaming copy of n bytes with 16-byte accesses: the measured HBM ceiling
+__global__ void __launch_bounds__(256) k_copy16(const double2 *__restrict__ a, double2 *__restrict__ b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+__global__ void __launch_bounds__(256) k_read16(const double2 *__restrict__ a, double *out, size_t n) {
+  double s = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { double2 v = a[i]; s += v.x + v.y; }
+  if (s == 1.2345e300) out[0] = s;
+}
+// mode 0: copy (bytes read + written = 2n*16), mode 1: read only
+extern "C" int qexhip_tune_stream(qexhip_handle c, int mode, size_t mbytes, int nblocks, int nrep, double *gbs) {
+  if (!c) return -1;
+  size_t n = mbytes * 1048576 / 16;
+  double2 *a, *b;
+  HIPCHK(hipMalloc((void **)&a, n * 16));
+  HIPCHK(hipMalloc((void **)&b, n * 16));
+  HIPCHK(hipMemsetAsync(a, 1, n * 16, c->stream));
+  HIPCHK(hipMemsetAsync(b, 0, n * 16, c->stream));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  auto run = [&]() {
+    if (mode == 0) k_copy16<<<nblocks, 256, 0, c->stream>>>(a, b, n);
+    else k_read16<<<nblocks, 256, 0, c->stream>>>(a, (double *)b, n);
+  };
+  for (int i = 0; i < 2; i++) run();
+  HIPCHK(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < nrep; i++) run();
+  HIPCHK(hipEventRecord(e1, c->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  double bytes = (mode == 0 ? 2.0 : 1.0) * n * 16.0 * nrep;
+  *gbs = bytes / (ms * 1e-3) / 1e9;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b);
+  return 0;
+}

@@ -159,3 +159,30 @@ int links_upload(qexhip_ctx *c, const double *fat, const double *lng) {
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
+
+// ---- host-callable test hooks for the index arithmetic (no GPU needed) ----
+// The same inline functions the kernels use, evaluated on the host, so that the CPU test suite
+// (tests/test_host_logic.py, incl. the 2-rank gloo test) can check site order, neighbour sense
+// and ghost-zone positions against the oracle's tables.
+extern "C" int qexhip_debug_geom(const int latLocal[4], int depth, int halo, int out[8]) {
+  Geom g;
+  if (geom_init(g, latLocal, depth, halo)) return -1;
+  out[0] = g.Vh; out[1] = g.F; out[2] = g.ntile; out[3] = g.gtile; out[4] = g.etile;
+  out[5] = g.depth; out[6] = g.halo; out[7] = g.Xh;
+  return 0;
+}
+extern "C" int qexhip_debug_nbr_pos(const int latLocal[4], int depth, int halo, int c, int parity, int mu, int hop) {
+  Geom g;
+  if (geom_init(g, latLocal, depth, halo)) return -1;
+  if (c < 0 || c >= g.Vh || mu < 0 || mu > 3) return -1;
+  SiteXYZT s = site_coord(g, c, parity);
+  return halo ? nbr_pos<true>(g, c, s, mu, hop) : nbr_pos<false>(g, c, s, mu, hop);
+}
+extern "C" int qexhip_debug_site_coord(const int latLocal[4], int c, int parity, int x[4]) {
+  Geom g;
+  if (geom_init(g, latLocal, 1, 0)) return -1;
+  if (c < 0 || c >= g.Vh) return -1;
+  SiteXYZT s = site_coord(g, c, parity);
+  x[0] = 2 * s.xh + s.o; x[1] = s.y; x[2] = s.z; x[3] = s.t;
+  return 0;
+}

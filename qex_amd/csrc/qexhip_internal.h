@@ -89,6 +89,8 @@ struct qexhip_ctx {
   // timers
   int timers_on = 0;
   std::map<std::string, TimerSlot> timers;
+  // tuning switches (env QEXHIP_SWZ / QEXHIP_NTSTORE, read at init)
+  int opt_swz = 0, opt_ntstore = 1;
   // natural gauge (flow)
   GaugeNat *gn = nullptr;
 };
@@ -139,6 +141,8 @@ struct DslashOpts {
   int neg = 0;                     // 1: subtract the hop sum (stagDM)
   double post = 1.0;               // out *= post  (stagD's 0.5*sc)
   int dot = 0;                     // 1: write block partials of Re<xs,out> and reduce into dot_out
+                                   // 2: leave the partials in c->partials[0..*nparts_out) (deferred)
+  int *nparts_out = nullptr;
   double *dot_out = nullptr;       // device scalar
   const int *done = nullptr;       // device flag: skip when set
 };
@@ -158,13 +162,12 @@ int read_scalars(qexhip_ctx *c, const double *dev, int n, double *host);  // syn
 int blas_grid(const qexhip_ctx *c, int parity_count);
 // CG fused kernels
 int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity);
-int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity);
+int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity, int ndot);
 int cg_init(qexhip_ctx *c, double r2req, int maxits);  // after b2 (dscal[0]) and r2 (dscal[1]) are known
-int cg_finish(qexhip_ctx *c);
 
 // ---- solver.cpp ----
 int get_work(qexhip_ctx *c, int slot, DevField **f);
-int op_xx(qexhip_ctx *c, DevField &r, DevField &x, double m2, int par_even, int dot, const int *done);
+int op_xx(qexhip_ctx *c, DevField &r, DevField &x, double m2, int par_even, int dot, const int *done, int *ndot = nullptr);
 int op_D(qexhip_ctx *c, DevField &r, DevField &x, double m, double sc);
 int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2req, int maxits,
                  int par_even, int *iters, double *r2_over_b2, double *hist, int histcap);

@@ -24,3 +24,15 @@ __device__ __forceinline__ double block_sum_256(double v) {
   __syncthreads();
   return r;
 }
+
+// same, result broadcast to every thread of the workgroup
+__device__ __forceinline__ double block_sum_256_all(double v) {
+  __shared__ double smb[4];
+  v = wave_sum(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) smb[w] = v;
+  __syncthreads();
+  double r = (smb[0] + smb[1]) + (smb[2] + smb[3]);
+  __syncthreads();
+  return r;
+}

@@ -10,7 +10,7 @@ struct SiteXYZT {
   int xh, y, z, t, o;  // x = 2*xh + o
 };
 
-__device__ __forceinline__ SiteXYZT site_coord(const Geom &g, int c, int parity) {
+__host__ __device__ __forceinline__ SiteXYZT site_coord(const Geom &g, int c, int parity) {
   SiteXYZT s;
   unsigned r = (unsigned)c;
   s.xh = r % (unsigned)g.Xh; r /= (unsigned)g.Xh;
@@ -21,12 +21,12 @@ __device__ __forceinline__ SiteXYZT site_coord(const Geom &g, int c, int parity)
   return s;
 }
 
-__device__ __forceinline__ int wrap(int v, int n) { return v >= n ? v - n : (v < 0 ? v + n : v); }
+__host__ __device__ __forceinline__ int wrap(int v, int n) { return v >= n ? v - n : (v < 0 ? v + n : v); }
 
 // position, in the field of the OPPOSITE parity, of the site s + hop*mu (hop = +-1, +-3).
 // With g.halo, t-hops that leave the local lattice land in the ghost zones.
 template <bool HALO>
-__device__ __forceinline__ int nbr_pos(const Geom &g, int c, const SiteXYZT &s, int mu, int hop) {
+__host__ __device__ __forceinline__ int nbr_pos(const Geom &g, int c, const SiteXYZT &s, int mu, int hop) {
   if (mu == 0) {
     int x = 2 * s.xh + s.o;
     int xn = wrap(x + hop, g.X[0]);

@@ -27,7 +27,7 @@ int get_work(qexhip_ctx *c, int slot, DevField **f) {
 }
 
 // r[px] = 4 m2 x - (2D)(2D) x : stagDP onto the other parity, stagDM back (stagD.nim:434-456)
-int op_xx(qexhip_ctx *c, DevField &r, DevField &x, double m2, int par_even, int dot, const int *done) {
+int op_xx(qexhip_ctx *c, DevField &r, DevField &x, double m2, int par_even, int dot, const int *done, int *ndot) {
   DevField *t;
   CHK(get_work(c, WK_T, &t));
   const int px = par_even ? 0 : 1, py = 1 - px;
@@ -38,7 +38,8 @@ int op_xx(qexhip_ctx *c, DevField &r, DevField &x, double m2, int par_even, int 
   o2.cb = 4.0 * m2;
   o2.xs = &x;
   o2.neg = 1;
-  o2.dot = dot;
+  o2.dot = (dot && ndot) ? 2 : dot;
+  o2.nparts_out = ndot;
   o2.dot_out = &c->cg->pAp;
   o2.done = done;
   if (o2.cb == 0.0 && dot) { qexhip_set_error("op_xx: dot with m2 == 0 unsupported"); return -1; }
@@ -111,9 +112,10 @@ int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2
     if (n <= 0) break;
     for (int i = 0; i < n; i++) {
       CHK(cg_xpay(c, *p, *r, par));                                   // cg.nim:186-193
-      CHK(op_xx(c, *Ap, *p, m2, par_even, 1, &c->cg->done));          // cg.nim:200, qLAp :206
-      CHK(cg_update(c, x, *r, *p, *Ap, par));                         // cg.nim:208-213
-      CHK(cg_finish(c));
+      int ndot = 0;                                                   // single rank: <p,Ap> partials are
+      CHK(op_xx(c, *Ap, *p, m2, par_even, 1, &c->cg->done,            // summed inside cg_update
+                c->nranks > 1 ? nullptr : &ndot));                    // cg.nim:200, qLAp :206
+      CHK(cg_update(c, x, *r, *p, *Ap, par, ndot));                   // cg.nim:208-213 + loop bookkeeping
     }
     CHK(read_cg(c, &st));
   }

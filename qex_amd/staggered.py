@@ -108,7 +108,8 @@ class Context:
 
     # timers
     def timers_enable(self, on=True):
-        check(lib().qexhip_timers_enable(self._h, 1 if on else 0))
+        """on: False/0 off, True/1 every kernel class, 2 only the Dslash sweeps."""
+        check(lib().qexhip_timers_enable(self._h, int(on)))
 
     def timers_reset(self):
         check(lib().qexhip_timers_reset(self._h))

@@ -1,0 +1,156 @@
+"""CPU-only tests of the host logic: the C-ABI library loads and exports every declared symbol,
+fails loudly without a GPU, and the index arithmetic shared by all kernels (site order,
+neighbour sense, ghost-zone positions) agrees with the oracle.  Includes the world_size-2 gloo
+rehearsal of the t-sharded Dslash: same slab decomposition, same ghost layout
+(evaluated by the library's own index functions), same message order as csrc/comm.cpp.
+"""
+import ctypes as C
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    import qex_amd
+    from qex_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "qexhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(qexhip_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 35
+    L = qex_amd.lib()
+    bound = {s[0] for s in _lib.SYMBOLS}
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/qexhip.h but not exported"
+        assert name in bound, f"{name} not bound in qex_amd/_lib.py"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (qexhip_[a-z0-9_]+)", out))
+    assert set(declared) <= exported
+
+
+def test_product_never_touches_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    for d, _, files in os.walk(os.path.join(ROOT, "qex_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")) or f == "Makefile":
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert "qex_oracle" not in txt and "libqexoracle" not in txt, os.path.join(d, f)
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), os.path.join(d, f)
+    out = subprocess.check_output(["ldd", os.path.join(ROOT, "qex_amd", "libqexhip.so")], text=True)
+    assert "oracle" not in out
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import qex_amd as q
+
+    with pytest.raises(q.QexHipError):
+        q.Context([8, 8, 8, 8])
+
+
+def _nbr(lat, depth, halo, c, p, mu, hop):
+    import qex_amd
+
+    return qex_amd.lib().qexhip_debug_nbr_pos((C.c_int * 4)(*lat), depth, halo, c, p, mu, hop)
+
+
+@pytest.mark.parametrize("lat", [[4, 4, 4, 4], [8, 4, 6, 4], [4, 6, 10, 6]])
+def test_index_arithmetic_matches_oracle(oracle, lat):
+    import qex_amd
+
+    L = qex_amd.lib()
+    lo = oracle.Layout(lat)
+    vh = lo.vol // 2
+    i4 = (C.c_int * 4)(*lat)
+    x = (C.c_int * 4)()
+    for p in (0, 1):
+        for c in range(vh):
+            idx = c + p * vh
+            assert L.qexhip_debug_site_coord(i4, c, p, x) == 0
+            assert list(x) == lo.coord(idx)
+            for mu in range(4):
+                for hop in (1, -1, 3, -3):
+                    if abs(hop) == 3 and lat[mu] < 4:
+                        continue
+                    ref = lo.neighbor(idx, mu, hop) - (1 - p) * vh   # position in the other parity
+                    assert _nbr(lat, 1, 0, c, p, mu, hop) == ref
+
+
+def test_ghost_zone_positions():
+    import qex_amd
+
+    lat = [8, 8, 8, 4]
+    out = (C.c_int * 8)()
+    assert qex_amd.lib().qexhip_debug_geom((C.c_int * 4)(*lat), 3, 1, out) == 0
+    vh, F, ntile, gtile, etile, depth, halo, xh = list(out)
+    assert (vh, F, depth, halo) == (1024, 256, 3, 1) and ntile * 64 == vh and gtile == 3 * F // 64
+    assert etile == ntile + 2 * gtile
+    for c in (0, 5, F - 1, F, vh - F, vh - 1):
+        t, cF = c // F, c % F
+        for hop in (1, -1, 3, -3):
+            pos = _nbr(lat, 3, 1, c, 0, 3, hop)
+            tn = t + hop
+            if tn >= lat[3]:
+                assert pos == vh + (tn - lat[3]) * F + cF              # ghost_hi: upper rank's t = tn - Xt
+            elif tn < 0:
+                assert pos == vh + 3 * F + (tn + 3) * F + cF           # ghost_lo: lower rank's t = Xt + tn
+            else:
+                assert pos == c + hop * F
+    # sharding needs whole tiles per t-slice
+    assert qex_amd.lib().qexhip_debug_geom((C.c_int * 4)(4, 4, 4, 4), 1, 1, out) != 0
+
+
+def test_shard_indices_roundtrip():
+    import qex_amd as q
+
+    lo = q.Layout([4, 6, 4, 8])
+    seen = np.zeros(lo.vol, dtype=int)
+    for r in range(2):
+        loc, idx = lo.shard_indices(2, r)
+        assert loc.lat == [4, 6, 4, 4]
+        seen[idx] += 1
+        # slab order is the slab's own even-odd order and parities agree (even slab offset)
+        assert np.array_equal(lo.coords[idx][:, :3], loc.coords[:, :3])
+        assert np.array_equal(lo.coords[idx][:, 3], loc.coords[:, 3] + r * 4)
+        assert np.array_equal(idx[: loc.vol // 2] < lo.vol // 2, np.ones(loc.vol // 2, bool))
+    assert np.all(seen == 1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("naik", [0, 1])
+def test_sharded_dslash_two_ranks_gloo(naik):
+    """world_size 2, gloo, CPU: t-sharded stagD2 == global stagD2 on every slab."""
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_rehearsal.py"),
+                               str(r), "2", str(naik)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for pp in procs:
+                pp.kill()
+            raise
+        outs.append(o)
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert "SHARDED_OK" in o, o
