@@ -144,7 +144,21 @@ __global__ void __launch_bounds__(256) k_read16(const double2 *__restrict__ a, d
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { double2 v = a[i]; s += v.x + v.y; }
   if (s == 1.2345e300) out[0] = s;
 }
-// mode 0: copy (bytes read + written = 2n*16), mode 1: read only
+__global__ void __launch_bounds__(256) k_read16_nt(const double2 *__restrict__ a, double *out, size_t n) {
+  double s = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    d2v v = __builtin_nontemporal_load((const d2v *)&a[i]);
+    s += v.x + v.y;
+  }
+  if (s == 1.2345e300) out[0] = s;
+}
+__global__ void __launch_bounds__(256) k_write16_nt(double2 *__restrict__ b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    d2v t; t.x = (double)i; t.y = 1.0;
+    __builtin_nontemporal_store(t, (d2v *)&b[i]);
+  }
+}
+// mode 0: copy (bytes read + written = 2n*16), mode 1: read only, 2: non-temporal read, 3: nt write
 extern "C" int qexhip_tune_stream(qexhip_handle c, int mode, size_t mbytes, int nblocks, int nrep, double *gbs) {
   if (!c) return -1;
   size_t n = mbytes * 1048576 / 16;
@@ -158,7 +172,9 @@ extern "C" int qexhip_tune_stream(qexhip_handle c, int mode, size_t mbytes, int 
   HIPCHK(hipEventCreate(&e1));
   auto run = [&]() {
     if (mode == 0) k_copy16<<<nblocks, 256, 0, c->stream>>>(a, b, n);
-    else k_read16<<<nblocks, 256, 0, c->stream>>>(a, (double *)b, n);
+    else if (mode == 1) k_read16<<<nblocks, 256, 0, c->stream>>>(a, (double *)b, n);
+    else if (mode == 2) k_read16_nt<<<nblocks, 256, 0, c->stream>>>(a, (double *)b, n);
+    else k_write16_nt<<<nblocks, 256, 0, c->stream>>>(b, n);
   };
   for (int i = 0; i < 2; i++) run();
   HIPCHK(hipEventRecord(e0, c->stream));
