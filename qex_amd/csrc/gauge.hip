@@ -11,6 +11,7 @@
 #include "qexhip_internal.h"
 #include "reduce.h"
 #include "su3.h"
+#include <cstdlib>
 
 struct GaugeNat {
   double2 *U = nullptr, *F = nullptr, *P = nullptr;
@@ -95,11 +96,30 @@ __global__ void __launch_bounds__(256) k_plaq_final(const double *partials, int 
 }
 
 // force: one lane per (mu, site).  F_mu(x) = TAH( U_mu(x) [cp * sum_nu (fwd + bwd staples)]^+ )
-__global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict__ G, double2 *F, double cp) {
-  int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= 4 * g.V) return;
-  int mu = j / g.V, i = j - mu * g.V;
-  int p = i >= g.Vh, c = i - p * g.Vh;
+// A workgroup = one 64-site tile x 4 directions (wavefront w handles mu = w), so the four
+// wavefronts that share most of their neighbour links run together; with `swz` the workgroups are
+// remapped so that each XCD sweeps a contiguous range of tiles (a contiguous t-range): every link
+// is used by 19 staple terms, and adjacent tiles on different XCDs would each re-fetch it from
+// beyond their own L2 (cdna_hip_programming.md T1).
+// flow mode (Pm != nullptr): the RK3 combination v = cf*f + cpm*p (wflow.nim:39,48,57) is formed here
+// and written over the momentum field, so the exp kernel reads one field less and F is not needed.
+__global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict__ G, double2 *F, double cp, int mode,
+                                               double2 *Pm, double cf, double cpm) {
+  int mu, p, c;
+  if (mode == 0) {
+    int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= 4 * g.V) return;
+    mu = j / g.V;
+    int i = j - mu * g.V;
+    p = i >= g.Vh; c = i - p * g.Vh;
+  } else {
+    int bid = blockIdx.x, nb = gridDim.x;
+    if (mode == 2 && (nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+    mu = threadIdx.x >> 6;
+    p = bid >= g.ntile;
+    c = (bid - p * g.ntile) * 64 + (threadIdx.x & 63);
+    if (c >= g.Vh) return;
+  }
   int x[4], xpm[4], y[4], z[4];
   coords_of(g, c, p, x);
   shifted(g, x, mu, 1, xpm);
@@ -121,30 +141,31 @@ __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict
   }
   size_t o = link_off(g, x, mu);
   M3 f = m3_tah(m3_mul_na(m3_load(G + o, 64), acc));
-  m3_store(F + o, 64, f);
+  if (Pm) {
+    M3 v;
+    if (cpm != 0.0) {
+      M3 pm = m3_load(Pm + o, 64);
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x + cpm * pm.e[k].x, cf * f.e[k].y + cpm * pm.e[k].y);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x, cf * f.e[k].y);
+    }
+    m3_store(Pm + o, 64, v);
+  } else {
+    m3_store(F + o, 64, f);
+  }
 }
 
-// RK3 stage: v = cf*F + cp*P ; U <- exp(v) U ; P <- v   (wflow.nim:36-62)
-__global__ void __launch_bounds__(256) k_exp_update(size_t nlinks_tiles, double2 *G, const double2 *F, double2 *P,
-                                                   double cf, double cpm, int store_p) {
+// RK3 stage, second half: U <- exp(v) U with v already in the momentum field (wflow.nim:40-43)
+__global__ void __launch_bounds__(256) k_exp_update(size_t nlinks_tiles, double2 *G, const double2 *V) {
   size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;  // (tile-of-links, lane)
   size_t tile = j >> 6;
   if (tile >= nlinks_tiles) return;
   size_t o = tile * 576 + (j & 63);
-  M3 f = m3_load(F + o, 64);
-  M3 v;
-  if (cpm != 0.0) {
-    M3 pm = m3_load(P + o, 64);
-#pragma unroll
-    for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x + cpm * pm.e[k].x, cf * f.e[k].y + cpm * pm.e[k].y);
-  } else {
-#pragma unroll
-    for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x, cf * f.e[k].y);
-  }
-  M3 e = m3_exp(v);
+  M3 e = m3_exp(m3_load(V + o, 64));
   M3 u = m3_load(G + o, 64);
   m3_store(G + o, 64, m3_mul(e, u));
-  if (store_p) m3_store(P + o, 64, v);
 }
 
 static int gn_alloc(qexhip_ctx *c) {
@@ -212,11 +233,13 @@ int gauge_plaq(qexhip_ctx *c, double out[6]) {
   return read_scalars(c, &c->dscal[16], 6, out);
 }
 
-static int force_dev(qexhip_ctx *c, double cplaq) {
+static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, double cpm = 0) {
   CHK(gn_alloc_fp(c));
   ScopedTimer tm(c, "staple", c->stream);
-  int n = 4 * c->g.V;
-  k_force<<<(n + 255) / 256, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0);
+  static int mode = -1;
+  if (mode < 0) { const char *e = getenv("QEXHIP_FORCE_MODE"); mode = e ? atoi(e) : 1; }
+  int nb = mode == 0 ? (4 * c->g.V + 255) / 256 : 2 * c->g.ntile;
+  k_force<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, flow ? c->gn->P : nullptr, cf, cpm);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -236,9 +259,9 @@ int gauge_wflow(qexhip_ctx *c, int nsteps, double eps) {
   const double cpm[3] = {0.0, -17.0 / 9.0, -1.0};
   for (int s = 0; s < nsteps; s++)
     for (int st = 0; st < 3; st++) {
-      CHK(force_dev(c, 1.0));
+      CHK(force_dev(c, 1.0, 1, cf[st], cpm[st]));
       ScopedTimer tm(c, "expupdate", c->stream);
-      k_exp_update<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->F, c->gn->P, cf[st], cpm[st], st < 2);
+      k_exp_update<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P);
       HIPCHK(hipGetLastError());
     }
   HIPCHK(hipStreamSynchronize(c->stream));

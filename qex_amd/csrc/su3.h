@@ -25,6 +25,11 @@ __device__ __forceinline__ void m3_store(double2 *p, int stride, const M3 &a) {
 #pragma unroll
   for (int k = 0; k < 9; k++) p[(size_t)k * stride] = a.e[k];
 }
+// The products are written as chained multiply-adds (s += a*b; s -= c*d; ...) so that hipcc
+// contracts every term into one v_fma_f64: 4 FMAs per complex multiply-accumulate, 108 per 3x3
+// product (a `cmul` temporary followed by an add costs 6 instructions per term).
+#define M3_MAC(sx, sy, ax, ay, bx, by) \
+  do { sx += (ax) * (bx); sx -= (ay) * (by); sy += (ax) * (by); sy += (ay) * (bx); } while (0)
 // a*b
 __device__ __forceinline__ M3 m3_mul(const M3 &a, const M3 &b) {
   M3 r;
@@ -32,10 +37,10 @@ __device__ __forceinline__ M3 m3_mul(const M3 &a, const M3 &b) {
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      double2 s = cmul(a.e[3 * i], b.e[j]);
+      double sx = 0.0, sy = 0.0;
 #pragma unroll
-      for (int k = 1; k < 3; k++) { double2 t = cmul(a.e[3 * i + k], b.e[3 * k + j]); s.x += t.x; s.y += t.y; }
-      r.e[3 * i + j] = s;
+      for (int k = 0; k < 3; k++) M3_MAC(sx, sy, a.e[3 * i + k].x, a.e[3 * i + k].y, b.e[3 * k + j].x, b.e[3 * k + j].y);
+      r.e[3 * i + j] = make_double2(sx, sy);
     }
   return r;
 }
@@ -46,10 +51,10 @@ __device__ __forceinline__ M3 m3_mul_na(const M3 &a, const M3 &b) {
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      double2 s = cmulc(a.e[3 * i], b.e[3 * j]);
+      double sx = 0.0, sy = 0.0;
 #pragma unroll
-      for (int k = 1; k < 3; k++) { double2 t = cmulc(a.e[3 * i + k], b.e[3 * j + k]); s.x += t.x; s.y += t.y; }
-      r.e[3 * i + j] = s;
+      for (int k = 0; k < 3; k++) M3_MAC(sx, sy, a.e[3 * i + k].x, a.e[3 * i + k].y, b.e[3 * j + k].x, -b.e[3 * j + k].y);
+      r.e[3 * i + j] = make_double2(sx, sy);
     }
   return r;
 }
@@ -60,10 +65,10 @@ __device__ __forceinline__ M3 m3_mul_an(const M3 &a, const M3 &b) {
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      double2 s = ccmul(a.e[i], b.e[j]);
+      double sx = 0.0, sy = 0.0;
 #pragma unroll
-      for (int k = 1; k < 3; k++) { double2 t = ccmul(a.e[3 * k + i], b.e[3 * k + j]); s.x += t.x; s.y += t.y; }
-      r.e[3 * i + j] = s;
+      for (int k = 0; k < 3; k++) M3_MAC(sx, sy, a.e[3 * k + i].x, -a.e[3 * k + i].y, b.e[3 * k + j].x, b.e[3 * k + j].y);
+      r.e[3 * i + j] = make_double2(sx, sy);
     }
   return r;
 }
