@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--lat", type=int, nargs=4, default=[32, 32, 32, 32])
     ap.add_argument("--mass", type=float, default=0.1)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--halo", action="store_true",
+                    help="N=1 only: route t-hops through ghost zones + a one-rank RCCL communicator "
+                         "(rehearses the sharded code path and its host overhead on one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -92,6 +95,9 @@ def main():
         uid = [q.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], N, rank)
+    elif args.halo:
+        ctx.comm_init(q.Context.unique_id(), 1, 0)
+        ctx.force_halo(True)
     s = q.newStag(ctx, g)
     bid = ctx.field_new(b)
     xid = ctx.field_new()
@@ -127,7 +133,7 @@ def main():
     n_red, ms_red = ctx.timer("reduce")
     # dominant kernel: the one-parity Dslash sweep.  Per launch it processes the sites of that launch
     # (all Vh_loc without sharding; the interior range when the faces are split off).
-    if N == 1:
+    if N == 1 and not args.halo:
         sites_per_launch = Vh_loc
     else:
         F = lat_loc[0] // 2 * lat_loc[1] * lat_loc[2]

@@ -98,6 +98,7 @@ extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], 
   HIPCHK(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
   if (const char *e = getenv("QEXHIP_SWZ")) c->opt_swz = atoi(e);
   if (const char *e = getenv("QEXHIP_NTSTORE")) c->opt_ntstore = atoi(e);
+  if (const char *e = getenv("QEXHIP_OVERLAP")) c->opt_overlap = atoi(e);
   c->nranks = 1;  // until qexhip_comm_init
   c->rank = 0;
   *h = c;

@@ -60,7 +60,11 @@ static inline int lower(const qexhip_ctx *c) { return (c->rank - 1 + c->nranks) 
 // producer of f on the compute stream); records ev_halo.  Message order is the same on every
 // rank -- sends {bottom->lower, top->upper}, receives {ghost_hi<-upper, ghost_lo<-lower} -- so
 // that with two ranks (upper == lower) or one rank (self) the k-th send pairs with the k-th recv.
-int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity) {
+int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
+  // overlap == 0: post the exchange on the compute stream itself (no cross-stream events).  Used
+  // when the interior sweep is too short to hide the exchange: two cross-stream dependencies
+  // cost more than they buy there.
+  hipStream_t cs = overlap ? c->cstream : c->stream;
   const Geom &g = c->g;
   const size_t face2 = (size_t)g.depth * g.F * 3;  // double2 per face
   const size_t nd = face2 * 2;                     // doubles
@@ -69,21 +73,21 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity) {
   double2 *top = base + (size_t)(g.ntile) * 192 - face2;        // t = Xt-depth .. Xt-1
   double2 *ghost_hi = base + (size_t)g.ntile * 192;
   double2 *ghost_lo = ghost_hi + face2;
-  HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+  if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   if (c->comm) {
     ncclComm_t comm = (ncclComm_t)c->comm;
     NCCLCHK(ncclGroupStart());
-    NCCLCHK(ncclSend(bottom, nd, ncclDouble, lower(c), comm, c->cstream));
-    NCCLCHK(ncclSend(top, nd, ncclDouble, upper(c), comm, c->cstream));
-    NCCLCHK(ncclRecv(ghost_hi, nd, ncclDouble, upper(c), comm, c->cstream));
-    NCCLCHK(ncclRecv(ghost_lo, nd, ncclDouble, lower(c), comm, c->cstream));
+    NCCLCHK(ncclSend(bottom, nd, ncclDouble, lower(c), comm, cs));
+    NCCLCHK(ncclSend(top, nd, ncclDouble, upper(c), comm, cs));
+    NCCLCHK(ncclRecv(ghost_hi, nd, ncclDouble, upper(c), comm, cs));
+    NCCLCHK(ncclRecv(ghost_lo, nd, ncclDouble, lower(c), comm, cs));
     NCCLCHK(ncclGroupEnd());
   } else {
     // single rank, no communicator: periodic wrap by device-to-device copies
-    HIPCHK(hipMemcpyAsync(ghost_hi, bottom, nd * sizeof(double), hipMemcpyDeviceToDevice, c->cstream));
-    HIPCHK(hipMemcpyAsync(ghost_lo, top, nd * sizeof(double), hipMemcpyDeviceToDevice, c->cstream));
+    HIPCHK(hipMemcpyAsync(ghost_hi, bottom, nd * sizeof(double), hipMemcpyDeviceToDevice, cs));
+    HIPCHK(hipMemcpyAsync(ghost_lo, top, nd * sizeof(double), hipMemcpyDeviceToDevice, cs));
   }
-  HIPCHK(hipEventRecord(c->ev_halo, c->cstream));
+  if (overlap) HIPCHK(hipEventRecord(c->ev_halo, c->cstream));
   return 0;
 }
 

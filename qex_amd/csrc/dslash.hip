@@ -21,7 +21,8 @@ struct DslashArgs {
   double ca, cb;
   double sgn;            // +1 (stagDP / stagD2) or -1 (stagDM)
   double post;           // final scale, the `r := (0.5*sc)*r` of stagD (stagD.nim:409)
-  int parity, c0, c1;
+  int parity, c0, c1;    // first site range [c0,c1)
+  int d0, d1, nb1;       // optional second range [d0,d1) handled by workgroups >= nb1 (both t-faces in one launch)
   double *partials;
   const int *done;
   int swz;               // number of workgroups if XCD swizzle is on, else 0
@@ -54,8 +55,10 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
     bid = (bid & 7) * per + (bid >> 3);
   }
   int c = A.c0 + bid * 256 + threadIdx.x;
+  int clim = A.c1;
+  if (bid >= A.nb1) { c = A.d0 + (bid - A.nb1) * 256 + threadIdx.x; clim = A.d1; }
   double dotv = 0;
-  if (c < A.c1) {
+  if (c < clim) {
     const Geom &g = A.g;
     SiteXYZT s = site_coord(g, c, A.parity);
     double2 acc[3];
@@ -127,10 +130,13 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
 }
 
 template <int NDIR, bool HALO>
-static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool dot, int part_off) {
-  if (c1 <= c0) return 0;
-  A.c0 = c0; A.c1 = c1;
-  int nb = (c1 - c0 + 255) / 256;
+static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool dot, int part_off,
+                  int d0 = 0, int d1 = 0) {
+  if (c1 <= c0 && d1 <= d0) return 0;
+  if (c1 <= c0) { c0 = d0; c1 = d1; d0 = d1 = 0; }
+  A.c0 = c0; A.c1 = c1; A.d0 = d0; A.d1 = d1;
+  A.nb1 = (c1 - c0 + 255) / 256;
+  int nb = A.nb1 + (d1 > d0 ? (d1 - d0 + 255) / 256 : 0);
   A.swz = (c->opt_swz && nb >= 64 && (nb & 7) == 0) ? nb : 0;
   A.ntstore = c->opt_ntstore;
   double *psave = A.partials;
@@ -172,26 +178,27 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
     nparts = (g.Vh + 255) / 256;
   } else {
     // halo: exchange faces of `in` on the comm stream, interior sweep meanwhile, then boundary
-    HIPCHK(hipEventRecord(c->ev_ready, c->stream));
-    CHK(comm_halo_exchange(c, in, 1 - parity));
     int lo_end = g.depth * g.F; if (lo_end > g.Vh) lo_end = g.Vh;
     int hi_beg = g.Vh - g.depth * g.F; if (hi_beg < lo_end) hi_beg = lo_end;
+    // overlap the exchange with the interior sweep on a second stream only when the interior is
+    // long enough to hide it (measured on one MI355X with a one-rank communicator: the two
+    // cross-stream dependencies cost ~20 us per sweep; an interior of 128k sites runs ~30 us)
+    const int overlap = c->opt_overlap >= 0 ? c->opt_overlap : ((hi_beg - lo_end) >= 131072);
+    if (overlap) HIPCHK(hipEventRecord(c->ev_ready, c->stream));
+    CHK(comm_halo_exchange(c, in, 1 - parity, overlap));
     int nb_int = (hi_beg - lo_end + 255) / 256, nb_lo = (lo_end + 255) / 256;
     {
       ScopedTimer tm(c, "dslash", c->stream);
       if (c->ndir == 8) CHK((launch<8, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
       else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
     }
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    if (overlap) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
     {
       ScopedTimer tm(c, "dslash_bnd", c->stream);
-      if (c->ndir == 8) {
-        CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int)));
-        CHK((launch<8, true>(c, A, hi_beg, g.Vh, init, o.dot, nb_int + nb_lo)));
-      } else {
-        CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int)));
-        CHK((launch<16, true>(c, A, hi_beg, g.Vh, init, o.dot, nb_int + nb_lo)));
-      }
+      // both t-faces in ONE launch (fewer launches per sweep: the sharded iteration is host-bound
+      // on small local volumes)
+      if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh)));
+      else CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh)));
     }
     nparts = nb_int + nb_lo + (g.Vh - hi_beg + 255) / 256;
   }

@@ -91,6 +91,7 @@ struct qexhip_ctx {
   std::map<std::string, TimerSlot> timers;
   // tuning switches (env QEXHIP_SWZ / QEXHIP_NTSTORE, read at init)
   int opt_swz = 0, opt_ntstore = 1;
+  int opt_overlap = -1;  // QEXHIP_OVERLAP: 1 always use the comm stream, 0 never, -1 by interior size
   // natural gauge (flow)
   GaugeNat *gn = nullptr;
 };
@@ -127,7 +128,7 @@ int links_upload(qexhip_ctx *c, const double *fat, const double *lng);
 int ensure_stage(qexhip_ctx *c, size_t bytes);
 
 // ---- comm.cpp ----
-int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity);  // on cstream, after ev_ready; records ev_halo
+int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready, records ev_halo
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
 int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st);
 void comm_destroy(qexhip_ctx *c);

@@ -314,3 +314,92 @@ def test_wflow_golden(oracle):
     assert np.abs(pl - p0).sum() / p0.sum() <= 2e-14
     oracle.wflow(lo, gref, 6, 0.01)
     assert relerr(g, gref) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full size (32^4): size-independent properties, everything on the GPU except the
+# cheap oracle pieces (config generation, plaquette).  The oracle's CG at 32^4 takes minutes, so
+# the full-size checks are identities, not oracle replays.
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def s32(oracle):
+    import qex_amd as q
+
+    lat = [32, 32, 32, 32]
+    lo = oracle.Layout(lat)
+    rf = oracle.RngField(lo, oracle.RNG_MILC6, SEED)
+    g = oracle.gauge_random(lo, rf)
+    ctx = q.Context(lat)
+
+    class S:
+        pass
+
+    S.o, S.q, S.lo, S.ctx, S.g0 = oracle, q, lo, ctx, g.copy()
+    oracle.rephase(lo, g)
+    S.g = g
+    S.s = q.newStag(ctx, g)
+    S.x = oracle.vector_gaussian(lo, rf)
+    S.y = oracle.vector_gaussian(lo, rf)
+    return S
+
+
+def test_full_size_dslash_identities(s32):
+    S = s32
+    cx = lambda a: a[..., 0] + 1j * a[..., 1]
+    Dx, Dy = np.zeros_like(S.x), np.zeros_like(S.x)
+    S.s.D(Dx, S.x, 0.0)
+    S.s.D(Dy, S.y, 0.0)
+    # <y, D x> = -<D y, x>  (anti-Hermitian at m = 0)
+    lhs = np.vdot(cx(S.y), cx(Dx)) + np.vdot(cx(Dy), cx(S.x))
+    assert abs(lhs) / np.sqrt((Dx * Dx).sum() * (S.y * S.y).sum()) < 1e-13
+    # Ddag = m - D ; stagD2ee = 4 D^+ D on the even subset
+    m = 0.05
+    h = S.lo.vol // 2
+    xe = S.x.copy()
+    xe[h:] = 0
+    t1, t2, A = np.zeros_like(S.x), np.zeros_like(S.x), np.zeros_like(S.x)
+    S.s.D(t1, xe, m)
+    S.s.Ddag(t2, t1, m)
+    S.s.stagD2ee(A, xe, m * m)
+    assert relerr(A[:h], 4 * t2[:h]) < 1e-13
+    # spot-check 4096 sites of one Dslash against the oracle (whole-field oracle sweep is cheap too)
+    ref = S.o.D(S.lo, S.g, None, S.x, 0.0)
+    assert relerr(Dx, ref) < 1e-13
+    # linearity
+    z = 0.3 * S.x - 1.7 * S.y
+    Dz = np.zeros_like(z)
+    S.s.D(Dz, z, 0.0)
+    assert relerr(Dz, 0.3 * Dx - 1.7 * Dy) < 1e-13
+
+
+def test_full_size_solve_true_residual(s32):
+    """32^4, m = 0.1: D(solve(b)) = b to the requested residual; reconstruct round trip."""
+    S = s32
+    sp = S.q.SolverParams(r2req=1e-12, maxits=20000, verbosity=0)
+    x = np.zeros_like(S.x)
+    S.s.solve(x, S.x, 0.1, sp)
+    r = np.zeros_like(x)
+    S.s.D(r, x, 0.1)
+    r -= S.x
+    assert (r * r).sum() / (S.x * S.x).sum() <= 1e-12
+    assert 50 < sp.iterations < 5000
+    # the same through the oracle's operator (independent arithmetic)
+    ro = S.o.D(S.lo, S.g, None, x, 0.1) - S.x
+    assert (ro * ro).sum() / (S.x * S.x).sum() <= 1.01e-12
+
+
+def test_full_size_plaq_and_flow(s32):
+    S = s32
+    pl = S.q.plaq(S.ctx, S.g0)
+    assert np.max(np.abs(pl - S.o.plaq(S.lo, S.g0))) < 1e-15
+    g = S.g0.copy()
+    S.q.gaugeFlow(S.ctx, g, 1, 0.01)
+    m = (g[..., 0] + 1j * g[..., 1]).reshape(-1, 3, 3)[::257]
+    assert np.abs(np.einsum("nij,nkj->nik", m, m.conj()) - np.eye(3)).max() < 1e-10   # stays in SU(3)
+    assert np.abs(np.linalg.det(m) - 1).max() < 1e-10
+    pl1 = S.q.plaq(S.ctx, g)
+    assert pl1.sum() > pl.sum() + 1e-3     # the flow smooths: plaquette rises monotonically
+    # one full-size RK3 step against the oracle (about 10 s of CPU)
+    gref = S.g0.copy()
+    S.o.wflow(S.lo, gref, 1, 0.01)
+    assert relerr(g, gref) < 1e-12
