@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--halo", action="store_true",
                     help="N=1 only: route t-hops through ghost zones + a one-rank RCCL communicator "
                          "(rehearses the sharded code path and its host overhead on one GPU)")
+    ap.add_argument("--naik", action="store_true", help="add synthetic 3-hop (Naik) links: 16 links per site")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -98,7 +99,16 @@ def main():
     elif args.halo:
         ctx.comm_init(q.Context.unique_id(), 1, 0)
         ctx.force_halo(True)
-    s = q.newStag(ctx, g)
+    if args.naik:
+        g3 = 0.3 * q.synthetic_random_su3(lo, seed=555 + rank)
+        q.rephase(lo, g3, t_offset=rank * lt, t_global=lat[3])
+        s = q.newStag3(ctx, g, g3)
+    else:
+        s = q.newStag(ctx, g)
+    nd = 8 if args.naik else 4                  # s.g.len in QEX's flop formulas
+    b1 = 2 * nd * 144 + 96                      # bytes/site of a sweep: links once, vector in + out
+    flop_dslash = 2 * nd * 66 + (2 * nd - 1) * 6
+    flop_cg = 4 * nd * 72 + 60                  # stagSolve.nim:92
     bid = ctx.field_new(b)
     xid = ctx.field_new()
 
@@ -137,21 +147,21 @@ def main():
         sites_per_launch = Vh_loc
     else:
         F = lat_loc[0] // 2 * lat_loc[1] * lat_loc[2]
-        sites_per_launch = max(Vh_loc - 2 * F, 0)
+        sites_per_launch = max(Vh_loc - 2 * (3 if args.naik else 1) * F, 0)
     avg_ms = ms_int / max(n_int, 1)
-    b_alg = 0.5 * (B_SWEEP1 + B_SWEEP2) * sites_per_launch
+    b_alg = 0.5 * (b1 + b1 + 48) * sites_per_launch
     achieved_gbs = b_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # whole sweep incl. boundary launches, for the Dslash GFLOP/s figure
     sweep_ms = (ms_int + ms_bnd) / max(n_int, 1)
-    dslash_gflops = FLOP_DSLASH * Vh_loc * N / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    dslash_gflops = flop_dslash * Vh_loc * N / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
 
     out = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = FLOP_CG * (V // 2) * args.steps / dt / 1e9
+        value = flop_cg * (V // 2) * args.steps / dt / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "dslash_traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and lat == [32, 32, 32, 32] and N == 1 and not args.naik and not args.halo:
             try:
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch_32x4")
             except Exception:
@@ -176,7 +186,7 @@ def main():
             },
             "cg_iters_per_s": round(args.steps / dt, 2),
             "dslash_gflops": round(dslash_gflops, 1),
-            "dslash_gflops_qex582": round(dslash_gflops * 582.0 / 570.0, 1),
+            "dslash_gflops_qex582": round(dslash_gflops * (6 + 2 * nd * 72) / flop_dslash, 1),
             "dslash_us_per_sweep": round(sweep_ms * 1e3, 2),
             "kernel_ms": {"dslash": round(ms_int, 3), "dslash_bnd": round(ms_bnd, 3), "blas": round(ms_blas, 3),
                           "reduce": round(ms_red, 3), "wall": round(dt * 1e3, 3)},
@@ -189,7 +199,7 @@ def main():
             },
         }
         if N == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(lat_loc, g, b, args.mass, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(lat_loc, g, g3 if args.naik else None, b, args.mass, args.cpu_seconds)
     barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -198,7 +208,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(lat, g, b, mass, budget_s):
+def cpu_baseline(lat, g, g3, b, mass, budget_s):
     """The oracle's CG (plain C + OpenMP restatement of cg.nim / stagD.nim) on the same links and
     source, on the GPU box's host cores.  kind = "port": the reference itself is Nim and cannot be
     built here.  Bounded sample: calibrate on 2 iterations, then run ~budget_s worth."""
@@ -206,15 +216,16 @@ def cpu_baseline(lat, g, b, mass, budget_s):
 
     lo = o.Layout(lat)
     t0 = time.perf_counter()
-    o.solveXX(lo, g, None, b, mass, 0.0, 2, True)
+    o.solveXX(lo, g, g3, b, mass, 0.0, 2, True)
     per = (time.perf_counter() - t0) / 2.0
     n = int(max(3, min(400, budget_s / max(per, 1e-6))))
     t0 = time.perf_counter()
-    _, its, _, _ = o.solveXX(lo, g, None, b, mass, 0.0, n, True)
+    _, its, _, _ = o.solveXX(lo, g, g3, b, mass, 0.0, n, True)
     dt = time.perf_counter() - t0
     vh = lo.vol // 2
     return {
-        "value": round(FLOP_CG * vh * its / dt / 1e9, 3), "unit": "GFLOP/s", "cores": o.num_threads(),
+        "value": round((4 * (8 if g3 is not None else 4) * 72 + 60) * vh * its / dt / 1e9, 3), "unit": "GFLOP/s",
+        "cores": o.num_threads(),
         "kind": "port", "cg_iters_per_s": round(its / dt, 3),
         "sample": "%d CG iterations of the same %dx%dx%dx%d workload (same links/source), C+OpenMP oracle" % (
             its, lat[0], lat[1], lat[2], lat[3]),

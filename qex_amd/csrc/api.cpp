@@ -3,6 +3,7 @@
 // the same choreography as qudaSolveXX (src/quda/qudaWrapperImpl.nim:165-261).
 #include "qexhip_internal.h"
 #include "../../include/qexhip.h"
+#include <algorithm>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -89,7 +90,8 @@ extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], 
   HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
-  c->npartials = 3 * 2048 + 64;
+  c->part2_off = std::max(6144, (c->g.Vh + 255) / 256 + 8);   // >= 6*1024 for the plaquette partials
+  c->npartials = c->part2_off + 2048 + 64;
   HIPCHK(hipMalloc((void **)&c->partials, sizeof(double) * c->npartials));
   HIPCHK(hipMalloc((void **)&c->dscal, sizeof(double) * 64));
   HIPCHK(hipMemset(c->dscal, 0, sizeof(double) * 64));

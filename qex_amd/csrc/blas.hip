@@ -241,7 +241,7 @@ int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity) {
 int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity, int ndot) {
   size_t n = body2(c);
   int nb = grid_for(n);
-  double *r2p = c->partials + 4096;
+  double *r2p = c->partials + c->part2_off;
   {
     ScopedTimer tm(c, "blas", c->stream);
     k_cg_update<<<nb, 256, 0, c->stream>>>(x.par(parity), r.par(parity), p.par(parity), Ap.par(parity), n, c->cg, r2p,

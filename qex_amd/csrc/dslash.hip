@@ -203,9 +203,14 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
     nparts = nb_int + nb_lo + (g.Vh - hi_beg + 255) / 256;
   }
   if (o.dot) {
-    if (nparts > 4096) { qexhip_set_error("internal: partial buffer too small"); return -3; }
-    if (o.dot == 2 && o.nparts_out) *o.nparts_out = nparts;
-    else CHK(reduce_partials(c, nparts, o.dot_out));
+    if (nparts > c->part2_off) { qexhip_set_error("internal: partial buffer too small"); return -3; }
+    // deferred final sum (inside k_cg_update) only while every workgroup can afford to re-sum the
+    // partials itself; big local volumes take the separate one-block reduction
+    if (o.dot == 2 && o.nparts_out && nparts <= 4096) *o.nparts_out = nparts;
+    else {
+      if (o.nparts_out) *o.nparts_out = 0;
+      CHK(reduce_partials(c, nparts, o.dot_out));
+    }
   }
   return 0;
 }

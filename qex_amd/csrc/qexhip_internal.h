@@ -79,7 +79,8 @@ struct qexhip_ctx {
   int next_field = 1;
   // scratch
   double *stage = nullptr; size_t stage_bytes = 0;   // host-format staging on device
-  double *partials = nullptr; int npartials = 0;     // block partial sums
+  double *partials = nullptr; int npartials = 0;     // block partial sums: [0,part2_off) Dslash / redot, then 2048 for the CG update
+  int part2_off = 0;
   double *dscal = nullptr;                           // device scalars (reductions)
   CgScal *cg = nullptr;                              // device CG state
   double *hist = nullptr; int histcap = 0;           // device residual history

@@ -40,26 +40,28 @@ def rephase(lo, g, t_offset=0, t_global=None):
     stagPhase(lo, g, t_offset=t_offset)
 
 
-def synthetic_random_su3(lo, seed=987654321, spread=None):
+def synthetic_random_su3(lo, seed=987654321, spread=None, chunk=1 << 18):
     """Synthetic SU(3) configuration for benchmarks (numpy; NOT QEX's RngMilc6 stream -- the
-    oracle reproduces that one for the parity tests).  Haar-like: QR of a complex Gaussian,
-    phases fixed, determinant rotated to 1.  With `spread`, links are exp-like close to unity
-    (a 'warm' start, better conditioned)."""
+    oracle reproduces that one for the parity tests).  Rows 0,1 of a complex Gaussian matrix are
+    orthonormalised (Gram-Schmidt), row 2 = conj(row0 x row1), which gives det = 1 exactly.
+    With `spread`, links are close to unity (a 'warm' start, better conditioned).  Generated in
+    chunks to bound the temporary memory (a 48^3x96 field is 6 GB)."""
     rng = np.random.default_rng(seed)
     n = lo.vol * 4
-    a = rng.standard_normal((n, 3, 3)) + 1j * rng.standard_normal((n, 3, 3))
-    if spread is not None:
-        a = np.eye(3)[None] + spread * a
-    q, r = np.linalg.qr(a)
-    d = np.diagonal(r, axis1=1, axis2=2)
-    q = q * (d / np.abs(d))[:, None, :]
-    det = np.linalg.det(q)
-    q = q * np.exp(-1j * np.angle(det) / 3.0)[:, None, None]
-    g = np.empty((lo.vol, 4, 3, 3, 2))
-    q = q.reshape(lo.vol, 4, 3, 3)
-    g[..., 0] = q.real
-    g[..., 1] = q.imag
-    return g
+    g = np.empty((n, 3, 3, 2))
+    for i0 in range(0, n, chunk):
+        m = min(chunk, n - i0)
+        a = rng.standard_normal((m, 2, 3)) + 1j * rng.standard_normal((m, 2, 3))
+        if spread is not None:
+            a = np.eye(3)[None, :2] + spread * a
+        r0 = a[:, 0] / np.linalg.norm(a[:, 0], axis=1)[:, None]
+        r1 = a[:, 1] - np.sum(r0.conj() * a[:, 1], axis=1)[:, None] * r0
+        r1 /= np.linalg.norm(r1, axis=1)[:, None]
+        r2 = np.conj(np.cross(r0, r1))
+        q = np.stack([r0, r1, r2], axis=1)
+        g[i0:i0 + m, :, :, 0] = q.real
+        g[i0:i0 + m, :, :, 1] = q.imag
+    return g.reshape(lo.vol, 4, 3, 3, 2)
 
 
 def synthetic_gaussian_vector(lo, seed=12345):
