@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqexhip.so")
+LIB_PATH = os.environ.get("QEXHIP_LIB", os.path.join(_HERE, "libqexhip.so"))  # override: A/B builds
 _lib = None
 
 # every symbol include/qexhip.h declares: (name, restype, argtypes)

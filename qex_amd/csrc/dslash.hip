@@ -31,15 +31,24 @@ struct DslashArgs {
 
 typedef double d2v __attribute__((ext_vector_type(2)));
 
+// acc += U v  (SUB = false)  /  acc -= U v  (SUB = true); every term one v_fma_f64
+template <bool SUB>
 __device__ __forceinline__ void mv3(double2 acc[3], const double2 U[9], const double2 v[3]) {
 #pragma unroll
   for (int i = 0; i < 3; i++) {
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      acc[i].x += U[3 * i + j].x * v[j].x;
-      acc[i].x -= U[3 * i + j].y * v[j].y;
-      acc[i].y += U[3 * i + j].x * v[j].y;
-      acc[i].y += U[3 * i + j].y * v[j].x;
+      if (!SUB) {
+        acc[i].x += U[3 * i + j].x * v[j].x;
+        acc[i].x -= U[3 * i + j].y * v[j].y;
+        acc[i].y += U[3 * i + j].x * v[j].y;
+        acc[i].y += U[3 * i + j].y * v[j].x;
+      } else {
+        acc[i].x -= U[3 * i + j].x * v[j].x;
+        acc[i].x += U[3 * i + j].y * v[j].y;
+        acc[i].y -= U[3 * i + j].x * v[j].y;
+        acc[i].y -= U[3 * i + j].y * v[j].x;
+      }
     }
   }
 }
@@ -70,15 +79,15 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
     if (INIT) {
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        acc[k].x = A.cb * xsv[k].x;
-        acc[k].y = A.cb * xsv[k].y;
+        acc[k].x = (A.sgn * A.cb) * xsv[k].x;
+        acc[k].y = (A.sgn * A.cb) * xsv[k].y;
       }
       if (A.ca != 0.0) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
           double2 r = A.rin[vec_off(c, k)];
-          acc[k].x += A.ca * r.x;
-          acc[k].y += A.ca * r.y;
+          acc[k].x += (A.sgn * A.ca) * r.x;
+          acc[k].y += (A.sgn * A.ca) * r.y;
         }
       }
     } else {
@@ -86,31 +95,48 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
       for (int k = 0; k < 3; k++) acc[k] = make_double2(0.0, 0.0);
     }
     const double2 *w = A.W + (size_t)(c >> 6) * (NDIR * 576) + (c & 63);
-#pragma unroll
-    for (int d = 0; d < NDIR; d++) {
-      const int mu = (d >> 1) & 3;
-      const int hop = (d >= 8 ? 3 : 1) * ((d & 1) ? -1 : 1);
-      int pos = nbr_pos<HALO>(g, c, s, mu, hop);
-      double2 U[9], v[3];
+    // One loop iteration = the forward and the backward hop of one direction (fat links: pairs
+    // 0..3, 3-hop links: pairs 4..7).  How far the loop is unrolled decides how many link loads a
+    // wave keeps in flight.  Measured inside CG on 32^4 (scratch A/B builds, 2 rounds):
+    //   1-hop: rolled 117 us, x2 120 us, fully unrolled 113.6 us (all 96 loads in flight, 256 VGPRs)
+    //   Naik : rolled 215 us, x2 210 us, x4 222 us; FULLY unrolled hipcc hoists all 192 loads and
+    //          spills to scratch (290-330 us) -- never unroll the 16-link loop completely.
+    // mu/hop are wave-uniform, so the neighbour arithmetic of the rolled loop branches on scalars.
+    constexpr int UNR = (NDIR == 8) ? 4 : 2;
+#pragma unroll UNR
+    for (int pr = 0; pr < NDIR / 2; pr++) {
+      const int mu = pr & 3;
+      const int hop = pr >= 4 ? 3 : 1;
+      const int pf = nbr_pos<HALO>(g, c, s, mu, hop);
+      const int pb = nbr_pos<HALO>(g, c, s, mu, -hop);
+      const double2 *wp = w + (size_t)pr * 1152;
+      double2 U[9], W[9], vf[3], vb[3];
+      // links are read exactly once per sweep: stream them past the caches (non-temporal), which
+      // leaves L2 / Infinity Cache to the 8x re-read neighbour vectors.  Measured on MI355X,
+      // 32^4: 120 us -> 108 us per sweep (scratch/tune_dslash.py, profiles/r01_tune_dslash.log).
 #pragma unroll
       for (int k = 0; k < 9; k++) {
-        // links are read exactly once per sweep: stream them past the caches (non-temporal), which
-        // leaves L2 / Infinity Cache to the 8x re-read neighbour vectors.  Measured on MI355X,
-        // 32^4: 120 us -> 108 us per sweep (scratch/tune_dslash.py, profiles/r01_tune_dslash.log).
-        d2v t = __builtin_nontemporal_load((const d2v *)&w[(size_t)d * 576 + k * 64]);
+        d2v t = __builtin_nontemporal_load((const d2v *)&wp[k * 64]);
         U[k] = make_double2(t.x, t.y);
       }
-      const double sg = (d & 1) ? -A.sgn : A.sgn;
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        double2 t = A.in[vec_off(pos, k)];
-        v[k] = make_double2(sg * t.x, sg * t.y);
+      for (int k = 0; k < 9; k++) {
+        d2v t = __builtin_nontemporal_load((const d2v *)&wp[576 + k * 64]);
+        W[k] = make_double2(t.x, t.y);
       }
-      mv3(acc, U, v);
+#pragma unroll
+      for (int k = 0; k < 3; k++) vf[k] = A.in[vec_off(pf, k)];
+#pragma unroll
+      for (int k = 0; k < 3; k++) vb[k] = A.in[vec_off(pb, k)];
+      // forward hops add, backward hops subtract (compile-time sign: no per-direction multiply).
+      // stagDM's overall minus sign is carried by the initial value and the final scale: negation is
+      // exact, so init - sum == -((-init) + sum) bit for bit.
+      mv3<false>(acc, U, vf);
+      mv3<true>(acc, W, vb);
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      acc[k].x *= A.post; acc[k].y *= A.post;
+      acc[k].x *= (A.sgn * A.post); acc[k].y *= (A.sgn * A.post);
       if (A.ntstore) {
         d2v t; t.x = acc[k].x; t.y = acc[k].y;
         __builtin_nontemporal_store(t, (d2v *)&A.out[vec_off(c, k)]);

@@ -30,7 +30,7 @@ __device__ __forceinline__ void mv3t(double2 acc[3], const double2 U[9], const d
 
 // VAR bit0: non-temporal link loads; bit1: scheduling fence per direction pair;
 //     bit2: non-temporal output stores; bit3: fence per single direction
-template <int VAR, int BS, int MINW>
+template <int VAR, int BS, int MINW, int NDIR = 8>
 __global__ void __launch_bounds__(BS, MINW) k_tune(TuneArgs A) {
   int bid = blockIdx.x;
   if (A.swz) {
@@ -44,11 +44,11 @@ __global__ void __launch_bounds__(BS, MINW) k_tune(TuneArgs A) {
   double2 acc[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) acc[k] = make_double2(0.0, 0.0);
-  const double2 *w = A.W + (size_t)(c >> 6) * (8 * 576) + (c & 63);
+  const double2 *w = A.W + (size_t)(c >> 6) * (NDIR * 576) + (c & 63);
 #pragma unroll
-  for (int d = 0; d < 8; d++) {
+  for (int d = 0; d < NDIR; d++) {
     const int mu = (d >> 1) & 3;
-    const int hop = (d & 1) ? -1 : 1;
+    const int hop = (d >= 8 ? 3 : 1) * ((d & 1) ? -1 : 1);
     int pos = nbr_pos<false>(g, c, s, mu, hop);
     double2 U[9], v[3];
 #pragma unroll
@@ -81,16 +81,17 @@ __global__ void __launch_bounds__(BS, MINW) k_tune(TuneArgs A) {
   }
 }
 
-template <int VAR, int BS, int MINW>
+template <int VAR, int BS, int MINW, int NDIR = 8>
 static void launch_tune(TuneArgs &A, int swz_on, hipStream_t st) {
   int nb = (A.g.Vh + BS - 1) / BS;
   A.swz = (swz_on && nb >= 64 && (nb & 7) == 0) ? nb : 0;
-  k_tune<VAR, BS, MINW><<<nb, BS, 0, st>>>(A);
+  k_tune<VAR, BS, MINW, NDIR><<<nb, BS, 0, st>>>(A);
 }
 
 // variant ids: see table in tests/../scratch/tune_dslash.py
 extern "C" int qexhip_tune_dslash(qexhip_handle c, int variant, int swz, int nrep, double *avg_us) {
-  if (!c || !c->W || c->ndir != 8 || c->g.halo) { qexhip_set_error("tune: needs plain links, no halo"); return -1; }
+  if (!c || !c->W || c->g.halo) { qexhip_set_error("tune: needs links, no halo"); return -1; }
+  if ((variant >= 100) != (c->ndir == 16)) { qexhip_set_error("tune: variants >= 100 are the Naik ones"); return -1; }
   DevField *fin, *fout;
   CHK(get_work(c, WK_IN, &fin));
   CHK(get_work(c, WK_OUT, &fout));
@@ -119,6 +120,13 @@ extern "C" int qexhip_tune_dslash(qexhip_handle c, int variant, int swz, int nre
       case 11: launch_tune<0, 256, 4>(A, swz, c->stream); break;
       case 12: launch_tune<2, 256, 3>(A, swz, c->stream); break;
       case 13: launch_tune<7, 256, 1>(A, swz, c->stream); break;
+      case 100: launch_tune<5, 256, 1, 16>(A, swz, c->stream); break;
+      case 101: launch_tune<7, 256, 1, 16>(A, swz, c->stream); break;
+      case 102: launch_tune<13, 256, 1, 16>(A, swz, c->stream); break;
+      case 103: launch_tune<5, 128, 1, 16>(A, swz, c->stream); break;
+      case 104: launch_tune<5, 512, 1, 16>(A, swz, c->stream); break;
+      case 105: launch_tune<0, 256, 1, 16>(A, swz, c->stream); break;
+      case 106: launch_tune<5, 256, 3, 16>(A, swz, c->stream); break;
       default: break;
     }
   };
