@@ -1,0 +1,194 @@
+// qexhip.hpp -- C++ host-side mirror of QEX's staggered operator / solver interface over the C ABI.
+//
+// QEX's host code is Nim compiled to C; the toolchain is not available in this build image, so
+// this header is the compiled-language host layer above include/qexhip.h: same names, argument
+// meaning and error behaviour as the reference, so a test written against it reads like the
+// reference's own (tests/examples/testStagProp.nim, src/physics/stagSolve.nim:516-680):
+//
+//   Layout, ColorVector(), newGauge()         src/layout/layoutX.nim:70, src/physics/qcdTypes.nim
+//   setBC / stagPhase / rephase               src/gauge/gaugeUtils.nim:124-131, src/physics/stagD.nim:72-80,509-520
+//   newStag(g) / newStag3(g, g3)              src/physics/stagD.nim:522-564
+//   Staggered::D / Ddag / eoReconstruct       src/physics/stagD.nim:566-586
+//   Staggered::solveEE / solveOO / solve      src/physics/stagSolve.nim:134-138,224-294,347-446
+//   SolverParams                              src/solvers/solverBase.nim:10-58
+//   plaq / gaugeFlow                          src/gauge/gaugeUtils.nim:213-282, src/gauge/wflow.nim:21-67
+//
+// Header-only; link with -lqexhip.  Fields are std::vector<double> in the V=1 even-odd host format
+// (colour vector [vol][3][2], gauge [vol][4][3][3][2]).  Errors throw qex::Error (QEX aborts with
+// qexError, src/base/qexInternal.nim:37-45); not converging within maxits is not an error.
+#pragma once
+#include "qexhip.h"
+#include <array>
+#include <chrono>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace qex {
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+inline void check(int rc) {
+  if (rc != 0) throw Error(std::string("libqexhip error ") + std::to_string(rc) + ": " + qexhip_last_error());
+}
+
+using Field = std::vector<double>;
+
+// V=1 even-odd layout of the rank-local lattice (src/layout/qlayout.nim:110-131)
+struct Layout {
+  std::array<int, 4> physGeom;
+  int nSites, nEven;
+  std::vector<std::array<int, 4>> coords;  // coords[idx]
+  explicit Layout(const std::array<int, 4> &lat) : physGeom(lat) {
+    nSites = lat[0] * lat[1] * lat[2] * lat[3];
+    nEven = nSites / 2;
+    coords.resize(nSites);
+    std::array<int, 4> x;
+    for (x[3] = 0; x[3] < lat[3]; x[3]++)
+      for (x[2] = 0; x[2] < lat[2]; x[2]++)
+        for (x[1] = 0; x[1] < lat[1]; x[1]++)
+          for (x[0] = 0; x[0] < lat[0]; x[0]++) coords[index(x)] = x;
+  }
+  int index(const std::array<int, 4> &x) const {
+    int lex = 0, p = 0;
+    for (int i = 3; i >= 0; i--) lex = lex * physGeom[i] + x[i];
+    for (int i = 0; i < 4; i++) p += x[i];
+    return (p & 1) ? (lex + nSites) / 2 : lex / 2;
+  }
+  Field ColorVector() const { return Field((size_t)nSites * 6, 0.0); }
+  Field newGauge() const { return Field((size_t)nSites * 72, 0.0); }
+};
+
+// U_3 *= -1 on the last t slice (gaugeUtils.nim:124-131)
+inline void setBC(const Layout &lo, Field &g) {
+  for (int s = 0; s < lo.nSites; s++)
+    if (lo.coords[s][3] == lo.physGeom[3] - 1)
+      for (int k = 0; k < 18; k++) g[((size_t)s * 4 + 3) * 18 + k] *= -1.0;
+}
+// eta_mu from the bit masks [8,9,11,0] (stagD.nim:509-520)
+inline void stagPhase(const Layout &lo, Field &g, const std::array<int, 4> &phases = {8, 9, 11, 0}) {
+  for (int mu = 0; mu < 4; mu++)
+    for (int i = 0; i < lo.nSites; i++) {
+      int s = 0;
+      for (int k = 0; k < 4; k++) s += (phases[mu] >> k) & lo.coords[i][k];
+      if (s & 1)
+        for (int k = 0; k < 18; k++) g[((size_t)i * 4 + mu) * 18 + k] *= -1.0;
+    }
+}
+inline void rephase(const Layout &lo, Field &g) { setBC(lo, g); stagPhase(lo, g); }
+
+// solverBase.nim:10-58
+struct SolverParams {
+  double r2req = 1e-6;
+  int maxits = 50000;
+  int verbosity = 1;
+  // outputs
+  int calls = 0, iterations = 0, iterationsMax = 0;
+  double seconds = 0, flops = 0, r2 = 0;
+  std::vector<double> r2hist;  // "CG iteration: k  r2/b2:" values when histcap > 0
+  void resetStats() { calls = iterations = iterationsMax = 0; seconds = flops = r2 = 0; r2hist.clear(); }
+  int finalIterations() const { return iterations; }
+};
+
+class Context {
+ public:
+  qexhip_handle h = nullptr;
+  Layout lo;
+  explicit Context(const std::array<int, 4> &latLocal, int device = 0,
+                   const std::array<int, 4> &rankGeom = {1, 1, 1, 1}, const std::array<int, 4> &rankCoord = {0, 0, 0, 0})
+      : lo(latLocal) {
+    check(qexhip_init(&h, device, latLocal.data(), rankGeom.data(), rankCoord.data()));
+  }
+  ~Context() { if (h) qexhip_finalize(h); }
+  Context(const Context &) = delete;
+  Context &operator=(const Context &) = delete;
+  std::string info() const { char b[512]; check(qexhip_device_info(h, b, 512)); return b; }
+};
+
+class Staggered {
+  Context &c_;
+  int nlinks_;
+  double flops(int its) const { return double(nlinks_ * 4 * 72 + 60) * c_.lo.nEven * its; }  // stagSolve.nim:92
+  template <class F> void timed(SolverParams &sp, int &its, F &&f) {
+    auto t0 = std::chrono::steady_clock::now();
+    f();
+    sp.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    sp.calls += 1; sp.iterations += its; sp.iterationsMax = std::max(sp.iterationsMax, its); sp.flops += flops(its);
+  }
+
+ public:
+  Staggered(Context &c, const Field &g) : c_(c), nlinks_(4) { check(qexhip_stag_set_links(c.h, g.data(), nullptr)); }
+  Staggered(Context &c, const Field &g, const Field &g3) : c_(c), nlinks_(8) { check(qexhip_stag_set_links(c.h, g.data(), g3.data())); }
+  void D(Field &r, const Field &x, double m) { check(qexhip_stag_D(c_.h, r.data(), x.data(), m, 1.0)); }
+  void Ddag(Field &r, const Field &x, double m) { check(qexhip_stag_D(c_.h, r.data(), x.data(), m, -1.0)); }
+  void eoReconstruct(Field &r, const Field &b, double m) { check(qexhip_stag_eo_reconstruct(c_.h, r.data(), b.data(), m)); }
+  void stagD2(Field &r, const Field &x, int subset, double a, double b) { check(qexhip_stag_dslash(c_.h, r.data(), x.data(), subset, a, b)); }
+  void stagD2ee(Field &r, const Field &x, double m2) { check(qexhip_stag_op_xx(c_.h, r.data(), x.data(), m2, 1)); }
+  void stagD2oo(Field &r, const Field &x, double m2) { check(qexhip_stag_op_xx(c_.h, r.data(), x.data(), m2, 0)); }
+  // solveXX(s, r, x, m, sp, parEven): r <- solution, x = rhs (stagSolve.nim:57-132)
+  void solveXX(Field &r, const Field &x, double m, SolverParams &sp, bool parEven = true, int histcap = 0) {
+    int its = 0; double fin = 0;
+    std::vector<double> hist(histcap > 0 ? histcap : 1);
+    timed(sp, its, [&] {
+      check(qexhip_stag_solve_xx(c_.h, r.data(), x.data(), m, sp.r2req, sp.maxits, parEven ? 1 : 0, &its, &fin, hist.data(), histcap));
+    });
+    sp.r2 = fin;
+    sp.r2hist.assign(hist.begin(), hist.begin() + (histcap > 0 ? std::min(histcap, its + 1) : 0));
+  }
+  void solveEE(Field &r, const Field &x, double m, SolverParams &sp, int histcap = 0) { solveXX(r, x, m, sp, true, histcap); }
+  void solveOO(Field &r, const Field &x, double m, SolverParams &sp, int histcap = 0) { solveXX(r, x, m, sp, false, histcap); }
+  // Staggered.solve(x, b, m, sp): full lattice, even-odd preconditioned, true-residual restarts
+  void solve(Field &x, const Field &b, double m, SolverParams &sp) {
+    int its = 0; double fin = 0;
+    timed(sp, its, [&] { check(qexhip_stag_solve(c_.h, x.data(), b.data(), m, sp.r2req, sp.maxits, &its, &fin)); });
+    sp.r2 = fin;
+  }
+  // convenience form used by the reference's tests: s.solve(v2, v1, m, 1e-8) (stagSolve.nim:462-472)
+  void solve(Field &x, const Field &b, double m, double res) {
+    SolverParams sp; sp.r2req = res * res; sp.maxits = 100000;
+    solve(x, b, m, sp);
+  }
+  // multi-mass Staggered.solve(xs, b, ms, sp) (stagSolve.nim:347-446)
+  void solve(std::vector<Field> &xs, const Field &b, const std::vector<double> &ms, SolverParams &sp) {
+    std::vector<double *> p;
+    for (auto &x : xs) p.push_back(x.data());
+    int its = 0; double fin = 0;
+    timed(sp, its, [&] { check(qexhip_stag_solve_multi(c_.h, p.data(), b.data(), ms.data(), (int)ms.size(), sp.r2req, sp.maxits, &its, &fin)); });
+    sp.r2 = fin;
+  }
+};
+inline Staggered newStag(Context &c, const Field &g) { return Staggered(c, g); }
+inline Staggered newStag3(Context &c, const Field &g, const Field &g3) { return Staggered(c, g, g3); }
+
+// plaq(g) (gaugeUtils.nim:213-282)
+inline std::array<double, 6> plaq(Context &c, const Field &g) {
+  std::array<double, 6> p;
+  check(qexhip_gauge_set(c.h, g.data()));
+  check(qexhip_plaq(c.h, p.data()));
+  return p;
+}
+// g.gaugeFlow(steps, eps): measure(wflowT)  (wflow.nim:21-67); g is modified in place
+template <class Measure>
+inline void gaugeFlow(Context &c, Field &g, int steps, double eps, Measure &&measure) {
+  check(qexhip_gauge_set(c.h, g.data()));
+  for (int n = 1; n <= steps; n++) {
+    check(qexhip_wflow(c.h, 1, eps));
+    measure(n * eps);
+  }
+  check(qexhip_gauge_get(c.h, g.data()));
+}
+inline void gaugeFlow(Context &c, Field &g, int steps, double eps) {
+  check(qexhip_gauge_set(c.h, g.data()));
+  check(qexhip_wflow(c.h, steps, eps));
+  check(qexhip_gauge_get(c.h, g.data()));
+}
+
+// field algebra used by the reference's tests (fieldET.nim:605-625)
+inline double norm2(Context &c, const Field &x, int subset = QEXHIP_ALL) {
+  double r = 0;
+  check(qexhip_norm2(c.h, x.data(), subset, &r));
+  return r;
+}
+
+}  // namespace qex
