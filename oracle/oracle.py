@@ -67,6 +67,8 @@ def lib():
         L.qo_solve.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, vp]
         L.qo_solveXX_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp, ci]
         L.qo_solve_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, vp]
+        L.qo_flow_EQ.argtypes = [vp, vp, ci, vp]
+        L.qo_wline.argtypes = [vp, vp, C.POINTER(ci), ci, vp]
         L.qo_set_num_threads.argtypes = [ci]
         L.qo_set_num_threads(_cpu_share())
         _lib = L
@@ -220,6 +222,18 @@ def gauge_deriv(lo, g, cplaq=1.0):
 
 def wflow(lo, g, nsteps, eps):
     lib().qo_wflow(lo._h, _p(g), nsteps, eps)
+
+
+def flow_EQ(lo, g, loop=1):
+    out = np.zeros(3)
+    lib().qo_flow_EQ(lo._h, _p(g), loop, _p(out))
+    return out
+
+
+def wline(lo, g, path):
+    out = np.zeros(2)
+    lib().qo_wline(lo._h, _p(g), (C.c_int * len(path))(*path), len(path), _p(out))
+    return complex(out[0], out[1])
 
 
 def su3_fn(name, x):

@@ -1079,3 +1079,143 @@ void qo_set_num_threads(int n) {
   (void)n;
 #endif
 }
+
+/* ------------------------------------------------------------------ */
+/* flow observables: F_munu from clover-type loops, E, Q, Wilson lines */
+/* (src/gauge/gaugeUtils.nim:1079-1270)           */
+/* ------------------------------------------------------------------ */
+/* ordered product of links along `path` (entries +-(d+1)) starting and ending at site x
+ * ("origin=true" of gaugeProd, gaugeUtils.nim:951-1077; convention fixed by
+ * tests/base/tgaugeprod.nim:13-19: [1,2,-1,-2] is the plaquette U_0(x)U_1(x+0)U_0(x+1)^+U_1(x)^+) */
+static void path_prod(const qo_layout *lo, const double *g, int x, const int *path, int n, double *out) {
+  double m[18], t[18];
+  m_unit(m);
+  int cur = x;
+  for (int i = 0; i < n; i++) {
+    int s = path[i];
+    if (s > 0) {
+      int d = s - 1;
+      m_mul(t, m, GLINK(g, cur, d));
+      cur = lo->nb[d][0][cur];
+    } else {
+      int d = -s - 1;
+      cur = lo->nb[d][1][cur];
+      m_mul_na(t, m, GLINK(g, cur, d));
+    }
+    m_copy(m, t);
+  }
+  m_copy(out, m);
+}
+
+/* allCorners (gaugeUtils.nim:1114-1126): the rotations of a closed path that start at a corner */
+static int all_corners(const int *path, int np, int out[][16]) {
+  int n = 0, old = 0;
+  for (int i = 0; i < np; i++) {
+    if (path[i] != old) {
+      for (int j = 0; j < np; j++) out[n][j] = path[(j + i) % np];
+      n++;
+      old = path[i];
+    }
+  }
+  return n;
+}
+
+/* fmunuCoeffs (gaugeUtils.nim:1128-1146) */
+static void fmunu_coeffs(int loop, double k[5]) {
+  for (int i = 0; i < 5; i++) k[i] = 0;
+  if (loop == 1) { k[0] = 1.0; return; }
+  k[4] = (loop == 3) ? 1.0 / 90.0 : (loop == 5 ? 1.0 / 180.0 : 0.0);
+  k[0] = 19.0 / 9.0 - 55.0 * k[4];
+  k[1] = 1.0 / 36.0 - 16.0 * k[4];
+  k[2] = 64.0 * k[4] - 32.0 / 45.0;
+  k[3] = 1.0 / 15.0 - 6.0 * k[4];
+}
+
+/* fmunu(g, mu, nu, loop) (gaugeUtils.nim:1162-1218): traceless anti-Hermitian F_munu from the
+ * 1x1 (, 2x2, 1x2/2x1, 1x3/3x1, 3x3) clover leaves.  f: [vol][18] */
+static void fmunu_plane(const qo_layout *lo, const double *g, int mu, int nu, int loop, double *f) {
+  int paths[32][16], lens[32], group[32], np = 0;
+  const int a = mu + 1, b = nu + 1;
+  int tmp[8][16];
+#define ADDLOOP(grp, ...) do { const int p_[] = {__VA_ARGS__}; int l_ = (int)(sizeof(p_) / sizeof(int)); \
+    int c_ = all_corners(p_, l_, tmp); for (int q_ = 0; q_ < c_; q_++) { for (int j_ = 0; j_ < l_; j_++) paths[np][j_] = tmp[q_][j_]; lens[np] = l_; group[np] = grp; np++; } } while (0)
+  ADDLOOP(0, -a, -b, a, b);                                             /* 1x1 */
+  if (loop >= 3) ADDLOOP(1, -a, -a, -b, -b, a, a, b, b);                /* 2x2 */
+  if (loop >= 4) {
+    ADDLOOP(2, -a, -a, -b, a, a, b);                                    /* 2x1 */
+    ADDLOOP(2, -a, -b, -b, a, b, b);                                    /* 1x2 */
+    ADDLOOP(3, -a, -a, -a, -b, a, a, a, b);                             /* 3x1 */
+    ADDLOOP(3, -a, -b, -b, -b, a, b, b, b);                             /* 1x3 */
+  }
+  if (loop == 3 || loop == 5) ADDLOOP(4, -a, -a, -a, -b, -b, -b, a, a, a, b, b, b);  /* 3x3 */
+#undef ADDLOOP
+  static const int lpc[5] = {4, 4, 8, 8, 4};
+  double cs[5];
+  fmunu_coeffs(loop, cs);
+#pragma omp parallel for schedule(static)
+  for (int x = 0; x < lo->vol; x++) {
+    double acc[18], grp[5][18], m[18];
+    m_zero(acc);
+    for (int j = 0; j < 5; j++) m_zero(grp[j]);
+    for (int p = 0; p < np; p++) {
+      path_prod(lo, g, x, paths[p], lens[p], m);
+      for (int k = 0; k < 18; k++) grp[group[p]][k] += m[k];
+    }
+    for (int j = 0; j < 5; j++) {
+      const double ni = cs[j] / (double)lpc[j];
+      for (int k = 0; k < 18; k++) acc[k] += ni * grp[j][k];
+    }
+    qo_projectTAH(&f[(size_t)x * 18], acc);
+  }
+}
+
+/* reTrMul (gaugeUtils.nim:1234-1239): sum_x Re tr( x y ) */
+static double retr_mul(const qo_layout *lo, const double *x, const double *y) {
+  double s = 0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
+  for (int i = 0; i < lo->vol; i++) {
+    const double *a = &x[(size_t)i * 18], *b = &y[(size_t)i * 18];
+    double t = 0;
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) t += RE(a, r, c) * RE(b, c, r) - IM(a, r, c) * IM(b, c, r);
+    s += t;
+  }
+  return s;
+}
+
+/* EQ of tests/base/twflow_topo.nim:4-10: [E_s, E_t, Q] from fmunu(loop), densityE
+ * (gaugeUtils.nim:1241-1257) and topoQ (:1259-1271) */
+void qo_flow_EQ(const qo_layout *lo, const double *g, int loop, double out[3]) {
+  double *F[6];
+  for (int i = 0; i < 6; i++) F[i] = (double *)malloc(sizeof(double) * 18 * (size_t)lo->vol);
+  for (int mu = 1; mu < 4; mu++)
+    for (int nu = 0; nu < mu; nu++) fmunu_plane(lo, g, mu, nu, loop, F[(mu * (mu - 1)) / 2 + nu]);
+  double es = 0, et = 0;
+  for (int mu = 1; mu < 4; mu++)
+    for (int nu = 0; nu < mu; nu++) {
+      const double *f = F[(mu * (mu - 1)) / 2 + nu];
+      double t = retr_mul(lo, f, f);
+      if (mu < 3) es += t; else et += t;
+    }
+  const double vi = -1.0 / (double)lo->vol;
+  /* f[1][0] f[3][2] - f[2][0] f[3][1] + f[2][1] f[3][0] */
+  double a = retr_mul(lo, F[0], F[5]), b = retr_mul(lo, F[1], F[4]), c = retr_mul(lo, F[2], F[3]);
+  out[0] = vi * es;
+  out[1] = vi * et;
+  out[2] = -1.0 / (4.0 * 3.14159265358979323846 * 3.14159265358979323846) * (a - b + c);
+  for (int i = 0; i < 6; i++) free(F[i]);
+}
+
+/* wline (gaugeUtils.nim:1079-1112): volume- and colour-averaged trace of the path product */
+void qo_wline(const qo_layout *lo, const double *g, const int *path, int n, double out[2]) {
+  double sr = 0, si = 0;
+#pragma omp parallel for reduction(+ : sr, si) schedule(static)
+  for (int x = 0; x < lo->vol; x++) {
+    double m[18];
+    path_prod(lo, g, x, path, n, m);
+    sr += RE(m,0,0) + RE(m,1,1) + RE(m,2,2);
+    si += IM(m,0,0) + IM(m,1,1) + IM(m,2,2);
+  }
+  const double fac = 1.0 / ((double)lo->vol * 3.0);
+  out[0] = sr * fac; out[1] = si * fac;
+}

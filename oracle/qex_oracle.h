@@ -73,6 +73,10 @@ void qo_gauge_force(const qo_layout *lo, const double *g, double *f);   /* gauge
 void qo_gauge_deriv(const qo_layout *lo, const double *g, double *f, double cplaq); /* :148-204 */
 void qo_wflow(const qo_layout *lo, double *g, int nsteps, double eps);  /* wflow.nim:21-67 */
 
+/* ---- flow observables (gaugeUtils.nim:1079-1270): out = {E_s, E_t, Q} ---- */
+void qo_flow_EQ(const qo_layout *lo, const double *g, int loop, double out[3]);
+void qo_wline(const qo_layout *lo, const double *g, const int *path, int n, double out[2]);
+
 /* ---- field algebra (fieldET.nim:605-625,704-724) ; parity: 0 even, 1 odd, 2 all ---- */
 double qo_norm2(const qo_layout *lo, const double *x, int parity);
 double qo_redot(const qo_layout *lo, const double *x, const double *y, int parity);

@@ -35,6 +35,55 @@ def test_G2_wilson_flow_plaquettes(oracle):
     assert np.abs(pl - p0).sum() / p0.sum() <= 2e-14
 
 
+G3_TABLES = {
+    # tests/base/twflow_topo.nim:29-62: [E_s, E_t, Q] for loop = 1,3,4,5
+    "t0": {1: [0.9278998428166274, 0.9259837153220379, -0.1798124862963527],
+           3: [2.099099182199596, 2.096760447628166, -0.5037001984505194],
+           4: [3.627286981133991, 3.619461449116142, -0.6989980450588869],
+           5: [2.769773748283728, 2.765062802182978, -0.6040403379495964]},
+    "fine": {1: [0.6597045206103821, 0.6563289799384344, 0.03799796090979355],
+             3: [1.458814621776772, 1.453027521663594, 0.01066005399628158],
+             4: [2.109560159995052, 2.104682631200975, 0.08902327151785866],
+             5: [1.749675334680512, 1.744341716556223, 0.05315490339585562]},
+    "coarse": {1: [0.3330415059918272, 0.3290982076857988, 0.00251688258620615],
+               3: [0.7073852695739449, 0.6993729505801789, -0.008560219145048894],
+               4: [0.9144248903211708, 0.9058947912540163, 0.02577408143748513],
+               5: [0.8013051494825723, 0.7930601360032297, 0.01073616156391243]},
+}
+
+
+def test_G3_wilson_flow_and_topological_charge(oracle):
+    """tests/base/twflow_topo.nim:19-62 (CT = 1e-11): MRG32k3a seed 17^13, warm(0.4); E_s, E_t, Q
+    from fmunu(loop) for loop 1,3,4,5 at t=0, after gaugeFlow(20, 0.005), and after a further
+    gaugeFlow(1, 0.1).  Pins MRG32k3a gaussians, randTah3, warm, exp, the flow and fmunu/E/Q."""
+    o = oracle
+    lo = o.Layout([8, 8, 8, 8])
+    rf = o.RngField(lo, o.RNG_MRG32K3A, 17 ** 13)
+    g = o.gauge_warm(lo, 0.4, rf)
+
+    def check(tab):
+        for loop, want in G3_TABLES[tab].items():
+            got = o.flow_EQ(lo, g, loop)
+            assert np.max(np.abs(got / np.array(want) - 1)) < 1e-11, (tab, loop, got)
+
+    check("t0")
+    o.wflow(lo, g, 20, 0.005)
+    check("fine")
+    o.wflow(lo, g, 1, 0.1)
+    check("coarse")
+
+
+def test_wilson_line_plaquette(oracle):
+    """tests/base/tgaugeprod.nim:13-19: plaq vs the ordered path product [mu,nu,-mu,-nu]."""
+    o = oracle
+    lo = o.Layout([8, 8, 8, 8])
+    g = o.gauge_random(lo)
+    pl = o.plaq(lo, g)
+    lines = [[1, 2, -1, -2], [1, 3, -1, -3], [2, 3, -2, -3], [1, 4, -1, -4], [2, 4, -2, -4], [3, 4, -3, -4]]
+    wl = np.array([o.wline(lo, g, p).real / 6.0 for p in lines])
+    assert np.max(np.abs(pl - wl)) < 1e-15
+
+
 def test_G4_mrg32k3a(oracle):
     """tests/base/tmrg32k3a.nim:9-27 (CT = 1e-13 relative)."""
     o = oracle
