@@ -153,6 +153,11 @@ int qexhip_plaq(qexhip_handle h, double out[6]);
 int qexhip_gauge_force(qexhip_handle h, double *f, double cplaq);
 /* gaugeFlow(steps, eps) (src/gauge/wflow.nim:21-67): RK3 Wilson flow of the resident gauge field */
 int qexhip_wflow(qexhip_handle h, int nsteps, double eps);
+/* EQ of the flow drivers (src/flow/gauge_flow.nim:360-379, tests/base/twflow_topo.nim:4-10):
+ * out = {E_s, E_t, Q} from f = g.fmunu(loop), f.densityE, f.topoQ
+ * (src/gauge/gaugeUtils.nim:1162-1271); loop in {1,3,4,5} selects the clover improvement
+ * (1x1 | +2x2+3x3 | +2x2+1x2+1x3 | all five loop shapes, coefficients of :1128-1146). */
+int qexhip_flow_EQ(qexhip_handle h, int loop, double out[3]);
 
 /* ---------------- kernel timers ----------------
  * hipEvent pairs around launches of the named kernel class on the context stream

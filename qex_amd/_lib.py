@@ -49,6 +49,7 @@ SYMBOLS = [
     ("qexhip_plaq", _ci, [_vp, _vp]),
     ("qexhip_gauge_force", _ci, [_vp, _vp, _cd]),
     ("qexhip_wflow", _ci, [_vp, _ci, _cd]),
+    ("qexhip_flow_EQ", _ci, [_vp, _ci, _vp]),
     ("qexhip_timers_enable", _ci, [_vp, _ci]),
     ("qexhip_timers_reset", _ci, [_vp]),
     ("qexhip_timers_get", _ci, [_vp, C.c_char_p, C.POINTER(C.c_long), _pd]),

@@ -12,6 +12,7 @@
 #include "reduce.h"
 #include "su3.h"
 #include <cstdlib>
+#include <initializer_list>
 
 struct GaugeNat {
   double2 *U = nullptr, *F = nullptr, *P = nullptr;
@@ -166,6 +167,164 @@ __global__ void __launch_bounds__(256) k_exp_update(size_t nlinks_tiles, double2
   M3 e = m3_exp(m3_load(V + o, 64));
   M3 u = m3_load(G + o, 64);
   m3_store(G + o, 64, m3_mul(e, u));
+}
+
+// ---------------- flow observables: F_munu (clover loops), E_s, E_t, Q   ----------------
+// fmunu / densityE / topoQ (src/gauge/gaugeUtils.nim:1162-1271).  The closed paths (all corner
+// rotations of the 1x1, 2x2, 1x2, 2x1, 1x3, 3x1, 3x3 loops, gaugeUtils.nim:1114-1160) are generated on
+// the host into a table; one lane per site walks them (links come from L2), forms the two
+// traceless anti-Hermitian F of a dual pair at a time (F10&F32, F20&F31, F21&F30) and
+// accumulates -Re tr(F F) and the Q density, so no F field is ever written.
+struct ObsPath { signed char step[12]; int len; double coef; };
+struct ObsTable { int np; ObsPath p[28]; };   // paths of plane (mu,nu) = (1,0); others by substitution
+
+__device__ __forceinline__ M3 path_prod(const Geom &g, const double2 *__restrict__ G, const int x0[4],
+                                        const ObsPath &P, int mu, int nu) {
+  int x[4] = {x0[0], x0[1], x0[2], x0[3]};
+  M3 m;
+  bool first = true;
+  for (int i = 0; i < P.len; i++) {
+    const int s = P.step[i];                 // +-1: direction mu, +-2: direction nu
+    const int d = (s == 1 || s == -1) ? mu : nu;
+    M3 u;
+    if (s > 0) {
+      u = m3_load(G + link_off(g, x, d), 64);
+      x[d] = x[d] + 1 >= g.X[d] ? 0 : x[d] + 1;
+      m = first ? u : m3_mul(m, u);
+    } else {
+      x[d] = x[d] == 0 ? g.X[d] - 1 : x[d] - 1;
+      u = m3_load(G + link_off(g, x, d), 64);
+      if (first) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+          for (int q = 0; q < 3; q++) m.e[3 * r + q] = make_double2(u.e[3 * q + r].x, -u.e[3 * q + r].y);
+      } else {
+        m = m3_mul_na(m, u);
+      }
+    }
+    first = false;
+  }
+  return m;
+}
+__device__ __forceinline__ M3 fmunu_site(const Geom &g, const double2 *__restrict__ G, const int x[4],
+                                         const ObsTable *T, int mu, int nu) {
+  M3 acc = m3_zero();
+  for (int p = 0; p < T->np; p++) {
+    M3 m = path_prod(g, G, x, T->p[p], mu, nu);
+    m3_axpy(acc, T->p[p].coef, m);
+  }
+  return m3_tah(acc);
+}
+// Re tr(a b)
+__device__ __forceinline__ double m3_retr_mul(const M3 &a, const M3 &b) {
+  double s = 0;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int q = 0; q < 3; q++) s += a.e[3 * r + q].x * b.e[3 * q + r].x - a.e[3 * r + q].y * b.e[3 * q + r].y;
+  return s;
+}
+__global__ void __launch_bounds__(256) k_flow_obs(Geom g, const double2 *__restrict__ G, const ObsTable *T, double *partials) {
+  double es = 0, et = 0, q = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < g.V; i += gridDim.x * 256) {
+    int p = i >= g.Vh, c = i - p * g.Vh;
+    int x[4];
+    coords_of(g, c, p, x);
+    // dual pairs and the sign of their term in Q = -(1/4pi^2) (F10 F32 - F20 F31 + F21 F30)
+    const int pm[3][4] = {{1, 0, 3, 2}, {2, 0, 3, 1}, {2, 1, 3, 0}};
+    const double sg[3] = {1.0, -1.0, 1.0};
+#pragma unroll 1
+    for (int k = 0; k < 3; k++) {
+      M3 fa = fmunu_site(g, G, x, T, pm[k][0], pm[k][1]);
+      M3 fb = fmunu_site(g, G, x, T, pm[k][2], pm[k][3]);
+      es += m3_retr_mul(fa, fa);          // (mu,nu) with mu < 3 is spatial
+      et += m3_retr_mul(fb, fb);          // the partner always has mu = 3
+      q += sg[k] * m3_retr_mul(fa, fb);
+    }
+  }
+  double r;
+  r = block_sum_256(es); if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  r = block_sum_256(et); if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = r;
+  r = block_sum_256(q);  if (threadIdx.x == 0) partials[2 * gridDim.x + blockIdx.x] = r;
+}
+__global__ void __launch_bounds__(256) k_obs_final(const double *partials, int nb, double vol, double *out) {
+  for (int k = 0; k < 3; k++) {
+    double acc = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += partials[(size_t)k * nb + i];
+    double r = block_sum_256(acc);
+    if (threadIdx.x == 0) out[k] = (k < 2) ? -r / vol : -r / (4.0 * 3.14159265358979323846 * 3.14159265358979323846);
+  }
+}
+
+// host: build the path table for plane (mu,nu) -> (step +-1, step +-2)
+static int obs_all_corners(const int *path, int np, int out[][12]) {
+  int n = 0, old = 0;
+  for (int i = 0; i < np; i++)
+    if (path[i] != old) {
+      for (int j = 0; j < np; j++) out[n][j] = path[(j + i) % np];
+      n++;
+      old = path[i];
+    }
+  return n;
+}
+static int obs_build_table(int loop, ObsTable &T) {
+  if (loop != 1 && loop != 3 && loop != 4 && loop != 5) { qexhip_set_error("fmunu uses loop in [1,3,4,5], but got %d", loop); return -1; }
+  double k[5] = {0, 0, 0, 0, 0};
+  if (loop == 1) k[0] = 1.0;
+  else {
+    k[4] = (loop == 3) ? 1.0 / 90.0 : (loop == 5 ? 1.0 / 180.0 : 0.0);
+    k[0] = 19.0 / 9.0 - 55.0 * k[4];
+    k[1] = 1.0 / 36.0 - 16.0 * k[4];
+    k[2] = 64.0 * k[4] - 32.0 / 45.0;
+    k[3] = 1.0 / 15.0 - 6.0 * k[4];
+  }
+  static const int lpc[5] = {4, 4, 8, 8, 4};
+  T.np = 0;
+  auto add = [&](int grp, std::initializer_list<int> l) {
+    int path[12], n = 0, tmp[8][12];
+    for (int v : l) path[n++] = v;
+    int c = obs_all_corners(path, n, tmp);
+    for (int q = 0; q < c; q++) {
+      ObsPath &P = T.p[T.np++];
+      for (int j = 0; j < n; j++) P.step[j] = (signed char)tmp[q][j];
+      P.len = n;
+      P.coef = k[grp] / lpc[grp];
+    }
+  };
+  const int a = 1, b = 2;
+  add(0, {-a, -b, a, b});
+  if (loop >= 3) add(1, {-a, -a, -b, -b, a, a, b, b});
+  if (loop >= 4) {
+    add(2, {-a, -a, -b, a, a, b});
+    add(2, {-a, -b, -b, a, b, b});
+    add(3, {-a, -a, -a, -b, a, a, a, b});
+    add(3, {-a, -b, -b, -b, a, b, b, b});
+  }
+  if (loop == 3 || loop == 5) add(4, {-a, -a, -a, -b, -b, -b, a, a, a, b, b, b});
+  return 0;
+}
+
+int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  for (int d = 0; d < 4; d++)
+    if (loop > 1 && c->g.X[d] < 4) { qexhip_set_error("improved fmunu needs extents >= 4"); return -1; }
+  ObsTable T;
+  CHK(obs_build_table(loop, T));
+  static ObsTable *dT = nullptr;
+  if (!dT) HIPCHK(hipMalloc((void **)&dT, sizeof(ObsTable)));
+  HIPCHK(hipMemcpyAsync(dT, &T, sizeof(T), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // T is a stack object
+  int nb = (c->g.V + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  {
+    ScopedTimer tm(c, "flowobs", c->stream);
+    k_flow_obs<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, dT, c->partials);
+    HIPCHK(hipGetLastError());
+  }
+  k_obs_final<<<1, 256, 0, c->stream>>>(c->partials, nb, (double)c->g.V, &c->dscal[24]);
+  HIPCHK(hipGetLastError());
+  return read_scalars(c, &c->dscal[24], 3, out);
 }
 
 static int gn_alloc(qexhip_ctx *c) {

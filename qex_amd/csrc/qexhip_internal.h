@@ -186,4 +186,5 @@ int gauge_get(qexhip_ctx *c, double *g);
 int gauge_plaq(qexhip_ctx *c, double out[6]);
 int gauge_force(qexhip_ctx *c, double *f_host, double cplaq);
 int gauge_wflow(qexhip_ctx *c, int nsteps, double eps);
+int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]);
 void gauge_free(qexhip_ctx *c);

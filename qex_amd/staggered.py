@@ -286,6 +286,16 @@ def gaugeForce(ctx, g, cplaq=1.0):
     return f
 
 
+def flowEQ(ctx, loop=1, g=None):
+    """[E_s, E_t, Q] of the resident (or given) gauge field: g.fmunu(loop) -> densityE, topoQ
+    (gaugeUtils.nim:1162-1271; `EQ` of src/flow/gauge_flow.nim:360-379)."""
+    if g is not None:
+        check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+    out = np.zeros(3)
+    check(lib().qexhip_flow_EQ(ctx._h, int(loop), _p(out)))
+    return out
+
+
 def gaugeFlow(ctx, g, steps, eps, measure=None):
     """g.gaugeFlow(steps, eps): measure (wflow.nim:21-67).  g is modified in place."""
     check(lib().qexhip_gauge_set(ctx._h, _p(g)))

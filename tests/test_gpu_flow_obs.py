@@ -1,0 +1,49 @@
+"""GPU parity of the flow observables: fmunu(loop) -> E_s, E_t, Q through the
+HIP kernels, against the reference's golden set G3 (tests/base/twflow_topo.nim:19-62) and the oracle.
+"""
+import numpy as np
+import pytest
+
+from test_oracle_golden import G3_TABLES
+
+pytestmark = pytest.mark.gpu
+
+
+def test_G3_on_gpu(oracle):
+    """The whole twflow_topo.nim sequence with the flow AND the observables on the GPU."""
+    import qex_amd as q
+
+    o = oracle
+    lo = o.Layout([8, 8, 8, 8])
+    rf = o.RngField(lo, o.RNG_MRG32K3A, 17 ** 13)
+    g = o.gauge_warm(lo, 0.4, rf)
+    ctx = q.Context([8, 8, 8, 8])
+
+    def check(tab):
+        for loop, want in G3_TABLES[tab].items():
+            got = q.flowEQ(ctx, loop)
+            assert np.max(np.abs(got / np.array(want) - 1)) < 1e-11, (tab, loop, got)   # CT of the reference test
+
+    q.plaq(ctx, g)                       # uploads g
+    check("t0")
+    q.gaugeFlow(ctx, g, 20, 0.005)
+    check("fine")
+    q.gaugeFlow(ctx, g, 1, 0.1)
+    check("coarse")
+
+
+def test_flow_obs_vs_oracle_other_lattice(oracle):
+    import qex_amd as q
+
+    o = oracle
+    lat = [4, 6, 8, 4]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 987654321)
+    g = o.gauge_warm(lo, 0.3, rf)
+    ctx = q.Context(lat)
+    for loop in (1, 3, 4, 5):
+        got = q.flowEQ(ctx, loop, g)
+        want = o.flow_EQ(lo, g, loop)
+        assert np.max(np.abs(got - want)) < 1e-12 * max(1.0, np.abs(want).max()), (loop, got, want)
+    with pytest.raises(q.QexHipError):
+        q.flowEQ(ctx, 2)                 # fmunu uses loop in [1,3,4,5]
