@@ -38,6 +38,20 @@ ScopedTimer::~ScopedTimer() {
   (void)hipEventRecord(s->ev[s->used + 1], st);
   s->used += 2;
 }
+bool timer_event_pair(qexhip_ctx *c, const char *name, hipEvent_t *e0, hipEvent_t *e1) {
+  if (!c->timers_on) return false;
+  if (c->timers_on == 2 && strncmp(name, "dslash", 6) != 0) return false;
+  TimerSlot *s = &c->timers[name];
+  if (s->used + 2 > s->ev.size()) {
+    size_t old = s->ev.size();
+    s->ev.resize(old + 512);
+    for (size_t i = old; i < s->ev.size(); i++) (void)hipEventCreate(&s->ev[i]);
+  }
+  *e0 = s->ev[s->used];
+  *e1 = s->ev[s->used + 1];
+  s->used += 2;
+  return true;
+}
 int timers_collect(qexhip_ctx *c) {
   HIPCHK(hipStreamSynchronize(c->stream));
   for (auto &kv : c->timers) {

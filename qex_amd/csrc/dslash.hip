@@ -10,6 +10,7 @@
 #include "qexhip_internal.h"
 #include "site_index.h"
 #include "reduce.h"
+#include <hip/hip_ext.h>
 
 struct DslashArgs {
   Geom g;
@@ -155,9 +156,19 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
   }
 }
 
+// Launch with the HIP extension that attaches a start and a stop event to the kernel itself
+// (hipExtLaunchKernelGGL): the pair brackets exactly the kernel's execution, like the duration
+// rocprofv3 reports, instead of the record-to-record interval of two stream markers.
+template <class K>
+static void launch_timed(qexhip_ctx *c, const char *tname, K kernel, dim3 grid, dim3 block, DslashArgs &A) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timer_event_pair(c, tname, &e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, 0, c->stream, e0, e1, 0, A);
+  else hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, A);
+}
+
 template <int NDIR, bool HALO>
 static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool dot, int part_off,
-                  int d0 = 0, int d1 = 0) {
+                  int d0 = 0, int d1 = 0, const char *tname = "dslash") {
   if (c1 <= c0 && d1 <= d0) return 0;
   if (c1 <= c0) { c0 = d0; c1 = d1; d0 = d1 = 0; }
   A.c0 = c0; A.c1 = c1; A.d0 = d0; A.d1 = d1;
@@ -168,10 +179,10 @@ static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool 
   double *psave = A.partials;
   A.partials = psave ? psave + part_off : nullptr;
   dim3 grid(nb), block(256);
-  if (init && dot) k_dslash<NDIR, HALO, true, true><<<grid, block, 0, c->stream>>>(A);
-  else if (init) k_dslash<NDIR, HALO, true, false><<<grid, block, 0, c->stream>>>(A);
-  else if (dot) k_dslash<NDIR, HALO, false, true><<<grid, block, 0, c->stream>>>(A);
-  else k_dslash<NDIR, HALO, false, false><<<grid, block, 0, c->stream>>>(A);
+  if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true>, grid, block, A);
+  else if (init) launch_timed(c, tname, k_dslash<NDIR, HALO, true, false>, grid, block, A);
+  else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true>, grid, block, A);
+  else launch_timed(c, tname, k_dslash<NDIR, HALO, false, false>, grid, block, A);
   A.partials = psave;
   HIPCHK(hipGetLastError());
   return 0;
@@ -198,7 +209,6 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
   if (o.ca != 0.0 && !A.rin) { qexhip_set_error("dslash_sweep: a-term needs rin"); return -1; }
   int nparts = 0;
   if (!g.halo) {
-    ScopedTimer tm(c, "dslash", c->stream);
     if (c->ndir == 8) CHK((launch<8, false>(c, A, 0, g.Vh, init, o.dot, 0)));
     else CHK((launch<16, false>(c, A, 0, g.Vh, init, o.dot, 0)));
     nparts = (g.Vh + 255) / 256;
@@ -213,18 +223,14 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
     if (overlap) HIPCHK(hipEventRecord(c->ev_ready, c->stream));
     CHK(comm_halo_exchange(c, in, 1 - parity, overlap));
     int nb_int = (hi_beg - lo_end + 255) / 256, nb_lo = (lo_end + 255) / 256;
-    {
-      ScopedTimer tm(c, "dslash", c->stream);
-      if (c->ndir == 8) CHK((launch<8, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
-      else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
-    }
+    if (c->ndir == 8) CHK((launch<8, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
+    else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
     if (overlap) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
     {
-      ScopedTimer tm(c, "dslash_bnd", c->stream);
       // both t-faces in ONE launch (fewer launches per sweep: the sharded iteration is host-bound
       // on small local volumes)
-      if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh)));
-      else CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh)));
+      if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd")));
+      else CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd")));
     }
     nparts = nb_int + nb_lo + (g.Vh - hi_beg + 255) / 256;
   }

@@ -119,6 +119,8 @@ struct ScopedTimer {
   ~ScopedTimer();
 };
 int timers_collect(qexhip_ctx *c);
+// reserve an event pair of timer class `name` (false when timing is off for that class)
+bool timer_event_pair(qexhip_ctx *c, const char *name, hipEvent_t *e0, hipEvent_t *e1);
 
 // ---- layout.hip ----
 int geom_init(Geom &g, const int X[4], int depth, int halo);
