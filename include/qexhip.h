@@ -153,6 +153,12 @@ int qexhip_plaq(qexhip_handle h, double out[6]);
 int qexhip_gauge_force(qexhip_handle h, double *f, double cplaq);
 /* gaugeFlow(steps, eps) (src/gauge/wflow.nim:21-67): RK3 Wilson flow of the resident gauge field */
 int qexhip_wflow(qexhip_handle h, int nsteps, double eps);
+/* The action-selectable variants used by the fork's flow driver (src/flow/flow.nim:22-90):
+ *   kind 0 ("Wilson" | "rect"): GaugeActionCoeffs(plaq: cplaq, rect: c2), gaugeForce / gaugeActionDeriv
+ *           incl. the rectangle part (src/gauge/gaugeAction.nim:148-350);
+ *   kind 1 ("adj"):             GaugeActionCoeffs(plaq: cplaq, adjplaq: c2), forceA / gaugeADeriv (:683-747). */
+int qexhip_gauge_force_general(qexhip_handle h, double *f, double cplaq, double c2, int kind);
+int qexhip_wflow_general(qexhip_handle h, int nsteps, double eps, double cplaq, double c2, int kind);
 /* EQ of the flow drivers (src/flow/gauge_flow.nim:360-379, tests/base/twflow_topo.nim:4-10):
  * out = {E_s, E_t, Q} from f = g.fmunu(loop), f.densityE, f.topoQ
  * (src/gauge/gaugeUtils.nim:1162-1271); loop in {1,3,4,5} selects the clover improvement

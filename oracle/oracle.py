@@ -67,6 +67,10 @@ def lib():
         L.qo_solve.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, vp]
         L.qo_solveXX_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp, ci]
         L.qo_solve_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, vp]
+        L.qo_gauge_action.restype = cd
+        L.qo_gauge_action.argtypes = [vp, vp, cd, cd, ci]
+        L.qo_gauge_force_general.argtypes = [vp, vp, vp, cd, cd, ci]
+        L.qo_wflow_general.argtypes = [vp, vp, ci, cd, cd, cd, ci]
         L.qo_flow_EQ.argtypes = [vp, vp, ci, vp]
         L.qo_wline.argtypes = [vp, vp, C.POINTER(ci), ci, vp]
         L.qo_set_num_threads.argtypes = [ci]
@@ -222,6 +226,20 @@ def gauge_deriv(lo, g, cplaq=1.0):
 
 def wflow(lo, g, nsteps, eps):
     lib().qo_wflow(lo._h, _p(g), nsteps, eps)
+
+
+def gauge_action(lo, g, cplaq=1.0, c2=0.0, kind=0):
+    return lib().qo_gauge_action(lo._h, _p(g), cplaq, c2, kind)
+
+
+def gauge_force_general(lo, g, cplaq=1.0, c2=0.0, kind=0):
+    f = lo.new_gauge()
+    lib().qo_gauge_force_general(lo._h, _p(g), _p(f), cplaq, c2, kind)
+    return f
+
+
+def wflow_general(lo, g, nsteps, eps, cplaq=1.0, c2=0.0, kind=0):
+    lib().qo_wflow_general(lo._h, _p(g), nsteps, eps, cplaq, c2, kind)
 
 
 def flow_EQ(lo, g, loop=1):

@@ -1219,3 +1219,129 @@ void qo_wline(const qo_layout *lo, const double *g, const int *path, int n, doub
   const double fac = 1.0 / ((double)lo->vol * 3.0);
   out[0] = sr * fac; out[1] = si * fac;
 }
+
+/* ------------------------------------------------------------------ */
+/* gauge actions with rectangle / adjoint-plaquette terms and their     */
+/* derivatives (completes SURVEY 8 row a14)                             */
+/* ------------------------------------------------------------------ */
+/* the 18 rectangle "staples" of link (x,mu): for every nu != mu and both signs of nu the three
+ * 5-link paths from x to x+mu that close a 1x2 or 2x1 rectangle with U_mu(x)^+.  This is what
+ * the rect part of gaugeActionDeriv accumulates through its stf/stu/ru fields
+ * (gaugeAction.nim:205-241,275-331): f[mu] += cr * (every rectangle through the link, opened). */
+static void rect_staples(const qo_layout *lo, const double *g, int x, int mu, double *acc, double cr) {
+  const int a = mu + 1;
+  double m[18];
+  for (int nu = 0; nu < 4; nu++) {
+    if (nu == mu) continue;
+    for (int sgn = -1; sgn <= 1; sgn += 2) {
+      const int b = sgn * (nu + 1);
+      const int p1[5] = {b, b, a, -b, -b};      /* 1 (mu) x 2 (nu): the link is the short side */
+      const int p2[5] = {b, a, a, -b, -a};      /* 2 (mu) x 1 (nu): the link is the first long-side link */
+      const int p3[5] = {-a, b, a, a, -b};      /*                  the link is the second one */
+      path_prod(lo, g, x, p1, 5, m); m_axpy(acc, cr, m);
+      path_prod(lo, g, x, p2, 5, m); m_axpy(acc, cr, m);
+      path_prod(lo, g, x, p3, 5, m); m_axpy(acc, cr, m);
+    }
+  }
+}
+
+/* gaugeActionDeriv with c.plaq and c.rect (gaugeAction.nim:148-332) */
+void qo_gauge_deriv_rect(const qo_layout *lo, const double *g, double *f, double cplaq, double crect) {
+  qo_gauge_deriv(lo, g, f, cplaq);
+  if (crect == 0.0) return;
+  const double cr = crect / 3.0;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < lo->vol * 4; i++) rect_staples(lo, g, i / 4, i % 4, &f[(size_t)i * 18], cr);
+}
+
+/* gaugeADeriv (gaugeAction.nim:683-740): every plaquette staple S of link U weighted by
+ * cp + ca*tr(S^+ U), cp = c.plaq/nc, ca = 2 c.adjplaq/nc^2 */
+void qo_gauge_deriv_adj(const qo_layout *lo, const double *g, double *f, double cplaq, double cadj) {
+  const double cp = cplaq / 3.0, ca = 2.0 * cadj / 9.0;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < lo->vol * 4; i++) {
+    const int x = i / 4, mu = i % 4, a = mu + 1;
+    double acc[18], s[18];
+    m_zero(acc);
+    const double *U = GLINK(g, x, mu);
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      for (int sgn = -1; sgn <= 1; sgn += 2) {
+        const int b = sgn * (nu + 1);
+        const int p[3] = {b, a, -b};
+        path_prod(lo, g, x, p, 3, s);
+        /* t = dot(S, U) = tr(S^+ U) */
+        double tr = 0, ti = 0;
+        for (int k = 0; k < 9; k++) { tr += s[2 * k] * U[2 * k] + s[2 * k + 1] * U[2 * k + 1]; ti += s[2 * k] * U[2 * k + 1] - s[2 * k + 1] * U[2 * k]; }
+        const double wr = cp + ca * tr, wi = ca * ti;
+        for (int k = 0; k < 9; k++) { acc[2 * k] += wr * s[2 * k] - wi * s[2 * k + 1]; acc[2 * k + 1] += wr * s[2 * k + 1] + wi * s[2 * k]; }
+      }
+    }
+    m_copy(&f[(size_t)i * 18], acc);
+  }
+}
+
+/* force = TAH(U f^+) for the general actions: kind 0: plaq+rect (gaugeForce, gaugeAction.nim:334-338),
+ * kind 1: plaq+adjplaq (forceA, :742-747) */
+void qo_gauge_force_general(const qo_layout *lo, const double *g, double *f, double cplaq, double c2, int kind) {
+  if (kind == 0) qo_gauge_deriv_rect(lo, g, f, cplaq, c2);
+  else qo_gauge_deriv_adj(lo, g, f, cplaq, c2);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < lo->vol * 4; i++) {
+    double s[18];
+    m_mul_na(s, &g[(size_t)i * 18], &f[(size_t)i * 18]);
+    qo_projectTAH(&f[(size_t)i * 18], s);
+  }
+}
+
+/* gaugeAction1 (gaugeAction.nim:61-142): -(1/nc) (c.plaq sum ReTr P + c.rect sum ReTr R), 6 plaquette
+ * and 12 rectangle types per site; actionA (:614-681): c.plaq (a0 - sum ReTr P/nc) + c.adjplaq (a0 - sum |tr P|^2/nc^2) */
+double qo_gauge_action(const qo_layout *lo, const double *g, double cplaq, double c2, int kind) {
+  double sp = 0, sr = 0, sa = 0;
+#pragma omp parallel for reduction(+ : sp, sr, sa) schedule(static)
+  for (int x = 0; x < lo->vol; x++) {
+    double m[18];
+    for (int mu = 1; mu < 4; mu++)
+      for (int nu = 0; nu < mu; nu++) {
+        const int a = mu + 1, b = nu + 1;
+        const int pl[4] = {a, b, -a, -b};
+        path_prod(lo, g, x, pl, 4, m);
+        const double tr = RE(m,0,0) + RE(m,1,1) + RE(m,2,2), ti = IM(m,0,0) + IM(m,1,1) + IM(m,2,2);
+        sp += tr;
+        sa += tr * tr + ti * ti;
+        if (kind == 0 && c2 != 0.0) {
+          const int r1[6] = {a, a, b, -a, -a, -b}, r2[6] = {a, b, b, -a, -b, -b};
+          path_prod(lo, g, x, r1, 6, m); sr += RE(m,0,0) + RE(m,1,1) + RE(m,2,2);
+          path_prod(lo, g, x, r2, 6, m); sr += RE(m,0,0) + RE(m,1,1) + RE(m,2,2);
+        }
+      }
+  }
+  if (kind == 0) return (-1.0 / 3.0) * (cplaq * sp + c2 * sr);
+  const double a0 = 0.5 * 12.0 * (double)lo->vol;
+  return cplaq * (a0 - sp / 3.0) + c2 * (a0 - sa / 9.0);
+}
+
+/* gaugeFlow with an action choice (src/flow/flow.nim:22-90): kind 0 "Wilson"/"rect", kind 1 "adj" */
+void qo_wflow_general(const qo_layout *lo, double *g, int nsteps, double eps, double cplaq, double c2, int kind) {
+  size_t n = (size_t)lo->vol * 4 * 18;
+  double *p = (double *)malloc(sizeof(double) * n);
+  double *f = (double *)malloc(sizeof(double) * n);
+  const double epsnc = eps * 3.0;
+  for (int step = 0; step < nsteps; step++)
+    for (int stage = 0; stage < 3; stage++) {
+      qo_gauge_force_general(lo, g, f, cplaq, c2, kind);
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < lo->vol * 4; i++) {
+        double v[18], e[18], t[18];
+        double *gi = &g[(size_t)i * 18], *fi = &f[(size_t)i * 18], *pi = &p[(size_t)i * 18];
+        if (stage == 0) for (int k = 0; k < 18; k++) v[k] = (-1.0 / 4.0) * epsnc * fi[k];
+        else if (stage == 1) for (int k = 0; k < 18; k++) v[k] = (-8.0 / 9.0) * epsnc * fi[k] + (-17.0 / 9.0) * pi[k];
+        else for (int k = 0; k < 18; k++) v[k] = (-3.0 / 4.0) * epsnc * fi[k] - pi[k];
+        qo_exp(e, v);
+        m_mul(t, e, gi);
+        if (stage < 2) m_copy(pi, v);
+        m_copy(gi, t);
+      }
+    }
+  free(p); free(f);
+}

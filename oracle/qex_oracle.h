@@ -73,6 +73,11 @@ void qo_gauge_force(const qo_layout *lo, const double *g, double *f);   /* gauge
 void qo_gauge_deriv(const qo_layout *lo, const double *g, double *f, double cplaq); /* :148-204 */
 void qo_wflow(const qo_layout *lo, double *g, int nsteps, double eps);  /* wflow.nim:21-67 */
 
+/* ---- general gauge actions: kind 0 plaq+rect (gaugeAction.nim:61-142,148-332), kind 1 plaq+adjplaq (:614-747) ---- */
+double qo_gauge_action(const qo_layout *lo, const double *g, double cplaq, double c2, int kind);
+void qo_gauge_force_general(const qo_layout *lo, const double *g, double *f, double cplaq, double c2, int kind);
+void qo_wflow_general(const qo_layout *lo, double *g, int nsteps, double eps, double cplaq, double c2, int kind); /* flow/flow.nim:22-90 */
+
 /* ---- flow observables (gaugeUtils.nim:1079-1270): out = {E_s, E_t, Q} ---- */
 void qo_flow_EQ(const qo_layout *lo, const double *g, int loop, double out[3]);
 void qo_wline(const qo_layout *lo, const double *g, const int *path, int n, double out[2]);

@@ -414,5 +414,13 @@ extern "C" int qexhip_gauge_set(qexhip_handle c, const double *g) { if (!c || !g
 extern "C" int qexhip_gauge_get(qexhip_handle c, double *g) { if (!c || !g) return QEXHIP_ERR_ARG; return gauge_get(c, g); }
 extern "C" int qexhip_plaq(qexhip_handle c, double out[6]) { if (!c || !out) return QEXHIP_ERR_ARG; return gauge_plaq(c, out); }
 extern "C" int qexhip_gauge_force(qexhip_handle c, double *f, double cplaq) { if (!c || !f) return QEXHIP_ERR_ARG; return gauge_force(c, f, cplaq); }
+extern "C" int qexhip_gauge_force_general(qexhip_handle c, double *f, double cplaq, double c2, int kind) {
+  if (!c || !f || kind < 0 || kind > 1) return QEXHIP_ERR_ARG;
+  return gauge_force(c, f, cplaq, c2, kind);
+}
+extern "C" int qexhip_wflow_general(qexhip_handle c, int nsteps, double eps, double cplaq, double c2, int kind) {
+  if (!c || nsteps < 0 || kind < 0 || kind > 1) return QEXHIP_ERR_ARG;
+  return gauge_wflow(c, nsteps, eps, cplaq, c2, kind);
+}
 extern "C" int qexhip_flow_EQ(qexhip_handle c, int loop, double out[3]) { if (!c || !out) return QEXHIP_ERR_ARG; return gauge_flow_obs(c, loop, out); }
 extern "C" int qexhip_wflow(qexhip_handle c, int nsteps, double eps) { if (!c || nsteps < 0) return QEXHIP_ERR_ARG; return gauge_wflow(c, nsteps, eps); }

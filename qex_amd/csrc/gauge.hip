@@ -327,6 +327,89 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
   return read_scalars(c, &c->dscal[24], 3, out);
 }
 
+// ---------------- general gauge actions: plaq + rect, plaq + adjplaq (completes row a14) ----------------
+// gaugeActionDeriv with c.rect (src/gauge/gaugeAction.nim:205-241,275-331) and gaugeADeriv / forceA
+// (:683-747), as used by the action-selectable flow of src/flow/flow.nim:22-90.  Same lane
+// mapping as k_force.  The 18 rectangle staples of a link are walked as 5-link paths.
+__device__ const signed char RECT_STEPS[6][5] = {
+    {2, 2, 1, -2, -2}, {2, 1, 1, -2, -1}, {-1, 2, 1, 1, -2},          // +nu
+    {-2, -2, 1, 2, 2}, {-2, 1, 1, 2, -1}, {-1, -2, 1, 1, 2}};         // -nu
+__global__ void __launch_bounds__(256) k_force_gen(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
+                                                   double c2, int kind, double2 *Pm, double cf, double cpm) {
+  const int bid = blockIdx.x;
+  const int mu = threadIdx.x >> 6;
+  const int p = bid >= g.ntile;
+  const int c = (bid - p * g.ntile) * 64 + (threadIdx.x & 63);
+  if (c >= g.Vh) return;
+  int x[4], xpm[4], y[4], z[4];
+  coords_of(g, c, p, x);
+  shifted(g, x, mu, 1, xpm);
+  const size_t o = link_off(g, x, mu);
+  const M3 U = m3_load(G + o, 64);
+  M3 acc = m3_zero();
+#pragma unroll 1
+  for (int nu = 0; nu < 4; nu++) {
+    if (nu == mu) continue;
+#pragma unroll 1
+    for (int dir = 0; dir < 2; dir++) {
+      M3 s;
+      if (dir == 0) {
+        shifted(g, x, nu, 1, y);
+        M3 t = m3_mul_na(m3_load(G + link_off(g, y, mu), 64), m3_load(G + link_off(g, xpm, nu), 64));
+        s = m3_mul(m3_load(G + link_off(g, x, nu), 64), t);
+      } else {
+        shifted(g, x, nu, -1, y);
+        shifted(g, y, mu, 1, z);
+        M3 t = m3_mul_an(m3_load(G + link_off(g, y, nu), 64), m3_load(G + link_off(g, y, mu), 64));
+        s = m3_mul(t, m3_load(G + link_off(g, z, nu), 64));
+      }
+      if (kind == 1) {
+        // weight cp + ca*tr(S^+ U), ca = 2 c.adjplaq/nc^2 (gaugeAction.nim:694,705-706)
+        double tr = 0, ti = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+          tr += s.e[k].x * U.e[k].x + s.e[k].y * U.e[k].y;
+          ti += s.e[k].x * U.e[k].y - s.e[k].y * U.e[k].x;
+        }
+        const double wr = cp + c2 * tr, wi = c2 * ti;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+          acc.e[k].x += wr * s.e[k].x - wi * s.e[k].y;
+          acc.e[k].y += wr * s.e[k].y + wi * s.e[k].x;
+        }
+      } else {
+        m3_axpy(acc, cp, s);
+      }
+    }
+    if (kind == 0 && c2 != 0.0) {
+#pragma unroll 1
+      for (int q = 0; q < 6; q++) {
+        ObsPath P;
+        P.len = 5;
+#pragma unroll
+        for (int k = 0; k < 5; k++) P.step[k] = RECT_STEPS[q][k];
+        M3 m = path_prod(g, G, x, P, mu, nu);
+        m3_axpy(acc, c2, m);
+      }
+    }
+  }
+  M3 f = m3_tah(m3_mul_na(U, acc));
+  if (Pm) {
+    M3 v;
+    if (cpm != 0.0) {
+      M3 pm = m3_load(Pm + o, 64);
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x + cpm * pm.e[k].x, cf * f.e[k].y + cpm * pm.e[k].y);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x, cf * f.e[k].y);
+    }
+    m3_store(Pm + o, 64, v);
+  } else {
+    m3_store(F + o, 64, f);
+  }
+}
+
 static int gn_alloc(qexhip_ctx *c) {
   if (c->gn) return 0;
   if (c->g.halo) { qexhip_set_error("gauge/flow kernels are single-GPU (no t sharding)"); return -3; }
@@ -392,24 +475,33 @@ int gauge_plaq(qexhip_ctx *c, double out[6]) {
   return read_scalars(c, &c->dscal[16], 6, out);
 }
 
-static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, double cpm = 0) {
+static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, double cpm = 0, double c2 = 0, int kind = 0) {
   CHK(gn_alloc_fp(c));
   ScopedTimer tm(c, "staple", c->stream);
   static int mode = -1;
   if (mode < 0) { const char *e = getenv("QEXHIP_FORCE_MODE"); mode = e ? atoi(e) : 1; }
   int nb = mode == 0 ? (4 * c->g.V + 255) / 256 : 2 * c->g.ntile;
-  k_force<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, flow ? c->gn->P : nullptr, cf, cpm);
+  if (c2 != 0.0) {
+    // kind 0: cr = c.rect/nc ; kind 1: ca = 2 c.adjplaq/nc^2
+    const double k2 = kind == 0 ? c2 / 3.0 : 2.0 * c2 / 9.0;
+    k_force_gen<<<2 * c->g.ntile, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind,
+                                                       flow ? c->gn->P : nullptr, cf, cpm);
+  } else {
+    k_force<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, flow ? c->gn->P : nullptr, cf, cpm);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
-int gauge_force(qexhip_ctx *c, double *f_host, double cplaq) {
+int gauge_force(qexhip_ctx *c, double *f_host, double cplaq, double c2, int kind) {
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
-  CHK(force_dev(c, cplaq));
+  if (kind == 0 && c2 != 0.0) for (int d = 0; d < 4; d++) if (c->g.X[d] < 4) { qexhip_set_error("rectangle action needs extents >= 4"); return -1; }
+  CHK(force_dev(c, cplaq, 0, 0, 0, c2, kind));
   return download_nat(c, c->gn->F, f_host);
 }
 
-int gauge_wflow(qexhip_ctx *c, int nsteps, double eps) {
+int gauge_wflow(qexhip_ctx *c, int nsteps, double eps, double cplaq, double c2, int kind) {
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  if (kind == 0 && c2 != 0.0) for (int d = 0; d < 4; d++) if (c->g.X[d] < 4) { qexhip_set_error("rectangle action needs extents >= 4"); return -1; }
   CHK(gn_alloc_fp(c));
   const double epsnc = eps * 3.0;
   const size_t ltiles = (size_t)2 * c->g.ntile * 4;
@@ -418,7 +510,7 @@ int gauge_wflow(qexhip_ctx *c, int nsteps, double eps) {
   const double cpm[3] = {0.0, -17.0 / 9.0, -1.0};
   for (int s = 0; s < nsteps; s++)
     for (int st = 0; st < 3; st++) {
-      CHK(force_dev(c, 1.0, 1, cf[st], cpm[st]));
+      CHK(force_dev(c, cplaq, 1, cf[st], cpm[st], c2, kind));
       ScopedTimer tm(c, "expupdate", c->stream);
       k_exp_update<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P);
       HIPCHK(hipGetLastError());

@@ -186,7 +186,7 @@ int solve_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, con
 int gauge_set(qexhip_ctx *c, const double *g);
 int gauge_get(qexhip_ctx *c, double *g);
 int gauge_plaq(qexhip_ctx *c, double out[6]);
-int gauge_force(qexhip_ctx *c, double *f_host, double cplaq);
-int gauge_wflow(qexhip_ctx *c, int nsteps, double eps);
+int gauge_force(qexhip_ctx *c, double *f_host, double cplaq, double c2 = 0.0, int kind = 0);
+int gauge_wflow(qexhip_ctx *c, int nsteps, double eps, double cplaq = 1.0, double c2 = 0.0, int kind = 0);
 int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]);
 void gauge_free(qexhip_ctx *c);

@@ -279,10 +279,18 @@ def plaq(ctx, g=None):
     return out
 
 
-def gaugeForce(ctx, g, cplaq=1.0):
+_FLOW_KIND = {"Wilson": 0, "rect": 0, "adj": 1}
+
+
+def gaugeForce(ctx, g, cplaq=1.0, rect=0.0, adjplaq=0.0):
+    """gc.gaugeForce(g, f) (gaugeAction.nim:334-350) / gc.forceA(g, f) (:742-747) with
+    gc = GaugeActionCoeffs(plaq, rect | adjplaq)."""
+    if rect != 0.0 and adjplaq != 0.0:
+        raise ValueError("rect and adjplaq are separate code paths in QEX (gaugeForce vs forceA)")
     check(lib().qexhip_gauge_set(ctx._h, _p(g)))
     f = np.zeros_like(g)
-    check(lib().qexhip_gauge_force(ctx._h, _p(f), float(cplaq)))
+    kind = 1 if adjplaq != 0.0 else 0
+    check(lib().qexhip_gauge_force_general(ctx._h, _p(f), float(cplaq), float(adjplaq if kind else rect), kind))
     return f
 
 
@@ -296,13 +304,17 @@ def flowEQ(ctx, loop=1, g=None):
     return out
 
 
-def gaugeFlow(ctx, g, steps, eps, measure=None):
-    """g.gaugeFlow(steps, eps): measure (wflow.nim:21-67).  g is modified in place."""
+def gaugeFlow(ctx, g, steps, eps, measure=None, flow_act="Wilson", plaq=1.0, rect=0.0, adjplaq=0.0):
+    """g.gaugeFlow(steps, eps): measure (wflow.nim:21-67), or the fork's
+    gc.gaugeFlow(flow_act, g, steps, eps): measure (src/flow/flow.nim:22-90) with
+    gc = GaugeActionCoeffs(plaq, rect, adjplaq).  g is modified in place."""
+    kind = _FLOW_KIND[flow_act]
+    c2 = adjplaq if kind else rect
     check(lib().qexhip_gauge_set(ctx._h, _p(g)))
     if measure is None:
-        check(lib().qexhip_wflow(ctx._h, int(steps), float(eps)))
+        check(lib().qexhip_wflow_general(ctx._h, int(steps), float(eps), float(plaq), float(c2), kind))
     else:
         for n in range(1, steps + 1):
-            check(lib().qexhip_wflow(ctx._h, 1, float(eps)))
+            check(lib().qexhip_wflow_general(ctx._h, 1, float(eps), float(plaq), float(c2), kind))
             measure(n * eps)
     check(lib().qexhip_gauge_get(ctx._h, _p(g)))

@@ -1,0 +1,79 @@
+"""General gauge actions of the flow path (plaq + rect, plaq + adjplaq).
+
+CPU: the oracle's forces are the derivatives of the oracle's actions (restated from
+gaugeAction1 / actionA, src/gauge/gaugeAction.nim:61-142,614-681) -- a normalisation check that
+does not depend on the code under test.  GPU: the HIP force / flow against the oracle.
+"""
+import numpy as np
+import pytest
+
+
+def _tah(rng):
+    a = rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))
+    t = 0.5 * (a - a.conj().T)
+    return t - np.trace(t) / 3 * np.eye(3)
+
+
+def _expm(t):
+    w, v = np.linalg.eig(t)
+    return v @ np.diag(np.exp(w)) @ np.linalg.inv(v)
+
+
+@pytest.mark.parametrize("cp,c2,kind", [(1.3, 0.0, 0), (1.7, -0.12, 0), (0.9, 0.35, 1)])
+def test_force_is_minus_gradient_of_action(oracle, cp, c2, kind):
+    """d/de S(exp(eT) U_mu(x)) = -Re tr(T F_mu(x)) with F = gaugeForce / forceA."""
+    o = oracle
+    lo = o.Layout([4, 4, 4, 6])
+    g = o.gauge_warm(lo, 0.5, o.RngField(lo, o.RNG_MILC6, 5))
+    F = o.gauge_force_general(lo, g, cp, c2, kind)
+    Fc = F[..., 0] + 1j * F[..., 1]
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        x, mu, T, eps = int(rng.integers(lo.vol)), int(rng.integers(4)), _tah(rng), 1e-5
+        U = g[x, mu, :, :, 0] + 1j * g[x, mu, :, :, 1]
+        S = []
+        for e in (eps, -eps):
+            g2 = g.copy()
+            M = _expm(e * T) @ U
+            g2[x, mu, :, :, 0], g2[x, mu, :, :, 1] = M.real, M.imag
+            S.append(o.gauge_action(lo, g2, cp, c2, kind))
+        num = (S[0] - S[1]) / (2 * eps)
+        ana = -np.trace(T @ Fc[x, mu]).real
+        assert abs(num - ana) < 1e-6 * max(1.0, abs(ana))
+    # with c2 = 0 both code paths reduce to the Wilson force that golden set G2 pins
+    assert np.abs(o.gauge_force_general(lo, g, cp, 0.0, kind) - cp * o.gauge_force(lo, g)).max() < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cp,c2,kind", [(1.0, 0.0, 0), (1.7, -0.12, 0), (5.0 / 3.0, -1.0 / 12.0, 0), (0.9, 0.35, 1)])
+def test_gpu_force_general(oracle, cp, c2, kind):
+    import qex_amd as q
+
+    o = oracle
+    lat = [4, 6, 8, 4]
+    lo = o.Layout(lat)
+    g = o.gauge_warm(lo, 0.4, o.RngField(lo, o.RNG_MILC6, 11))
+    ctx = q.Context(lat)
+    f = q.gaugeForce(ctx, g, cplaq=cp, rect=c2 if kind == 0 else 0.0, adjplaq=c2 if kind == 1 else 0.0)
+    ref = o.gauge_force_general(lo, g, cp, c2, kind)
+    assert np.linalg.norm(f - ref) / np.linalg.norm(ref) < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act,cp,c2", [("rect", 5.0 / 3.0, -1.0 / 12.0), ("adj", 1.0, 0.25)])
+def test_gpu_flow_general(oracle, act, cp, c2):
+    """gc.gaugeFlow(flow_act, g, steps, eps) of src/flow/flow.nim:22-90 (Symanzik and adjoint flows)."""
+    import qex_amd as q
+
+    o = oracle
+    lat = [4, 4, 8, 4]
+    lo = o.Layout(lat)
+    g = o.gauge_warm(lo, 0.4, o.RngField(lo, o.RNG_MILC6, 12))
+    gref = g.copy()
+    ctx = q.Context(lat)
+    kind = 1 if act == "adj" else 0
+    q.gaugeFlow(ctx, g, 3, 0.01, flow_act=act, plaq=cp, rect=c2 if kind == 0 else 0.0, adjplaq=c2 if kind else 0.0)
+    o.wflow_general(lo, gref, 3, 0.01, cp, c2, kind)
+    assert np.linalg.norm(g - gref) / np.linalg.norm(gref) < 1e-12
+    p0, p1 = o.plaq(lo, gref).sum(), q.plaq(ctx, g).sum()
+    assert abs(p0 - p1) < 1e-13
