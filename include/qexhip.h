@@ -79,6 +79,10 @@ int qexhip_stag_dslash(qexhip_handle h, double *r, const double *x, int parity, 
  * Staggered.Ddag (sc=-1, :569-571):  r = m*x + sc*D*x */
 int qexhip_stag_D(qexhip_handle h, double *r, const double *x, double m, double sc);
 
+/* stagD with the accumulate coefficient: r = a*r + m*x + sc*D*x on both parities; a = 1, sc = -1 is
+ * Staggered.peqDdag (src/physics/stagD.nim:572-574) */
+int qexhip_stag_D_acc(qexhip_handle h, double *r, const double *x, double m, double sc, double a);
+
 /* stagD2ee / stagD2oo (src/physics/stagD.nim:434-469): r[par] = 4 m2 x - (2D_eo)(2D_oe) x */
 int qexhip_stag_op_xx(qexhip_handle h, double *r, const double *x, double m2, int par_even);
 
@@ -104,6 +108,11 @@ int qexhip_stag_solve_xx(qexhip_handle h, double *x, const double *b, double mas
  *   iters <- total CG iterations, r2_final <- |b - D x|^2/|b|^2 (sp.r2) */
 int qexhip_stag_solve(qexhip_handle h, double *x, const double *b, double mass, double r2req,
                       int maxits, int *iters, double *r2_final);
+
+/* the same with sp.usePrevSoln (src/physics/stagSolve.nim:234-243): with use_prev != 0 the solve
+ * starts from the x handed in (r = b - D x) instead of x = 0 */
+int qexhip_stag_solve_prev(qexhip_handle h, double *x, const double *b, double mass, double r2req,
+                           int maxits, int use_prev, int *iters, double *r2_final);
 
 /* multi-shift solveXX (src/physics/stagSolve.nim:296-345 + src/solvers/cgm.nim:84-315).
  * shifts[0] = base mass, shifts[k>0] = sigma_k added to m0^2; xs[k] full-volume vectors. */

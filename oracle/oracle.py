@@ -65,6 +65,7 @@ def lib():
         L.qo_eoReconstruct.argtypes = [vp, vp, vp, vp, vp, cd]
         L.qo_solveXX.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp, ci, vp]
         L.qo_solve.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, vp]
+        L.qo_solve_prev.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp]
         L.qo_solveXX_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp, ci]
         L.qo_solve_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, vp]
         L.qo_gauge_action.restype = cd
@@ -312,6 +313,14 @@ def solve(lo, fat, lng, b, m, r2req, maxits):
     x = np.zeros_like(b)
     fin = C.c_double(0)
     its = lib().qo_solve(lo._h, _p(fat), _p(lng), _p(x), _p(b), m, r2req, maxits, C.byref(fin))
+    return x, its, fin.value
+
+
+def solve_prev(lo, fat, lng, x0, b, m, r2req, maxits):
+    """Staggered.solve with sp.usePrevSoln = true (stagSolve.nim:234-243)."""
+    x = x0.copy()
+    fin = C.c_double(0)
+    its = lib().qo_solve_prev(lo._h, _p(fat), _p(lng), _p(x), _p(b), m, r2req, maxits, 1, C.byref(fin))
     return x, its, fin.value
 
 

@@ -908,15 +908,27 @@ static int solve_inner(const qo_layout *lo, const double *fat, const double *lng
   return its;
 }
 
+int qo_solve_prev(const qo_layout *lo, const double *fat, const double *lng,
+                  double *x, const double *b, double m, double r2req, int maxits, int use_prev, double *r2_final);
 int qo_solve(const qo_layout *lo, const double *fat, const double *lng,
              double *x, const double *b, double m, double r2req, int maxits, double *r2_final) {
+  return qo_solve_prev(lo, fat, lng, x, b, m, r2req, maxits, 0, r2_final);
+}
+/* sp.usePrevSoln (stagSolve.nim:234-243): start from the x handed in, r = b - D x */
+int qo_solve_prev(const qo_layout *lo, const double *fat, const double *lng,
+                  double *x, const double *b, double m, double r2req, int maxits, int use_prev, double *r2_final) {
   size_t n6 = (size_t)lo->vol * 6;
   double b2 = qo_norm2(lo, b, 2);
   const double r2stop = r2req * b2;
   double *r = (double *)malloc(sizeof(double) * n6);
   double *y = (double *)calloc(n6, sizeof(double));
-  memset(x, 0, sizeof(double) * n6);
-  memcpy(r, b, sizeof(double) * n6);
+  if (use_prev) {
+    qo_D(lo, fat, lng, r, x, m);
+    for (size_t i = 0; i < n6; i++) r[i] = b[i] - r[i];
+  } else {
+    memset(x, 0, sizeof(double) * n6);
+    memcpy(r, b, sizeof(double) * n6);
+  }
   double r2e = qo_norm2(lo, r, 0), r2o = qo_norm2(lo, r, 1);
   double r2 = r2e + r2o;
   int its = 0;

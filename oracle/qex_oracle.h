@@ -110,6 +110,8 @@ int qo_solveXX(const qo_layout *lo, const double *fat, const double *lng,
 /* full solve D x = b (stagSolve.nim:224-294); returns total CG iterations; r2_final = |b-Dx|^2/|b|^2 */
 int qo_solve(const qo_layout *lo, const double *fat, const double *lng,
              double *x, const double *b, double m, double r2req, int maxits, double *r2_final);
+int qo_solve_prev(const qo_layout *lo, const double *fat, const double *lng,
+                  double *x, const double *b, double m, double r2req, int maxits, int use_prev, double *r2_final);
 /* multi-shift solveXX (stagSolve.nim:296-345 + cgm.nim:84-315): shifts[0] is the base MASS,
  * shifts[k>0] = sigma_k.  xs = nmass pointers to full-volume vectors. */
 int qo_solveXX_multi(const qo_layout *lo, const double *fat, const double *lng,

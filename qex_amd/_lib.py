@@ -26,10 +26,12 @@ SYMBOLS = [
     ("qexhip_stag_set_links", _ci, [_vp, _vp, _vp]),
     ("qexhip_stag_dslash", _ci, [_vp, _vp, _vp, _ci, _cd, _cd]),
     ("qexhip_stag_D", _ci, [_vp, _vp, _vp, _cd, _cd]),
+    ("qexhip_stag_D_acc", _ci, [_vp, _vp, _vp, _cd, _cd, _cd]),
     ("qexhip_stag_op_xx", _ci, [_vp, _vp, _vp, _cd, _ci]),
     ("qexhip_stag_eo_reconstruct", _ci, [_vp, _vp, _vp, _cd]),
     ("qexhip_stag_solve_xx", _ci, [_vp, _vp, _vp, _cd, _cd, _ci, _ci, _pi, _pd, _vp, _ci]),
     ("qexhip_stag_solve", _ci, [_vp, _vp, _vp, _cd, _cd, _ci, _pi, _pd]),
+    ("qexhip_stag_solve_prev", _ci, [_vp, _vp, _vp, _cd, _cd, _ci, _ci, _pi, _pd]),
     ("qexhip_stag_solve_xx_multi", _ci, [_vp, _vp, _vp, _vp, _ci, _cd, _ci, _ci, _pi, _vp, _ci]),
     ("qexhip_stag_solve_multi", _ci, [_vp, _vp, _vp, _vp, _ci, _cd, _ci, _pi, _pd]),
     ("qexhip_norm2", _ci, [_vp, _vp, _ci, _pd]),

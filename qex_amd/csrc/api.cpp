@@ -225,6 +225,16 @@ extern "C" int qexhip_stag_D(qexhip_handle c, double *r, const double *x, double
   return field_download(c, *fr, r);
 }
 
+extern "C" int qexhip_stag_D_acc(qexhip_handle c, double *r, const double *x, double m, double sc, double a) {
+  if (!c || !r || !x || sc == 0.0) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx, *fr;
+  CHK(host_in(c, WK_IN, x, &fx));
+  CHK(host_in(c, WK_OUT, r, &fr));
+  CHK(op_D(c, *fr, *fx, m, sc, a));
+  return field_download(c, *fr, r);
+}
+
 extern "C" int qexhip_stag_op_xx(qexhip_handle c, double *r, const double *x, double m2, int par_even) {
   if (!c || !r || !x) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
@@ -267,6 +277,18 @@ extern "C" int qexhip_stag_solve(qexhip_handle c, double *x, const double *b, do
   CHK(host_in(c, WK_IN, b, &fb));
   CHK(get_work(c, WK_OUT, &fx));
   CHK(solve_full_dev(c, *fx, *fb, mass, r2req, maxits, iters, r2_final));
+  return field_download(c, *fx, x);
+}
+
+extern "C" int qexhip_stag_solve_prev(qexhip_handle c, double *x, const double *b, double mass, double r2req,
+                                      int maxits, int use_prev, int *iters, double *r2_final) {
+  if (!c || !x || !b) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fb, *fx;
+  CHK(host_in(c, WK_IN, b, &fb));
+  if (use_prev) CHK(host_in(c, WK_OUT, x, &fx));
+  else CHK(get_work(c, WK_OUT, &fx));
+  CHK(solve_full_dev(c, *fx, *fb, mass, r2req, maxits, iters, r2_final, use_prev));
   return field_download(c, *fx, x);
 }
 

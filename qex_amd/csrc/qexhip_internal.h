@@ -172,11 +172,11 @@ int cg_init(qexhip_ctx *c, double r2req, int maxits);  // after b2 (dscal[0]) an
 // ---- solver.cpp ----
 int get_work(qexhip_ctx *c, int slot, DevField **f);
 int op_xx(qexhip_ctx *c, DevField &r, DevField &x, double m2, int par_even, int dot, const int *done, int *ndot = nullptr);
-int op_D(qexhip_ctx *c, DevField &r, DevField &x, double m, double sc);
+int op_D(qexhip_ctx *c, DevField &r, DevField &x, double m, double sc, double a = 0.0);
 int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2req, int maxits,
                  int par_even, int *iters, double *r2_over_b2, double *hist, int histcap);
 int solve_full_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2req, int maxits,
-                   int *iters, double *r2_final);
+                   int *iters, double *r2_final, int use_prev = 0);
 int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, const double *shifts,
                        int nmass, double r2req, int maxits, int par_even, int *iters, double *hist, int histcap);
 int solve_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, const double *masses,

@@ -58,9 +58,9 @@ static int op_stagD(qexhip_ctx *c, DevField &r, DevField &x, int parity, double 
   return dslash_sweep(c, r, x, parity, o);
 }
 
-int op_D(qexhip_ctx *c, DevField &r, DevField &x, double m, double sc) {
-  CHK(op_stagD(c, r, x, 0, m, sc, 0.0));
-  CHK(op_stagD(c, r, x, 1, m, sc, 0.0));
+int op_D(qexhip_ctx *c, DevField &r, DevField &x, double m, double sc, double a) {
+  CHK(op_stagD(c, r, x, 0, m, sc, a));
+  CHK(op_stagD(c, r, x, 1, m, sc, a));
   return 0;
 }
 
@@ -176,7 +176,7 @@ static int solve_inner(qexhip_ctx *c, DevField &x, DevField &b, double m, double
 }
 
 int solve_full_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2req, int maxits,
-                   int *iters, double *r2_final) {
+                   int *iters, double *r2_final, int use_prev) {
   DevField *r, *y;
   CHK(get_work(c, WK_R2, &r));
   CHK(get_work(c, WK_Y, &y));
@@ -184,8 +184,13 @@ int solve_full_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double 
   double b2;
   CHK(read_scalars(c, &c->dscal[2], 1, &b2));
   const double r2stop = r2req * b2;
-  CHK(blas_zero(c, x, 2));
-  CHK(blas_copy(c, *r, b, 2));
+  if (use_prev) {                                  // sp.usePrevSoln (stagSolve.nim:234-238)
+    CHK(op_D(c, *r, x, mass, 1.0));
+    CHK(blas_axpby(c, 1.0, b, -1.0, *r, *r, 2));
+  } else {
+    CHK(blas_zero(c, x, 2));
+    CHK(blas_copy(c, *r, b, 2));
+  }
   double r2e, r2o;
   CHK(norm2_eo(c, *r, &r2e, &r2o));
   double r2 = r2e + r2o;

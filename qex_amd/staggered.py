@@ -189,6 +189,10 @@ class Staggered:
     def Ddag(self, r, x, m):
         check(lib().qexhip_stag_D(self.ctx._h, _p(r), _p(x), float(m), -1.0))
 
+    def peqDdag(self, r, x, m):
+        """r += m*x - D*x  (stagD.nim:572-574)"""
+        check(lib().qexhip_stag_D_acc(self.ctx._h, _p(r), _p(x), float(m), -1.0, 1.0))
+
     def eoReconstruct(self, r, b, m):
         check(lib().qexhip_stag_eo_reconstruct(self.ctx._h, _p(r), _p(b), float(m)))
 
@@ -239,8 +243,8 @@ class Staggered:
             check(lib().qexhip_stag_solve_multi(self.ctx._h, ptrs, _p(b), _p(ms), len(x), float(sp.r2req),
                                                 int(sp.maxits), C.byref(its), C.byref(fin)))
         else:
-            check(lib().qexhip_stag_solve(self.ctx._h, _p(x), _p(b), float(m), float(sp.r2req), int(sp.maxits),
-                                          C.byref(its), C.byref(fin)))
+            check(lib().qexhip_stag_solve_prev(self.ctx._h, _p(x), _p(b), float(m), float(sp.r2req), int(sp.maxits),
+                                               1 if sp.usePrevSoln else 0, C.byref(its), C.byref(fin)))
         sp.calls += 1
         sp.iterations += its.value
         sp.iterationsMax = max(sp.iterationsMax, its.value)
