@@ -89,6 +89,14 @@ int qexhip_stag_op_xx(qexhip_handle h, double *r, const double *x, double m2, in
 /* eoReconstruct (src/physics/stagD.nim:583-586): r.odd = (b.odd - D_oe r.even)/m, r.even kept */
 int qexhip_stag_eo_reconstruct(qexhip_handle h, double *r, const double *b, double m);
 
+/* Shifted outer product of the fermion force:
+ *   f[mu](s) (+)= scale(parity of s) * x(s) (x) x(s+mu)^+     f: double[vol][4][3][3][2]
+ * stagDeriv (src/physics/stagD.nim:634-664) is scale_even = +1, scale_odd = -1, accumulate = 1 (the
+ * caller then rephases f); the loop of fforce (src/stagg_pv_hmc/staghmc_spv.nim:831-854) is
+ * scale_even = scale_odd = scale with accumulate = 0 for the first field and 1 afterwards. */
+int qexhip_stag_outer(qexhip_handle h, double *f, const double *x, double scale_even, double scale_odd,
+                      int accumulate);
+
 /* ---------------- solvers ----------------
  * solveEE / solveOO = solveXX (src/physics/stagSolve.nim:57-138), the backend seam next to
  * sbQuda (:105-118 -> qudaSolveEE/OO, src/quda/qudaWrapperImpl.nim:263-267).

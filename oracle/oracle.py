@@ -65,6 +65,7 @@ def lib():
         L.qo_eoReconstruct.argtypes = [vp, vp, vp, vp, vp, cd]
         L.qo_solveXX.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp, ci, vp]
         L.qo_solve.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, vp]
+        L.qo_stag_outer.argtypes = [vp, vp, vp, cd, cd, ci]
         L.qo_solve_prev.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp]
         L.qo_solveXX_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp, ci]
         L.qo_solve_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, vp]
@@ -314,6 +315,10 @@ def solve(lo, fat, lng, b, m, r2req, maxits):
     fin = C.c_double(0)
     its = lib().qo_solve(lo._h, _p(fat), _p(lng), _p(x), _p(b), m, r2req, maxits, C.byref(fin))
     return x, its, fin.value
+
+
+def stag_outer(lo, f, x, scale_even, scale_odd, accumulate):
+    lib().qo_stag_outer(lo._h, _p(f), _p(x), scale_even, scale_odd, 1 if accumulate else 0)
 
 
 def solve_prev(lo, fat, lng, x0, b, m, r2req, maxits):

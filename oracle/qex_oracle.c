@@ -1357,3 +1357,29 @@ void qo_wflow_general(const qo_layout *lo, double *g, int nsteps, double eps, do
     }
   free(p); free(f);
 }
+
+/* ------------------------------------------------------------------ */
+/* fermion-force outer product                       */
+/* ------------------------------------------------------------------ */
+/* f[mu](s) (+)= scale(parity of s) * x(s) (x) x(s+mu)^+ :
+ *   stagDeriv   (stagD.nim:634-664): +1 on even sites, -1 on odd sites, accumulate (then s.rephase f)
+ *   fforce loop (stagg_pv_hmc/staghmc_spv.nim:831-854): the same scale on both parities,
+ *                f := for the first field, f += afterwards */
+void qo_stag_outer(const qo_layout *lo, double *f, const double *x, double scale_even, double scale_odd, int accumulate) {
+#pragma omp parallel for schedule(static)
+  for (int s = 0; s < lo->vol; s++) {
+    const double sc = s < lo->volh ? scale_even : scale_odd;
+    for (int mu = 0; mu < 4; mu++) {
+      const double *a = &x[6 * (size_t)s], *b = &x[6 * (size_t)lo->nb[mu][0][s]];
+      double *m = &f[((size_t)s * 4 + mu) * 18];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+          /* x_i * conj(y_j) */
+          const double re = a[2 * i] * b[2 * j] + a[2 * i + 1] * b[2 * j + 1];
+          const double im = a[2 * i + 1] * b[2 * j] - a[2 * i] * b[2 * j + 1];
+          if (accumulate) { RE(m,i,j) += sc * re; IM(m,i,j) += sc * im; }
+          else { RE(m,i,j) = sc * re; IM(m,i,j) = sc * im; }
+        }
+    }
+  }
+}

@@ -101,6 +101,9 @@ void qo_stagD2xx(const qo_layout *lo, const double *fat, const double *lng,
 void qo_eoReconstruct(const qo_layout *lo, const double *fat, const double *lng,
                       double *r, const double *b, double m);
 
+/* fermion-force outer product f[mu](s) (+)= scale * x(s) (x) x(s+mu)^+ (stagD.nim:634-664, staghmc_spv.nim:831-854) */
+void qo_stag_outer(const qo_layout *lo, double *f, const double *x, double scale_even, double scale_odd, int accumulate);
+
 /* ---- solvers ---- */
 /* solveXX (stagSolve.nim:57-132) = CgState.solve (cg.nim:55-272) with op stagD2ee|oo(m^2).
  * r2hist[k] = r2/b2 after iteration k (k=0: initial), up to histcap entries. */

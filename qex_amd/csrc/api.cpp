@@ -256,6 +256,13 @@ extern "C" int qexhip_stag_eo_reconstruct(qexhip_handle c, double *r, const doub
   return field_download(c, *fr, r);
 }
 
+extern "C" int qexhip_stag_outer(qexhip_handle c, double *f, const double *x, double scale_even, double scale_odd,
+                                 int accumulate) {
+  if (!c || !f || !x) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return stag_outer_host(c, f, x, scale_even, scale_odd, accumulate);
+}
+
 // ---- solvers ----
 extern "C" int qexhip_stag_solve_xx(qexhip_handle c, double *x, const double *b, double mass, double r2req,
                                     int maxits, int par_even, int *iters, double *r2_over_b2, double *hist,

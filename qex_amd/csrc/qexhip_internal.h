@@ -182,6 +182,9 @@ int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, 
 int solve_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, const double *masses,
                     int nmass, double r2req, int maxits, int *iters, double *r2_final);
 
+// ---- force.hip ----
+int stag_outer_host(qexhip_ctx *c, double *f_host, const double *x_host, double se, double so, int accumulate);
+
 // ---- gauge.hip ----
 int gauge_set(qexhip_ctx *c, const double *g);
 int gauge_get(qexhip_ctx *c, double *g);

@@ -193,6 +193,14 @@ class Staggered:
         """r += m*x - D*x  (stagD.nim:572-574)"""
         check(lib().qexhip_stag_D_acc(self.ctx._h, _p(r), _p(x), float(m), -1.0, 1.0))
 
+    def stagDeriv(self, f, x):
+        """stagDeriv(s, f, x) without the final rephase (stagD.nim:634-663): f[mu] +-= x (x) x(+mu)^+"""
+        check(lib().qexhip_stag_outer(self.ctx._h, _p(f), _p(x), 1.0, -1.0, 1))
+
+    def outer(self, f, psi, scale, accumulate):
+        """f[mu][i][a,b] (:= | +=) scale * psi[i][a] * psi(i+mu)[b].adj  (staghmc_spv.nim:831-854)"""
+        check(lib().qexhip_stag_outer(self.ctx._h, _p(f), _p(psi), float(scale), float(scale), 1 if accumulate else 0))
+
     def eoReconstruct(self, r, b, m):
         check(lib().qexhip_stag_eo_reconstruct(self.ctx._h, _p(r), _p(b), float(m)))
 

@@ -56,3 +56,40 @@ def test_usePrevSoln(S):
     assert relerr(x1, xr) < 1e-7
     r = S.o.D(S.lo, S.g, None, x1, 0.1) - S.x
     assert (r * r).sum() / (S.x * S.x).sum() <= 1e-12
+
+
+@pytest.mark.parametrize("halo", [False, True])
+def test_fermion_force_outer_product(oracle, halo):
+    """stagDeriv (stagD.nim:634-664) and the fforce loop (staghmc_spv.nim:831-854)."""
+    import qex_amd as q
+
+    o = oracle
+    lat = [8, 8, 8, 4]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 4242)
+    g = o.gauge_random(lo, rf)
+    o.rephase(lo, g)
+    x, f0 = o.vector_gaussian(lo, rf), o.gauge_random_tah(lo, rf)
+    ctx = q.Context(lat)
+    if halo:
+        ctx.force_halo(True)
+    s = q.newStag(ctx, g)
+    f = f0.copy()
+    s.stagDeriv(f, x)
+    ref = f0.copy()
+    o.stag_outer(lo, ref, x, 1.0, -1.0, True)
+    assert relerr(f, ref) < 1e-14
+    f = f0.copy()
+    s.outer(f, x, 0.37, accumulate=False)          # first field: f := scale psi psi^+
+    s.outer(f, x, -1.9, accumulate=True)           # later fields: f += ...
+    ref = f0.copy()
+    o.stag_outer(lo, ref, x, 0.37, 0.37, False)
+    o.stag_outer(lo, ref, x, -1.9, -1.9, True)
+    assert relerr(f, ref) < 1e-14
+    # property: tr f[mu](s) = scale * <x(s+mu), x(s)>, so sum_s tr f = scale * <shift x, x>
+    fc, xc = ref[..., 0] + 1j * ref[..., 1], x[..., 0] + 1j * x[..., 1]
+    for mu in range(4):
+        nb = np.array([lo.neighbor(i, mu, 1) for i in range(lo.vol)])
+        want = (0.37 - 1.9) * np.vdot(xc[nb], xc)
+        got = np.trace(fc[:, mu], axis1=1, axis2=2).sum()
+        assert abs(got - want) < 1e-9 * abs(want)
