@@ -182,6 +182,17 @@ int qexhip_wflow_general(qexhip_handle h, int nsteps, double eps, double cplaq, 
  * (1x1 | +2x2+3x3 | +2x2+1x2+1x3 | all five loop shapes, coefficients of :1128-1146). */
 int qexhip_flow_EQ(qexhip_handle h, int loop, double out[3]);
 
+/* ---------------- link construction upstream of the solver ----------------
+ * g, fl, ll: double[vol][4][3][3][2].
+ * qexhip_fat7: makeImpLinks (src/gauge/fat7l.nim:77-161), coef = {oneLink, threeStaple, fiveStaple,
+ *   sevenStaple, lepage} (Fat7lCoefs :5-10); ll (nullable) <- naik * U U U.
+ * qexhip_hisq_smear: HisqCoefs.init + smear (src/physics/hisqLinks.nim:9-43): fat7 -> projectU ->
+ *   fat7 + Naik; the input already carries BC + staggered phases (tests/examples/testStagProp.nim:24-33).
+ * qexhip_nhyp_smear: the forward part of HypCoefs.smear (src/gauge/hypsmear.nim:49-144,260-275). */
+int qexhip_fat7(qexhip_handle h, const double *g, const double coef[5], double *fl, double *ll, double naik);
+int qexhip_hisq_smear(qexhip_handle h, const double *g, double *fl, double *ll);
+int qexhip_nhyp_smear(qexhip_handle h, const double *g, double *fl, double alpha1, double alpha2, double alpha3);
+
 /* ---------------- kernel timers ----------------
  * hipEvent pairs around launches of the named kernel class on the context stream
  * (the tic/toc hooks of src/physics/stagD.nim:354-395, src/solvers/cg.nim:175-241).

@@ -65,6 +65,9 @@ def lib():
         L.qo_eoReconstruct.argtypes = [vp, vp, vp, vp, vp, cd]
         L.qo_solveXX.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp, ci, vp]
         L.qo_solve.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, vp]
+        L.qo_fat7.argtypes = [vp, vp, vp, vp, vp, vp, cd]
+        L.qo_hisq_smear.argtypes = [vp, vp, vp, vp]
+        L.qo_nhyp_smear.argtypes = [vp, vp, vp, cd, cd, cd]
         L.qo_stag_outer.argtypes = [vp, vp, vp, cd, cd, ci]
         L.qo_solve_prev.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp]
         L.qo_solveXX_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp, ci]
@@ -315,6 +318,26 @@ def solve(lo, fat, lng, b, m, r2req, maxits):
     fin = C.c_double(0)
     its = lib().qo_solve(lo._h, _p(fat), _p(lng), _p(x), _p(b), m, r2req, maxits, C.byref(fin))
     return x, its, fin.value
+
+
+def fat7(lo, g, coef, naik=0.0, g_long=None):
+    """makeImpLinks (fat7l.nim:77-161); coef = (oneLink, threeStaple, fiveStaple, sevenStaple, lepage)."""
+    fl, ll = lo.new_gauge(), lo.new_gauge()
+    c = np.array(coef, dtype=np.float64)
+    lib().qo_fat7(lo._h, _p(fl), _p(g), _p(c), _p(ll), _p(g if g_long is None else g_long), naik)
+    return fl, ll
+
+
+def hisq_smear(lo, g):
+    fl, ll = lo.new_gauge(), lo.new_gauge()
+    lib().qo_hisq_smear(lo._h, _p(g), _p(fl), _p(ll))
+    return fl, ll
+
+
+def nhyp_smear(lo, g, a1=0.4, a2=0.5, a3=0.5):
+    fl = lo.new_gauge()
+    lib().qo_nhyp_smear(lo._h, _p(g), _p(fl), a1, a2, a3)
+    return fl
 
 
 def stag_outer(lo, f, x, scale_even, scale_odd, accumulate):

@@ -1383,3 +1383,139 @@ void qo_stag_outer(const qo_layout *lo, double *f, const double *x, double scale
     }
   }
 }
+
+/* ------------------------------------------------------------------ */
+/* link smearing: HISQ (fat7 + Naik) and nHYP     */
+/* ------------------------------------------------------------------ */
+/* single-matrix fields: double m[vol][18]; gauge fields [vol][4][18] are addressed through
+ * (base pointer, stride in doubles between sites). */
+typedef struct { const double *p; size_t stride; } mview;
+static inline const double *MV(mview v, int s) { return v.p + (size_t)s * v.stride; }
+static inline mview gauge_view(const double *g, int mu) { mview v = {g + (size_t)mu * 18, 72}; return v; }
+static inline mview field_view(const double *f) { mview v = {f, 18}; return v; }
+
+/* the generic staple of computeGenStaple (fat7l.nim:24-75) = symStaple (smearutil.nim:3-20):
+ *   st(x) = A(x) B(x+nu) A(x+mu)^+  +  A(x-nu)^+ B(x-nu) A(x-nu+mu)
+ * A: side links (direction nu), B: middle "link" field (direction mu) */
+static void gen_staple_site(const qo_layout *lo, mview A, mview B, int mu, int nu, int x, double *st) {
+  double t[18], u[18];
+  const int xpn = lo->nb[nu][0][x], xpm = lo->nb[mu][0][x], xmn = lo->nb[nu][1][x];
+  m_mul_na(t, MV(B, xpn), MV(A, xpm));
+  m_mul(st, MV(A, x), t);
+  m_mul_an(t, MV(A, xmn), MV(B, xmn));
+  m_mul(u, t, MV(A, lo->nb[mu][0][xmn]));
+  for (int k = 0; k < 18; k++) st[k] += u[k];
+}
+/* staple field (optional) and acc += coef*staple */
+static void gen_staple(const qo_layout *lo, double *staple, double *acc, size_t acc_stride, double coef,
+                       mview A, mview B, int mu, int nu) {
+#pragma omp parallel for schedule(static)
+  for (int x = 0; x < lo->vol; x++) {
+    double st[18];
+    gen_staple_site(lo, A, B, mu, nu, x, st);
+    if (staple) m_copy(&staple[(size_t)x * 18], st);
+    if (acc) m_axpy(&acc[(size_t)x * acc_stride], coef, st);
+  }
+}
+
+/* makeImpLinks (fat7l.nim:77-161).  fl, ll: gauge-format outputs; gf, gfLong inputs */
+void qo_fat7(const qo_layout *lo, double *fl, const double *gf, const double coef[5], double *ll,
+             const double *gfLong, double naik) {
+  const double c3 = coef[1], c5 = coef[2], c7 = coef[3], cL = coef[4];
+  const double c1 = coef[0] - 6.0 * cL;          /* Lepage fix-up, fat7l.nim:104-105 */
+  const int have5 = (c5 != 0.0) || (c7 != 0.0) || (cL != 0.0);
+  const int have3 = (c3 != 0.0) || have5;
+  size_t n = (size_t)lo->vol * 18;
+  double *staple = (double *)malloc(sizeof(double) * n), *temp = (double *)malloc(sizeof(double) * n);
+  for (int dir = 0; dir < 4; dir++) {
+    for (int x = 0; x < lo->vol; x++) m_scale(&fl[((size_t)x * 4 + dir) * 18], c1, &gf[((size_t)x * 4 + dir) * 18]);
+    if (!have3) continue;
+    double *acc = fl + (size_t)dir * 18;
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == dir) continue;
+      gen_staple(lo, staple, acc, 72, c3, gauge_view(gf, nu), gauge_view(gf, dir), dir, nu);
+      if (cL != 0.0) gen_staple(lo, NULL, acc, 72, cL, gauge_view(gf, nu), field_view(staple), dir, nu);
+      if (c5 != 0.0 || c7 != 0.0)
+        for (int rho = 0; rho < 4; rho++) {
+          if (rho == dir || rho == nu) continue;
+          gen_staple(lo, temp, acc, 72, c5, gauge_view(gf, rho), field_view(staple), dir, rho);
+          if (c7 != 0.0)
+            for (int sig = 0; sig < 4; sig++) {
+              if (sig == dir || sig == nu || sig == rho) continue;
+              gen_staple(lo, NULL, acc, 72, c7, gauge_view(gf, sig), field_view(temp), dir, sig);
+            }
+        }
+    }
+  }
+  if (naik != 0.0 && ll) {
+    /* ll[dir](x) = naik * U(x) U(x+dir) U(x+2dir)   (fat7l.nim:146-156) */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < lo->vol * 4; i++) {
+      const int x = i / 4, dir = i % 4;
+      const int x1 = lo->nb[dir][0][x], x2 = lo->nb[dir][0][x1];
+      double t[18], u[18];
+      m_mul(t, GLINK(gfLong, x1, dir), GLINK(gfLong, x2, dir));
+      m_mul(u, GLINK(gfLong, x, dir), t);
+      m_scale(&ll[(size_t)i * 18], naik, u);
+    }
+  }
+  free(staple); free(temp);
+}
+
+/* HisqCoefs.init + smear (physics/hisqLinks.nim:9-43) */
+void qo_hisq_smear(const qo_layout *lo, const double *g, double *fl, double *ll) {
+  const double f7lf = 0.0, naik = 1.0;
+  /* setHisqFat7 (hisqLinks.nim:9-14) */
+  const double c_first[5] = {(1.0 + 3.0 * f7lf + 0.0) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f7lf / 16.0};
+  const double f2 = 2.0 - f7lf;
+  const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
+  size_t n = (size_t)lo->vol * 72;
+  double *t1 = (double *)malloc(sizeof(double) * n), *t2 = (double *)malloc(sizeof(double) * n);
+  qo_fat7(lo, t1, g, c_first, NULL, g, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < lo->vol * 4; i++) qo_projectU(&t2[(size_t)i * 18], &t1[(size_t)i * 18]);
+  qo_fat7(lo, fl, t2, c_second, ll, t2, -naik / 24.0);
+  free(t1); free(t2);
+}
+
+/* nHYP smearing, forward part of smearGetForce (gauge/hypsmear.nim:49-144):
+ *   l1[mu,nu] = P( (1-a1) U_mu + a1/2 staple_nu(U_nu; U_mu) )
+ *   l2[mu,nu] = P( (1-a2) U_mu + a2/4 sum_{a != mu,nu} staple_a(l1[a,b]; l1[mu,b]) ),  b = 6-mu-nu-a
+ *   fl[mu]    = P( (1-a3) U_mu + a3/6 sum_{nu != mu} staple_nu(l2[nu,mu]; l2[mu,nu]) ) */
+void qo_nhyp_smear(const qo_layout *lo, const double *g, double *fl, double a1, double a2, double a3) {
+  size_t n = (size_t)lo->vol * 18;
+  double *l1[4][4], *l2[4][4], *tmp = (double *)malloc(sizeof(double) * n);
+  for (int mu = 0; mu < 4; mu++) for (int nu = 0; nu < 4; nu++) { l1[mu][nu] = l2[mu][nu] = NULL; if (mu != nu) { l1[mu][nu] = (double *)malloc(sizeof(double) * n); l2[mu][nu] = (double *)malloc(sizeof(double) * n); } }
+  const double alp1 = a1 / 2.0, alp2 = a2 / 4.0, alp3 = a3 / 6.0;
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      for (int x = 0; x < lo->vol; x++) m_scale(&tmp[(size_t)x * 18], 1 - a1, GLINK(g, x, mu));
+      gen_staple(lo, NULL, tmp, 18, alp1, gauge_view(g, nu), gauge_view(g, mu), mu, nu);
+#pragma omp parallel for schedule(static)
+      for (int x = 0; x < lo->vol; x++) qo_projectU(&l1[mu][nu][(size_t)x * 18], &tmp[(size_t)x * 18]);
+    }
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      for (int x = 0; x < lo->vol; x++) m_scale(&tmp[(size_t)x * 18], 1 - a2, GLINK(g, x, mu));
+      for (int a = 0; a < 4; a++) {
+        if (a == mu || a == nu) continue;
+        const int b = 1 + 2 + 3 - mu - nu - a;
+        gen_staple(lo, NULL, tmp, 18, alp2, field_view(l1[a][b]), field_view(l1[mu][b]), mu, a);
+      }
+#pragma omp parallel for schedule(static)
+      for (int x = 0; x < lo->vol; x++) qo_projectU(&l2[mu][nu][(size_t)x * 18], &tmp[(size_t)x * 18]);
+    }
+  for (int mu = 0; mu < 4; mu++) {
+    for (int x = 0; x < lo->vol; x++) m_scale(&tmp[(size_t)x * 18], 1 - a3, GLINK(g, x, mu));
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      gen_staple(lo, NULL, tmp, 18, alp3, field_view(l2[nu][mu]), field_view(l2[mu][nu]), mu, nu);
+    }
+#pragma omp parallel for schedule(static)
+    for (int x = 0; x < lo->vol; x++) qo_projectU(&fl[((size_t)x * 4 + mu) * 18], &tmp[(size_t)x * 18]);
+  }
+  for (int mu = 0; mu < 4; mu++) for (int nu = 0; nu < 4; nu++) if (mu != nu) { free(l1[mu][nu]); free(l2[mu][nu]); }
+  free(tmp);
+}

@@ -78,6 +78,12 @@ double qo_gauge_action(const qo_layout *lo, const double *g, double cplaq, doubl
 void qo_gauge_force_general(const qo_layout *lo, const double *g, double *f, double cplaq, double c2, int kind);
 void qo_wflow_general(const qo_layout *lo, double *g, int nsteps, double eps, double cplaq, double c2, int kind); /* flow/flow.nim:22-90 */
 
+/* ---- link smearing: fat7/HISQ (gauge/fat7l.nim:24-161, physics/hisqLinks.nim:9-43),
+ * nHYP forward smearing (gauge/hypsmear.nim:49-144).  coef = {oneLink, threeStaple, fiveStaple, sevenStaple, lepage} ---- */
+void qo_fat7(const qo_layout *lo, double *fl, const double *gf, const double coef[5], double *ll, const double *gfLong, double naik);
+void qo_hisq_smear(const qo_layout *lo, const double *g, double *fl, double *ll);
+void qo_nhyp_smear(const qo_layout *lo, const double *g, double *fl, double a1, double a2, double a3);
+
 /* ---- flow observables (gaugeUtils.nim:1079-1270): out = {E_s, E_t, Q} ---- */
 void qo_flow_EQ(const qo_layout *lo, const double *g, int loop, double out[3]);
 void qo_wline(const qo_layout *lo, const double *g, const int *path, int n, double out[2]);

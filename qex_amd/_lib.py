@@ -55,6 +55,9 @@ SYMBOLS = [
     ("qexhip_flow_EQ", _ci, [_vp, _ci, _vp]),
     ("qexhip_gauge_force_general", _ci, [_vp, _vp, _cd, _cd, _ci]),
     ("qexhip_wflow_general", _ci, [_vp, _ci, _cd, _cd, _cd, _ci]),
+    ("qexhip_fat7", _ci, [_vp, _vp, _pd, _vp, _vp, _cd]),
+    ("qexhip_hisq_smear", _ci, [_vp, _vp, _vp, _vp]),
+    ("qexhip_nhyp_smear", _ci, [_vp, _vp, _vp, _cd, _cd, _cd]),
     ("qexhip_timers_enable", _ci, [_vp, _ci]),
     ("qexhip_timers_reset", _ci, [_vp]),
     ("qexhip_timers_get", _ci, [_vp, C.c_char_p, C.POINTER(C.c_long), _pd]),

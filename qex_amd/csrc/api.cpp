@@ -438,6 +438,23 @@ extern "C" int qexhip_dev_solve_xx(qexhip_handle c, int x_id, int b_id, double m
   return solve_xx_dev(c, *fx, *fb, mass, r2req, maxits, par_even, iters, r2_over_b2, hist, histcap);
 }
 
+// ---- link smearing ----
+extern "C" int qexhip_fat7(qexhip_handle c, const double *g, const double coef[5], double *fl, double *ll, double naik) {
+  if (!c || !g || !coef || !fl) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return smear_fat7_host(c, g, coef, fl, ll, naik);
+}
+extern "C" int qexhip_hisq_smear(qexhip_handle c, const double *g, double *fl, double *ll) {
+  if (!c || !g || !fl || !ll) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return smear_hisq_host(c, g, fl, ll);
+}
+extern "C" int qexhip_nhyp_smear(qexhip_handle c, const double *g, double *fl, double a1, double a2, double a3) {
+  if (!c || !g || !fl) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return smear_nhyp_host(c, g, fl, a1, a2, a3);
+}
+
 // ---- gauge / flow ----
 extern "C" int qexhip_gauge_set(qexhip_handle c, const double *g) { if (!c || !g) return QEXHIP_ERR_ARG; return gauge_set(c, g); }
 extern "C" int qexhip_gauge_get(qexhip_handle c, double *g) { if (!c || !g) return QEXHIP_ERR_ARG; return gauge_get(c, g); }

@@ -185,6 +185,11 @@ int solve_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, con
 // ---- force.hip ----
 int stag_outer_host(qexhip_ctx *c, double *f_host, const double *x_host, double se, double so, int accumulate);
 
+// ---- smear.hip ----
+int smear_fat7_host(qexhip_ctx *c, const double *g_host, const double coef[5], double *fl_host, double *ll_host, double naik);
+int smear_hisq_host(qexhip_ctx *c, const double *g_host, double *fl_host, double *ll_host);
+int smear_nhyp_host(qexhip_ctx *c, const double *g_host, double *fl_host, double a1, double a2, double a3);
+
 // ---- gauge.hip ----
 int gauge_set(qexhip_ctx *c, const double *g);
 int gauge_get(qexhip_ctx *c, double *g);

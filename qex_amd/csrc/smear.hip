@@ -1,0 +1,345 @@
+// smear.hip -- link construction upstream of the solver: fat7 / HISQ and nHYP smearing
+// (forward direction).
+//
+// Restates (file:line in ctpeterson/qex):
+//   computeGenStaple / makeImpLinks     src/gauge/fat7l.nim:24-161
+//   HisqCoefs.init / smear              src/physics/hisqLinks.nim:9-43
+//   symStaple                           src/gauge/smearutil.nim:3-20
+//   nHYP forward smearing               src/gauge/hypsmear.nim:49-144
+//   projectU = x (x^+x + 1e-20)^(-1/2)  src/maths/matrixFunctions.nim:79-182,279-313
+// Everything is built from ONE field-level kernel, the generic staple
+//   st(x) = A(x) B(x+nu) A(x+mu)^+ + A(x-nu)^+ B(x-nu) A(x-nu+mu)
+// (A: side links of direction nu, B: any matrix field standing for the mu link), plus scale,
+// projectU and the 3-link Naik product.  One lane per site; matrix fields use the tile layout
+// [parity][tile][9][64] (a gauge field is four of them interleaved: [parity][tile][mu][9][64]).
+// Single GPU (periodic wrap), like the flow kernels.
+#include "qexhip_internal.h"
+#include "su3.h"
+#include <cmath>
+
+struct MView {        // read-only matrix field view
+  const double2 *p;
+  int tstride;        // double2 between consecutive tiles (576 for a single field, 4*576 inside a gauge field)
+};
+struct MViewW {
+  double2 *p;
+  int tstride;
+};
+
+__device__ __forceinline__ void coords_sm(const Geom &g, int c, int p, int x[4]) {
+  unsigned r = (unsigned)c;
+  int xh = r % (unsigned)g.Xh; r /= (unsigned)g.Xh;
+  x[1] = r % (unsigned)g.X[1]; r /= (unsigned)g.X[1];
+  x[2] = r % (unsigned)g.X[2];
+  x[3] = r / (unsigned)g.X[2];
+  x[0] = 2 * xh + ((x[1] + x[2] + x[3] + p) & 1);
+}
+__device__ __forceinline__ size_t site_off(const Geom &g, const int x[4], int tstride) {
+  int lex = x[0] + g.X[0] * (x[1] + g.X[1] * (x[2] + g.X[2] * x[3]));
+  int p = (x[0] + x[1] + x[2] + x[3]) & 1;
+  int c = lex >> 1;
+  return ((size_t)p * g.ntile + (c >> 6)) * tstride + (c & 63);
+}
+__device__ __forceinline__ void shift_sm(const Geom &g, const int x[4], int mu, int d, int y[4]) {
+  y[0] = x[0]; y[1] = x[1]; y[2] = x[2]; y[3] = x[3];
+  int v = y[mu] + d;
+  y[mu] = v >= g.X[mu] ? v - g.X[mu] : (v < 0 ? v + g.X[mu] : v);
+}
+
+// staple field (optional) and acc += coef * staple (optional)
+__global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  int x[4], xpn[4], xpm[4], xmn[4], xmnpm[4];
+  coords_sm(g, c, p, x);
+  shift_sm(g, x, nu, 1, xpn);
+  shift_sm(g, x, mu, 1, xpm);
+  shift_sm(g, x, nu, -1, xmn);
+  shift_sm(g, xmn, mu, 1, xmnpm);
+  M3 t = m3_mul_na(m3_load(B.p + site_off(g, xpn, B.tstride), 64), m3_load(A.p + site_off(g, xpm, A.tstride), 64));
+  M3 s = m3_mul(m3_load(A.p + site_off(g, x, A.tstride), 64), t);
+  t = m3_mul_an(m3_load(A.p + site_off(g, xmn, A.tstride), 64), m3_load(B.p + site_off(g, xmn, B.tstride), 64));
+  M3 u = m3_mul(t, m3_load(A.p + site_off(g, xmnpm, A.tstride), 64));
+#pragma unroll
+  for (int k = 0; k < 9; k++) { s.e[k].x += u.e[k].x; s.e[k].y += u.e[k].y; }
+  if (st.p) m3_store(st.p + site_off(g, x, st.tstride), 64, s);
+  if (acc.p) {
+    double2 *a = acc.p + site_off(g, x, acc.tstride);
+    M3 o = m3_load(a, 64);
+    m3_axpy(o, coef, s);
+    m3_store(a, 64, o);
+  }
+}
+// dst = coef * src
+__global__ void __launch_bounds__(256) k_mscale(Geom g, MViewW dst, double coef, MView src) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  const size_t od = ((size_t)p * g.ntile + (c >> 6)) * dst.tstride + (c & 63);
+  const size_t os = ((size_t)p * g.ntile + (c >> 6)) * src.tstride + (c & 63);
+  M3 m = m3_load(src.p + os, 64);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { m.e[k].x *= coef; m.e[k].y *= coef; }
+  m3_store(dst.p + od, 64, m);
+}
+
+// eigs3 + rsqrtPHM3f + rsqrtPHM3 + projectU (matrixFunctions.nim:79-182,279-313)
+__device__ __forceinline__ M3 m3_projectU(const M3 &x) {
+  M3 t = m3_mul_an(x, x);
+  m3_add_diag(t, 1e-20);
+  const double tr = t.e[0].x + t.e[4].x + t.e[8].x;
+  M3 t2 = m3_mul(t, t);
+  const double p2 = t2.e[0].x + t2.e[4].x + t2.e[8].x;
+  // Re det (matrixFunctions.nim:72-75)
+  const double2 d01 = make_double2(t.e[0].x * t.e[4].x - t.e[0].y * t.e[4].y - (t.e[1].x * t.e[3].x - t.e[1].y * t.e[3].y),
+                                   t.e[0].x * t.e[4].y + t.e[0].y * t.e[4].x - (t.e[1].x * t.e[3].y + t.e[1].y * t.e[3].x));
+  const double2 d20 = make_double2(t.e[2].x * t.e[3].x - t.e[2].y * t.e[3].y - (t.e[0].x * t.e[5].x - t.e[0].y * t.e[5].y),
+                                   t.e[2].x * t.e[3].y + t.e[2].y * t.e[3].x - (t.e[0].x * t.e[5].y + t.e[0].y * t.e[5].x));
+  const double2 d12 = make_double2(t.e[1].x * t.e[5].x - t.e[1].y * t.e[5].y - (t.e[2].x * t.e[4].x - t.e[2].y * t.e[4].y),
+                                   t.e[1].x * t.e[5].y + t.e[1].y * t.e[5].x - (t.e[2].x * t.e[4].y + t.e[2].y * t.e[4].x));
+  const double det = (d01.x * t.e[8].x - d01.y * t.e[8].y) + (d20.x * t.e[7].x - d20.y * t.e[7].y) + (d12.x * t.e[6].x - d12.y * t.e[6].y);
+  // eigs3
+  const double tr3 = (1.0 / 3.0) * tr, p23 = (1.0 / 3.0) * p2, tr32 = tr3 * tr3;
+  const double q = fabs(0.5 * (p23 - tr32));
+  const double r = 0.25 * tr3 * (5 * tr32 - p2) - 0.5 * det;
+  const double sq = sqrt(q), sq3 = q * sq;
+  const double isq3c = fmin(3e38, fmax(-3e38, 1.0 / sq3));
+  const double rsq3 = fmin(1.0, fmax(-1.0, r * isq3c));
+  const double th = (1.0 / 3.0) * acos(rsq3);
+  const double st = sin(th), ct = cos(th);
+  const double sqc = sq * ct, sqs = 1.73205080756887729352 * sq * st;
+  const double ll = tr3 + sqc;
+  const double l0 = tr3 - 2 * sqc, l1 = ll + sqs, l2 = ll - sqs;
+  // rsqrtPHM3f
+  const double sl0 = sqrt(fabs(l0)), sl1 = sqrt(fabs(l1)), sl2 = sqrt(fabs(l2));
+  const double u = sl0 + sl1 + sl2, w = sl0 * sl1 * sl2;
+  const double d = w * (sl0 + sl1) * (sl0 + sl2) * (sl1 + sl2);
+  const double di = 1 / d;
+  const double c0 = (w * u * u + l0 * sl0 * (l1 + l2) + l1 * sl1 * (l0 + l2) + l2 * sl2 * (l0 + l1)) * di;
+  const double c1 = -(tr * u + w) * di;
+  const double c2 = u * di;
+  M3 rs;
+#pragma unroll
+  for (int k = 0; k < 9; k++) rs.e[k] = make_double2(c1 * t.e[k].x + c2 * t2.e[k].x, c1 * t.e[k].y + c2 * t2.e[k].y);
+  m3_add_diag(rs, c0);
+  return m3_mul(x, rs);
+}
+__global__ void __launch_bounds__(256) k_projectU(Geom g, MViewW dst, MView src) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  const size_t od = ((size_t)p * g.ntile + (c >> 6)) * dst.tstride + (c & 63);
+  const size_t os = ((size_t)p * g.ntile + (c >> 6)) * src.tstride + (c & 63);
+  m3_store(dst.p + od, 64, m3_projectU(m3_load(src.p + os, 64)));
+}
+// ll(x) = naik * U(x) U(x+d) U(x+2d)   (fat7l.nim:146-156)
+__global__ void __launch_bounds__(256) k_naik(Geom g, MViewW dst, MView U, int dir, double naik) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  int x[4], x1[4], x2[4];
+  coords_sm(g, c, p, x);
+  shift_sm(g, x, dir, 1, x1);
+  shift_sm(g, x1, dir, 1, x2);
+  M3 t = m3_mul(m3_load(U.p + site_off(g, x1, U.tstride), 64), m3_load(U.p + site_off(g, x2, U.tstride), 64));
+  M3 m = m3_mul(m3_load(U.p + site_off(g, x, U.tstride), 64), t);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { m.e[k].x *= naik; m.e[k].y *= naik; }
+  m3_store(dst.p + site_off(g, x, dst.tstride), 64, m);
+}
+
+// host [idx][mu][9] <-> gauge tiles (same as gauge.hip; local copies keep this file self-contained)
+__global__ void __launch_bounds__(256) k_sm_to_tiles(Geom g, const double2 *__restrict__ host, double2 *G) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  int p = i >= g.Vh, c = i - p * g.Vh;
+  for (int mu = 0; mu < 4; mu++) {
+    double2 *w = G + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    for (int k = 0; k < 9; k++) w[k * 64] = host[((size_t)i * 4 + mu) * 9 + k];
+  }
+}
+__global__ void __launch_bounds__(256) k_sm_from_tiles(Geom g, double2 *__restrict__ host, const double2 *G) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  int p = i >= g.Vh, c = i - p * g.Vh;
+  for (int mu = 0; mu < 4; mu++) {
+    const double2 *w = G + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    for (int k = 0; k < 9; k++) host[((size_t)i * 4 + mu) * 9 + k] = w[k * 64];
+  }
+}
+
+namespace {
+struct Smear {
+  qexhip_ctx *c;
+  Geom g;
+  size_t gsz, fsz;  // double2 per gauge field / per single matrix field
+  std::vector<double2 *> owned;
+  explicit Smear(qexhip_ctx *c_) : c(c_), g(c_->g) {
+    fsz = (size_t)2 * g.ntile * 576;
+    gsz = 4 * fsz;
+  }
+  ~Smear() { (void)hipStreamSynchronize(c->stream); for (auto p : owned) (void)hipFree(p); }
+  int alloc(double2 **p, size_t n) {
+    HIPCHK(hipMalloc((void **)p, n * sizeof(double2)));
+    HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(double2), c->stream));
+    owned.push_back(*p);
+    return 0;
+  }
+  int nb() const { return (g.V + 255) / 256; }
+  MView gv(const double2 *G, int mu) const { return MView{G + (size_t)mu * 576, 4 * 576}; }
+  MViewW gvw(double2 *G, int mu) const { return MViewW{G + (size_t)mu * 576, 4 * 576}; }
+  MView fv(const double2 *F) const { return MView{F, 576}; }
+  MViewW fvw(double2 *F) const { return MViewW{F, 576}; }
+  int upload(double2 *G, const double *host) {
+    const size_t bytes = (size_t)g.V * 72 * sizeof(double);
+    CHK(ensure_stage(c, bytes));
+    HIPCHK(hipMemcpyAsync(c->stage, host, bytes, hipMemcpyHostToDevice, c->stream));
+    k_sm_to_tiles<<<nb(), 256, 0, c->stream>>>(g, (const double2 *)c->stage, G);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int download(double *host, const double2 *G) {
+    const size_t bytes = (size_t)g.V * 72 * sizeof(double);
+    CHK(ensure_stage(c, bytes));
+    k_sm_from_tiles<<<nb(), 256, 0, c->stream>>>(g, (double2 *)c->stage, G);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  int staple(MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef) {
+    ScopedTimer tm(c, "smear", c->stream);
+    k_gen_staple<<<nb(), 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  // makeImpLinks (fat7l.nim:77-161) on device gauge fields
+  int fat7(double2 *fl, const double2 *gf, const double coef[5], double2 *ll, const double2 *gfLong, double naik) {
+    const double c3 = coef[1], c5 = coef[2], c7 = coef[3], cL = coef[4];
+    const double c1 = coef[0] - 6.0 * cL;
+    const bool have5 = (c5 != 0.0) || (c7 != 0.0) || (cL != 0.0);
+    const bool have3 = (c3 != 0.0) || have5;
+    double2 *stp = nullptr, *tmp = nullptr;
+    CHK(alloc(&stp, fsz));
+    CHK(alloc(&tmp, fsz));
+    const MViewW none{nullptr, 0};
+    for (int dir = 0; dir < 4; dir++) {
+      k_mscale<<<nb(), 256, 0, c->stream>>>(g, gvw(fl, dir), c1, gv(gf, dir));
+      HIPCHK(hipGetLastError());
+      if (!have3) continue;
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == dir) continue;
+        CHK(staple(gv(gf, nu), gv(gf, dir), dir, nu, fvw(stp), gvw(fl, dir), c3));
+        if (cL != 0.0) CHK(staple(gv(gf, nu), fv(stp), dir, nu, none, gvw(fl, dir), cL));
+        if (c5 != 0.0 || c7 != 0.0)
+          for (int rho = 0; rho < 4; rho++) {
+            if (rho == dir || rho == nu) continue;
+            CHK(staple(gv(gf, rho), fv(stp), dir, rho, fvw(tmp), gvw(fl, dir), c5));
+            if (c7 != 0.0)
+              for (int sig = 0; sig < 4; sig++) {
+                if (sig == dir || sig == nu || sig == rho) continue;
+                CHK(staple(gv(gf, sig), fv(tmp), dir, sig, none, gvw(fl, dir), c7));
+              }
+          }
+      }
+    }
+    if (naik != 0.0 && ll)
+      for (int dir = 0; dir < 4; dir++) {
+        k_naik<<<nb(), 256, 0, c->stream>>>(g, gvw(ll, dir), gv(gfLong, dir), dir, naik);
+        HIPCHK(hipGetLastError());
+      }
+    return 0;
+  }
+};
+}  // namespace
+
+static int smear_check(qexhip_ctx *c, int min_extent) {
+  if (c->g.halo) { qexhip_set_error("link smearing kernels are single-GPU (no t sharding)"); return -3; }
+  for (int d = 0; d < 4; d++)
+    if (c->g.X[d] < min_extent) { qexhip_set_error("smearing needs lattice extents >= %d", min_extent); return -1; }
+  return 0;
+}
+
+int smear_fat7_host(qexhip_ctx *c, const double *g_host, const double coef[5], double *fl_host, double *ll_host, double naik) {
+  CHK(smear_check(c, 4));
+  Smear S(c);
+  double2 *G, *FL, *LL = nullptr;
+  CHK(S.alloc(&G, S.gsz));
+  CHK(S.alloc(&FL, S.gsz));
+  if (ll_host && naik != 0.0) CHK(S.alloc(&LL, S.gsz));
+  CHK(S.upload(G, g_host));
+  CHK(S.fat7(FL, G, coef, LL, G, naik));
+  CHK(S.download(fl_host, FL));
+  if (LL) CHK(S.download(ll_host, LL));
+  return 0;
+}
+
+// HisqCoefs.init + smear (hisqLinks.nim:9-43)
+int smear_hisq_host(qexhip_ctx *c, const double *g_host, double *fl_host, double *ll_host) {
+  CHK(smear_check(c, 4));
+  const double f7lf = 0.0, naik = 1.0, f2 = 2.0 - f7lf;
+  const double c_first[5] = {(1.0 + 3.0 * f7lf + 0.0) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f7lf / 16.0};
+  const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
+  Smear S(c);
+  double2 *G, *T1, *T2, *FL, *LL;
+  CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&T1, S.gsz)); CHK(S.alloc(&T2, S.gsz)); CHK(S.alloc(&FL, S.gsz)); CHK(S.alloc(&LL, S.gsz));
+  CHK(S.upload(G, g_host));
+  CHK(S.fat7(T1, G, c_first, nullptr, G, 0.0));
+  for (int mu = 0; mu < 4; mu++) {
+    k_projectU<<<S.nb(), 256, 0, c->stream>>>(S.g, S.gvw(T2, mu), S.gv(T1, mu));
+    HIPCHK(hipGetLastError());
+  }
+  CHK(S.fat7(FL, T2, c_second, LL, T2, -naik / 24.0));
+  CHK(S.download(fl_host, FL));
+  CHK(S.download(ll_host, LL));
+  return 0;
+}
+
+// nHYP forward smearing (hypsmear.nim:49-144)
+int smear_nhyp_host(qexhip_ctx *c, const double *g_host, double *fl_host, double a1, double a2, double a3) {
+  CHK(smear_check(c, 2));
+  Smear S(c);
+  const Geom &g = S.g;
+  double2 *G, *FL, *tmp, *l1[4][4], *l2[4][4];
+  CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&FL, S.gsz)); CHK(S.alloc(&tmp, S.fsz));
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      l1[mu][nu] = l2[mu][nu] = nullptr;
+      if (mu != nu) { CHK(S.alloc(&l1[mu][nu], S.fsz)); CHK(S.alloc(&l2[mu][nu], S.fsz)); }
+    }
+  CHK(S.upload(G, g_host));
+  const double alp1 = a1 / 2.0, alp2 = a2 / 4.0, alp3 = a3 / 6.0;
+  const MViewW none{nullptr, 0};
+  const int nb = S.nb();
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      k_mscale<<<nb, 256, 0, c->stream>>>(g, S.fvw(tmp), 1 - a1, S.gv(G, mu));
+      CHK(S.staple(S.gv(G, nu), S.gv(G, mu), mu, nu, none, S.fvw(tmp), alp1));
+      k_projectU<<<nb, 256, 0, c->stream>>>(g, S.fvw(l1[mu][nu]), S.fv(tmp));
+      HIPCHK(hipGetLastError());
+    }
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      k_mscale<<<nb, 256, 0, c->stream>>>(g, S.fvw(tmp), 1 - a2, S.gv(G, mu));
+      for (int a = 0; a < 4; a++) {
+        if (a == mu || a == nu) continue;
+        const int b = 6 - mu - nu - a;
+        CHK(S.staple(S.fv(l1[a][b]), S.fv(l1[mu][b]), mu, a, none, S.fvw(tmp), alp2));
+      }
+      k_projectU<<<nb, 256, 0, c->stream>>>(g, S.fvw(l2[mu][nu]), S.fv(tmp));
+      HIPCHK(hipGetLastError());
+    }
+  for (int mu = 0; mu < 4; mu++) {
+    k_mscale<<<nb, 256, 0, c->stream>>>(g, S.fvw(tmp), 1 - a3, S.gv(G, mu));
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      CHK(S.staple(S.fv(l2[nu][mu]), S.fv(l2[mu][nu]), mu, nu, none, S.fvw(tmp), alp3));
+    }
+    k_projectU<<<nb, 256, 0, c->stream>>>(g, S.gvw(FL, mu), S.fv(tmp));
+    HIPCHK(hipGetLastError());
+  }
+  return S.download(fl_host, FL);
+}

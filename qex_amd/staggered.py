@@ -330,3 +330,31 @@ def gaugeFlow(ctx, g, steps, eps, measure=None, flow_act="Wilson", plaq=1.0, rec
             check(lib().qexhip_wflow_general(ctx._h, 1, float(eps), float(plaq), float(c2), kind))
             measure(n * eps)
     check(lib().qexhip_gauge_get(ctx._h, _p(g)))
+
+
+# ---- link construction (src/gauge/fat7l.nim, src/physics/hisqLinks.nim, src/gauge/hypsmear.nim) ----
+class HisqCoefs:
+    """hisqLinks.nim:3-24: `var hc: HisqCoefs; hc.init(); hc.smear(g, fl, ll)`"""
+
+    def init(self):
+        return self
+
+    def smear(self, ctx, g, fl, ll):
+        check(lib().qexhip_hisq_smear(ctx._h, _p(g), _p(fl), _p(ll)))
+
+
+class HypCoefs:
+    """hypsmear.nim:15-18,260-275: `coef.smear(g, fl)` (forward smearing only)"""
+
+    def __init__(self, alpha1=0.4, alpha2=0.5, alpha3=0.5):
+        self.alpha1, self.alpha2, self.alpha3 = alpha1, alpha2, alpha3
+
+    def smear(self, ctx, g, fl):
+        check(lib().qexhip_nhyp_smear(ctx._h, _p(g), _p(fl), float(self.alpha1), float(self.alpha2), float(self.alpha3)))
+
+
+def makeImpLinks(ctx, fl, g, coef, ll=None, naik=0.0):
+    """makeImpLinks(fl, gf, coef, ll, gfLong, naik) with gfLong = gf (fat7l.nim:77-165);
+    coef = (oneLink, threeStaple, fiveStaple, sevenStaple, lepage)."""
+    cf = (C.c_double * 5)(*[float(v) for v in coef])
+    check(lib().qexhip_fat7(ctx._h, _p(g), cf, _p(fl), _p(ll), float(naik)))

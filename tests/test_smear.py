@@ -1,0 +1,111 @@
+"""Link construction upstream of the solver (forward direction):
+fat7 / HISQ (src/gauge/fat7l.nim, src/physics/hisqLinks.nim) and nHYP (src/gauge/hypsmear.nim).
+
+The reference holds no known-answer vector for these (its only test, tests/examples/testStagProp.nim,
+asserts not-NaN), so the oracle restatement is pinned by properties that fix every coefficient and
+index: free-field normalisation (9/8 and 1/24 for HISQ with staggered phases, identity for nHYP),
+gauge covariance, unitarity; the HIP path is then held to the oracle.
+"""
+import numpy as np
+import pytest
+
+cx = lambda a: a[..., 0] + 1j * a[..., 1]
+
+
+def _transform(o, lo, g, seed=0):
+    G = np.zeros((lo.vol, 3, 3, 2))
+    for i in range(lo.vol):
+        G[i] = o.su3_fn("qo_projectSU", np.random.default_rng(seed + i).standard_normal((3, 3, 2)))
+    Gc, gc = cx(G), cx(g)
+    nb = [np.array([lo.neighbor(i, mu, 1) for i in range(lo.vol)]) for mu in range(4)]
+    g2 = np.zeros_like(g)
+    for mu in range(4):
+        m = np.einsum("nij,njk,nlk->nil", Gc, gc[:, mu], Gc[nb[mu]].conj())
+        g2[:, mu, :, :, 0], g2[:, mu, :, :, 1] = m.real, m.imag
+    return Gc, g2
+
+
+def test_oracle_smearing_properties(oracle):
+    o = oracle
+    lo = o.Layout([4, 4, 4, 6])
+    # free field with staggered phases: HISQ gives the Naik-improved normalisation 9/8 and 1/24
+    gu = o.gauge_unit(lo)
+    o.stagPhase(lo, gu)
+    fl, ll = o.hisq_smear(lo, gu)
+    assert np.abs(fl[:, :, 0, 0, 0] / gu[:, :, 0, 0, 0] - 1.125).max() < 1e-14
+    assert np.abs(np.abs(ll[:, :, 0, 0, 0]) - 1.0 / 24.0).max() < 1e-15
+    assert np.abs(fl[:, :, 0, 1]).max() == 0
+    # ... and the long link is naik * the product of the three phased links
+    for i in range(0, lo.vol, 17):
+        for mu in range(4):
+            j, k = lo.neighbor(i, mu, 1), lo.neighbor(i, mu, 2)
+            assert abs(ll[i, mu, 0, 0, 0] - (-1.0 / 24.0) * gu[i, mu, 0, 0, 0] * gu[j, mu, 0, 0, 0] * gu[k, mu, 0, 0, 0]) < 1e-15
+    # nHYP of the unit field is the unit field
+    g1 = o.gauge_unit(lo)
+    assert np.abs(o.nhyp_smear(lo, g1) - g1).max() < 1e-15
+    # gauge covariance + unitarity on a rough field
+    g = o.gauge_warm(lo, 0.5, o.RngField(lo, o.RNG_MILC6, 3))
+    Gc, g2 = _transform(o, lo, g)
+    nb1 = [np.array([lo.neighbor(i, mu, 1) for i in range(lo.vol)]) for mu in range(4)]
+    nb3 = [np.array([lo.neighbor(i, mu, 3) for i in range(lo.vol)]) for mu in range(4)]
+    f1, f2 = cx(o.nhyp_smear(lo, g)), cx(o.nhyp_smear(lo, g2))
+    h1, h2 = [cx(a) for a in o.hisq_smear(lo, g)], [cx(a) for a in o.hisq_smear(lo, g2)]
+    for mu in range(4):
+        assert np.abs(np.einsum("nij,njk,nlk->nil", Gc, f1[:, mu], Gc[nb1[mu]].conj()) - f2[:, mu]).max() < 1e-11
+        assert np.abs(np.einsum("nij,njk,nlk->nil", Gc, h1[0][:, mu], Gc[nb1[mu]].conj()) - h2[0][:, mu]).max() < 1e-11
+        assert np.abs(np.einsum("nij,njk,nlk->nil", Gc, h1[1][:, mu], Gc[nb3[mu]].conj()) - h2[1][:, mu]).max() < 1e-11
+    m = f1.reshape(-1, 3, 3)
+    assert np.abs(np.einsum("nij,nkj->nik", m, m.conj()) - np.eye(3)).max() < 1e-13      # nHYP links are unitary
+    # alpha = 0 is the identity map up to projectU of an already unitary link
+    assert np.abs(o.nhyp_smear(lo, g, 0.0, 0.0, 0.0) - g).max() < 1e-13
+    # fat7 with only the one-link term is a rescaling
+    fl, _ = o.fat7(lo, g, (0.7, 0, 0, 0, 0))
+    assert np.abs(fl - 0.7 * g).max() < 1e-15
+
+
+@pytest.mark.gpu
+def test_gpu_hisq_and_fat7(oracle):
+    import qex_amd as q
+
+    o = oracle
+    lat = [4, 6, 8, 4]
+    lo = o.Layout(lat)
+    g = o.gauge_random(lo, seed=987654321)
+    o.rephase(lo, g)                                  # g.setBC; g.stagPhase (testStagProp.nim:24-26)
+    ctx = q.Context(lat)
+    fl, ll = np.zeros_like(g), np.zeros_like(g)
+    hc = q.HisqCoefs().init()
+    hc.smear(ctx, g, fl, ll)
+    rfl, rll = o.hisq_smear(lo, g)
+    assert np.linalg.norm(fl - rfl) / np.linalg.norm(rfl) < 1e-13
+    assert np.linalg.norm(ll - rll) / np.linalg.norm(rll) < 1e-13
+    # a fat7 with every term switched on, incl. Lepage and Naik
+    coef = (0.9, -0.11, 0.021, -0.0043, -0.07)
+    q.makeImpLinks(ctx, fl, g, coef, ll, naik=-0.05)
+    rfl, rll = o.fat7(lo, g, coef, naik=-0.05)
+    assert np.linalg.norm(fl - rfl) / np.linalg.norm(rfl) < 1e-13
+    assert np.linalg.norm(ll - rll) / np.linalg.norm(rll) < 1e-13
+    # the smeared links drive the Naik operator exactly like the oracle's (testStagProp.nim:34-50)
+    s = q.newStag3(ctx, fl, ll)
+    v1 = np.zeros((lo.vol, 3, 2))
+    v1[0, 0, 0] = 1.0
+    v2 = np.zeros_like(v1)
+    s.D(v2, v1, 0.001)
+    assert np.isfinite(v2).all()
+    assert np.linalg.norm(v2 - o.D(lo, rfl, rll, v1, 0.001)) / np.linalg.norm(v2) < 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_nhyp(oracle):
+    import qex_amd as q
+
+    o = oracle
+    lat = [4, 6, 8, 4]
+    lo = o.Layout(lat)
+    g = o.gauge_warm(lo, 0.5, o.RngField(lo, o.RNG_MILC6, 7))
+    ctx = q.Context(lat)
+    fl = np.zeros_like(g)
+    q.HypCoefs(0.4, 0.5, 0.5).smear(ctx, g, fl)        # the alphas of tests/extra/staghmc_sh (ref.0:66-70)
+    ref = o.nhyp_smear(lo, g, 0.4, 0.5, 0.5)
+    assert np.linalg.norm(fl - ref) / np.linalg.norm(ref) < 1e-12
+    assert q.plaq(ctx, fl).sum() > q.plaq(ctx, g).sum()   # smearing smooths
