@@ -193,6 +193,17 @@ int qexhip_fat7(qexhip_handle h, const double *g, const double coef[5], double *
 int qexhip_hisq_smear(qexhip_handle h, const double *g, double *fl, double *ll);
 int qexhip_nhyp_smear(qexhip_handle h, const double *g, double *fl, double alpha1, double alpha2, double alpha3);
 
+/* Smear on the device and hand the result straight to the operator (replaces smear -> rephase ->
+ * set_links without moving the smeared links over PCIe):
+ *   hisq: Staggered.g <- HisqCoefs.smear(g) (fat + long); g carries BC + phases already
+ *         (tests/examples/testStagProp.nim:24-40: g.setBC; g.stagPhase; hc.smear(g, fl, ll); newStag3(fl, ll))
+ *   nhyp: Staggered.g <- rephase(HypCoefs.smear(g)) with the fork's per-direction boundary flags
+ *         (src/stagg_pv_hmc/staghmc_spv.nim:367-401,601-604): antiperiodic[mu] != 0 flips U_mu on the last
+ *         slice of direction mu (NULL: t only, as gaugeUtils.nim:124-131); phases NULL = {8,9,11,0}. */
+int qexhip_stag_set_links_hisq(qexhip_handle h, const double *g);
+int qexhip_stag_set_links_nhyp(qexhip_handle h, const double *g, double alpha1, double alpha2, double alpha3,
+                               const int antiperiodic[4], const int phases[4]);
+
 /* ---------------- kernel timers ----------------
  * hipEvent pairs around launches of the named kernel class on the context stream
  * (the tic/toc hooks of src/physics/stagD.nim:354-395, src/solvers/cg.nim:175-241).

@@ -455,6 +455,21 @@ extern "C" int qexhip_nhyp_smear(qexhip_handle c, const double *g, double *fl, d
   return smear_nhyp_host(c, g, fl, a1, a2, a3);
 }
 
+extern "C" int qexhip_stag_set_links_hisq(qexhip_handle c, const double *g) {
+  if (!c || !g) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return smear_set_links_hisq(c, g);
+}
+extern "C" int qexhip_stag_set_links_nhyp(qexhip_handle c, const double *g, double a1, double a2, double a3,
+                                          const int antiperiodic[4], const int phases[4]) {
+  if (!c || !g) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  static const int defph[4] = {8, 9, 11, 0};
+  int mask = 0;
+  for (int mu = 0; mu < 4; mu++) if (antiperiodic ? antiperiodic[mu] : (mu == 3)) mask |= 1 << mu;
+  return smear_set_links_nhyp(c, g, a1, a2, a3, mask, phases ? phases : defph);
+}
+
 // ---- gauge / flow ----
 extern "C" int qexhip_gauge_set(qexhip_handle c, const double *g) { if (!c || !g) return QEXHIP_ERR_ARG; return gauge_set(c, g); }
 extern "C" int qexhip_gauge_get(qexhip_handle c, double *g) { if (!c || !g) return QEXHIP_ERR_ARG; return gauge_get(c, g); }

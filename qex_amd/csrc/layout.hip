@@ -160,6 +160,45 @@ int links_upload(qexhip_ctx *c, const double *fat, const double *lng) {
   return 0;
 }
 
+// Dslash-ready links from a DEVICE gauge field in the natural tile layout [parity][tile][mu][9][64]
+// (the output of the smearing kernels): same W as k_links_to_tiles builds from the host format.
+__global__ void __launch_bounds__(256) k_links_from_nat(Geom g, const double2 *__restrict__ N, double2 *W, int ndir, int dbase, int hop) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  int p = i >= g.Vh, c = i - p * g.Vh;
+  SiteXYZT s = site_coord(g, c, p);
+  double2 *w = W + ((size_t)p * g.ntile + (c >> 6)) * ndir * 576 + (c & 63);
+  for (int mu = 0; mu < 4; mu++) {
+    const double2 *U = N + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    double2 *wf = w + (size_t)(dbase + 2 * mu) * 576;
+    for (int k = 0; k < 9; k++) wf[k * 64] = U[k * 64];
+    int cb = nbr_pos<false>(g, c, s, mu, -hop);
+    const double2 *B = N + (((size_t)(1 - p) * g.ntile + (cb >> 6)) * 4 + mu) * 576 + (cb & 63);
+    double2 *wb = w + (size_t)(dbase + 2 * mu + 1) * 576;
+    for (int r = 0; r < 3; r++)
+      for (int q = 0; q < 3; q++) {
+        double2 v = B[(q * 3 + r) * 64];
+        wb[(r * 3 + q) * 64] = make_double2(v.x, -v.y);
+      }
+  }
+}
+int links_from_natural(qexhip_ctx *c, const double2 *fat, const double2 *lng) {
+  const Geom &g = c->g;
+  if (g.halo) { qexhip_set_error("links_from_natural: single GPU only"); return -3; }
+  int ndir = lng ? 16 : 8;
+  if (lng) for (int i = 0; i < 4; i++) if (g.X[i] < 4) { qexhip_set_error("Naik links need local extents >= 4"); return -1; }
+  size_t wbytes = (size_t)2 * g.ntile * ndir * 576 * sizeof(double2);
+  if (c->W && c->ndir != ndir) { HIPCHK(hipFree(c->W)); c->W = nullptr; }
+  if (!c->W) { HIPCHK(hipMalloc((void **)&c->W, wbytes)); }
+  HIPCHK(hipMemsetAsync(c->W, 0, wbytes, c->stream));
+  c->ndir = ndir;
+  k_links_from_nat<<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fat, c->W, ndir, 0, 1);
+  if (lng) k_links_from_nat<<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, lng, c->W, ndir, 8, 3);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // ---- host-callable test hooks for the index arithmetic (no GPU needed) ----
 // The same inline functions the kernels use, evaluated on the host, so that the CPU test suite
 // (tests/test_host_logic.py, incl. the 2-rank gloo test) can check site order, neighbour sense

@@ -129,6 +129,7 @@ int field_upload(qexhip_ctx *c, DevField &f, const double *host);      // host M
 int field_download(qexhip_ctx *c, const DevField &f, double *host);
 int links_upload(qexhip_ctx *c, const double *fat, const double *lng);
 int ensure_stage(qexhip_ctx *c, size_t bytes);
+int links_from_natural(qexhip_ctx *c, const double2 *fat, const double2 *lng);
 
 // ---- comm.cpp ----
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready, records ev_halo
@@ -189,6 +190,8 @@ int stag_outer_host(qexhip_ctx *c, double *f_host, const double *x_host, double 
 int smear_fat7_host(qexhip_ctx *c, const double *g_host, const double coef[5], double *fl_host, double *ll_host, double naik);
 int smear_hisq_host(qexhip_ctx *c, const double *g_host, double *fl_host, double *ll_host);
 int smear_nhyp_host(qexhip_ctx *c, const double *g_host, double *fl_host, double a1, double a2, double a3);
+int smear_set_links_hisq(qexhip_ctx *c, const double *g_host);
+int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, int bcmask, const int ph[4]);
 
 // ---- gauge.hip ----
 int gauge_set(qexhip_ctx *c, const double *g);

@@ -251,8 +251,86 @@ struct Smear {
       }
     return 0;
   }
+  // HisqCoefs.init + smear (hisqLinks.nim:9-43) on device fields
+  int hisq(const double2 *G, double2 *FL, double2 *LL) {
+    const double f7lf = 0.0, naik = 1.0, f2 = 2.0 - f7lf;
+    const double c_first[5] = {(1.0 + 3.0 * f7lf + 0.0) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f7lf / 16.0};
+    const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
+    double2 *T1, *T2;
+    CHK(alloc(&T1, gsz)); CHK(alloc(&T2, gsz));
+    CHK(fat7(T1, G, c_first, nullptr, G, 0.0));
+    for (int mu = 0; mu < 4; mu++) {
+      k_projectU<<<nb(), 256, 0, c->stream>>>(g, gvw(T2, mu), gv(T1, mu));
+      HIPCHK(hipGetLastError());
+    }
+    return fat7(FL, T2, c_second, LL, T2, -naik / 24.0);
+  }
+  // nHYP forward smearing (hypsmear.nim:49-144) on device fields
+  int nhyp(const double2 *G, double2 *FL, double a1, double a2, double a3) {
+    double2 *tmp, *l1[4][4], *l2[4][4];
+    CHK(alloc(&tmp, fsz));
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        l1[mu][nu] = l2[mu][nu] = nullptr;
+        if (mu != nu) { CHK(alloc(&l1[mu][nu], fsz)); CHK(alloc(&l2[mu][nu], fsz)); }
+      }
+    const double alp1 = a1 / 2.0, alp2 = a2 / 4.0, alp3 = a3 / 6.0;
+    const MViewW none{nullptr, 0};
+    const int nblk = nb();
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        k_mscale<<<nblk, 256, 0, c->stream>>>(g, fvw(tmp), 1 - a1, gv(G, mu));
+        CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(tmp), alp1));
+        k_projectU<<<nblk, 256, 0, c->stream>>>(g, fvw(l1[mu][nu]), fv(tmp));
+        HIPCHK(hipGetLastError());
+      }
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        k_mscale<<<nblk, 256, 0, c->stream>>>(g, fvw(tmp), 1 - a2, gv(G, mu));
+        for (int a = 0; a < 4; a++) {
+          if (a == mu || a == nu) continue;
+          const int b = 6 - mu - nu - a;
+          CHK(staple(fv(l1[a][b]), fv(l1[mu][b]), mu, a, none, fvw(tmp), alp2));
+        }
+        k_projectU<<<nblk, 256, 0, c->stream>>>(g, fvw(l2[mu][nu]), fv(tmp));
+        HIPCHK(hipGetLastError());
+      }
+    for (int mu = 0; mu < 4; mu++) {
+      k_mscale<<<nblk, 256, 0, c->stream>>>(g, fvw(tmp), 1 - a3, gv(G, mu));
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        CHK(staple(fv(l2[nu][mu]), fv(l2[mu][nu]), mu, nu, none, fvw(tmp), alp3));
+      }
+      k_projectU<<<nblk, 256, 0, c->stream>>>(g, gvw(FL, mu), fv(tmp));
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }
 };
 }  // namespace
+
+// setBC_cust + stagPhase on a device gauge field (stagg_pv_hmc/staghmc_spv.nim:367-401,
+// gauge/gaugeUtils.nim:124-131, physics/stagD.nim:509-520): sign flips only
+__global__ void __launch_bounds__(256) k_rephase(Geom g, double2 *G, int bcmask, int ph0, int ph1, int ph2, int ph3) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  int x[4];
+  coords_sm(g, c, p, x);
+  const int ph[4] = {ph0, ph1, ph2, ph3};
+  for (int mu = 0; mu < 4; mu++) {
+    int s = 0;
+    for (int k = 0; k < 4; k++) s += (ph[mu] >> k) & x[k];
+    if (((bcmask >> mu) & 1) && x[mu] == g.X[mu] - 1) s += 1;
+    if (s & 1) {
+      double2 *w = G + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+      for (int k = 0; k < 9; k++) { double2 v = w[k * 64]; w[k * 64] = make_double2(-v.x, -v.y); }
+    }
+  }
+}
+
 
 static int smear_check(qexhip_ctx *c, int min_extent) {
   if (c->g.halo) { qexhip_set_error("link smearing kernels are single-GPU (no t sharding)"); return -3; }
@@ -275,71 +353,46 @@ int smear_fat7_host(qexhip_ctx *c, const double *g_host, const double coef[5], d
   return 0;
 }
 
-// HisqCoefs.init + smear (hisqLinks.nim:9-43)
 int smear_hisq_host(qexhip_ctx *c, const double *g_host, double *fl_host, double *ll_host) {
   CHK(smear_check(c, 4));
-  const double f7lf = 0.0, naik = 1.0, f2 = 2.0 - f7lf;
-  const double c_first[5] = {(1.0 + 3.0 * f7lf + 0.0) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f7lf / 16.0};
-  const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
   Smear S(c);
-  double2 *G, *T1, *T2, *FL, *LL;
-  CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&T1, S.gsz)); CHK(S.alloc(&T2, S.gsz)); CHK(S.alloc(&FL, S.gsz)); CHK(S.alloc(&LL, S.gsz));
+  double2 *G, *FL, *LL;
+  CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&FL, S.gsz)); CHK(S.alloc(&LL, S.gsz));
   CHK(S.upload(G, g_host));
-  CHK(S.fat7(T1, G, c_first, nullptr, G, 0.0));
-  for (int mu = 0; mu < 4; mu++) {
-    k_projectU<<<S.nb(), 256, 0, c->stream>>>(S.g, S.gvw(T2, mu), S.gv(T1, mu));
-    HIPCHK(hipGetLastError());
-  }
-  CHK(S.fat7(FL, T2, c_second, LL, T2, -naik / 24.0));
+  CHK(S.hisq(G, FL, LL));
   CHK(S.download(fl_host, FL));
-  CHK(S.download(ll_host, LL));
-  return 0;
+  return S.download(ll_host, LL);
 }
 
-// nHYP forward smearing (hypsmear.nim:49-144)
 int smear_nhyp_host(qexhip_ctx *c, const double *g_host, double *fl_host, double a1, double a2, double a3) {
   CHK(smear_check(c, 2));
   Smear S(c);
-  const Geom &g = S.g;
-  double2 *G, *FL, *tmp, *l1[4][4], *l2[4][4];
-  CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&FL, S.gsz)); CHK(S.alloc(&tmp, S.fsz));
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) {
-      l1[mu][nu] = l2[mu][nu] = nullptr;
-      if (mu != nu) { CHK(S.alloc(&l1[mu][nu], S.fsz)); CHK(S.alloc(&l2[mu][nu], S.fsz)); }
-    }
+  double2 *G, *FL;
+  CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&FL, S.gsz));
   CHK(S.upload(G, g_host));
-  const double alp1 = a1 / 2.0, alp2 = a2 / 4.0, alp3 = a3 / 6.0;
-  const MViewW none{nullptr, 0};
-  const int nb = S.nb();
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) {
-      if (nu == mu) continue;
-      k_mscale<<<nb, 256, 0, c->stream>>>(g, S.fvw(tmp), 1 - a1, S.gv(G, mu));
-      CHK(S.staple(S.gv(G, nu), S.gv(G, mu), mu, nu, none, S.fvw(tmp), alp1));
-      k_projectU<<<nb, 256, 0, c->stream>>>(g, S.fvw(l1[mu][nu]), S.fv(tmp));
-      HIPCHK(hipGetLastError());
-    }
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) {
-      if (nu == mu) continue;
-      k_mscale<<<nb, 256, 0, c->stream>>>(g, S.fvw(tmp), 1 - a2, S.gv(G, mu));
-      for (int a = 0; a < 4; a++) {
-        if (a == mu || a == nu) continue;
-        const int b = 6 - mu - nu - a;
-        CHK(S.staple(S.fv(l1[a][b]), S.fv(l1[mu][b]), mu, a, none, S.fvw(tmp), alp2));
-      }
-      k_projectU<<<nb, 256, 0, c->stream>>>(g, S.fvw(l2[mu][nu]), S.fv(tmp));
-      HIPCHK(hipGetLastError());
-    }
-  for (int mu = 0; mu < 4; mu++) {
-    k_mscale<<<nb, 256, 0, c->stream>>>(g, S.fvw(tmp), 1 - a3, S.gv(G, mu));
-    for (int nu = 0; nu < 4; nu++) {
-      if (nu == mu) continue;
-      CHK(S.staple(S.fv(l2[nu][mu]), S.fv(l2[mu][nu]), mu, nu, none, S.fvw(tmp), alp3));
-    }
-    k_projectU<<<nb, 256, 0, c->stream>>>(g, S.gvw(FL, mu), S.fv(tmp));
-    HIPCHK(hipGetLastError());
-  }
+  CHK(S.nhyp(G, FL, a1, a2, a3));
   return S.download(fl_host, FL);
+}
+
+// smear on the device and hand the result straight to the Dslash (no PCIe round trip of the
+// smeared links): Staggered.g <- HISQ(g) / rephase(nHYP(g))
+int smear_set_links_hisq(qexhip_ctx *c, const double *g_host) {
+  CHK(smear_check(c, 4));
+  Smear S(c);
+  double2 *G, *FL, *LL;
+  CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&FL, S.gsz)); CHK(S.alloc(&LL, S.gsz));
+  CHK(S.upload(G, g_host));
+  CHK(S.hisq(G, FL, LL));
+  return links_from_natural(c, FL, LL);
+}
+int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, int bcmask, const int ph[4]) {
+  CHK(smear_check(c, 2));
+  Smear S(c);
+  double2 *G, *FL;
+  CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&FL, S.gsz));
+  CHK(S.upload(G, g_host));
+  CHK(S.nhyp(G, FL, a1, a2, a3));
+  k_rephase<<<S.nb(), 256, 0, c->stream>>>(S.g, FL, bcmask, ph[0], ph[1], ph[2], ph[3]);
+  HIPCHK(hipGetLastError());
+  return links_from_natural(c, FL, nullptr);
 }

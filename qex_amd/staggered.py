@@ -175,12 +175,24 @@ class Context:
 class Staggered:
     """Staggered[G,T] (stagD.nim:19-22): the links `g` carry BC and phases (rephase)."""
 
-    def __init__(self, ctx, g, g3=None):
+    def __init__(self, ctx, g, g3=None, smear=None, bc="pppa"):
+        """smear = None: g (, g3) are the final links.  smear = HisqCoefs(): the operator uses the
+        HISQ fat + long links of g, built on the device.  smear = HypCoefs(...): it uses
+        rephase(nHYP(g)) with boundary string `bc` ('a' = antiperiodic, as input_hmc.xml:44)."""
         self.ctx = ctx
         self.g = g
         self.g3 = g3
-        self.nlinks = 8 if g3 is not None else 4
-        check(lib().qexhip_stag_set_links(ctx._h, _p(g), _p(g3)))
+        if smear is None:
+            self.nlinks = 8 if g3 is not None else 4
+            check(lib().qexhip_stag_set_links(ctx._h, _p(g), _p(g3)))
+        elif isinstance(smear, HisqCoefs):
+            self.nlinks = 8
+            check(lib().qexhip_stag_set_links_hisq(ctx._h, _p(g)))
+        else:
+            self.nlinks = 4
+            ap = (C.c_int * 4)(*[1 if ch == "a" else 0 for ch in bc])
+            check(lib().qexhip_stag_set_links_nhyp(ctx._h, _p(g), float(smear.alpha1), float(smear.alpha2),
+                                                   float(smear.alpha3), ap, None))
 
     # r = m*x + D*x  /  r = m*x - D*x
     def D(self, r, x, m):

@@ -109,3 +109,39 @@ def test_gpu_nhyp(oracle):
     ref = o.nhyp_smear(lo, g, 0.4, 0.5, 0.5)
     assert np.linalg.norm(fl - ref) / np.linalg.norm(ref) < 1e-12
     assert q.plaq(ctx, fl).sum() > q.plaq(ctx, g).sum()   # smearing smooths
+
+
+@pytest.mark.gpu
+def test_gpu_operator_on_device_smeared_links(oracle):
+    """Staggered(..., smear=...) smears on the device and feeds the Dslash directly; it must act
+    exactly like smear -> (rephase) -> newStag through host memory, and like the oracle."""
+    import qex_amd as q
+
+    o = oracle
+    lat = [4, 6, 8, 4]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 99)
+    g = o.gauge_warm(lo, 0.5, rf)
+    x = o.vector_gaussian(lo, rf)
+    ctx = q.Context(lat)
+    y, y2 = np.zeros_like(x), np.zeros_like(x)
+    # HISQ: phases first, then smear (testStagProp.nim:24-40)
+    gp = g.copy()
+    o.rephase(lo, gp)
+    s = q.Staggered(ctx, gp, smear=q.HisqCoefs().init())
+    s.D(y, x, 0.05)
+    rfl, rll = o.hisq_smear(lo, gp)
+    assert np.linalg.norm(y - o.D(lo, rfl, rll, x, 0.05)) / np.linalg.norm(y) < 1e-12
+    # nHYP: smear the unphased field, then BC + phases (staghmc_spv.nim:601-604)
+    for bc in ("pppa", "aaaa", "pppp"):
+        s = q.Staggered(ctx, g, smear=q.HypCoefs(0.4, 0.5, 0.5), bc=bc)
+        s.D(y, x, 0.05)
+        sm = o.nhyp_smear(lo, g, 0.4, 0.5, 0.5)
+        for mu, ch in enumerate(bc):                   # setBC_cust (staghmc_spv.nim:367-390)
+            if ch == "a":
+                last = np.array([lo.coord(i)[mu] == lat[mu] - 1 for i in range(lo.vol)])
+                sm[last, mu] *= -1.0
+        o.stagPhase(lo, sm)
+        assert np.linalg.norm(y - o.D(lo, sm, None, x, 0.05)) / np.linalg.norm(y) < 1e-12
+        q.newStag(ctx, sm).D(y2, x, 0.05)
+        assert np.linalg.norm(y - y2) / np.linalg.norm(y) < 1e-13
