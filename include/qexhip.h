@@ -204,6 +204,19 @@ int qexhip_stag_set_links_hisq(qexhip_handle h, const double *g);
 int qexhip_stag_set_links_nhyp(qexhip_handle h, const double *g, double alpha1, double alpha2, double alpha3,
                                const int antiperiodic[4], const int phases[4]);
 
+/* nHYP smeared-force chain = the closure smearGetForce returns (src/gauge/hypsmear.nim:49-247):
+ *   prepare: smear g (alphas as HypCoefs) and keep the 12+12+12+12+4 intermediate link fields on the
+ *            device; fl (nullable) receives the smeared links.  Replaces `coef.smearGetForce(gf, fl, info)`
+ *            (src/stagg_pv_hmc/staghmc_spv.nim:989-993).  The state refers to THIS g.
+ *   force:   smearedForce(f, chain): chain = dS/dV^+ w.r.t. the smeared links ([vol][4][3][3][2]),
+ *            f = dS/dU^+ w.r.t. the thin links, through projectUderiv + symStapleDeriv
+ *            (src/maths/matrixFunctions.nim:329-357, src/gauge/smearutil.nim:22-50); f may alias chain
+ *            (the fork calls f.smeared_force(f), staghmc_spv.nim:740).
+ *   release: drop the closure (QEX: GC of the closure, hypsmear.nim:249-263). */
+int qexhip_nhyp_prepare(qexhip_handle h, const double *g, double alpha1, double alpha2, double alpha3, double *fl);
+int qexhip_nhyp_force(qexhip_handle h, double *f, const double *chain);
+int qexhip_nhyp_release(qexhip_handle h);
+
 /* ---------------- kernel timers ----------------
  * hipEvent pairs around launches of the named kernel class on the context stream
  * (the tic/toc hooks of src/physics/stagD.nim:354-395, src/solvers/cg.nim:175-241).

@@ -68,6 +68,9 @@ def lib():
         L.qo_fat7.argtypes = [vp, vp, vp, vp, vp, vp, cd]
         L.qo_hisq_smear.argtypes = [vp, vp, vp, vp]
         L.qo_nhyp_smear.argtypes = [vp, vp, vp, cd, cd, cd]
+        L.qo_nhyp_force.argtypes = [vp, vp, vp, vp, vp, cd, cd, cd]
+        L.qo_projectUderiv.argtypes = [vp, vp, vp, vp]
+        L.qo_force_projTAH.argtypes = [vp, vp, vp, ci]
         L.qo_stag_outer.argtypes = [vp, vp, vp, cd, cd, ci]
         L.qo_solve_prev.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp]
         L.qo_solveXX_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp, ci]
@@ -338,6 +341,26 @@ def nhyp_smear(lo, g, a1=0.4, a2=0.5, a3=0.5):
     fl = lo.new_gauge()
     lib().qo_nhyp_smear(lo._h, _p(g), _p(fl), a1, a2, a3)
     return fl
+
+
+def nhyp_force(lo, g, chain, a1=0.4, a2=0.5, a3=0.5):
+    """smearGetForce(g) then smearedForce(f, chain): returns (smeared links, f)."""
+    fl, f = lo.new_gauge(), lo.new_gauge()
+    lib().qo_nhyp_force(lo._h, _p(g), _p(fl), _p(f), _p(np.ascontiguousarray(chain)), a1, a2, a3)
+    return fl, f
+
+
+def projectUderiv(x, chain):
+    """projectUderiv(r, x, c) (matrixFunctions.nim:353-357): u = projectU(x) first."""
+    x, chain = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(chain, dtype=np.float64)
+    u, r = np.zeros_like(x), np.zeros_like(x)
+    lib().qo_projectU(_p(u), _p(x))
+    lib().qo_projectUderiv(_p(r), _p(u), _p(x), _p(chain))
+    return r
+
+
+def force_projTAH(lo, f, g, adj=False):
+    lib().qo_force_projTAH(lo._h, _p(f), _p(g), 1 if adj else 0)
 
 
 def stag_outer(lo, f, x, scale_even, scale_odd, accumulate):

@@ -1519,3 +1519,230 @@ void qo_nhyp_smear(const qo_layout *lo, const double *g, double *fl, double a1, 
   for (int mu = 0; mu < 4; mu++) for (int nu = 0; nu < 4; nu++) if (mu != nu) { free(l1[mu][nu]); free(l2[mu][nu]); }
   free(tmp);
 }
+
+/* ------------------------------------------------------------------ */
+/* nHYP smeared-force chain (backward direction)     */
+/* ------------------------------------------------------------------ */
+#include <complex.h>
+typedef double complex cx_t;
+static inline void to_cx(cx_t *c, const double *m) { for (int i = 0; i < 9; i++) c[i] = m[2 * i] + I * m[2 * i + 1]; }
+static inline void from_cx(double *m, const cx_t *c) { for (int i = 0; i < 9; i++) { m[2 * i] = creal(c[i]); m[2 * i + 1] = cimag(c[i]); } }
+static inline void cx_mul(cx_t *r, const cx_t *a, const cx_t *b) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    cx_t s = 0; for (int k = 0; k < 3; k++) s += a[3 * i + k] * b[3 * k + j];
+    r[3 * i + j] = s;
+  }
+}
+/* adjugate, nc = 3 (maths/projUderiv.nim:8-38) */
+static void cx_adjugate(cx_t *r, const cx_t *x) {
+  r[0] = x[4] * x[8] - x[5] * x[7]; r[1] = x[7] * x[2] - x[8] * x[1]; r[2] = x[1] * x[5] - x[2] * x[4];
+  r[3] = x[5] * x[6] - x[3] * x[8]; r[4] = x[8] * x[0] - x[6] * x[2]; r[5] = x[2] * x[3] - x[0] * x[5];
+  r[6] = x[3] * x[7] - x[4] * x[6]; r[7] = x[6] * x[1] - x[7] * x[0]; r[8] = x[0] * x[4] - x[1] * x[3];
+}
+/* inverse, nc = 3, c = 1 (maths/matinv.nim:90-115) */
+static void cx_inverse(cx_t *r, const cx_t *x) {
+  const cx_t det0 = x[0] * x[4] - x[1] * x[3], det1 = x[2] * x[3] - x[0] * x[5], det2 = x[1] * x[5] - x[2] * x[4];
+  const cx_t det = det0 * x[8] + det1 * x[7] + det2 * x[6];
+  const cx_t idet = 1.0 / det;
+  r[0] = idet * (x[4] * x[8] - x[5] * x[7]); r[1] = idet * (x[7] * x[2] - x[8] * x[1]); r[2] = idet * det2;
+  r[3] = idet * (x[5] * x[6] - x[3] * x[8]); r[4] = idet * (x[8] * x[0] - x[6] * x[2]); r[5] = idet * det1;
+  r[6] = idet * (x[3] * x[7] - x[4] * x[6]); r[7] = idet * (x[6] * x[1] - x[7] * x[0]); r[8] = idet * det0;
+}
+/* sylsolve, nc = 3: solves A X + X A = C (maths/projUderiv.nim:96-147) */
+static void cx_sylsolve(cx_t *x, const cx_t *a, const cx_t *c) {
+  cx_t ad[9], ac[9], ca[9], aca[9], adc[9], cad[9], adcad[9];
+  cx_adjugate(ad, a);
+  const cx_t t = a[0] + a[4] + a[8], s = ad[0] + ad[4] + ad[8];
+  const cx_t r = a[0] * ad[0] + a[1] * ad[3] + a[2] * ad[6];
+  cx_mul(ac, a, c); cx_mul(ca, c, a); cx_mul(aca, ac, a);
+  cx_mul(adc, ad, c); cx_mul(cad, c, ad); cx_mul(adcad, adc, ad);
+  const cx_t c2 = 1.0 / (2.0 * (s * t - r)), c0 = c2 * (s + t * t), c1 = c2 * (t / r), c4 = c2 * t;
+  for (int i = 0; i < 9; i++) x[i] = c0 * c[i] + c1 * adcad[i] + c2 * (aca[i] - adc[i] - cad[i]) - c4 * (ac[i] + ca[i]);
+}
+/* projectUderiv(r, u, x, chain) (maths/matrixFunctions.nim:329-351):
+ * F with  d Re tr(C^+ U(X)) = Re tr(dX^+ F),  U = X (X^+X)^{-1/2}.  r may alias chain. */
+void qo_projectUderiv(double *r, const double *u, const double *x, const double *chain) {
+  double t[18], zr[18];
+  m_mul_an(t, x, x);
+  m_add_diag(t, 1e-20);
+  rsqrtPHM3(zr, t);
+  cx_t z[9], y[9], rr[9], cc[9], uu[9], xx[9], t1[9], t2[9];
+  to_cx(z, zr); to_cx(cc, chain); to_cx(uu, u); to_cx(xx, x);
+  cx_inverse(y, z);
+  cx_mul(rr, cc, z);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {       /* t1 = u^+ r */
+    cx_t s = 0; for (int k = 0; k < 3; k++) s += conj(uu[3 * k + i]) * rr[3 * k + j];
+    t1[3 * i + j] = s;
+  }
+  cx_sylsolve(t2, y, t1);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t1[3 * i + j] = t2[3 * i + j] + conj(t2[3 * j + i]);
+  cx_mul(t2, xx, t1);
+  for (int i = 0; i < 9; i++) rr[i] -= t2[i];
+  from_cx(r, rr);
+}
+
+/* symStapleDeriv (gauge/smearutil.nim:22-50), gathered per site:
+ *   f1(x) += g2(x) g1(x+mu) c(x+nu)^+ + c(x) g1(x+mu) g2(x+nu)^+
+ *          + [g2^+ g1 c(+nu) + c^+ g1 g2(+nu)](x-mu)
+ *   f2(x) += g1(x) c(x+nu) g1(x+mu)^+ + [g1^+ c g1(+mu)](x-nu)
+ * g1: side links (direction nu), g2: middle links (direction mu), c: chain of the staple sum */
+static void staple_deriv(const qo_layout *lo, double *f1, size_t f1s, double *f2, size_t f2s,
+                         mview g1, mview g2, const double *c, int mu, int nu) {
+#pragma omp parallel for schedule(static)
+  for (int x = 0; x < lo->vol; x++) {
+    const int xpm = lo->nb[mu][0][x], xpn = lo->nb[nu][0][x], xmm = lo->nb[mu][1][x], xmn = lo->nb[nu][1][x];
+    const int xmmpn = lo->nb[nu][0][xmm], xmnpm = lo->nb[mu][0][xmn];
+    const double *C = c;
+    double t[18], u[18], a1[18], a2[18];
+    m_zero(a1); m_zero(a2);
+    m_mul_na(t, MV(g1, xpm), &C[(size_t)xpn * 18]); m_mul(u, MV(g2, x), t); m_axpy(a1, 1.0, u);
+    m_mul_na(t, MV(g1, xpm), MV(g2, xpn)); m_mul(u, &C[(size_t)x * 18], t); m_axpy(a1, 1.0, u);
+    m_mul(t, MV(g1, xmm), &C[(size_t)xmmpn * 18]); m_mul_an(u, MV(g2, xmm), t); m_axpy(a1, 1.0, u);
+    m_mul(t, MV(g1, xmm), MV(g2, xmmpn)); m_mul_an(u, &C[(size_t)xmm * 18], t); m_axpy(a1, 1.0, u);
+    m_mul_na(t, &C[(size_t)xpn * 18], MV(g1, xpm)); m_mul(u, MV(g1, x), t); m_axpy(a2, 1.0, u);
+    m_mul(t, &C[(size_t)xmn * 18], MV(g1, xmnpm)); m_mul_an(u, MV(g1, xmn), t); m_axpy(a2, 1.0, u);
+    /* f1 and f2 may be the same gauge field (different mu) but never the same matrix */
+    m_axpy(&f1[(size_t)x * f1s], 1.0, a1);
+    m_axpy(&f2[(size_t)x * f2s], 1.0, a2);
+  }
+}
+
+/* smearGetForce + smearedForce(f, chain) with keepProj (gauge/hypsmear.nim:49-247).
+ * g: thin links; chain: d/dV^+ of the action w.r.t. the smeared links; f (out, may alias chain):
+ * d/dU^+ w.r.t. the thin links.  fl (optional): the smeared links. */
+void qo_nhyp_force(const qo_layout *lo, const double *g, double *fl, double *f, const double *chain,
+                   double a1, double a2, double a3) {
+  const size_t n = (size_t)lo->vol * 18;
+  const int V = lo->vol;
+  double *l1x[4][4], *l1[4][4], *l2x[4][4], *l2[4][4], *fl1[4][4], *fl2[4][4], *flx[4], *fc[4];
+#define NEWF() ((double *)calloc(n, sizeof(double)))
+  for (int mu = 0; mu < 4; mu++) {
+    flx[mu] = NEWF(); fc[mu] = NEWF();
+    for (int nu = 0; nu < 4; nu++) {
+      l1x[mu][nu] = l1[mu][nu] = l2x[mu][nu] = l2[mu][nu] = fl1[mu][nu] = fl2[mu][nu] = NULL;
+      if (mu != nu) { l1x[mu][nu] = NEWF(); l1[mu][nu] = NEWF(); l2x[mu][nu] = NEWF(); l2[mu][nu] = NEWF(); fl1[mu][nu] = NEWF(); fl2[mu][nu] = NEWF(); }
+    }
+  }
+  const double alp1 = a1 / 2.0, alp2 = a2 / 4.0, alp3 = a3 / 6.0, ma1 = 1 - a1, ma2 = 1 - a2, ma3 = 1 - a3;
+  /* forward (hypsmear.nim:98-143) */
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      for (int x = 0; x < V; x++) m_scale(&l1x[mu][nu][(size_t)x * 18], ma1, GLINK(g, x, mu));
+      gen_staple(lo, NULL, l1x[mu][nu], 18, alp1, gauge_view(g, nu), gauge_view(g, mu), mu, nu);
+#pragma omp parallel for schedule(static)
+      for (int x = 0; x < V; x++) qo_projectU(&l1[mu][nu][(size_t)x * 18], &l1x[mu][nu][(size_t)x * 18]);
+    }
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      for (int x = 0; x < V; x++) m_scale(&l2x[mu][nu][(size_t)x * 18], ma2, GLINK(g, x, mu));
+      for (int a = 0; a < 4; a++) {
+        if (a == mu || a == nu) continue;
+        const int b = 1 + 2 + 3 - mu - nu - a;
+        gen_staple(lo, NULL, l2x[mu][nu], 18, alp2, field_view(l1[a][b]), field_view(l1[mu][b]), mu, a);
+      }
+#pragma omp parallel for schedule(static)
+      for (int x = 0; x < V; x++) qo_projectU(&l2[mu][nu][(size_t)x * 18], &l2x[mu][nu][(size_t)x * 18]);
+    }
+  for (int mu = 0; mu < 4; mu++) {
+    for (int x = 0; x < V; x++) m_scale(&flx[mu][(size_t)x * 18], ma3, GLINK(g, x, mu));
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      gen_staple(lo, NULL, flx[mu], 18, alp3, field_view(l2[nu][mu]), field_view(l2[mu][nu]), mu, nu);
+    }
+    if (fl) {
+#pragma omp parallel for schedule(static)
+      for (int x = 0; x < V; x++) qo_projectU(&fl[((size_t)x * 4 + mu) * 18], &flx[mu][(size_t)x * 18]);
+    }
+  }
+  if (f && chain) {
+    /* backward (hypsmear.nim:146-245) */
+    /* proj flx -> fl: fc <- chain (u recomputed from x, matrixFunctions.nim:353-357) */
+    for (int mu = 0; mu < 4; mu++) {
+#pragma omp parallel for schedule(static)
+      for (int x = 0; x < V; x++) {
+        double u[18];
+        qo_projectU(u, &flx[mu][(size_t)x * 18]);
+        qo_projectUderiv(&fc[mu][(size_t)x * 18], u, &flx[mu][(size_t)x * 18], &chain[((size_t)x * 4 + mu) * 18]);
+      }
+    }
+    for (int mu = 0; mu < 4; mu++)
+      for (int x = 0; x < V; x++) {
+        m_scale(&f[((size_t)x * 4 + mu) * 18], ma3, &fc[mu][(size_t)x * 18]);
+        for (int k = 0; k < 18; k++) fc[mu][(size_t)x * 18 + k] *= alp3;
+      }
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        staple_deriv(lo, fl2[nu][mu], 18, fl2[mu][nu], 18, field_view(l2[nu][mu]), field_view(l2[mu][nu]), fc[mu], mu, nu);
+      }
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+#pragma omp parallel for schedule(static)
+        for (int x = 0; x < V; x++) {
+          double *p = &fl2[mu][nu][(size_t)x * 18];
+          qo_projectUderiv(p, &l2[mu][nu][(size_t)x * 18], &l2x[mu][nu][(size_t)x * 18], p);
+        }
+      }
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        for (int x = 0; x < V; x++) {
+          double *p = &fl2[mu][nu][(size_t)x * 18];
+          m_axpy(&f[((size_t)x * 4 + mu) * 18], ma2, p);
+          for (int k = 0; k < 18; k++) p[k] *= alp2;
+        }
+      }
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        for (int a = 0; a < 4; a++) {
+          if (a == mu || a == nu) continue;
+          const int b = 1 + 2 + 3 - mu - nu - a;
+          staple_deriv(lo, fl1[a][b], 18, fl1[mu][b], 18, field_view(l1[a][b]), field_view(l1[mu][b]), fl2[mu][nu], mu, a);
+        }
+      }
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+#pragma omp parallel for schedule(static)
+        for (int x = 0; x < V; x++) {
+          double *p = &fl1[mu][nu][(size_t)x * 18];
+          qo_projectUderiv(p, &l1[mu][nu][(size_t)x * 18], &l1x[mu][nu][(size_t)x * 18], p);
+        }
+      }
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        for (int x = 0; x < V; x++) {
+          double *p = &fl1[mu][nu][(size_t)x * 18];
+          m_axpy(&f[((size_t)x * 4 + mu) * 18], ma1, p);
+          for (int k = 0; k < 18; k++) p[k] *= alp1;
+        }
+      }
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        staple_deriv(lo, f + (size_t)nu * 18, 72, f + (size_t)mu * 18, 72, gauge_view(g, nu), gauge_view(g, mu), fl1[mu][nu], mu, nu);
+      }
+  }
+  for (int mu = 0; mu < 4; mu++) {
+    free(flx[mu]); free(fc[mu]);
+    for (int nu = 0; nu < 4; nu++) if (mu != nu) { free(l1x[mu][nu]); free(l1[mu][nu]); free(l2x[mu][nu]); free(l2[mu][nu]); free(fl1[mu][nu]); free(fl2[mu][nu]); }
+  }
+#undef NEWF
+}
+
+/* projTAH(f, g) of the fork (stagg_pv_hmc/staghmc_spv_gforce.nim:256-291):
+ * adj = 0 ("no_adj", matter):  f <- TAH(f g^+);  adj = 1 ("adj", gauge):  f <- TAH(g f^+) */
+void qo_force_projTAH(const qo_layout *lo, double *f, const double *g, int adj) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < lo->vol * 4; i++) {
+    double s[18];
+    if (adj) m_mul_na(s, &g[(size_t)i * 18], &f[(size_t)i * 18]);
+    else m_mul_na(s, &f[(size_t)i * 18], &g[(size_t)i * 18]);
+    qo_projectTAH(&f[(size_t)i * 18], s);
+  }
+}

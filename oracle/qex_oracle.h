@@ -83,6 +83,14 @@ void qo_wflow_general(const qo_layout *lo, double *g, int nsteps, double eps, do
 void qo_fat7(const qo_layout *lo, double *fl, const double *gf, const double coef[5], double *ll, const double *gfLong, double naik);
 void qo_hisq_smear(const qo_layout *lo, const double *g, double *fl, double *ll);
 void qo_nhyp_smear(const qo_layout *lo, const double *g, double *fl, double a1, double a2, double a3);
+/* nHYP smeared-force chain: smearGetForce + smearedForce(f, chain) (gauge/hypsmear.nim:49-247, keepProj),
+ * symStapleDeriv (gauge/smearutil.nim:22-50), projectUderiv / sylsolve / inverse
+ * (maths/matrixFunctions.nim:329-357, maths/projUderiv.nim:8-147, maths/matinv.nim:90-115).
+ * fl (nullable) receives the smeared links; f may alias chain. */
+void qo_projectUderiv(double *r, const double *u, const double *x, const double *chain);
+void qo_nhyp_force(const qo_layout *lo, const double *g, double *fl, double *f, const double *chain, double a1, double a2, double a3);
+/* projTAH(f, g) of the fork (stagg_pv_hmc/staghmc_spv_gforce.nim:256-291): adj=0 TAH(f g^+), adj=1 TAH(g f^+) */
+void qo_force_projTAH(const qo_layout *lo, double *f, const double *g, int adj);
 
 /* ---- flow observables (gaugeUtils.nim:1079-1270): out = {E_s, E_t, Q} ---- */
 void qo_flow_EQ(const qo_layout *lo, const double *g, int loop, double out[3]);

@@ -60,6 +60,9 @@ SYMBOLS = [
     ("qexhip_nhyp_smear", _ci, [_vp, _vp, _vp, _cd, _cd, _cd]),
     ("qexhip_stag_set_links_hisq", _ci, [_vp, _vp]),
     ("qexhip_stag_set_links_nhyp", _ci, [_vp, _vp, _cd, _cd, _cd, _pi, _pi]),
+    ("qexhip_nhyp_prepare", _ci, [_vp, _vp, _cd, _cd, _cd, _vp]),
+    ("qexhip_nhyp_force", _ci, [_vp, _vp, _vp]),
+    ("qexhip_nhyp_release", _ci, [_vp]),
     ("qexhip_timers_enable", _ci, [_vp, _ci]),
     ("qexhip_timers_reset", _ci, [_vp]),
     ("qexhip_timers_get", _ci, [_vp, C.c_char_p, C.POINTER(C.c_long), _pd]),

@@ -128,6 +128,7 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
   for (auto &kv : c->fields) (void)hipFree(kv.second.d);
   c->fields.clear();
   for (auto &kv : c->timers) for (auto e : kv.second.ev) (void)hipEventDestroy(e);
+  nhyp_state_free(c);
   gauge_free(c);
   comm_destroy(c);
   if (c->W) (void)hipFree(c->W);
@@ -468,6 +469,23 @@ extern "C" int qexhip_stag_set_links_nhyp(qexhip_handle c, const double *g, doub
   int mask = 0;
   for (int mu = 0; mu < 4; mu++) if (antiperiodic ? antiperiodic[mu] : (mu == 3)) mask |= 1 << mu;
   return smear_set_links_nhyp(c, g, a1, a2, a3, mask, phases ? phases : defph);
+}
+
+extern "C" int qexhip_nhyp_prepare(qexhip_handle c, const double *g, double a1, double a2, double a3, double *fl) {
+  if (!c || !g) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return nhyp_prepare(c, g, a1, a2, a3, fl);
+}
+extern "C" int qexhip_nhyp_force(qexhip_handle c, double *f, const double *chain) {
+  if (!c || !f || !chain) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return nhyp_force_host(c, f, chain);
+}
+extern "C" int qexhip_nhyp_release(qexhip_handle c) {
+  if (!c) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  nhyp_state_free(c);
+  return 0;
 }
 
 // ---- gauge / flow ----

@@ -95,6 +95,7 @@ struct qexhip_ctx {
   int opt_overlap = -1;  // QEXHIP_OVERLAP: 1 always use the comm stream, 0 never, -1 by interior size
   // natural gauge (flow)
   GaugeNat *gn = nullptr;
+  void *nhyp = nullptr;   // NhypState (smear.hip): the smearGetForce closure
 };
 
 // work-field slots (get_work)
@@ -191,6 +192,9 @@ int smear_fat7_host(qexhip_ctx *c, const double *g_host, const double coef[5], d
 int smear_hisq_host(qexhip_ctx *c, const double *g_host, double *fl_host, double *ll_host);
 int smear_nhyp_host(qexhip_ctx *c, const double *g_host, double *fl_host, double a1, double a2, double a3);
 int smear_set_links_hisq(qexhip_ctx *c, const double *g_host);
+void nhyp_state_free(qexhip_ctx *c);
+int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, double *fl_host);
+int nhyp_force_host(qexhip_ctx *c, double *f_host, const double *chain_host);
 int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, int bcmask, const int ph[4]);
 
 // ---- gauge.hip ----

@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(256) k_mscale(Geom g, MViewW dst, double coef,
 }
 
 // eigs3 + rsqrtPHM3f + rsqrtPHM3 + projectU (matrixFunctions.nim:79-182,279-313)
-__device__ __forceinline__ M3 m3_projectU(const M3 &x) {
+// z = (x^+ x + 1e-20)^(-1/2)   (projectUrsqrt, matrixFunctions.nim:301-306)
+__device__ __forceinline__ M3 m3_rsqrt_xdx(const M3 &x) {
   M3 t = m3_mul_an(x, x);
   m3_add_diag(t, 1e-20);
   const double tr = t.e[0].x + t.e[4].x + t.e[8].x;
@@ -123,7 +124,145 @@ __device__ __forceinline__ M3 m3_projectU(const M3 &x) {
 #pragma unroll
   for (int k = 0; k < 9; k++) rs.e[k] = make_double2(c1 * t.e[k].x + c2 * t2.e[k].x, c1 * t.e[k].y + c2 * t2.e[k].y);
   m3_add_diag(rs, c0);
-  return m3_mul(x, rs);
+  return rs;
+}
+__device__ __forceinline__ M3 m3_projectU(const M3 &x) { return m3_mul(x, m3_rsqrt_xdx(x)); }
+
+// ---- projectUderiv and its pieces (matrixFunctions.nim:329-357, projUderiv.nim:8-38,96-147, matinv.nim:90-115)
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cinv(double2 a) { const double d = 1.0 / (a.x * a.x + a.y * a.y); return make_double2(a.x * d, -a.y * d); }
+__device__ __forceinline__ double2 cm2(double2 a, double2 b, double2 c, double2 d) { return csub(cmul(a, b), cmul(c, d)); }  // ab - cd
+__device__ __forceinline__ M3 m3_adjugate(const M3 &m) {
+  const double2 *x = m.e;
+  M3 r;
+  r.e[0] = cm2(x[4], x[8], x[5], x[7]); r.e[1] = cm2(x[7], x[2], x[8], x[1]); r.e[2] = cm2(x[1], x[5], x[2], x[4]);
+  r.e[3] = cm2(x[5], x[6], x[3], x[8]); r.e[4] = cm2(x[8], x[0], x[6], x[2]); r.e[5] = cm2(x[2], x[3], x[0], x[5]);
+  r.e[6] = cm2(x[3], x[7], x[4], x[6]); r.e[7] = cm2(x[6], x[1], x[7], x[0]); r.e[8] = cm2(x[0], x[4], x[1], x[3]);
+  return r;
+}
+__device__ __forceinline__ M3 m3_inverse(const M3 &m) {
+  const double2 *x = m.e;
+  const double2 det0 = cm2(x[0], x[4], x[1], x[3]), det1 = cm2(x[2], x[3], x[0], x[5]), det2 = cm2(x[1], x[5], x[2], x[4]);
+  const double2 det = cadd(cadd(cmul(det0, x[8]), cmul(det1, x[7])), cmul(det2, x[6]));
+  const double2 idet = cinv(det);
+  M3 r;
+  r.e[0] = cmul(idet, cm2(x[4], x[8], x[5], x[7])); r.e[1] = cmul(idet, cm2(x[7], x[2], x[8], x[1])); r.e[2] = cmul(idet, det2);
+  r.e[3] = cmul(idet, cm2(x[5], x[6], x[3], x[8])); r.e[4] = cmul(idet, cm2(x[8], x[0], x[6], x[2])); r.e[5] = cmul(idet, det1);
+  r.e[6] = cmul(idet, cm2(x[3], x[7], x[4], x[6])); r.e[7] = cmul(idet, cm2(x[6], x[1], x[7], x[0])); r.e[8] = cmul(idet, det0);
+  return r;
+}
+// A X + X A = C
+__device__ __forceinline__ M3 m3_sylsolve(const M3 &a, const M3 &c) {
+  const M3 ad = m3_adjugate(a);
+  const double2 t = cadd(cadd(a.e[0], a.e[4]), a.e[8]), s = cadd(cadd(ad.e[0], ad.e[4]), ad.e[8]);
+  const double2 r = cadd(cadd(cmul(a.e[0], ad.e[0]), cmul(a.e[1], ad.e[3])), cmul(a.e[2], ad.e[6]));
+  const double2 two_d = csub(cmul(s, t), r);
+  const double2 c2 = cinv(make_double2(2.0 * two_d.x, 2.0 * two_d.y));
+  const double2 c0 = cmul(c2, cadd(s, cmul(t, t))), c1 = cmul(c2, cmul(t, cinv(r))), c4 = cmul(c2, t);
+  const M3 ac = m3_mul(a, c), ca = m3_mul(c, a);
+  M3 x;
+  {
+    const M3 aca = m3_mul(ac, a);
+#pragma unroll
+    for (int k = 0; k < 9; k++) x.e[k] = cadd(cmul(c0, c.e[k]), csub(cmul(c2, aca.e[k]), cmul(c4, cadd(ac.e[k], ca.e[k]))));
+  }
+  const M3 adc = m3_mul(ad, c), cad = m3_mul(c, ad);
+  const M3 adcad = m3_mul(adc, ad);
+#pragma unroll
+  for (int k = 0; k < 9; k++) x.e[k] = cadd(x.e[k], csub(cmul(c1, adcad.e[k]), cmul(c2, cadd(adc.e[k], cad.e[k]))));
+  return x;
+}
+// F with d Re tr(C^+ U(X)) = Re tr(dX^+ F)
+__device__ __forceinline__ M3 m3_projectUderiv(const M3 &u, const M3 &x, const M3 &chain) {
+  const M3 z = m3_rsqrt_xdx(x);
+  const M3 y = m3_inverse(z);
+  M3 r = m3_mul(chain, z);
+  M3 t1 = m3_mul_an(u, r);
+  const M3 t2 = m3_sylsolve(y, t1);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      t1.e[3 * i + j] = make_double2(t2.e[3 * i + j].x + t2.e[3 * j + i].x, t2.e[3 * i + j].y - t2.e[3 * j + i].y);
+  const M3 xt = m3_mul(x, t1);
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.e[k] = csub(r.e[k], xt.e[k]);
+  return r;
+}
+// dst = projectUderiv(U or projectU(X), X, C); dst may alias C
+__global__ void __launch_bounds__(256) k_projUderiv(Geom g, MViewW dst, MView U, MView X, MView C) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  const size_t t = (size_t)p * g.ntile + (c >> 6);
+  const int l = c & 63;
+  const M3 x = m3_load(X.p + t * X.tstride + l, 64);
+  const M3 u = U.p ? m3_load(U.p + t * U.tstride + l, 64) : m3_projectU(x);
+  const M3 ch = m3_load(C.p + t * C.tstride + l, 64);
+  m3_store(dst.p + t * dst.tstride + l, 64, m3_projectUderiv(u, x, ch));
+}
+// f (=|+=) ma * src ; src *= alp       (hypsmear.nim:171-173,201-205,229-233)
+__global__ void __launch_bounds__(256) k_acc_scale(Geom g, MViewW f, double ma, MViewW src, double alp, int accumulate) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  const size_t t = (size_t)p * g.ntile + (c >> 6);
+  const int l = c & 63;
+  M3 s = m3_load(src.p + t * src.tstride + l, 64);
+  M3 o = accumulate ? m3_load(f.p + t * f.tstride + l, 64) : m3_zero();
+  m3_axpy(o, ma, s);
+  m3_store(f.p + t * f.tstride + l, 64, o);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { s.e[k].x *= alp; s.e[k].y *= alp; }
+  m3_store(src.p + t * src.tstride + l, 64, s);
+}
+// symStapleDeriv (smearutil.nim:22-50) gathered per site:
+//   f1(x) += g2(x) g1(x+mu) c(x+nu)^+ + c(x) g1(x+mu) g2(x+nu)^+ + [g2^+ g1 c(+nu) + c^+ g1 g2(+nu)](x-mu)
+//   f2(x) += g1(x) c(x+nu) g1(x+mu)^+ + [g1^+ c g1(+mu)](x-nu)
+__global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  int x[4], xpm[4], xpn[4], xmm[4], xmn[4], xmmpn[4], xmnpm[4];
+  coords_sm(g, c, p, x);
+  shift_sm(g, x, mu, 1, xpm);
+  shift_sm(g, x, nu, 1, xpn);
+  shift_sm(g, x, mu, -1, xmm);
+  shift_sm(g, x, nu, -1, xmn);
+  shift_sm(g, xmm, nu, 1, xmmpn);
+  shift_sm(g, xmn, mu, 1, xmnpm);
+  const size_t o0 = ((size_t)p * g.ntile + (c >> 6));
+  const int l = c & 63;
+  const M3 g1pm = m3_load(g1.p + site_off(g, xpm, g1.tstride), 64);
+  const M3 cpn = m3_load(cf.p + site_off(g, xpn, cf.tstride), 64);
+  {
+    M3 a = m3_load(f1.p + o0 * f1.tstride + l, 64);
+    M3 t = m3_mul_na(g1pm, cpn);
+    M3 u = m3_mul(m3_load(g2.p + o0 * g2.tstride + l, 64), t);
+    m3_axpy(a, 1.0, u);
+    t = m3_mul_na(g1pm, m3_load(g2.p + site_off(g, xpn, g2.tstride), 64));
+    u = m3_mul(m3_load(cf.p + o0 * cf.tstride + l, 64), t);
+    m3_axpy(a, 1.0, u);
+    const M3 g1mm = m3_load(g1.p + site_off(g, xmm, g1.tstride), 64);
+    t = m3_mul(g1mm, m3_load(cf.p + site_off(g, xmmpn, cf.tstride), 64));
+    u = m3_mul_an(m3_load(g2.p + site_off(g, xmm, g2.tstride), 64), t);
+    m3_axpy(a, 1.0, u);
+    t = m3_mul(g1mm, m3_load(g2.p + site_off(g, xmmpn, g2.tstride), 64));
+    u = m3_mul_an(m3_load(cf.p + site_off(g, xmm, cf.tstride), 64), t);
+    m3_axpy(a, 1.0, u);
+    m3_store(f1.p + o0 * f1.tstride + l, 64, a);
+  }
+  {
+    M3 a = m3_load(f2.p + o0 * f2.tstride + l, 64);
+    M3 t = m3_mul_na(cpn, g1pm);
+    M3 u = m3_mul(m3_load(g1.p + o0 * g1.tstride + l, 64), t);
+    m3_axpy(a, 1.0, u);
+    t = m3_mul(m3_load(cf.p + site_off(g, xmn, cf.tstride), 64), m3_load(g1.p + site_off(g, xmnpm, g1.tstride), 64));
+    u = m3_mul_an(m3_load(g1.p + site_off(g, xmn, g1.tstride), 64), t);
+    m3_axpy(a, 1.0, u);
+    m3_store(f2.p + o0 * f2.tstride + l, 64, a);
+  }
 }
 __global__ void __launch_bounds__(256) k_projectU(Geom g, MViewW dst, MView src) {
   int i = blockIdx.x * 256 + threadIdx.x;
@@ -170,6 +309,9 @@ __global__ void __launch_bounds__(256) k_sm_from_tiles(Geom g, double2 *__restri
 }
 
 namespace {
+struct NhypKeep {
+  double2 *l1x[4][4], *l1[4][4], *l2x[4][4], *l2[4][4], *flx = nullptr;
+};
 struct Smear {
   qexhip_ctx *c;
   Geom g;
@@ -265,51 +407,159 @@ struct Smear {
     }
     return fat7(FL, T2, c_second, LL, T2, -naik / 24.0);
   }
-  // nHYP forward smearing (hypsmear.nim:49-144) on device fields
-  int nhyp(const double2 *G, double2 *FL, double a1, double a2, double a3) {
-    double2 *tmp, *l1[4][4], *l2[4][4];
-    CHK(alloc(&tmp, fsz));
+  // nHYP forward smearing (hypsmear.nim:49-144) on device fields; with `keep` the unprojected and
+  // projected level-1/2 fields and the unprojected level-3 sum stay alive for the force chain
+  int nhyp(const double2 *G, double2 *FL, double a1, double a2, double a3, NhypKeep *keep = nullptr) {
+    double2 *tmp = nullptr;
+    NhypKeep loc;
+    NhypKeep &K = keep ? *keep : loc;
+    if (!keep) CHK(alloc(&tmp, fsz));
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
-        l1[mu][nu] = l2[mu][nu] = nullptr;
-        if (mu != nu) { CHK(alloc(&l1[mu][nu], fsz)); CHK(alloc(&l2[mu][nu], fsz)); }
+        K.l1[mu][nu] = K.l2[mu][nu] = K.l1x[mu][nu] = K.l2x[mu][nu] = nullptr;
+        if (mu == nu) continue;
+        CHK(alloc(&K.l1[mu][nu], fsz)); CHK(alloc(&K.l2[mu][nu], fsz));
+        if (keep) { CHK(alloc(&K.l1x[mu][nu], fsz)); CHK(alloc(&K.l2x[mu][nu], fsz)); }
+        else K.l1x[mu][nu] = K.l2x[mu][nu] = tmp;
       }
+    if (keep) CHK(alloc(&K.flx, gsz));
     const double alp1 = a1 / 2.0, alp2 = a2 / 4.0, alp3 = a3 / 6.0;
     const MViewW none{nullptr, 0};
     const int nblk = nb();
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
-        k_mscale<<<nblk, 256, 0, c->stream>>>(g, fvw(tmp), 1 - a1, gv(G, mu));
-        CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(tmp), alp1));
-        k_projectU<<<nblk, 256, 0, c->stream>>>(g, fvw(l1[mu][nu]), fv(tmp));
+        k_mscale<<<nblk, 256, 0, c->stream>>>(g, fvw(K.l1x[mu][nu]), 1 - a1, gv(G, mu));
+        CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(K.l1x[mu][nu]), alp1));
+        k_projectU<<<nblk, 256, 0, c->stream>>>(g, fvw(K.l1[mu][nu]), fv(K.l1x[mu][nu]));
         HIPCHK(hipGetLastError());
       }
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
-        k_mscale<<<nblk, 256, 0, c->stream>>>(g, fvw(tmp), 1 - a2, gv(G, mu));
+        k_mscale<<<nblk, 256, 0, c->stream>>>(g, fvw(K.l2x[mu][nu]), 1 - a2, gv(G, mu));
         for (int a = 0; a < 4; a++) {
           if (a == mu || a == nu) continue;
           const int b = 6 - mu - nu - a;
-          CHK(staple(fv(l1[a][b]), fv(l1[mu][b]), mu, a, none, fvw(tmp), alp2));
+          CHK(staple(fv(K.l1[a][b]), fv(K.l1[mu][b]), mu, a, none, fvw(K.l2x[mu][nu]), alp2));
         }
-        k_projectU<<<nblk, 256, 0, c->stream>>>(g, fvw(l2[mu][nu]), fv(tmp));
+        k_projectU<<<nblk, 256, 0, c->stream>>>(g, fvw(K.l2[mu][nu]), fv(K.l2x[mu][nu]));
         HIPCHK(hipGetLastError());
       }
     for (int mu = 0; mu < 4; mu++) {
-      k_mscale<<<nblk, 256, 0, c->stream>>>(g, fvw(tmp), 1 - a3, gv(G, mu));
+      const MViewW x3 = keep ? gvw(K.flx, mu) : fvw(tmp);
+      k_mscale<<<nblk, 256, 0, c->stream>>>(g, x3, 1 - a3, gv(G, mu));
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
-        CHK(staple(fv(l2[nu][mu]), fv(l2[mu][nu]), mu, nu, none, fvw(tmp), alp3));
+        CHK(staple(fv(K.l2[nu][mu]), fv(K.l2[mu][nu]), mu, nu, none, x3, alp3));
       }
-      k_projectU<<<nblk, 256, 0, c->stream>>>(g, gvw(FL, mu), fv(tmp));
+      k_projectU<<<nblk, 256, 0, c->stream>>>(g, gvw(FL, mu), MView{x3.p, x3.tstride});
       HIPCHK(hipGetLastError());
     }
     return 0;
   }
 };
 }  // namespace
+
+// smearGetForce's closure (hypsmear.nim:49-247): everything smearedForce needs, resident on the device
+struct NhypState {
+  Smear S;
+  NhypKeep K;
+  double2 *G = nullptr, *FL = nullptr, *F = nullptr, *fc = nullptr, *fl1[4][4], *fl2[4][4];
+  double a1 = 0, a2 = 0, a3 = 0;
+  explicit NhypState(qexhip_ctx *c) : S(c) {}
+};
+void nhyp_state_free(qexhip_ctx *c) {
+  if (c->nhyp) { delete (NhypState *)c->nhyp; c->nhyp = nullptr; }
+}
+int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, double *fl_host) {
+  if (c->g.halo) { qexhip_set_error("nhyp force chain: single GPU only"); return -3; }
+  for (int i = 0; i < 4; i++) if (c->g.X[i] < 2) { qexhip_set_error("nhyp force chain needs local extents >= 2"); return -1; }
+  nhyp_state_free(c);
+  NhypState *st = new NhypState(c);
+  c->nhyp = st;
+  Smear &S = st->S;
+  st->a1 = a1; st->a2 = a2; st->a3 = a3;
+  CHK(S.alloc(&st->G, S.gsz)); CHK(S.alloc(&st->FL, S.gsz)); CHK(S.alloc(&st->F, S.gsz)); CHK(S.alloc(&st->fc, S.gsz));
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      st->fl1[mu][nu] = st->fl2[mu][nu] = nullptr;
+      if (mu != nu) { CHK(S.alloc(&st->fl1[mu][nu], S.fsz)); CHK(S.alloc(&st->fl2[mu][nu], S.fsz)); }
+    }
+  CHK(S.upload(st->G, g_host));
+  CHK(S.nhyp(st->G, st->FL, a1, a2, a3, &st->K));
+  if (fl_host) CHK(S.download(fl_host, st->FL));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+// smearedForce(f, chain) on the device field st->F (in: chain, out: f)   (hypsmear.nim:146-245)
+static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
+  Smear &S = st->S;
+  const Geom &g = S.g;
+  const int nblk = S.nb();
+  const double alp1 = st->a1 / 2.0, alp2 = st->a2 / 4.0, alp3 = st->a3 / 6.0;
+  const double ma1 = 1 - st->a1, ma2 = 1 - st->a2, ma3 = 1 - st->a3;
+  const MView noU{nullptr, 0};
+  ScopedTimer tm(c, "nhyp_force", c->stream);
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++)
+      if (mu != nu) {
+        HIPCHK(hipMemsetAsync(st->fl1[mu][nu], 0, S.fsz * sizeof(double2), c->stream));
+        HIPCHK(hipMemsetAsync(st->fl2[mu][nu], 0, S.fsz * sizeof(double2), c->stream));
+      }
+  for (int mu = 0; mu < 4; mu++) {
+    k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->fc, mu), noU, S.gv(st->K.flx, mu), S.gv(st->F, mu));
+    k_acc_scale<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->F, mu), ma3, S.gvw(st->fc, mu), alp3, 0);
+  }
+  HIPCHK(hipGetLastError());
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      k_staple_deriv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl2[nu][mu]), S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[nu][mu]),
+                                                  S.fv(st->K.l2[mu][nu]), S.gv(st->fc, mu), mu, nu);
+    }
+  HIPCHK(hipGetLastError());
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[mu][nu]), S.fv(st->K.l2x[mu][nu]), S.fv(st->fl2[mu][nu]));
+      k_acc_scale<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->F, mu), ma2, S.fvw(st->fl2[mu][nu]), alp2, 1);
+    }
+  HIPCHK(hipGetLastError());
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      for (int a = 0; a < 4; a++) {
+        if (a == mu || a == nu) continue;
+        const int b = 6 - mu - nu - a;
+        k_staple_deriv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl1[a][b]), S.fvw(st->fl1[mu][b]), S.fv(st->K.l1[a][b]),
+                                                    S.fv(st->K.l1[mu][b]), S.fv(st->fl2[mu][nu]), mu, a);
+      }
+    }
+  HIPCHK(hipGetLastError());
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl1[mu][nu]), S.fv(st->K.l1[mu][nu]), S.fv(st->K.l1x[mu][nu]), S.fv(st->fl1[mu][nu]));
+      k_acc_scale<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->F, mu), ma1, S.fvw(st->fl1[mu][nu]), alp1, 1);
+    }
+  HIPCHK(hipGetLastError());
+  for (int mu = 0; mu < 4; mu++)
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == mu) continue;
+      k_staple_deriv<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->F, nu), S.gvw(st->F, mu), S.gv(st->G, nu), S.gv(st->G, mu),
+                                                  S.fv(st->fl1[mu][nu]), mu, nu);
+    }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int nhyp_force_host(qexhip_ctx *c, double *f_host, const double *chain_host) {
+  NhypState *st = (NhypState *)c->nhyp;
+  if (!st) { qexhip_set_error("nhyp_force: call qexhip_nhyp_prepare first (smearGetForce)"); return -1; }
+  CHK(st->S.upload(st->F, chain_host));
+  CHK(nhyp_backward_dev(c, st));
+  return st->S.download(f_host, st->F);
+}
 
 // setBC_cust + stagPhase on a device gauge field (stagg_pv_hmc/staghmc_spv.nim:367-401,
 // gauge/gaugeUtils.nim:124-131, physics/stagD.nim:509-520): sign flips only

@@ -364,6 +364,18 @@ class HypCoefs:
     def smear(self, ctx, g, fl):
         check(lib().qexhip_nhyp_smear(ctx._h, _p(g), _p(fl), float(self.alpha1), float(self.alpha2), float(self.alpha3)))
 
+    def smearGetForce(self, ctx, g, fl=None):
+        """hypsmear.nim:49-247: smear g (into fl if given) and return the closure
+        `smearedForce(f, chain)`; the intermediate fields stay on the device until the closure's
+        `release()` (or the next smearGetForce on this context)."""
+        check(lib().qexhip_nhyp_prepare(ctx._h, _p(g), float(self.alpha1), float(self.alpha2), float(self.alpha3), _p(fl)))
+
+        def smearedForce(f, chain):
+            check(lib().qexhip_nhyp_force(ctx._h, _p(f), _p(chain)))
+
+        smearedForce.release = lambda: check(lib().qexhip_nhyp_release(ctx._h))
+        return smearedForce
+
 
 def makeImpLinks(ctx, fl, g, coef, ll=None, naik=0.0):
     """makeImpLinks(fl, gf, coef, ll, gfLong, naik) with gfLong = gf (fat7l.nim:77-165);

@@ -145,3 +145,60 @@ def test_gpu_operator_on_device_smeared_links(oracle):
         assert np.linalg.norm(y - o.D(lo, sm, None, x, 0.05)) / np.linalg.norm(y) < 1e-12
         q.newStag(ctx, sm).D(y2, x, 0.05)
         assert np.linalg.norm(y - y2) / np.linalg.norm(y) < 1e-13
+
+
+def test_oracle_nhyp_force_is_the_gradient(oracle):
+    """The restated chain rule (projectUderiv, symStapleDeriv, smearedForce) is held to the definition
+    the reference states and checks for projectUderiv itself (matrixFunctions.nim:323-327,570-591):
+    d Re tr(C^+ V(U)) = Re tr(dU^+ F)."""
+    o = oracle
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        X, Cm, d = rng.standard_normal((3, 3, 2)), rng.standard_normal((3, 3, 2)), 1e-6 * rng.standard_normal((3, 3, 2))
+        S = lambda X: (Cm * o.su3_fn("qo_projectU", X)).sum()
+        num, ana = (S(X + d) - S(X - d)) / 2, (d * o.projectUderiv(X, Cm)).sum()
+        assert abs(num - ana) < 1e-7 * abs(ana)
+    lo = o.Layout([4, 4, 4, 6])
+    g = o.gauge_warm(lo, 0.5, o.RngField(lo, o.RNG_MILC6, 3))
+    Cf = rng.standard_normal(g.shape)
+    fl, f = o.nhyp_force(lo, g, Cf, 0.4, 0.5, 0.5)
+    assert np.abs(fl - o.nhyp_smear(lo, g, 0.4, 0.5, 0.5)).max() == 0
+    S = lambda g: (Cf * o.nhyp_smear(lo, g, 0.4, 0.5, 0.5)).sum()
+    for t in range(3):
+        d = np.zeros_like(g)
+        if t == 0:
+            d = 1e-6 * rng.standard_normal(g.shape)
+        else:
+            d[int(rng.integers(lo.vol)), int(rng.integers(4))] = 1e-5 * rng.standard_normal((3, 3, 2))
+        num, ana = (S(g + d) - S(g - d)) / 2, (d * f).sum()
+        assert abs(num - ana) < 1e-7 * abs(ana)
+    # alpha = 0: V = P(U) and the chain is projectUderiv alone
+    _, f0 = o.nhyp_force(lo, g, Cf, 0.0, 0.0, 0.0)
+    i = 77
+    assert np.abs(f0[i, 2] - o.projectUderiv(g[i, 2], Cf[i, 2])).max() < 1e-13
+
+
+@pytest.mark.gpu
+def test_gpu_nhyp_force_chain(oracle):
+    import qex_amd as q
+
+    o = oracle
+    lat = [4, 6, 8, 4]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 21)
+    g = o.gauge_warm(lo, 0.5, rf)
+    chain = o.gauge_random_tah(lo, rf) + 0.3 * o.gauge_random(lo, rf)      # a generic (non-algebra) chain
+    ctx = q.Context(lat)
+    fl = np.zeros_like(g)
+    smearedForce = q.HypCoefs(0.4, 0.5, 0.5).smearGetForce(ctx, g, fl)
+    rfl, rf_ = o.nhyp_force(lo, g, chain, 0.4, 0.5, 0.5)
+    assert np.linalg.norm(fl - rfl) / np.linalg.norm(rfl) < 1e-12
+    f = np.zeros_like(g)
+    smearedForce(f, chain)
+    assert np.linalg.norm(f - rf_) / np.linalg.norm(rf_) < 1e-11
+    f2 = chain.copy()
+    smearedForce(f2, f2)                                  # f.smeared_force(f) (staghmc_spv.nim:740)
+    assert np.array_equal(f, f2)
+    smearedForce.release()
+    with pytest.raises(q.QexHipError):
+        smearedForce(f, chain)
