@@ -216,6 +216,16 @@ int qexhip_stag_set_links_nhyp(qexhip_handle h, const double *g, double alpha1, 
 int qexhip_nhyp_prepare(qexhip_handle h, const double *g, double alpha1, double alpha2, double alpha3, double *fl);
 int qexhip_nhyp_force(qexhip_handle h, double *f, const double *chain);
 int qexhip_nhyp_release(qexhip_handle h);
+/* The two MD forces of the fork's HMC that run through the closure, start to finish on the device:
+ *   gauge:   gforce(act, g, sg, f, smear_force) (src/stagg_pv_hmc/staghmc_spv.nim:217-228): derivative of the
+ *            gauge action on the SMEARED links (gaugeForceCust / forceACust, staghmc_spv_gforce.nim:17-253;
+ *            coefficients as qexhip_gauge_force_general), smearedForce, projTAH(g, "adj") = TAH(g f^+).
+ *   fermion: fforce + smeared_one_link_force (staghmc_spv.nim:716-865): f = sum_k scale[k] psi_k(s) (x) psi_k(s+mu)^+
+ *            (psi_k full-volume vectors, host), f.rephase (setBC_cust + stagPhase), odd sites *= -1,
+ *            smearedForce, projTAH(gf) = TAH(f g^+).  antiperiodic / phases as qexhip_stag_set_links_nhyp. */
+int qexhip_nhyp_gauge_force(qexhip_handle h, double *f, double cplaq, double crect, double cadjplaq);
+int qexhip_nhyp_fermion_force(qexhip_handle h, double *f, const double *const *psi, const double *scale, int n,
+                              const int antiperiodic[4], const int phases[4]);
 
 /* ---------------- kernel timers ----------------
  * hipEvent pairs around launches of the named kernel class on the context stream

@@ -343,6 +343,15 @@ def nhyp_smear(lo, g, a1=0.4, a2=0.5, a3=0.5):
     return fl
 
 
+def gauge_deriv_general(lo, g, cplaq, c2, kind):
+    """gaugeForceCust (kind 0, plaq+rect) / forceACust (kind 1, plaq+adjplaq): the derivative, no projection"""
+    f = lo.new_gauge()
+    fn = lib().qo_gauge_deriv_rect if kind == 0 else lib().qo_gauge_deriv_adj
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+    fn(lo._h, _p(g), _p(f), cplaq, c2)
+    return f
+
+
 def nhyp_force(lo, g, chain, a1=0.4, a2=0.5, a3=0.5):
     """smearGetForce(g) then smearedForce(f, chain): returns (smeared links, f)."""
     fl, f = lo.new_gauge(), lo.new_gauge()

@@ -75,6 +75,8 @@ void qo_wflow(const qo_layout *lo, double *g, int nsteps, double eps);  /* wflow
 
 /* ---- general gauge actions: kind 0 plaq+rect (gaugeAction.nim:61-142,148-332), kind 1 plaq+adjplaq (:614-747) ---- */
 double qo_gauge_action(const qo_layout *lo, const double *g, double cplaq, double c2, int kind);
+void qo_gauge_deriv_rect(const qo_layout *lo, const double *g, double *f, double cplaq, double crect);
+void qo_gauge_deriv_adj(const qo_layout *lo, const double *g, double *f, double cplaq, double cadj);
 void qo_gauge_force_general(const qo_layout *lo, const double *g, double *f, double cplaq, double c2, int kind);
 void qo_wflow_general(const qo_layout *lo, double *g, int nsteps, double eps, double cplaq, double c2, int kind); /* flow/flow.nim:22-90 */
 

@@ -63,6 +63,8 @@ SYMBOLS = [
     ("qexhip_nhyp_prepare", _ci, [_vp, _vp, _cd, _cd, _cd, _vp]),
     ("qexhip_nhyp_force", _ci, [_vp, _vp, _vp]),
     ("qexhip_nhyp_release", _ci, [_vp]),
+    ("qexhip_nhyp_gauge_force", _ci, [_vp, _vp, _cd, _cd, _cd]),
+    ("qexhip_nhyp_fermion_force", _ci, [_vp, _vp, _vp, _vp, _ci, _pi, _pi]),
     ("qexhip_timers_enable", _ci, [_vp, _ci]),
     ("qexhip_timers_reset", _ci, [_vp]),
     ("qexhip_timers_get", _ci, [_vp, C.c_char_p, C.POINTER(C.c_long), _pd]),

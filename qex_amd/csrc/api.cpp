@@ -481,6 +481,21 @@ extern "C" int qexhip_nhyp_force(qexhip_handle c, double *f, const double *chain
   HIPCHK(hipSetDevice(c->device));
   return nhyp_force_host(c, f, chain);
 }
+extern "C" int qexhip_nhyp_gauge_force(qexhip_handle c, double *f, double cplaq, double crect, double cadj) {
+  if (!c || !f) return QEXHIP_ERR_ARG;
+  if (crect != 0.0 && cadj != 0.0) { qexhip_set_error("rect and adjplaq together are not a QEX action"); return QEXHIP_ERR_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  return nhyp_gauge_force(c, f, cplaq, cadj != 0.0 ? cadj : crect, cadj != 0.0 ? 1 : 0);
+}
+extern "C" int qexhip_nhyp_fermion_force(qexhip_handle c, double *f, const double *const *psi, const double *scale, int n,
+                                         const int antiperiodic[4], const int phases[4]) {
+  if (!c || !f || !psi || !scale) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  static const int defph[4] = {8, 9, 11, 0};
+  int mask = 0;
+  for (int mu = 0; mu < 4; mu++) if (antiperiodic ? antiperiodic[mu] : (mu == 3)) mask |= 1 << mu;
+  return nhyp_fermion_force(c, f, psi, scale, n, mask, phases ? phases : defph);
+}
 extern "C" int qexhip_nhyp_release(qexhip_handle c) {
   if (!c) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));

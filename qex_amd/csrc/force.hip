@@ -60,6 +60,16 @@ __global__ void __launch_bounds__(256) k_force_from_tiles(Geom g, double2 *__res
   }
 }
 
+// f (:= | +=) scale * x (x) x(+mu)^+ on a DEVICE force field in the natural layout (single GPU)
+int stag_outer_dev(qexhip_ctx *c, DevField &fx, double2 *F, double se, double so, int accumulate) {
+  const Geom &g = c->g;
+  if (g.halo) { qexhip_set_error("stag_outer_dev: single GPU only"); return -3; }
+  ScopedTimer tm(c, "outer", c->stream);
+  k_outer<false><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fx.par(0), fx.par(1), F, se, so, accumulate);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // host f (in/out, [vol][4][3][3][2]) and host x; the force field lives in a scratch buffer
 int stag_outer_host(qexhip_ctx *c, double *f_host, const double *x_host, double se, double so, int accumulate) {
   const Geom &g = c->g;

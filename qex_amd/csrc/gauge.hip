@@ -335,7 +335,7 @@ __device__ const signed char RECT_STEPS[6][5] = {
     {2, 2, 1, -2, -2}, {2, 1, 1, -2, -1}, {-1, 2, 1, 1, -2},          // +nu
     {-2, -2, 1, 2, 2}, {-2, 1, 1, 2, -1}, {-1, -2, 1, 1, 2}};         // -nu
 __global__ void __launch_bounds__(256) k_force_gen(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
-                                                   double c2, int kind, double2 *Pm, double cf, double cpm) {
+                                                   double c2, int kind, double2 *Pm, double cf, double cpm, int raw) {
   const int bid = blockIdx.x;
   const int mu = threadIdx.x >> 6;
   const int p = bid >= g.ntile;
@@ -393,6 +393,10 @@ __global__ void __launch_bounds__(256) k_force_gen(Geom g, const double2 *__rest
       }
     }
   }
+  if (raw) {   // the derivative itself (gaugeActionDeriv / gaugeForceCust), no projection
+    m3_store(F + o, 64, acc);
+    return;
+  }
   M3 f = m3_tah(m3_mul_na(U, acc));
   if (Pm) {
     M3 v;
@@ -408,6 +412,17 @@ __global__ void __launch_bounds__(256) k_force_gen(Geom g, const double2 *__rest
   } else {
     m3_store(F + o, 64, f);
   }
+}
+
+// gaugeForceCust / forceACust of the fork (stagg_pv_hmc/staghmc_spv_gforce.nim:17-253) = the action's
+// derivative without the projection, on arbitrary device gauge fields in the natural layout
+int gauge_deriv_dev(qexhip_ctx *c, const double2 *G, double2 *F, double cplaq, double c2, int kind) {
+  if (kind == 0 && c2 != 0.0) for (int d = 0; d < 4; d++) if (c->g.X[d] < 4) { qexhip_set_error("rectangle action needs extents >= 4"); return -1; }
+  const double k2 = kind == 0 ? c2 / 3.0 : 2.0 * c2 / 9.0;
+  ScopedTimer tm(c, "staple", c->stream);
+  k_force_gen<<<2 * c->g.ntile, 256, 0, c->stream>>>(c->g, G, F, cplaq / 3.0, k2, kind, nullptr, 0.0, 0.0, 1);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 static int gn_alloc(qexhip_ctx *c) {
@@ -485,7 +500,7 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
     // kind 0: cr = c.rect/nc ; kind 1: ca = 2 c.adjplaq/nc^2
     const double k2 = kind == 0 ? c2 / 3.0 : 2.0 * c2 / 9.0;
     k_force_gen<<<2 * c->g.ntile, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind,
-                                                       flow ? c->gn->P : nullptr, cf, cpm);
+                                                       flow ? c->gn->P : nullptr, cf, cpm, 0);
   } else {
     k_force<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, flow ? c->gn->P : nullptr, cf, cpm);
   }

@@ -193,6 +193,10 @@ int smear_hisq_host(qexhip_ctx *c, const double *g_host, double *fl_host, double
 int smear_nhyp_host(qexhip_ctx *c, const double *g_host, double *fl_host, double a1, double a2, double a3);
 int smear_set_links_hisq(qexhip_ctx *c, const double *g_host);
 void nhyp_state_free(qexhip_ctx *c);
+int gauge_deriv_dev(qexhip_ctx *c, const double2 *G, double2 *F, double cplaq, double c2, int kind);
+int stag_outer_dev(qexhip_ctx *c, DevField &fx, double2 *F, double se, double so, int accumulate);
+int nhyp_gauge_force(qexhip_ctx *c, double *f_host, double cplaq, double c2, int kind);
+int nhyp_fermion_force(qexhip_ctx *c, double *f_host, const double *const *psi, const double *scale, int n, int bcmask, const int ph[4]);
 int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, double *fl_host);
 int nhyp_force_host(qexhip_ctx *c, double *f_host, const double *chain_host);
 int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, int bcmask, const int ph[4]);

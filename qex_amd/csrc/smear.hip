@@ -646,3 +646,45 @@ int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double 
   HIPCHK(hipGetLastError());
   return links_from_natural(c, FL, nullptr);
 }
+
+// projTAH(f, g) of the fork (stagg_pv_hmc/staghmc_spv_gforce.nim:256-291) on device gauge-layout fields:
+// adj = 0 (matter):  f <- TAH(f g^+);  adj = 1 (gauge):  f <- TAH(g f^+)
+__global__ void __launch_bounds__(256) k_force_projtah(size_t nlinks_tiles, double2 *F, const double2 *__restrict__ G, int adj) {
+  size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t tile = j >> 6;
+  if (tile >= nlinks_tiles) return;
+  size_t o = tile * 576 + (j & 63);
+  const M3 f = m3_load(F + o, 64), u = m3_load(G + o, 64);
+  m3_store(F + o, 64, m3_tah(adj ? m3_mul_na(u, f) : m3_mul_na(f, u)));
+}
+static int nhyp_finish(qexhip_ctx *c, NhypState *st, int adj, double *f_host) {
+  CHK(nhyp_backward_dev(c, st));
+  const size_t ltiles = (size_t)2 * c->g.ntile * 4;
+  k_force_projtah<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, st->F, st->G, adj);
+  HIPCHK(hipGetLastError());
+  return st->S.download(f_host, st->F);
+}
+// gforce(act, g, sg, f, smear_force) (stagg_pv_hmc/staghmc_spv.nim:217-228): derivative of the gauge
+// action on the SMEARED links -> smearedForce -> TAH(g f^+) with the thin links
+int nhyp_gauge_force(qexhip_ctx *c, double *f_host, double cplaq, double c2, int kind) {
+  NhypState *st = (NhypState *)c->nhyp;
+  if (!st) { qexhip_set_error("nhyp_gauge_force: call qexhip_nhyp_prepare first (smearGetForce)"); return -1; }
+  CHK(gauge_deriv_dev(c, st->FL, st->F, cplaq, c2, kind));
+  return nhyp_finish(c, st, 1, f_host);
+}
+// fforce + smeared_one_link_force (stagg_pv_hmc/staghmc_spv.nim:716-865): sum_k scale_k psi_k (x) psi_k(+mu)^+,
+// rephase (BC + staggered phases) and odd-site sign, smearedForce, TAH(f g^+)
+int nhyp_fermion_force(qexhip_ctx *c, double *f_host, const double *const *psi, const double *scale, int n, int bcmask, const int ph[4]) {
+  NhypState *st = (NhypState *)c->nhyp;
+  if (!st) { qexhip_set_error("nhyp_fermion_force: call qexhip_nhyp_prepare first (smearGetForce)"); return -1; }
+  if (n < 1) { qexhip_set_error("nhyp_fermion_force: n < 1"); return -1; }
+  DevField *fx;
+  CHK(get_work(c, WK_IN, &fx));
+  for (int k = 0; k < n; k++) {
+    CHK(field_upload(c, *fx, psi[k]));
+    CHK(stag_outer_dev(c, *fx, st->F, scale[k], -scale[k], k > 0));
+  }
+  k_rephase<<<st->S.nb(), 256, 0, c->stream>>>(st->S.g, st->F, bcmask, ph[0], ph[1], ph[2], ph[3]);
+  HIPCHK(hipGetLastError());
+  return nhyp_finish(c, st, 0, f_host);
+}

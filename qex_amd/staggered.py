@@ -373,6 +373,19 @@ class HypCoefs:
         def smearedForce(f, chain):
             check(lib().qexhip_nhyp_force(ctx._h, _p(f), _p(chain)))
 
+        def gforce(f, plaq=1.0, rect=0.0, adjplaq=0.0):
+            """gforce(act, g, sg, f, smear_force) (staghmc_spv.nim:217-228)"""
+            check(lib().qexhip_nhyp_gauge_force(ctx._h, _p(f), float(plaq), float(rect), float(adjplaq)))
+
+        def fforce(f, psis, scales, bc="aaaa"):
+            """fforce + smeared_one_link_force (staghmc_spv.nim:716-865) for the fields psis"""
+            n = len(psis)
+            arr = (C.c_void_p * n)(*[p.ctypes.data for p in psis])
+            sc = (C.c_double * n)(*[float(v) for v in scales])
+            ap = (C.c_int * 4)(*[1 if ch == "a" else 0 for ch in bc])
+            check(lib().qexhip_nhyp_fermion_force(ctx._h, _p(f), arr, sc, n, ap, None))
+
+        smearedForce.gforce, smearedForce.fforce = gforce, fforce
         smearedForce.release = lambda: check(lib().qexhip_nhyp_release(ctx._h))
         return smearedForce
 

@@ -202,3 +202,50 @@ def test_gpu_nhyp_force_chain(oracle):
     smearedForce.release()
     with pytest.raises(q.QexHipError):
         smearedForce(f, chain)
+
+
+@pytest.mark.gpu
+def test_gpu_nhyp_md_forces(oracle):
+    """The fork's two MD forces through the closure: gforce(act, g, sg, f, smear_force)
+    (staghmc_spv.nim:217-228) and fforce + smeared_one_link_force (staghmc_spv.nim:716-865)."""
+    import qex_amd as q
+
+    o = oracle
+    lat = [4, 6, 8, 4]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 33)
+    g = o.gauge_warm(lo, 0.5, rf)
+    ctx = q.Context(lat)
+    sg = np.zeros_like(g)
+    sf = q.HypCoefs(0.4, 0.5, 0.5).smearGetForce(ctx, g, sg)
+    # gauge sector, three actions
+    for cp, c2, kind in [(1.0, 0.0, 0), (5.0 / 3.0, -1.0 / 12.0, 0), (0.9, 0.35, 1)]:
+        f = np.zeros_like(g)
+        sf.gforce(f, plaq=cp, rect=c2 if kind == 0 else 0.0, adjplaq=c2 if kind == 1 else 0.0)
+        chain = o.gauge_deriv_general(lo, sg, cp, c2, kind)
+        _, ref = o.nhyp_force(lo, g, chain, 0.4, 0.5, 0.5)
+        o.force_projTAH(lo, ref, g, adj=True)
+        assert np.linalg.norm(f - ref) / np.linalg.norm(ref) < 1e-11
+    # matter sector: two fields, different scales, bc = "aaaa" (input_hmc.xml:44) and the default "pppa"
+    psis = [o.vector_gaussian(lo, rf), o.vector_gaussian(lo, rf)]
+    scales = [0.37, -1.9]
+    odd = np.arange(lo.vol) >= lo.vol // 2
+    for bc in ("aaaa", "pppa"):
+        f = np.zeros_like(g)
+        sf.fforce(f, psis, scales, bc=bc)
+        ref = np.zeros_like(g)
+        for k, (p, s) in enumerate(zip(psis, scales)):
+            o.stag_outer(lo, ref, p, s, s, k > 0)
+        for mu, ch in enumerate(bc):                   # f.rephase (staghmc_spv.nim:723)
+            if ch == "a":
+                last = np.array([lo.coord(i)[mu] == lat[mu] - 1 for i in range(lo.vol)])
+                ref[last, mu] *= -1.0
+        o.stagPhase(lo, ref)
+        ref[odd] *= -1.0                               # odd sites re-signed (:730-732)
+        _, ref = o.nhyp_force(lo, g, ref, 0.4, 0.5, 0.5)
+        o.force_projTAH(lo, ref, g, adj=False)
+        assert np.linalg.norm(f - ref) / np.linalg.norm(ref) < 1e-11
+        # the force is in the algebra
+        fc = cx(f)
+        assert np.abs(fc + np.conj(np.swapaxes(fc, -1, -2))).max() < 1e-12
+        assert np.abs(np.trace(fc, axis1=-2, axis2=-1)).max() < 1e-12
