@@ -47,8 +47,10 @@ __device__ __forceinline__ void shift_sm(const Geom &g, const int x[4], int mu, 
 }
 
 // staple field (optional) and acc += coef * staple (optional)
-__global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, int swz) {
+  int bid = blockIdx.x;
+  if (swz && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // contiguous site range per XCD
+  int i = bid * 256 + threadIdx.x;
   if (i >= g.V) return;
   const int p = i >= g.Vh, c = i - p * g.Vh;
   int x[4], xpn[4], xpm[4], xmn[4], xmnpm[4];
@@ -220,8 +222,11 @@ __global__ void __launch_bounds__(256) k_acc_scale(Geom g, MViewW f, double ma, 
 // symStapleDeriv (smearutil.nim:22-50) gathered per site:
 //   f1(x) += g2(x) g1(x+mu) c(x+nu)^+ + c(x) g1(x+mu) g2(x+nu)^+ + [g2^+ g1 c(+nu) + c^+ g1 g2(+nu)](x-mu)
 //   f2(x) += g1(x) c(x+nu) g1(x+mu)^+ + [g1^+ c g1(+mu)](x-nu)
-__global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+template <int PART>   // 0: f1 and f2, 1: f1 only, 2: f2 only
+__global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu, int swz) {
+  int bid = blockIdx.x;
+  if (swz && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // contiguous site range per XCD
+  int i = bid * 256 + threadIdx.x;
   if (i >= g.V) return;
   const int p = i >= g.Vh, c = i - p * g.Vh;
   int x[4], xpm[4], xpn[4], xmm[4], xmn[4], xmmpn[4], xmnpm[4];
@@ -234,33 +239,30 @@ __global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW 
   shift_sm(g, xmn, mu, 1, xmnpm);
   const size_t o0 = ((size_t)p * g.ntile + (c >> 6));
   const int l = c & 63;
-  const M3 g1pm = m3_load(g1.p + site_off(g, xpm, g1.tstride), 64);
-  const M3 cpn = m3_load(cf.p + site_off(g, xpn, cf.tstride), 64);
-  {
+  if (PART != 2) {
     M3 a = m3_load(f1.p + o0 * f1.tstride + l, 64);
-    M3 t = m3_mul_na(g1pm, cpn);
-    M3 u = m3_mul(m3_load(g2.p + o0 * g2.tstride + l, 64), t);
-    m3_axpy(a, 1.0, u);
-    t = m3_mul_na(g1pm, m3_load(g2.p + site_off(g, xpn, g2.tstride), 64));
-    u = m3_mul(m3_load(cf.p + o0 * cf.tstride + l, 64), t);
-    m3_axpy(a, 1.0, u);
-    const M3 g1mm = m3_load(g1.p + site_off(g, xmm, g1.tstride), 64);
-    t = m3_mul(g1mm, m3_load(cf.p + site_off(g, xmmpn, cf.tstride), 64));
-    u = m3_mul_an(m3_load(g2.p + site_off(g, xmm, g2.tstride), 64), t);
-    m3_axpy(a, 1.0, u);
-    t = m3_mul(g1mm, m3_load(g2.p + site_off(g, xmmpn, g2.tstride), 64));
-    u = m3_mul_an(m3_load(cf.p + site_off(g, xmm, cf.tstride), 64), t);
-    m3_axpy(a, 1.0, u);
+    {
+      const M3 g1pm = m3_load(g1.p + site_off(g, xpm, g1.tstride), 64);
+      M3 t = m3_mul_na(g1pm, m3_load(cf.p + site_off(g, xpn, cf.tstride), 64));
+      m3_mac(a, m3_load(g2.p + o0 * g2.tstride + l, 64), t);
+      t = m3_mul_na(g1pm, m3_load(g2.p + site_off(g, xpn, g2.tstride), 64));
+      m3_mac(a, m3_load(cf.p + o0 * cf.tstride + l, 64), t);
+    }
+    {
+      const M3 g1mm = m3_load(g1.p + site_off(g, xmm, g1.tstride), 64);
+      M3 t = m3_mul(g1mm, m3_load(cf.p + site_off(g, xmmpn, cf.tstride), 64));
+      m3_mac_an(a, m3_load(g2.p + site_off(g, xmm, g2.tstride), 64), t);
+      t = m3_mul(g1mm, m3_load(g2.p + site_off(g, xmmpn, g2.tstride), 64));
+      m3_mac_an(a, m3_load(cf.p + site_off(g, xmm, cf.tstride), 64), t);
+    }
     m3_store(f1.p + o0 * f1.tstride + l, 64, a);
   }
-  {
+  if (PART != 1) {
     M3 a = m3_load(f2.p + o0 * f2.tstride + l, 64);
-    M3 t = m3_mul_na(cpn, g1pm);
-    M3 u = m3_mul(m3_load(g1.p + o0 * g1.tstride + l, 64), t);
-    m3_axpy(a, 1.0, u);
+    M3 t = m3_mul_na(m3_load(cf.p + site_off(g, xpn, cf.tstride), 64), m3_load(g1.p + site_off(g, xpm, g1.tstride), 64));
+    m3_mac(a, m3_load(g1.p + o0 * g1.tstride + l, 64), t);
     t = m3_mul(m3_load(cf.p + site_off(g, xmn, cf.tstride), 64), m3_load(g1.p + site_off(g, xmnpm, g1.tstride), 64));
-    u = m3_mul_an(m3_load(g1.p + site_off(g, xmn, g1.tstride), 64), t);
-    m3_axpy(a, 1.0, u);
+    m3_mac_an(a, m3_load(g1.p + site_off(g, xmn, g1.tstride), 64), t);
     m3_store(f2.p + o0 * f2.tstride + l, 64, a);
   }
 }
@@ -352,7 +354,9 @@ struct Smear {
   }
   int staple(MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef) {
     ScopedTimer tm(c, "smear", c->stream);
-    k_gen_staple<<<nb(), 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef);
+    static int swz = -1;
+    if (swz < 0) { const char *e = getenv("QEXHIP_SMEAR_SWZ"); swz = e ? atoi(e) : 1; }
+    k_gen_staple<<<nb(), 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -409,12 +413,12 @@ struct Smear {
   }
   // nHYP forward smearing (hypsmear.nim:49-144) on device fields; with `keep` the unprojected and
   // projected level-1/2 fields and the unprojected level-3 sum stay alive for the force chain
-  int nhyp(const double2 *G, double2 *FL, double a1, double a2, double a3, NhypKeep *keep = nullptr) {
+  int nhyp(const double2 *G, double2 *FL, double a1, double a2, double a3, NhypKeep *keep = nullptr, bool reuse = false) {
     double2 *tmp = nullptr;
     NhypKeep loc;
     NhypKeep &K = keep ? *keep : loc;
     if (!keep) CHK(alloc(&tmp, fsz));
-    for (int mu = 0; mu < 4; mu++)
+    for (int mu = 0; mu < 4 && !reuse; mu++)
       for (int nu = 0; nu < 4; nu++) {
         K.l1[mu][nu] = K.l2[mu][nu] = K.l1x[mu][nu] = K.l2x[mu][nu] = nullptr;
         if (mu == nu) continue;
@@ -422,7 +426,7 @@ struct Smear {
         if (keep) { CHK(alloc(&K.l1x[mu][nu], fsz)); CHK(alloc(&K.l2x[mu][nu], fsz)); }
         else K.l1x[mu][nu] = K.l2x[mu][nu] = tmp;
       }
-    if (keep) CHK(alloc(&K.flx, gsz));
+    if (keep && !reuse) CHK(alloc(&K.flx, gsz));
     const double alp1 = a1 / 2.0, alp2 = a2 / 4.0, alp3 = a3 / 6.0;
     const MViewW none{nullptr, 0};
     const int nblk = nb();
@@ -475,24 +479,46 @@ void nhyp_state_free(qexhip_ctx *c) {
 int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, double *fl_host) {
   if (c->g.halo) { qexhip_set_error("nhyp force chain: single GPU only"); return -3; }
   for (int i = 0; i < 4; i++) if (c->g.X[i] < 2) { qexhip_set_error("nhyp force chain needs local extents >= 2"); return -1; }
-  nhyp_state_free(c);
-  NhypState *st = new NhypState(c);
-  c->nhyp = st;
+  NhypState *st = (NhypState *)c->nhyp;
+  const bool fresh = !st;       // a second smearGetForce on this context reuses the ~70 device fields
+  if (fresh) {
+    st = new NhypState(c);
+    c->nhyp = st;
+  }
   Smear &S = st->S;
   st->a1 = a1; st->a2 = a2; st->a3 = a3;
-  CHK(S.alloc(&st->G, S.gsz)); CHK(S.alloc(&st->FL, S.gsz)); CHK(S.alloc(&st->F, S.gsz)); CHK(S.alloc(&st->fc, S.gsz));
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) {
-      st->fl1[mu][nu] = st->fl2[mu][nu] = nullptr;
-      if (mu != nu) { CHK(S.alloc(&st->fl1[mu][nu], S.fsz)); CHK(S.alloc(&st->fl2[mu][nu], S.fsz)); }
-    }
+  if (fresh) {
+    CHK(S.alloc(&st->G, S.gsz)); CHK(S.alloc(&st->FL, S.gsz)); CHK(S.alloc(&st->F, S.gsz)); CHK(S.alloc(&st->fc, S.gsz));
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        st->fl1[mu][nu] = st->fl2[mu][nu] = nullptr;
+        if (mu != nu) { CHK(S.alloc(&st->fl1[mu][nu], S.fsz)); CHK(S.alloc(&st->fl2[mu][nu], S.fsz)); }
+      }
+  }
   CHK(S.upload(st->G, g_host));
-  CHK(S.nhyp(st->G, st->FL, a1, a2, a3, &st->K));
+  CHK(S.nhyp(st->G, st->FL, a1, a2, a3, &st->K, !fresh));
   if (fl_host) CHK(S.download(fl_host, st->FL));
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 // smearedForce(f, chain) on the device field st->F (in: chain, out: f)   (hypsmear.nim:146-245)
+static int staple_deriv(qexhip_ctx *c, const Geom &g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu) {
+  static int variant = -1, swz = 0;
+  if (variant < 0) {
+    const char *e = getenv("QEXHIP_SDERIV");
+    variant = e ? atoi(e) % 10 : 0;
+    swz = e ? atoi(e) / 10 : 1;
+  }
+  const int nblk = (g.V + 255) / 256;
+  if (variant == 0) {
+    k_staple_deriv<0><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz);
+  } else {
+    k_staple_deriv<1><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz);
+    k_staple_deriv<2><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
   Smear &S = st->S;
   const Geom &g = S.g;
@@ -515,8 +541,8 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
   for (int mu = 0; mu < 4; mu++)
     for (int nu = 0; nu < 4; nu++) {
       if (nu == mu) continue;
-      k_staple_deriv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl2[nu][mu]), S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[nu][mu]),
-                                                  S.fv(st->K.l2[mu][nu]), S.gv(st->fc, mu), mu, nu);
+      CHK(staple_deriv(c, g, S.fvw(st->fl2[nu][mu]), S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[nu][mu]),
+                                                  S.fv(st->K.l2[mu][nu]), S.gv(st->fc, mu), mu, nu));
     }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
@@ -532,8 +558,8 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
       for (int a = 0; a < 4; a++) {
         if (a == mu || a == nu) continue;
         const int b = 6 - mu - nu - a;
-        k_staple_deriv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl1[a][b]), S.fvw(st->fl1[mu][b]), S.fv(st->K.l1[a][b]),
-                                                    S.fv(st->K.l1[mu][b]), S.fv(st->fl2[mu][nu]), mu, a);
+        CHK(staple_deriv(c, g, S.fvw(st->fl1[a][b]), S.fvw(st->fl1[mu][b]), S.fv(st->K.l1[a][b]),
+                                                    S.fv(st->K.l1[mu][b]), S.fv(st->fl2[mu][nu]), mu, a));
       }
     }
   HIPCHK(hipGetLastError());
@@ -547,8 +573,8 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
   for (int mu = 0; mu < 4; mu++)
     for (int nu = 0; nu < 4; nu++) {
       if (nu == mu) continue;
-      k_staple_deriv<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->F, nu), S.gvw(st->F, mu), S.gv(st->G, nu), S.gv(st->G, mu),
-                                                  S.fv(st->fl1[mu][nu]), mu, nu);
+      CHK(staple_deriv(c, g, S.gvw(st->F, nu), S.gvw(st->F, mu), S.gv(st->G, nu), S.gv(st->G, mu),
+                                                  S.fv(st->fl1[mu][nu]), mu, nu));
     }
   HIPCHK(hipGetLastError());
   return 0;

@@ -72,6 +72,40 @@ __device__ __forceinline__ M3 m3_mul_an(const M3 &a, const M3 &b) {
     }
   return r;
 }
+// r += a*b, r += a*b^dagger, r += a^dagger*b  (accumulating forms: no temporary product matrix)
+__device__ __forceinline__ void m3_mac(M3 &r, const M3 &a, const M3 &b) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double sx = r.e[3 * i + j].x, sy = r.e[3 * i + j].y;
+#pragma unroll
+      for (int k = 0; k < 3; k++) M3_MAC(sx, sy, a.e[3 * i + k].x, a.e[3 * i + k].y, b.e[3 * k + j].x, b.e[3 * k + j].y);
+      r.e[3 * i + j] = make_double2(sx, sy);
+    }
+}
+__device__ __forceinline__ void m3_mac_na(M3 &r, const M3 &a, const M3 &b) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double sx = r.e[3 * i + j].x, sy = r.e[3 * i + j].y;
+#pragma unroll
+      for (int k = 0; k < 3; k++) M3_MAC(sx, sy, a.e[3 * i + k].x, a.e[3 * i + k].y, b.e[3 * j + k].x, -b.e[3 * j + k].y);
+      r.e[3 * i + j] = make_double2(sx, sy);
+    }
+}
+__device__ __forceinline__ void m3_mac_an(M3 &r, const M3 &a, const M3 &b) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double sx = r.e[3 * i + j].x, sy = r.e[3 * i + j].y;
+#pragma unroll
+      for (int k = 0; k < 3; k++) M3_MAC(sx, sy, a.e[3 * k + i].x, -a.e[3 * k + i].y, b.e[3 * k + j].x, b.e[3 * k + j].y);
+      r.e[3 * i + j] = make_double2(sx, sy);
+    }
+}
 __device__ __forceinline__ void m3_axpy(M3 &r, double a, const M3 &x) {
 #pragma unroll
   for (int k = 0; k < 9; k++) { r.e[k].x += a * x.e[k].x; r.e[k].y += a * x.e[k].y; }
