@@ -199,7 +199,9 @@ int qexhip_nhyp_smear(qexhip_handle h, const double *g, double *fl, double alpha
  *         (tests/examples/testStagProp.nim:24-40: g.setBC; g.stagPhase; hc.smear(g, fl, ll); newStag3(fl, ll))
  *   nhyp: Staggered.g <- rephase(HypCoefs.smear(g)) with the fork's per-direction boundary flags
  *         (src/stagg_pv_hmc/staghmc_spv.nim:367-401,601-604): antiperiodic[mu] != 0 flips U_mu on the last
- *         slice of direction mu (NULL: t only, as gaugeUtils.nim:124-131); phases NULL = {8,9,11,0}. */
+ *         slice of direction mu (NULL: t only, as gaugeUtils.nim:124-131); phases NULL = {8,9,11,0}.
+ *         g == NULL: take the links the closure of qexhip_nhyp_prepare already smeared (the alphas are
+ *         ignored), which is what smearRephase does (src/examples/staghmc_sh.nim:303-312). */
 int qexhip_stag_set_links_hisq(qexhip_handle h, const double *g);
 int qexhip_stag_set_links_nhyp(qexhip_handle h, const double *g, double alpha1, double alpha2, double alpha3,
                                const int antiperiodic[4], const int phases[4]);

@@ -71,6 +71,9 @@ def lib():
         L.qo_nhyp_force.argtypes = [vp, vp, vp, vp, vp, cd, cd, cd]
         L.qo_projectUderiv.argtypes = [vp, vp, vp, vp]
         L.qo_force_projTAH.argtypes = [vp, vp, vp, ci]
+        L.qo_gauge_exp_update.argtypes = [vp, vp, vp, cd]
+        L.qo_gauge_projectSU.argtypes = [vp, vp]
+        L.qo_field_uniform.argtypes = [vp, vp, ci, vp, ci]
         L.qo_stag_outer.argtypes = [vp, vp, vp, cd, cd, ci]
         L.qo_solve_prev.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp]
         L.qo_solveXX_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp, ci]
@@ -366,6 +369,23 @@ def projectUderiv(x, chain):
     lib().qo_projectU(_p(u), _p(x))
     lib().qo_projectUderiv(_p(r), _p(u), _p(x), _p(chain))
     return r
+
+
+def gauge_exp_update(lo, g, p, t):
+    """g := exp(t p) g (mdt, staghmc_sh.nim:429-435)"""
+    lib().qo_gauge_exp_update(lo._h, _p(g), _p(p), float(t))
+
+
+def gauge_projectSU(lo, g):
+    lib().qo_gauge_projectSU(lo._h, _p(g))
+
+
+def vector_u1(lo, rf):
+    """ftmp.u1 r (distributionUtils.nim:182-211): each colour component exp(2 pi i u), u = r.uniform (float32)"""
+    u = np.zeros((lo.vol, 3))
+    lib().qo_field_uniform(lo._h, rf._h, 3, _p(u), 0)
+    n = 2.0 * np.pi * u
+    return np.stack([np.cos(n), np.sin(n)], axis=-1)
 
 
 def force_projTAH(lo, f, g, adj=False):

@@ -1746,3 +1746,20 @@ void qo_force_projTAH(const qo_layout *lo, double *f, const double *g, int adj) 
     qo_projectTAH(&f[(size_t)i * 18], s);
   }
 }
+
+/* MD gauge update mdt (src/examples/staghmc_sh.nim:429-435): g[mu][s] := exp(t p[mu][s]) g[mu][s] */
+void qo_gauge_exp_update(const qo_layout *lo, double *g, const double *p, double t) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < lo->vol * 4; i++) {
+    double tp[18], e[18], r[18];
+    m_scale(tp, t, &p[(size_t)i * 18]);
+    qo_exp(e, tp);
+    m_mul(r, e, &g[(size_t)i * 18]);
+    m_copy(&g[(size_t)i * 18], r);
+  }
+}
+/* g.projectSU on a gauge field (gaugeUtils.nim:1333-1334), the "reunit" of the HMC examples */
+void qo_gauge_projectSU(const qo_layout *lo, double *g) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < lo->vol * 4; i++) qo_projectSU(&g[(size_t)i * 18], &g[(size_t)i * 18]);
+}

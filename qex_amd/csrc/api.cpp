@@ -463,7 +463,7 @@ extern "C" int qexhip_stag_set_links_hisq(qexhip_handle c, const double *g) {
 }
 extern "C" int qexhip_stag_set_links_nhyp(qexhip_handle c, const double *g, double a1, double a2, double a3,
                                           const int antiperiodic[4], const int phases[4]) {
-  if (!c || !g) return QEXHIP_ERR_ARG;
+  if (!c) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
   static const int defph[4] = {8, 9, 11, 0};
   int mask = 0;

@@ -663,6 +663,15 @@ int smear_set_links_hisq(qexhip_ctx *c, const double *g_host) {
 }
 int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, int bcmask, const int ph[4]) {
   CHK(smear_check(c, 2));
+  if (!g_host) {
+    // reuse the links the closure already smeared (qexhip_nhyp_prepare): copy, rephase, hand over
+    NhypState *st = (NhypState *)c->nhyp;
+    if (!st) { qexhip_set_error("set_links_nhyp(g = NULL) needs qexhip_nhyp_prepare first"); return -1; }
+    HIPCHK(hipMemcpyAsync(st->F, st->FL, st->S.gsz * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    k_rephase<<<st->S.nb(), 256, 0, c->stream>>>(st->S.g, st->F, bcmask, ph[0], ph[1], ph[2], ph[3]);
+    HIPCHK(hipGetLastError());
+    return links_from_natural(c, st->F, nullptr);
+  }
   Smear S(c);
   double2 *G, *FL;
   CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&FL, S.gsz));

@@ -178,7 +178,8 @@ class Staggered:
     def __init__(self, ctx, g, g3=None, smear=None, bc="pppa"):
         """smear = None: g (, g3) are the final links.  smear = HisqCoefs(): the operator uses the
         HISQ fat + long links of g, built on the device.  smear = HypCoefs(...): it uses
-        rephase(nHYP(g)) with boundary string `bc` ('a' = antiperiodic, as input_hmc.xml:44)."""
+        rephase(nHYP(g)) with boundary string `bc` ('a' = antiperiodic, as input_hmc.xml:44); with
+        g = None the links come from the closure of a preceding HypCoefs.smearGetForce."""
         self.ctx = ctx
         self.g = g
         self.g3 = g3
@@ -191,7 +192,7 @@ class Staggered:
         else:
             self.nlinks = 4
             ap = (C.c_int * 4)(*[1 if ch == "a" else 0 for ch in bc])
-            check(lib().qexhip_stag_set_links_nhyp(ctx._h, _p(g), float(smear.alpha1), float(smear.alpha2),
+            check(lib().qexhip_stag_set_links_nhyp(ctx._h, _p(g) if g is not None else None, float(smear.alpha1), float(smear.alpha2),
                                                    float(smear.alpha3), ap, None))
 
     # r = m*x + D*x  /  r = m*x - D*x

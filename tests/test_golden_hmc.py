@@ -1,0 +1,129 @@
+"""Golden set G7: the reference's HMC regression log tests/extra/staghmc_sh/ref.0,
+which its own harness (tests/extra/staghmc_sh/run) compares at 2e-11 relative.
+
+`Begin H` of trajectory 1 is a closed-form consequence of the path this repository implements
+(src/examples/staghmc_sh.nim:716-765): momentum refresh p.randomTAH(r) -> T; nHYP smear + setBC +
+stagPhase; psi_i gaussian; phi_i = D(-h_i)^-1 D(-m_i) psi_i (even sites); the action solves
+psi_i = D(m_i)^-1 D(h_i) phi_i and Sf_i = |psi_i|^2 / 2.  It pins RngMilc6 gaussians, randomTAH,
+Staggered.D (phases, boundary, normalisation, mass sign) and Staggered.solve (even-odd CG +
+reconstruction, r2req = 1e-24) to numbers printed by the reference itself.
+"""
+import numpy as np
+import pytest
+
+LAT = [8, 8, 8, 8]
+SEED = 987654321
+MASS, HMASSES = 0.1, [0.2, 0.4]
+ARSQ = 9.999999999999999e-25
+# tests/extra/staghmc_sh/ref.0:117
+BEGIN_H = 18451.47947589929
+BEGIN_SF = [6115.074514620805, 6296.481015505035, 6143.045791623304]
+BEGIN_T = -103.1218458498552
+RTOL = 2e-11          # tests/extra/staghmc_sh/run:45
+
+
+def begin_H(lo, o, D, solve):
+    """staghmc_sh.nim:716-765 with g = unit; D(x, m) and solve(b, m) are the operator under test."""
+    rf = o.RngField(lo, o.RNG_MILC6, SEED)
+    p = o.gauge_random_tah(lo, rf)                         # p.randomTAH r
+    T = 0.5 * (p * p).sum() - 16.0 * lo.vol
+    psi = [o.vector_gaussian(lo, rf) for _ in range(len(HMASSES) + 1)]
+    n = len(psi)
+    phi = []
+    for i in range(n):
+        mi = -MASS if i == 0 else -HMASSES[i - 1]
+        ph = solve(D(psi[i], mi), -HMASSES[i]) if i != n - 1 else D(psi[i], mi)
+        ph = ph.copy()
+        ph[lo.vol // 2:] = 0                               # phi.odd := 0
+        phi.append(ph)
+    fa = []
+    for i in range(n - 1):                                 # faction (:339-364)
+        x = solve(D(phi[i], HMASSES[i]), MASS if i == 0 else HMASSES[i - 1])
+        fa.append((x * x).sum())
+    x = solve(phi[-1], HMASSES[-1])
+    fa.append((x * x).sum())
+    return T, [0.5 * v for v in fa]
+
+
+def check(T, Sf):
+    assert abs(T - BEGIN_T) < RTOL * abs(16.0 * 4096)      # T is a difference of two ~6.5e4 numbers
+    for a, b in zip(Sf, BEGIN_SF):
+        assert abs(a - b) < RTOL * b
+    assert abs(sum(Sf) + T - BEGIN_H) < RTOL * BEGIN_H     # Sg = 0 on the unit gauge
+
+
+def test_oracle_reproduces_reference_begin_H(oracle):
+    o = oracle
+    lo = o.Layout(LAT)
+    sg = o.nhyp_smear(lo, o.gauge_unit(lo), 0.4, 0.5, 0.5)
+    o.rephase(lo, sg)
+    D = lambda x, m: o.D(lo, sg, None, x, m)
+    solve = lambda b, m: o.solve(lo, sg, None, b, m, ARSQ, 1000000)[0]
+    check(*begin_H(lo, o, D, solve))
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_reference_begin_H(oracle):
+    import qex_amd as q
+
+    o = oracle
+    lo = o.Layout(LAT)
+    ctx = q.Context(LAT)
+    s = q.Staggered(ctx, o.gauge_unit(lo), smear=q.HypCoefs(0.4, 0.5, 0.5), bc="pppa")   # smear + setBC + stagPhase on device
+
+    def D(x, m):
+        r = np.zeros_like(x)
+        s.D(r, x, m)
+        return r
+
+    def solve(b, m):
+        x = np.zeros_like(b)
+        s.solve(x, b, m, q.SolverParams(r2req=ARSQ, maxits=1000000, verbosity=0))
+        return x
+
+    check(*begin_H(lo, o, D, solve))
+
+
+# ---- the whole first trajectory: End H, pbp, plaquette, Polyakov loops (ref.0:118-126) ----
+def _check_trajectory(r, R):
+    b = r.refresh()
+    check(b["T"], b["Sf"])
+    r.evolve()
+    e = r.finish_energies()
+    G = R.GOLD["end"]
+    for k in ("H", "Sg", "T"):
+        assert abs(e[k] - G[k]) < RTOL * abs(G[k]), (k, e[k], G[k])
+    for a, g_ in zip(e["Sf"], G["Sf"]):
+        assert abs(a - g_) < RTOL * g_
+    m = r.measure()
+    for a, g_ in zip(m["pbp"], R.GOLD["pbp"]):
+        assert abs(a - g_) < RTOL * g_
+    for a, g_ in zip(m["plaq"], R.GOLD["plaq"]):
+        assert abs(a - g_) < RTOL * g_
+    for a, g_ in zip(m["ploop"], R.GOLD["ploop"]):
+        assert abs(a - g_) < RTOL * max(abs(g_), 0.1)
+    assert m["pbp_iters"] == [R.GOLD["pbp_iters"]] * 2                 # "stagSolve: 101" twice (ref.0:122,124)
+    # Solver[force] statistics count:avg:max per mass (ref.0:134-136) and Solver[action] maxima (:130-132)
+    fi = r.stats["force_iters"]
+    for j, (avg, mx) in enumerate([(80, 98), (69, 82), (49, 55)]):
+        v = fi[j::3]
+        assert len(v) == 12 and sum(v) // len(v) == avg and max(v) == mx
+    assert r.stats["action_iters"][-3:] == [99, 82, 54]
+
+
+def test_oracle_replays_reference_trajectory(oracle):
+    """G7 in full: the oracle's nHYP smearing + force chain, fermion and adjoint-plaquette gauge
+    forces, D and solve carry the reference's first HMC trajectory to its printed End H, pbp,
+    plaquettes and Polyakov loops (the reference's harness compares these at 2e-11)."""
+    import hmc_replay as R
+
+    _check_trajectory(R.Replay(oracle, R.OracleBackend(oracle, oracle.Layout(R.LAT))), R)
+
+
+@pytest.mark.gpu
+def test_gpu_replays_reference_trajectory(oracle):
+    """The same trajectory with every hot-path operator running through libqexhip."""
+    import qex_amd as q
+    import hmc_replay as R
+
+    _check_trajectory(R.Replay(oracle, R.HipBackend(q, R.LAT, oracle)), R)
