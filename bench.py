@@ -105,6 +105,7 @@ def main():
         s = q.newStag3(ctx, g, g3)
     else:
         s = q.newStag(ctx, g)
+    _, compressed, _ = s.links_info()           # SU(3)-up-to-sign links are streamed as 2 rows + sign bit
     nd = 8 if args.naik else 4                  # s.g.len in QEX's flop formulas
     b1 = 2 * nd * 144 + 96                      # bytes/site of a sweep: links once, vector in + out
     flop_dslash = 2 * nd * 66 + (2 * nd - 1) * 6
@@ -116,22 +117,23 @@ def main():
         if N > 1:
             dist.barrier()
 
-    # warmup
-    ctx.dev_solve_xx(xid, bid, args.mass, 0.0, max(args.warmup, 1), True)
-    device_sync()
+    def timed_cg(steps, warmup):
+        ctx.dev_solve_xx(xid, bid, args.mass, 0.0, max(warmup, 1), True)      # warmup
+        device_sync()
+        ctx.timers_enable(int(os.environ.get("QEX_BENCH_TIMERS", "2")))  # 2: Dslash sweeps only
+        ctx.timers_reset()
+        barrier()
+        device_sync()
+        t0 = time.perf_counter()
+        its, _, _ = ctx.dev_solve_xx(xid, bid, args.mass, 0.0, steps, True)
+        device_sync()
+        barrier()
+        t1 = time.perf_counter()
+        ctx.timers_enable(False)
+        assert its == steps, (its, steps)
+        return t1 - t0
 
-    ctx.timers_enable(int(os.environ.get("QEX_BENCH_TIMERS", "2")))  # 2: Dslash sweeps only
-    ctx.timers_reset()
-    barrier()
-    device_sync()
-    t0 = time.perf_counter()
-    its, fin, _ = ctx.dev_solve_xx(xid, bid, args.mass, 0.0, args.steps, True)
-    device_sync()
-    barrier()
-    t1 = time.perf_counter()
-    ctx.timers_enable(False)
-    assert its == args.steps, (its, args.steps)
-    dt = t1 - t0
+    dt = timed_cg(args.steps, args.warmup)
     if N > 1:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -149,8 +151,10 @@ def main():
         F = lat_loc[0] // 2 * lat_loc[1] * lat_loc[2]
         sites_per_launch = max(Vh_loc - 2 * (3 if args.naik else 1) * F, 0)
     avg_ms = ms_int / max(n_int, 1)
-    b_alg = 0.5 * (b1 + b1 + 48) * sites_per_launch
+    b_alg = 0.5 * (b1 + b1 + 48) * sites_per_launch                     # 144 B per link
+    b_streamed = b_alg - 2 * nd * {0: 0, 1: 48, 2: 32}[compressed] * sites_per_launch   # 96 / 112 B per compressed link
     achieved_gbs = b_alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    streamed_gbs = b_streamed / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # whole sweep incl. boundary launches, for the Dslash GFLOP/s figure
     sweep_ms = (ms_int + ms_bnd) / max(n_int, 1)
     dslash_gflops = flop_dslash * Vh_loc * N / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
@@ -163,7 +167,7 @@ def main():
         tf = os.path.join(ROOT, "profiles", "dslash_traffic.json")
         if os.path.exists(tf) and lat == [32, 32, 32, 32] and N == 1 and not args.naik and not args.halo:
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch_32x4")
+                traffic = json.load(open(tf)).get({0: "hbm_bytes_per_launch_32x4", 1: "hbm_bytes_per_launch_32x4_recon12"}.get(compressed, "none"))
             except Exception:
                 traffic = None
         out = {
@@ -183,6 +187,8 @@ def main():
                 "workload": "%dx%dx%dx%d SU(3) even/odd staggered CG (2 Dslash sweeps + BLAS per step), mass %g, "
                             "t split over %d GPU(s)" % (lat[0], lat[1], lat[2], lat[3], args.mass, N),
                 "lattice": lat, "mass": args.mass, "parallelism": "t-shard x%d" % N,
+                "links": {0: "18 reals (144 B/link)", 1: "su3 rows 0,1 + sign bit (96 B/link, row 2 rebuilt in registers)",
+                          2: "u3 rows 0,1 + determinant (112 B/link, row 2 rebuilt in registers)"}[compressed],
             },
             "cg_iters_per_s": round(args.steps / dt, 2),
             "dslash_gflops": round(dslash_gflops, 1),
@@ -196,8 +202,24 @@ def main():
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
                 "launches": n_int, "avg_us": round(avg_ms * 1e3, 2),
                 "alg_bytes_per_launch": int(b_alg), "traffic": traffic,
+                # what the kernel is asked to stream (= alg_bytes unless the links are compressed)
+                "streamed_bytes_per_launch": int(b_streamed), "achieved_streamed": round(streamed_gbs, 1),
+                "frac_streamed": round(streamed_gbs / HBM_PEAK_GBS, 4),
             },
         }
+        if N == 1 and compressed and not args.halo:
+            # the same workload with link compression switched off (all 18 reals streamed)
+            ctx.set_option("recon", 0)
+            s = q.newStag3(ctx, g, g3) if args.naik else q.newStag(ctx, g)
+            k2 = max(args.steps // 2, 10)
+            dt2 = timed_cg(k2, args.warmup)
+            n2, ms2 = ctx.timer("dslash")
+            out["full18_links"] = {
+                "cg_iters_per_s": round(k2 / dt2, 2), "value": round(flop_cg * (V // 2) * k2 / dt2 / 1e9, 2),
+                "dslash_us_per_sweep": round(1e3 * ms2 / max(n2, 1), 2),
+                "roofline_frac": round(b_alg / (ms2 / max(n2, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            }
+            ctx.set_option("recon", 2)
         if N == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(lat_loc, g, g3 if args.naik else None, b, args.mass, args.cpu_seconds)
     barrier()

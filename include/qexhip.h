@@ -193,6 +193,19 @@ int qexhip_fat7(qexhip_handle h, const double *g, const double coef[5], double *
 int qexhip_hisq_smear(qexhip_handle h, const double *g, double *fl, double *ll);
 int qexhip_nhyp_smear(qexhip_handle h, const double *g, double *fl, double alpha1, double alpha2, double alpha3);
 
+/* Storage format the library chose for the operator's links at the last set_links call.  A unitary link is fixed
+ * by rows 0,1 and its determinant (row2 = det * conj(row0 x row1)), and the sweep is HBM-bound, so:
+ *   1: every link is SU(3) up to a sign (thin links with BC + staggered phases): rows 0,1 + a sign bit, 96 B/link
+ *   2: every link is U(3) (nHYP-smeared links): rows 0,1 + det, 112 B/link
+ *   0: otherwise (HISQ fat links, QEX's `random` start, which is unitary only to 1e-11): all 18 reals, 144 B/link
+ * chosen only if ALL links reproduce their stored row 2 to 1e-14; max_dev = the largest deviation found for the
+ * chosen format.  Row 2 is rebuilt in registers.  QEXHIP_RECON=0|1|2 caps the format.  No counterpart in QEX (its
+ * CPU Dslash always reads full links, stagD.nim:349-395); QUDA's reconstruct-12/13 is the precedent. */
+int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double *max_dev);
+/* Tuning switches, same names as the QEXHIP_<NAME> environment variables read at init: "recon" (link
+ * compression on/off, effective at the next set_links), "swz", "ntstore", "overlap". */
+int qexhip_set_option(qexhip_handle h, const char *name, int value);
+
 /* Smear on the device and hand the result straight to the operator (replaces smear -> rephase ->
  * set_links without moving the smeared links over PCIe):
  *   hisq: Staggered.g <- HisqCoefs.smear(g) (fat + long); g carries BC + phases already

@@ -2,6 +2,7 @@
 // Host-pointer entry points upload into work fields, run the device path, download the result:
 // the same choreography as qudaSolveXX (src/quda/qudaWrapperImpl.nim:165-261).
 #include "qexhip_internal.h"
+#include <string>
 #include "../../include/qexhip.h"
 #include <algorithm>
 #include <cstdarg>
@@ -115,6 +116,7 @@ extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], 
   if (const char *e = getenv("QEXHIP_SWZ")) c->opt_swz = atoi(e);
   if (const char *e = getenv("QEXHIP_NTSTORE")) c->opt_ntstore = atoi(e);
   if (const char *e = getenv("QEXHIP_OVERLAP")) c->opt_overlap = atoi(e);
+  if (const char *e = getenv("QEXHIP_RECON")) c->opt_recon = atoi(e);
   c->nranks = 1;  // until qexhip_comm_init
   c->rank = 0;
   *h = c;
@@ -132,6 +134,8 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
   gauge_free(c);
   comm_destroy(c);
   if (c->W) (void)hipFree(c->W);
+  if (c->Wc) (void)hipFree(c->Wc);
+  if (c->Ws) (void)hipFree(c->Ws);
   if (c->stage) (void)hipFree(c->stage);
   if (c->partials) (void)hipFree(c->partials);
   if (c->dscal) (void)hipFree(c->dscal);
@@ -456,6 +460,23 @@ extern "C" int qexhip_nhyp_smear(qexhip_handle c, const double *g, double *fl, d
   return smear_nhyp_host(c, g, fl, a1, a2, a3);
 }
 
+extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
+  if (!c || !name) return QEXHIP_ERR_ARG;
+  const std::string n(name);
+  if (n == "recon") c->opt_recon = value;            // takes effect at the next set_links
+  else if (n == "swz") c->opt_swz = value;
+  else if (n == "ntstore") c->opt_ntstore = value;
+  else if (n == "overlap") c->opt_overlap = value;
+  else { qexhip_set_error("unknown option"); return QEXHIP_ERR_ARG; }
+  return 0;
+}
+extern "C" int qexhip_stag_links_info(qexhip_handle c, int *nlinks, int *compressed, double *max_dev) {
+  if (!c) return QEXHIP_ERR_ARG;
+  if (nlinks) *nlinks = c->W ? c->ndir : 0;
+  if (compressed) *compressed = c->recon;
+  if (max_dev) *max_dev = c->recon_dev;
+  return 0;
+}
 extern "C" int qexhip_stag_set_links_hisq(qexhip_handle c, const double *g) {
   if (!c || !g) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));

@@ -14,7 +14,8 @@
 
 struct DslashArgs {
   Geom g;
-  const double2 *W;      // links of the output parity
+  const double2 *W;      // links of the output parity (RECON: rows 0,1 only, [tile][dir][6][64])
+  const unsigned long long *S;   // RECON: sign masks [tile][dir], bit = lane
   const double2 *in;     // hop source (opposite parity half)
   double2 *out;          // output parity half
   const double2 *rin;    // a-term
@@ -54,7 +55,30 @@ __device__ __forceinline__ void mv3(double2 acc[3], const double2 U[9], const do
   }
 }
 
-template <int NDIR, bool HALO, bool INIT, bool DOT>
+// rows 0,1 of a link -> full link: row 2 = det * conj(row0 x row1); det = +-1 (format 1) or U[6] (format 2)
+template <int FMT>
+__device__ __forceinline__ void recon_row2(double2 U[9], bool neg) {
+  const double2 ph = U[6];
+  double2 r2[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int a = (k + 1) % 3, b = (k + 2) % 3;
+    double rx = U[a].x * U[3 + b].x;
+    rx -= U[a].y * U[3 + b].y;
+    rx -= U[b].x * U[3 + a].x;
+    rx += U[b].y * U[3 + a].y;
+    double ry = U[b].x * U[3 + a].y;
+    ry += U[b].y * U[3 + a].x;
+    ry -= U[a].x * U[3 + b].y;
+    ry -= U[a].y * U[3 + b].x;
+    if (FMT == 1) r2[k] = make_double2(neg ? -rx : rx, neg ? -ry : ry);
+    else r2[k] = make_double2(ph.x * rx - ph.y * ry, ph.x * ry + ph.y * rx);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) U[6 + k] = r2[k];
+}
+
+template <int NDIR, bool HALO, bool INIT, bool DOT, int RECON>
 __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
   if (A.done && *A.done) return;
   int bid = blockIdx.x;
@@ -95,7 +119,10 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
 #pragma unroll
       for (int k = 0; k < 3; k++) acc[k] = make_double2(0.0, 0.0);
     }
-    const double2 *w = A.W + (size_t)(c >> 6) * (NDIR * 576) + (c & 63);
+    constexpr int NLOAD = RECON == 1 ? 6 : (RECON == 2 ? 7 : 9);
+    constexpr int LROW = NLOAD * 64;             // double2 per (tile, direction)
+    const double2 *w = A.W + (size_t)(c >> 6) * (NDIR * LROW) + (c & 63);
+    const unsigned long long *sm = RECON == 1 ? A.S + (size_t)(c >> 6) * NDIR : nullptr;
     // One loop iteration = the forward and the backward hop of one direction (fat links: pairs
     // 0..3, 3-hop links: pairs 4..7).  How far the loop is unrolled decides how many link loads a
     // wave keeps in flight.  Measured inside CG on 32^4 (scratch A/B builds, 2 rounds):
@@ -103,27 +130,36 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
     //   Naik : rolled 215 us, x2 210 us, x4 222 us; FULLY unrolled hipcc hoists all 192 loads and
     //          spills to scratch (290-330 us) -- never unroll the 16-link loop completely.
     // mu/hop are wave-uniform, so the neighbour arithmetic of the rolled loop branches on scalars.
-    constexpr int UNR = (NDIR == 8) ? 4 : 2;
+    // compressed 8-link kernel (rows 0,1 + sign, 864 B/site): rolled 80.2 us, x2 81.9, x4 83.5 (32^4, in CG)
+    constexpr int UNR = (NDIR == 8) ? (RECON ? 1 : 4) : 2;
 #pragma unroll UNR
     for (int pr = 0; pr < NDIR / 2; pr++) {
       const int mu = pr & 3;
       const int hop = pr >= 4 ? 3 : 1;
       const int pf = nbr_pos<HALO>(g, c, s, mu, hop);
       const int pb = nbr_pos<HALO>(g, c, s, mu, -hop);
-      const double2 *wp = w + (size_t)pr * 1152;
+      const double2 *wp = w + (size_t)pr * (2 * LROW);
       double2 U[9], W[9], vf[3], vb[3];
       // links are read exactly once per sweep: stream them past the caches (non-temporal), which
       // leaves L2 / Infinity Cache to the 8x re-read neighbour vectors.  Measured on MI355X,
       // 32^4: 120 us -> 108 us per sweep (scratch/tune_dslash.py, profiles/r01_tune_dslash.log).
 #pragma unroll
-      for (int k = 0; k < 9; k++) {
+      for (int k = 0; k < NLOAD; k++) {
         d2v t = __builtin_nontemporal_load((const d2v *)&wp[k * 64]);
         U[k] = make_double2(t.x, t.y);
       }
 #pragma unroll
-      for (int k = 0; k < 9; k++) {
-        d2v t = __builtin_nontemporal_load((const d2v *)&wp[576 + k * 64]);
+      for (int k = 0; k < NLOAD; k++) {
+        d2v t = __builtin_nontemporal_load((const d2v *)&wp[LROW + k * 64]);
         W[k] = make_double2(t.x, t.y);
+      }
+      if (RECON == 1) {
+        const int lane = c & 63;
+        recon_row2<1>(U, (sm[2 * pr] >> lane) & 1ull);
+        recon_row2<1>(W, (sm[2 * pr + 1] >> lane) & 1ull);
+      } else if (RECON == 2) {
+        recon_row2<2>(U, false);
+        recon_row2<2>(W, false);
       }
 #pragma unroll
       for (int k = 0; k < 3; k++) vf[k] = A.in[vec_off(pf, k)];
@@ -174,15 +210,23 @@ static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool 
   A.c0 = c0; A.c1 = c1; A.d0 = d0; A.d1 = d1;
   A.nb1 = (c1 - c0 + 255) / 256;
   int nb = A.nb1 + (d1 > d0 ? (d1 - d0 + 255) / 256 : 0);
-  A.swz = (c->opt_swz && nb >= 64 && (nb & 7) == 0) ? nb : 0;
+  const int swz = c->opt_swz >= 0 ? c->opt_swz : (c->recon != 0);
+  A.swz = (swz && nb >= 64 && (nb & 7) == 0) ? nb : 0;
   A.ntstore = c->opt_ntstore;
   double *psave = A.partials;
   A.partials = psave ? psave + part_off : nullptr;
   dim3 grid(nb), block(256);
-  if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true>, grid, block, A);
-  else if (init) launch_timed(c, tname, k_dslash<NDIR, HALO, true, false>, grid, block, A);
-  else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true>, grid, block, A);
-  else launch_timed(c, tname, k_dslash<NDIR, HALO, false, false>, grid, block, A);
+#define QX_LAUNCH(R) \
+  do { \
+    if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true, R>, grid, block, A); \
+    else if (init) launch_timed(c, tname, k_dslash<NDIR, HALO, true, false, R>, grid, block, A); \
+    else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true, R>, grid, block, A); \
+    else launch_timed(c, tname, k_dslash<NDIR, HALO, false, false, R>, grid, block, A); \
+  } while (0)
+  if (c->recon == 1) QX_LAUNCH(1);
+  else if (c->recon == 2) QX_LAUNCH(2);
+  else QX_LAUNCH(0);
+#undef QX_LAUNCH
   A.partials = psave;
   HIPCHK(hipGetLastError());
   return 0;
@@ -193,7 +237,13 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
   if (!c->W) { qexhip_set_error("staggered links not set (qexhip_stag_set_links)"); return -3; }
   DslashArgs A;
   A.g = g;
-  A.W = c->W + (size_t)parity * g.ntile * c->ndir * 576;
+  if (c->recon) {
+    A.W = c->Wc + (size_t)parity * g.ntile * c->ndir * (c->recon == 1 ? 384 : 448);
+    A.S = c->Ws + (size_t)parity * g.ntile * c->ndir;
+  } else {
+    A.W = c->W + (size_t)parity * g.ntile * c->ndir * 576;
+    A.S = nullptr;
+  }
   A.in = in.par(1 - parity);
   A.out = out.par(parity);
   A.rin = o.rin ? o.rin->par(parity) : nullptr;

@@ -3,6 +3,7 @@
 // tiled device layout described in qexhip_internal.h  (kernel K11 of SURVEY.md 2.3).
 #include "qexhip_internal.h"
 #include "site_index.h"
+#include <cstring>
 
 int geom_init(Geom &g, const int X[4], int depth, int halo) {
   for (int i = 0; i < 4; i++) {
@@ -157,6 +158,89 @@ int links_upload(qexhip_ctx *c, const double *fat, const double *lng) {
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(c->stream));
+  return links_compress(c);
+}
+
+// ---- link compression --------------------------------------------------------------------------
+// The sweep is HBM-bound with >10x VALU slack, so bytes are what count.  A unitary link is fixed by
+// its first two rows and its determinant: row2 = det * conj(row0 x row1).
+//   format 1 (96 B/link): thin staggered links = SU(3) times the +-1 of boundary condition and
+//             staggered phase, det = +-1: rows 0,1 + one sign bit per link (64-bit mask per tile row);
+//   format 2 (112 B/link): U(3) links (nHYP-smeared: projectU output), rows 0,1 + det as a 7th double2;
+//   format 0 (144 B/link): everything else (HISQ fat links are not unitary), all 18 reals.
+// The format is chosen per set_links: the most compact one that EVERY link of the operator
+// satisfies to 1e-14; row 2 is rebuilt in registers by the Dslash kernel.
+template <int FMT>
+__global__ void __launch_bounds__(256) k_links_compress(size_t nrows, const double2 *__restrict__ W, double2 *Wc,
+                                                        unsigned long long *Ws, unsigned int *maxdev) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;     // (row = (parity, tile, dir), lane)
+  const size_t row = j >> 6;
+  if (row >= nrows) return;
+  const int l = j & 63;
+  const double2 *w = W + row * 576 + l;
+  constexpr int NR = FMT == 1 ? 6 : 7;
+  double2 *o = Wc + row * (NR * 64) + l;
+  double2 u[9], r[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) u[k] = w[k * 64];
+#pragma unroll
+  for (int k = 0; k < 6; k++) o[k * 64] = u[k];
+  double n2 = 0, px = 0, py = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int a = (k + 1) % 3, b = (k + 2) % 3;
+    // conj(u0[a] u1[b] - u0[b] u1[a])
+    r[k].x = (u[a].x * u[3 + b].x - u[a].y * u[3 + b].y) - (u[b].x * u[3 + a].x - u[b].y * u[3 + a].y);
+    r[k].y = -((u[a].x * u[3 + b].y + u[a].y * u[3 + b].x) - (u[b].x * u[3 + a].y + u[b].y * u[3 + a].x));
+    n2 += r[k].x * r[k].x + r[k].y * r[k].y;
+    px += u[6 + k].x * r[k].x + u[6 + k].y * r[k].y;     // sum row2[k] * conj(r[k])
+    py += u[6 + k].y * r[k].x - u[6 + k].x * r[k].y;
+  }
+  double2 ph;                                            // det estimate: <r, row2> / <r, r>
+  if (n2 > 0) ph = make_double2(px / n2, py / n2); else ph = make_double2(1.0, 0.0);
+  if (FMT == 1) ph = make_double2(ph.x < 0 ? -1.0 : 1.0, 0.0);
+  double dev = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double rx = ph.x * r[k].x - ph.y * r[k].y, ry = ph.x * r[k].y + ph.y * r[k].x;
+    dev = fmax(dev, fmax(fabs(u[6 + k].x - rx), fabs(u[6 + k].y - ry)));
+  }
+  if (FMT == 1) {
+    const unsigned long long mask = __ballot(ph.x < 0);
+    if (l == 0) Ws[row] = mask;
+  } else {
+    o[6 * 64] = ph;
+  }
+  atomicMax(maxdev, __float_as_uint((float)dev));        // dev >= 0: the uint order is the float order
+}
+int links_compress(qexhip_ctx *c) {
+  const Geom &g = c->g;
+  c->recon = 0;
+  if (!c->opt_recon || !c->W) return 0;
+  const size_t nrows = (size_t)2 * g.ntile * c->ndir;
+  if (c->Wc_rows < nrows) {
+    if (c->Wc) HIPCHK(hipFree(c->Wc));
+    if (c->Ws) HIPCHK(hipFree(c->Ws));
+    HIPCHK(hipMalloc((void **)&c->Wc, nrows * 448 * sizeof(double2)));
+    HIPCHK(hipMalloc((void **)&c->Ws, nrows * sizeof(unsigned long long)));
+    c->Wc_rows = nrows;
+  }
+  unsigned int *flag = (unsigned int *)&c->dscal[30];
+  const unsigned nblk = (unsigned)((nrows * 64 + 255) / 256);
+  for (int fmt = 1; fmt <= 2; fmt++) {
+    if (fmt == 2 && c->opt_recon == 1) break;          // QEXHIP_RECON=1: sign format only
+    HIPCHK(hipMemsetAsync(flag, 0, sizeof(unsigned int), c->stream));
+    if (fmt == 1) k_links_compress<1><<<nblk, 256, 0, c->stream>>>(nrows, c->W, c->Wc, c->Ws, flag);
+    else k_links_compress<2><<<nblk, 256, 0, c->stream>>>(nrows, c->W, c->Wc, c->Ws, flag);
+    HIPCHK(hipGetLastError());
+    unsigned int bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, flag, sizeof(bits), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float dev;
+    memcpy(&dev, &bits, sizeof(dev));
+    if (fmt == 1 || dev <= 1e-14f) c->recon_dev = dev;
+    if (dev <= 1e-14f) { c->recon = fmt; break; }
+  }
   return 0;
 }
 
@@ -196,7 +280,7 @@ int links_from_natural(qexhip_ctx *c, const double2 *fat, const double2 *lng) {
   if (lng) k_links_from_nat<<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, lng, c->W, ndir, 8, 3);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
-  return 0;
+  return links_compress(c);
 }
 
 // ---- host-callable test hooks for the index arithmetic (no GPU needed) ----

@@ -91,7 +91,10 @@ struct qexhip_ctx {
   int timers_on = 0;
   std::map<std::string, TimerSlot> timers;
   // tuning switches (env QEXHIP_SWZ / QEXHIP_NTSTORE, read at init)
-  int opt_swz = 0, opt_ntstore = 1;
+  int opt_swz = -1, opt_ntstore = 1;   // swz: -1 = on for compressed links, off for 18-real links (measured)
+  // compressed links (recon = 1: rows 0,1 + sign mask; 2: rows 0,1 + det; row 2 rebuilt in the kernel)
+  double2 *Wc = nullptr; unsigned long long *Ws = nullptr; size_t Wc_rows = 0; int recon = 0; double recon_dev = 0;
+  int opt_recon = 2;      // QEXHIP_RECON: 0 keeps the 18-real links always, 1 sign format only, 2 also the U(3) format
   int opt_overlap = -1;  // QEXHIP_OVERLAP: 1 always use the comm stream, 0 never, -1 by interior size
   // natural gauge (flow)
   GaugeNat *gn = nullptr;
@@ -131,6 +134,7 @@ int field_download(qexhip_ctx *c, const DevField &f, double *host);
 int links_upload(qexhip_ctx *c, const double *fat, const double *lng);
 int ensure_stage(qexhip_ctx *c, size_t bytes);
 int links_from_natural(qexhip_ctx *c, const double2 *fat, const double2 *lng);
+int links_compress(qexhip_ctx *c);
 
 // ---- comm.cpp ----
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready, records ev_halo

@@ -114,6 +114,9 @@ class Context:
     def timers_reset(self):
         check(lib().qexhip_timers_reset(self._h))
 
+    def set_option(self, name, value):
+        check(lib().qexhip_set_option(self._h, name.encode(), int(value)))
+
     def timer(self, name):
         cnt, ms = C.c_long(0), C.c_double(0)
         check(lib().qexhip_timers_get(self._h, name.encode(), C.byref(cnt), C.byref(ms)))
@@ -196,6 +199,13 @@ class Staggered:
                                                    float(smear.alpha3), ap, None))
 
     # r = m*x + D*x  /  r = m*x - D*x
+    def links_info(self):
+        """(links per site, format, max deviation) of the operator's links; format 0: 18 reals,
+        1: rows 0,1 + sign bit (SU(3) x sign), 2: rows 0,1 + determinant (U(3))"""
+        n, cflag, dev = C.c_int(0), C.c_int(0), C.c_double(0)
+        check(lib().qexhip_stag_links_info(self.ctx._h, C.byref(n), C.byref(cflag), C.byref(dev)))
+        return n.value, cflag.value, dev.value
+
     def D(self, r, x, m):
         check(lib().qexhip_stag_D(self.ctx._h, _p(r), _p(x), float(m), 1.0))
 

@@ -403,3 +403,85 @@ def test_full_size_plaq_and_flow(s32):
     gref = S.g0.copy()
     S.o.wflow(S.lo, gref, 1, 0.01)
     assert relerr(g, gref) < 1e-12
+
+
+def test_link_compression_formats(oracle):
+    """Thin links (SU(3) x BC/phase signs) are stored as 2 rows + sign and rebuilt in the kernel;
+    smeared links keep all 18 reals.  Either way D agrees with the oracle, and the two storage
+    formats agree with each other to rounding on the same links."""
+    import os
+    import qex_amd as q
+
+    o = oracle
+    lat = [8, 4, 6, 4]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 5)
+    g = o.gauge_warm(lo, 0.5, rf)
+    o.rephase(lo, g)
+    x = o.vector_gaussian(lo, rf)
+    ctx = q.Context(lat)
+    s = q.newStag(ctx, g)
+    n, comp, dev = s.links_info()
+    assert n == 8 and comp == 1 and dev < 1e-14
+    y = np.zeros_like(x)
+    s.D(y, x, 0.1)
+    ref = o.D(lo, g, None, x, 0.1)
+    assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 1e-14
+    # QEX's g.random (projectSU of a gaussian matrix) is unitary only to ~1e-11: full format
+    gr = o.gauge_random(lo, rf)
+    o.rephase(lo, gr)
+    sr = q.newStag(ctx, gr)
+    assert not sr.links_info()[1] and sr.links_info()[2] > 1e-14
+    # a rescaled unitary link still has row2 proportional to conj(row0 x row1): format 2 stores the factor
+    s2 = q.newStag(ctx, 1.01 * g)
+    assert s2.links_info()[1] == 2
+    s2.D(y, x, 0.1)
+    assert np.linalg.norm(y - o.D(lo, 1.01 * g, None, x, 0.1)) / np.linalg.norm(ref) < 1e-14
+    # one generic (non-unitary) link anywhere -> full format
+    g2 = g.copy()
+    g2[lo.vol // 3, 2] += 1e-6 * np.random.default_rng(0).standard_normal((3, 3, 2))
+    s2 = q.newStag(ctx, g2)
+    assert s2.links_info()[1] == 0
+    s2.D(y, x, 0.1)
+    assert np.linalg.norm(y - o.D(lo, g2, None, x, 0.1)) / np.linalg.norm(ref) < 1e-14
+    # U(3) (nHYP links are projectU output) -> rows 0,1 + determinant
+    gw = o.gauge_warm(lo, 0.5, rf)
+    s3 = q.Staggered(ctx, gw, smear=q.HypCoefs(), bc="pppa")
+    assert s3.links_info()[1] == 2
+    s3.D(y, x, 0.1)
+    sm = o.nhyp_smear(lo, gw, 0.4, 0.5, 0.5)
+    o.rephase(lo, sm)
+    r3 = o.D(lo, sm, None, x, 0.1)
+    assert np.linalg.norm(y - r3) / np.linalg.norm(r3) < 1e-13
+    ctx.set_option("recon", 0)                       # the same links, all 18 reals streamed
+    s3 = q.Staggered(ctx, gw, smear=q.HypCoefs(), bc="pppa")
+    assert s3.links_info()[1] == 0
+    y0 = np.zeros_like(x)
+    s3.D(y0, x, 0.1)
+    ctx.set_option("recon", 2)
+    assert np.linalg.norm(y - y0) / np.linalg.norm(y0) < 1e-14
+    # Naik: fat and long both SU(3) up to sign -> compressed; mixed -> full
+    lat2 = [4, 4, 8, 6]
+    lo2 = o.Layout(lat2)
+    rf2 = o.RngField(lo2, o.RNG_MILC6, 6)
+    ga, gb = o.gauge_warm(lo2, 0.5, rf2), o.gauge_warm(lo2, 0.7, rf2)
+    o.rephase(lo2, ga)
+    x2 = o.vector_gaussian(lo2, rf2)
+    ctx2 = q.Context(lat2)
+    s4 = q.newStag3(ctx2, ga, gb)
+    assert s4.links_info()[:2] == (16, 1)
+    y2 = np.zeros_like(x2)
+    s4.D(y2, x2, 0.05)
+    r4 = o.D(lo2, ga, gb, x2, 0.05)
+    assert np.linalg.norm(y2 - r4) / np.linalg.norm(r4) < 1e-14
+    s5 = q.newStag3(ctx2, ga, 0.3 * gb)               # rescaled long links: factor stored with format 2
+    assert s5.links_info()[:2] == (16, 2)
+    s5.D(y2, x2, 0.05)
+    r5 = o.D(lo2, ga, 0.3 * gb, x2, 0.05)
+    assert np.linalg.norm(y2 - r5) / np.linalg.norm(r5) < 1e-14
+    fl, ll = o.hisq_smear(lo2, ga)                    # HISQ fat links are not unitary: 18 reals
+    s6 = q.newStag3(ctx2, fl, ll)
+    assert s6.links_info()[:2] == (16, 0)
+    s6.D(y2, x2, 0.05)
+    r6 = o.D(lo2, fl, ll, x2, 0.05)
+    assert np.linalg.norm(y2 - r6) / np.linalg.norm(r6) < 1e-14
