@@ -20,17 +20,21 @@ def relerr(a, b):
 
 
 class Setup:
-    def __init__(self, o, lat, naik=False, halo=False):
+    def __init__(self, o, lat, naik=False, halo=False, warm=False):
+        """warm=False: QEX's g.random start (projectSU of gaussians: unitary only to ~1e-11, so the
+        library keeps all 18 reals per link); warm=True: g.warm(0.5), unitary to 1e-15, which the
+        library stores compressed (2 rows + sign; with the 0.3-scaled long links 2 rows + factor)."""
         import qex_amd as q
 
         self.o, self.q = o, q
         self.lo = o.Layout(lat)
         self.rf = o.RngField(self.lo, o.RNG_MILC6, SEED)
-        self.g = o.gauge_random(self.lo, self.rf)
+        gen = (lambda: o.gauge_warm(self.lo, 0.5, self.rf)) if warm else (lambda: o.gauge_random(self.lo, self.rf))
+        self.g = gen()
         o.rephase(self.lo, self.g)
         self.g3 = None
         if naik:
-            self.g3 = o.gauge_random(self.lo, self.rf)
+            self.g3 = gen()
             o.rephase(self.lo, self.g3)
             self.g3 *= 0.3  # long links are not unitary in practice
         self.x = o.vector_gaussian(self.lo, self.rf)
@@ -39,6 +43,7 @@ class Setup:
         if halo:
             self.ctx.force_halo(True)
         self.s = q.newStag3(self.ctx, self.g, self.g3) if naik else q.newStag(self.ctx, self.g)
+        assert self.s.links_info()[1] == ((2 if naik else 1) if warm else 0)
 
 
 @pytest.fixture(scope="module")
@@ -49,6 +54,21 @@ def s8(oracle):
 @pytest.fixture(scope="module")
 def s8naik(oracle):
     return Setup(oracle, [8, 8, 8, 8], naik=True)
+
+
+@pytest.fixture(scope="module")
+def s8w(oracle):
+    return Setup(oracle, [8, 8, 8, 8], warm=True)
+
+
+@pytest.fixture(scope="module")
+def s8naikw(oracle):
+    return Setup(oracle, [8, 8, 8, 8], naik=True, warm=True)
+
+
+@pytest.fixture(scope="module")
+def soddw(oracle):
+    return Setup(oracle, [4, 6, 10, 6], warm=True)
 
 
 @pytest.fixture(scope="module")
@@ -80,7 +100,7 @@ def test_blas_hooks(s8):
     assert relerr(y2, ref) < 1e-15
 
 
-@pytest.mark.parametrize("fix", ["s8", "sodd", "s8naik"])
+@pytest.mark.parametrize("fix", ["s8", "sodd", "s8naik", "s8w", "soddw", "s8naikw"])
 @pytest.mark.parametrize("sub,par", [("even", 0), ("odd", 1), ("all", 2)])
 def test_stagD2(request, fix, sub, par):
     S = request.getfixturevalue(fix)
@@ -92,7 +112,7 @@ def test_stagD2(request, fix, sub, par):
         assert relerr(r_gpu, r_ref) < 1e-13, (fix, sub, a, b)
 
 
-@pytest.mark.parametrize("fix", ["s8", "sodd", "s8naik"])
+@pytest.mark.parametrize("fix", ["s8", "sodd", "s8naik", "s8w", "soddw", "s8naikw"])
 def test_D_Ddag(request, fix):
     S = request.getfixturevalue(fix)
     for m in (0.0, 0.1):
@@ -103,7 +123,7 @@ def test_D_Ddag(request, fix):
         assert relerr(r, S.o.Ddag(S.lo, S.g, S.g3, S.x, m)) < 1e-13
 
 
-@pytest.mark.parametrize("fix", ["s8", "sodd", "s8naik"])
+@pytest.mark.parametrize("fix", ["s8", "sodd", "s8naik", "s8w", "soddw", "s8naikw"])
 def test_stagD2ee_oo(request, fix):
     S = request.getfixturevalue(fix)
     h = S.lo.vol // 2
@@ -144,7 +164,7 @@ def history_tolerance(o, lo, g, g3, b, m, r2req, maxits, par_even, hist_ref):
     return min(0.1, max(1e-6, 1000.0 * spread)), spread
 
 
-@pytest.mark.parametrize("fix", ["s8", "sodd", "s8naik"])
+@pytest.mark.parametrize("fix", ["s8", "sodd", "s8naik", "s8w", "soddw", "s8naikw"])
 @pytest.mark.parametrize("par_even", [True, False])
 def test_solveXX_history(request, fix, par_even):
     """The `CG iteration: N  r2/b2:` history (cg.nim:215-217) must match the CPU path."""
@@ -181,7 +201,7 @@ def test_solveXX_maxits_and_zero_rhs(s8):
     assert sp.iterations == 0 and not x.any()               # b2 == 0 branch, cg.nim:139-144
 
 
-@pytest.mark.parametrize("fix", ["s8", "s8naik"])
+@pytest.mark.parametrize("fix", ["s8", "s8naik", "s8w", "s8naikw"])
 def test_solve_full(request, fix):
     S = request.getfixturevalue(fix)
     q = S.q
@@ -231,14 +251,15 @@ def test_multishift(s8):
         assert (r * r).sum() / (S.x * S.x).sum() <= 2e-12
 
 
+@pytest.mark.parametrize("warm", [False, True])
 @pytest.mark.parametrize("naik", [False, True])
-def test_forced_halo_equals_periodic(oracle, naik):
+def test_forced_halo_equals_periodic(oracle, naik, warm):
     """One rank, t-hops routed through ghost zones + the exchange path (RCCL self send/recv when
     a communicator exists, device copies otherwise) must reproduce the periodic-wrap kernel."""
     import qex_amd as q
 
-    A = Setup(oracle, [8, 8, 8, 8], naik=naik)
-    B = Setup(oracle, [8, 8, 8, 8], naik=naik, halo=True)
+    A = Setup(oracle, [8, 8, 8, 8], naik=naik, warm=warm)
+    B = Setup(oracle, [8, 8, 8, 8], naik=naik, halo=True, warm=warm)
     assert "halo=1" in B.ctx.info()
     for sub in ("even", "odd"):
         ra, rb = A.y.copy(), B.y.copy()
@@ -260,11 +281,12 @@ def test_forced_halo_equals_periodic(oracle, naik):
     assert relerr(xb, xa) < 1e-6
 
 
-def test_forced_halo_rccl_self(oracle):
+@pytest.mark.parametrize("warm", [False, True])
+def test_forced_halo_rccl_self(oracle, warm):
     """Same as above but through a one-rank RCCL communicator (ncclSend/ncclRecv to self)."""
     import qex_amd as q
 
-    A = Setup(oracle, [8, 8, 8, 8])
+    A = Setup(oracle, [8, 8, 8, 8], warm=warm)
     lo, g, x = A.lo, A.g, A.x
     ctx = q.Context([8, 8, 8, 8])
     ctx.comm_init(q.Context.unique_id(), 1, 0)
@@ -321,14 +343,14 @@ def test_wflow_golden(oracle):
 # cheap oracle pieces (config generation, plaquette).  The oracle's CG at 32^4 takes minutes, so
 # the full-size checks are identities, not oracle replays.
 # ---------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def s32(oracle):
+@pytest.fixture(scope="module", params=["random", "warm"])
+def s32(oracle, request):
     import qex_amd as q
 
     lat = [32, 32, 32, 32]
     lo = oracle.Layout(lat)
     rf = oracle.RngField(lo, oracle.RNG_MILC6, SEED)
-    g = oracle.gauge_random(lo, rf)
+    g = oracle.gauge_random(lo, rf) if request.param == "random" else oracle.gauge_warm(lo, 0.5, rf)
     ctx = q.Context(lat)
 
     class S:
