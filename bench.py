@@ -148,8 +148,12 @@ def main():
     if N == 1 and not args.halo:
         sites_per_launch = Vh_loc
     else:
+        # the library splits a sweep into interior + faces only when it overlaps the exchange with the
+        # interior (interior >= 131072 sites, dslash.hip); otherwise one launch covers the slab
         F = lat_loc[0] // 2 * lat_loc[1] * lat_loc[2]
-        sites_per_launch = max(Vh_loc - 2 * (3 if args.naik else 1) * F, 0)
+        interior = max(Vh_loc - 2 * (3 if args.naik else 1) * F, 0)
+        ov = int(os.environ.get("QEXHIP_OVERLAP", "-1"))
+        sites_per_launch = interior if (ov == 1 or (ov < 0 and interior >= 131072)) else Vh_loc
     avg_ms = ms_int / max(n_int, 1)
     b_alg = 0.5 * (b1 + b1 + 48) * sites_per_launch                     # 144 B per link
     b_streamed = b_alg - 2 * nd * {0: 0, 1: 48, 2: 32}[compressed] * sites_per_launch   # 96 / 112 B per compressed link

@@ -272,17 +272,22 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
     const int overlap = c->opt_overlap >= 0 ? c->opt_overlap : ((hi_beg - lo_end) >= 131072);
     if (overlap) HIPCHK(hipEventRecord(c->ev_ready, c->stream));
     CHK(comm_halo_exchange(c, in, 1 - parity, overlap));
-    int nb_int = (hi_beg - lo_end + 255) / 256, nb_lo = (lo_end + 255) / 256;
-    if (c->ndir == 8) CHK((launch<8, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
-    else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
-    if (overlap) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
-    {
-      // both t-faces in ONE launch (fewer launches per sweep: the sharded iteration is host-bound
-      // on small local volumes)
+    if (!overlap) {
+      // the exchange is already ordered before us on the compute stream: one launch over all sites
+      // (small local volumes are launch-latency-bound; this drops two launches per CG iteration)
+      if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, g.Vh, init, o.dot, 0)));
+      else CHK((launch<16, true>(c, A, 0, g.Vh, init, o.dot, 0)));
+      nparts = (g.Vh + 255) / 256;
+    } else {
+      int nb_int = (hi_beg - lo_end + 255) / 256, nb_lo = (lo_end + 255) / 256;
+      if (c->ndir == 8) CHK((launch<8, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
+      else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
+      HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+      // both t-faces in ONE launch (fewer launches per sweep)
       if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd")));
       else CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd")));
+      nparts = nb_int + nb_lo + (g.Vh - hi_beg + 255) / 256;
     }
-    nparts = nb_int + nb_lo + (g.Vh - hi_beg + 255) / 256;
   }
   if (o.dot) {
     if (nparts > c->part2_off) { qexhip_set_error("internal: partial buffer too small"); return -3; }

@@ -20,7 +20,7 @@ def relerr(a, b):
 
 
 class Setup:
-    def __init__(self, o, lat, naik=False, halo=False, warm=False):
+    def __init__(self, o, lat, naik=False, halo=False, warm=False, overlap=None):
         """warm=False: QEX's g.random start (projectSU of gaussians: unitary only to ~1e-11, so the
         library keeps all 18 reals per link); warm=True: g.warm(0.5), unitary to 1e-15, which the
         library stores compressed (2 rows + sign; with the 0.3-scaled long links 2 rows + factor)."""
@@ -42,6 +42,8 @@ class Setup:
         self.ctx = q.Context(lat)
         if halo:
             self.ctx.force_halo(True)
+        if overlap is not None:
+            self.ctx.set_option("overlap", overlap)      # 1: interior/boundary split + second stream
         self.s = q.newStag3(self.ctx, self.g, self.g3) if naik else q.newStag(self.ctx, self.g)
         assert self.s.links_info()[1] == ((2 if naik else 1) if warm else 0)
 
@@ -261,11 +263,16 @@ def test_forced_halo_equals_periodic(oracle, naik, warm):
     A = Setup(oracle, [8, 8, 8, 8], naik=naik, warm=warm)
     B = Setup(oracle, [8, 8, 8, 8], naik=naik, halo=True, warm=warm)
     assert "halo=1" in B.ctx.info()
+    C = Setup(oracle, [8, 8, 8, 8], naik=naik, halo=True, warm=warm, overlap=1)
     for sub in ("even", "odd"):
-        ra, rb = A.y.copy(), B.y.copy()
+        ra, rb, rc = A.y.copy(), B.y.copy(), C.y.copy()
         A.s.stagD2(ra, A.x, sub, 0.5, 0.25)
-        B.s.stagD2(rb, B.x, sub, 0.5, 0.25)
-        assert relerr(rb, ra) < 1e-15
+        B.s.stagD2(rb, B.x, sub, 0.5, 0.25)      # exchange first, then one launch over the slab
+        C.s.stagD2(rc, C.x, sub, 0.5, 0.25)      # exchange on the second stream, interior, then faces
+        assert relerr(rb, ra) < 1e-15 and relerr(rc, ra) < 1e-15
+    spc = q.SolverParams(r2req=1e-12, maxits=2000, verbosity=0)
+    xc = np.zeros_like(A.x)
+    C.s.solveEE(xc, C.x, 0.1, spc, histcap=4096)
     spa = q.SolverParams(r2req=1e-12, maxits=2000, verbosity=0)
     spb = q.SolverParams(r2req=1e-12, maxits=2000, verbosity=0)
     xa, xb = np.zeros_like(A.x), np.zeros_like(A.x)
@@ -279,6 +286,7 @@ def test_forced_halo_equals_periodic(oracle, naik, warm):
     tol, spread = history_tolerance(oracle, A.lo, A.g, A.g3, A.x, 0.1, 1e-12, 2000, True, hist)
     assert dev.max() < tol, (dev.max(), spread)
     assert relerr(xb, xa) < 1e-6
+    assert abs(spc.iterations - spa.iterations) <= 1 and relerr(xc, xa) < 1e-6
 
 
 @pytest.mark.parametrize("warm", [False, True])
