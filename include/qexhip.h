@@ -198,7 +198,7 @@ int qexhip_nhyp_smear(qexhip_handle h, const double *g, double *fl, double alpha
  *   1: every link is SU(3) up to a sign (thin links with BC + staggered phases): rows 0,1 + a sign bit, 96 B/link
  *   2: every link is U(3) (nHYP-smeared links): rows 0,1 + det, 112 B/link
  *   0: otherwise (HISQ fat links, QEX's `random` start, which is unitary only to 1e-11): all 18 reals, 144 B/link
- * chosen only if ALL links reproduce their stored row 2 to 1e-14; max_dev = the largest deviation found for the
+ * chosen only if ALL links reproduce their stored row 2 to 5e-14 (a few hundred ulp: exactly unitary links of a 48^3x96 lattice peak at ~2e-14); max_dev = the largest deviation found for the
  * chosen format.  Row 2 is rebuilt in registers.  QEXHIP_RECON=0|1|2 caps the format.  No counterpart in QEX (its
  * CPU Dslash always reads full links, stagD.nim:349-395); QUDA's reconstruct-12/13 is the precedent. */
 int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double *max_dev);

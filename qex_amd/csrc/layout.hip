@@ -169,7 +169,7 @@ int links_upload(qexhip_ctx *c, const double *fat, const double *lng) {
 //   format 2 (112 B/link): U(3) links (nHYP-smeared: projectU output), rows 0,1 + det as a 7th double2;
 //   format 0 (144 B/link): everything else (HISQ fat links are not unitary), all 18 reals.
 // The format is chosen per set_links: the most compact one that EVERY link of the operator
-// satisfies to 1e-14; row 2 is rebuilt in registers by the Dslash kernel.
+// satisfies to 5e-14; row 2 is rebuilt in registers by the Dslash kernel.
 template <int FMT>
 __global__ void __launch_bounds__(256) k_links_compress(size_t nrows, const double2 *__restrict__ W, double2 *Wc,
                                                         unsigned long long *Ws, unsigned int *maxdev) {
@@ -238,8 +238,8 @@ int links_compress(qexhip_ctx *c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     float dev;
     memcpy(&dev, &bits, sizeof(dev));
-    if (fmt == 1 || dev <= 1e-14f) c->recon_dev = dev;
-    if (dev <= 1e-14f) { c->recon = fmt; break; }
+    if (fmt == 1 || dev <= 5e-14f) c->recon_dev = dev;
+    if (dev <= 5e-14f) { c->recon = fmt; break; }
   }
   return 0;
 }
