@@ -37,6 +37,7 @@ typedef struct qexhip_ctx *qexhip_handle;
 #define QEXHIP_ERR_HIP (-2)
 #define QEXHIP_ERR_STATE (-3)
 #define QEXHIP_ERR_COMM (-4)
+#define QEXHIP_ERR_IO (-5)
 
 #define QEXHIP_EVEN 0
 #define QEXHIP_ODD 1
@@ -241,6 +242,18 @@ int qexhip_nhyp_release(qexhip_handle h);
 int qexhip_nhyp_gauge_force(qexhip_handle h, double *f, double cplaq, double crect, double cadjplaq);
 int qexhip_nhyp_fermion_force(qexhip_handle h, double *f, const double *const *psi, const double *scale, int n,
                               const int antiperiodic[4], const int phases[4]);
+
+/* ---------------- SciDAC/LIME gauge files (host only, no handle) ----------------
+ * loadGauge / saveGauge (src/gauge/gaugeUtils.nim:87-122) via Reader / Writer (src/io/readerQiolite.nim:37-239,
+ * src/io/writerQiolite.nim:28-187): one record of 4 x QDP_{F,D}3_ColorMatrix per site, sites x-fastest, big-endian,
+ * with the SciDAC checksum pair.  g is the library's host format (V=1 even-odd, [vol][4][3][3][2] doubles).
+ *   info:  lattice, record precision ('F' | 'D') and whether the file carries checksums (getFileLattice, readerQiolite.nim:11-17)
+ *   read:  fills g, returns the checksums it computed; QEXHIP_ERR_IO if they differ from the file's
+ *   write: precision 'F' | 'D' (saveGauge's prec); file_md / record_md NULL = QEX's defaults (gaugeUtils.nim:108-109) */
+int qexhip_io_gauge_info(const char *path, int lat[4], char *precision, int *checksums_present);
+int qexhip_io_read_gauge(const char *path, const int lat[4], double *g, unsigned *suma, unsigned *sumb);
+int qexhip_io_write_gauge(const char *path, const int lat[4], const double *g, char precision, const char *file_md,
+                          const char *record_md);
 
 /* ---------------- kernel timers ----------------
  * hipEvent pairs around launches of the named kernel class on the context stream

@@ -10,3 +10,4 @@ from .gauge import setBC, stagPhase, rephase, unit, synthetic_random_su3, synthe
 from .staggered import (  # noqa: F401
     Context, Staggered, SolverParams, newStag, newStag3, plaq, gaugeForce, gaugeFlow, flowEQ, HisqCoefs, HypCoefs, makeImpLinks, EVEN, ODD, ALL,
 )
+from .io import loadGauge, saveGauge, getFileLattice, gaugeFileInfo  # noqa: F401

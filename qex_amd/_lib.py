@@ -67,6 +67,9 @@ SYMBOLS = [
     ("qexhip_nhyp_release", _ci, [_vp]),
     ("qexhip_nhyp_gauge_force", _ci, [_vp, _vp, _cd, _cd, _cd]),
     ("qexhip_nhyp_fermion_force", _ci, [_vp, _vp, _vp, _vp, _ci, _pi, _pi]),
+    ("qexhip_io_gauge_info", _ci, [C.c_char_p, _pi, C.c_char_p, _pi]),
+    ("qexhip_io_read_gauge", _ci, [C.c_char_p, _pi, _vp, _vp, _vp]),
+    ("qexhip_io_write_gauge", _ci, [C.c_char_p, _pi, _vp, C.c_char, C.c_char_p, C.c_char_p]),
     ("qexhip_timers_enable", _ci, [_vp, _ci]),
     ("qexhip_timers_reset", _ci, [_vp]),
     ("qexhip_timers_get", _ci, [_vp, C.c_char_p, C.POINTER(C.c_long), _pd]),
