@@ -182,6 +182,17 @@ int qexhip_wflow_general(qexhip_handle h, int nsteps, double eps, double cplaq, 
  * (src/gauge/gaugeUtils.nim:1162-1271); loop in {1,3,4,5} selects the clover improvement
  * (1x1 | +2x2+3x3 | +2x2+1x2+1x3 | all five loop shapes, coefficients of :1128-1146). */
 int qexhip_flow_EQ(qexhip_handle h, int loop, double out[3]);
+/* The remaining gauge-sector pieces an HMC trajectory needs, on the resident field (set with qexhip_gauge_set):
+ *   action: gc.gaugeAction1(g) (crect) / gc.actionA(g) (cadjplaq) (src/gauge/gaugeAction.nim:61-142,614-681),
+ *           coefficients as GaugeActionCoeffs(plaq, rect | adjplaq); at most one of crect, cadjplaq non-zero
+ *   update: mdt, g[mu][s] := exp(t p[mu][s]) g[mu][s] (src/examples/staghmc_sh.nim:429-435); p host, [vol][4][3][3][2]
+ *   reunit: g.projectSU (src/gauge/gaugeUtils.nim:1333-1334; `reunit` of the HMC examples, staghmc_sh.nim:247-258)
+ *   wline:  g.wline(path) (gaugeUtils.nim:1079-1112): volume- and colour-averaged trace, out = {re, im}; path entries
+ *           +-(mu+1); the Polyakov loops of `ploop` are path = [mu+1] * L_mu (staghmc_sh.nim:281-291) */
+int qexhip_gauge_action(qexhip_handle h, double cplaq, double crect, double cadjplaq, double *out);
+int qexhip_gauge_update(qexhip_handle h, const double *p, double t);
+int qexhip_gauge_reunit(qexhip_handle h);
+int qexhip_wline(qexhip_handle h, const int *path, int n, double out[2]);
 
 /* ---------------- link construction upstream of the solver ----------------
  * g, fl, ll: double[vol][4][3][3][2].

@@ -67,6 +67,10 @@ SYMBOLS = [
     ("qexhip_nhyp_release", _ci, [_vp]),
     ("qexhip_nhyp_gauge_force", _ci, [_vp, _vp, _cd, _cd, _cd]),
     ("qexhip_nhyp_fermion_force", _ci, [_vp, _vp, _vp, _vp, _ci, _pi, _pi]),
+    ("qexhip_gauge_action", _ci, [_vp, _cd, _cd, _cd, _vp]),
+    ("qexhip_gauge_update", _ci, [_vp, _vp, _cd]),
+    ("qexhip_gauge_reunit", _ci, [_vp]),
+    ("qexhip_wline", _ci, [_vp, _pi, _ci, _vp]),
     ("qexhip_io_gauge_info", _ci, [C.c_char_p, _pi, C.c_char_p, _pi]),
     ("qexhip_io_read_gauge", _ci, [C.c_char_p, _pi, _vp, _vp, _vp]),
     ("qexhip_io_write_gauge", _ci, [C.c_char_p, _pi, _vp, C.c_char, C.c_char_p, C.c_char_p]),

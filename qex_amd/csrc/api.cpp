@@ -538,4 +538,25 @@ extern "C" int qexhip_wflow_general(qexhip_handle c, int nsteps, double eps, dou
   return gauge_wflow(c, nsteps, eps, cplaq, c2, kind);
 }
 extern "C" int qexhip_flow_EQ(qexhip_handle c, int loop, double out[3]) { if (!c || !out) return QEXHIP_ERR_ARG; return gauge_flow_obs(c, loop, out); }
+extern "C" int qexhip_gauge_action(qexhip_handle c, double cplaq, double crect, double cadj, double *out) {
+  if (!c || !out) return QEXHIP_ERR_ARG;
+  if (crect != 0.0 && cadj != 0.0) { qexhip_set_error("rect and adjplaq together are not a QEX action"); return QEXHIP_ERR_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  return gauge_action(c, cplaq, cadj != 0.0 ? cadj : crect, cadj != 0.0 ? 1 : 0, out);
+}
+extern "C" int qexhip_gauge_update(qexhip_handle c, const double *p, double t) {
+  if (!c || !p) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return gauge_md_update(c, p, t);
+}
+extern "C" int qexhip_gauge_reunit(qexhip_handle c) {
+  if (!c) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return gauge_reunit(c);
+}
+extern "C" int qexhip_wline(qexhip_handle c, const int *path, int n, double out[2]) {
+  if (!c || !path || !out) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return gauge_wline(c, path, n, out);
+}
 extern "C" int qexhip_wflow(qexhip_handle c, int nsteps, double eps) { if (!c || nsteps < 0) return QEXHIP_ERR_ARG; return gauge_wflow(c, nsteps, eps); }

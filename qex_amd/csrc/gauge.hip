@@ -159,12 +159,17 @@ __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict
 }
 
 // RK3 stage, second half: U <- exp(v) U with v already in the momentum field (wflow.nim:40-43)
-__global__ void __launch_bounds__(256) k_exp_update(size_t nlinks_tiles, double2 *G, const double2 *V) {
+__global__ void __launch_bounds__(256) k_exp_update(size_t nlinks_tiles, double2 *G, const double2 *V, double t) {
   size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;  // (tile-of-links, lane)
   size_t tile = j >> 6;
   if (tile >= nlinks_tiles) return;
   size_t o = tile * 576 + (j & 63);
-  M3 e = m3_exp(m3_load(V + o, 64));
+  M3 v = m3_load(V + o, 64);
+  if (t != 1.0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { v.e[k].x *= t; v.e[k].y *= t; }
+  }
+  M3 e = m3_exp(v);
   M3 u = m3_load(G + o, 64);
   m3_store(G + o, 64, m3_mul(e, u));
 }
@@ -527,9 +532,148 @@ int gauge_wflow(qexhip_ctx *c, int nsteps, double eps, double cplaq, double c2, 
     for (int st = 0; st < 3; st++) {
       CHK(force_dev(c, cplaq, 1, cf[st], cpm[st], c2, kind));
       ScopedTimer tm(c, "expupdate", c->stream);
-      k_exp_update<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P);
+      k_exp_update<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P, 1.0);
       HIPCHK(hipGetLastError());
     }
   HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------- MD building blocks on the resident gauge field (the HMC examples' mdt, reunit, gaction, ploop) ----
+// gaugeAction1 / actionA sums (src/gauge/gaugeAction.nim:61-142,614-681): sum ReTr P, sum |tr P|^2, sum ReTr R
+__global__ void __launch_bounds__(256) k_action(Geom g, const double2 *__restrict__ G, int rect, double *partials) {
+  double sp = 0, sa = 0, sr = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < g.V; i += gridDim.x * 256) {
+    int p = i >= g.Vh, c = i - p * g.Vh;
+    int x[4];
+    coords_of(g, c, p, x);
+#pragma unroll 1
+    for (int mu = 1; mu < 4; mu++)
+#pragma unroll 1
+      for (int nu = 0; nu < mu; nu++) {
+        ObsPath P;
+        P.len = 4; P.coef = 1.0;
+        P.step[0] = 1; P.step[1] = 2; P.step[2] = -1; P.step[3] = -2;
+        M3 m = path_prod(g, G, x, P, mu, nu);
+        const double tr = m.e[0].x + m.e[4].x + m.e[8].x, ti = m.e[0].y + m.e[4].y + m.e[8].y;
+        sp += tr;
+        sa += tr * tr + ti * ti;
+        if (rect) {
+          P.len = 6;
+          P.step[0] = 1; P.step[1] = 1; P.step[2] = 2; P.step[3] = -1; P.step[4] = -1; P.step[5] = -2;
+          m = path_prod(g, G, x, P, mu, nu);
+          sr += m.e[0].x + m.e[4].x + m.e[8].x;
+          P.step[0] = 1; P.step[1] = 2; P.step[2] = 2; P.step[3] = -1; P.step[4] = -2; P.step[5] = -2;
+          m = path_prod(g, G, x, P, mu, nu);
+          sr += m.e[0].x + m.e[4].x + m.e[8].x;
+        }
+      }
+  }
+  double r;
+  r = block_sum_256(sp); if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  r = block_sum_256(sa); if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = r;
+  r = block_sum_256(sr); if (threadIdx.x == 0) partials[2 * gridDim.x + blockIdx.x] = r;
+}
+__global__ void __launch_bounds__(256) k_sum3(const double *partials, int nb, double *out) {
+  for (int k = 0; k < 3; k++) {
+    double acc = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += partials[(size_t)k * nb + i];
+    double r = block_sum_256(acc);
+    if (threadIdx.x == 0) out[k] = r;
+  }
+}
+int gauge_action(qexhip_ctx *c, double cplaq, double c2, int kind, double *out) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  const int rect = (kind == 0 && c2 != 0.0);
+  if (rect) for (int d = 0; d < 4; d++) if (c->g.X[d] < 4) { qexhip_set_error("rectangle action needs extents >= 4"); return -1; }
+  int nb = (c->g.V + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  k_action<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, rect, c->partials);
+  k_sum3<<<1, 256, 0, c->stream>>>(c->partials, nb, &c->dscal[24]);
+  HIPCHK(hipGetLastError());
+  double s[3];
+  CHK(read_scalars(c, &c->dscal[24], 3, s));
+  if (kind == 0) *out = (-1.0 / 3.0) * (cplaq * s[0] + c2 * s[2]);
+  else {
+    const double a0 = 0.5 * 12.0 * (double)c->g.V;
+    *out = cplaq * (a0 - s[0] / 3.0) + c2 * (a0 - s[1] / 9.0);
+  }
+  return 0;
+}
+// mdt (src/examples/staghmc_sh.nim:429-435): U <- exp(t p) U on the resident field
+int gauge_md_update(qexhip_ctx *c, const double *p_host, double t) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  CHK(gn_alloc_fp(c));
+  const size_t bytes = (size_t)c->g.V * 72 * sizeof(double);
+  CHK(ensure_stage(c, bytes));
+  HIPCHK(hipMemcpyAsync(c->stage, p_host, bytes, hipMemcpyHostToDevice, c->stream));
+  k_gauge_to_tiles<<<(c->g.V + 255) / 256, 256, 0, c->stream>>>(c->g, (const double2 *)c->stage, c->gn->P);
+  const size_t ltiles = (size_t)2 * c->g.ntile * 4;
+  ScopedTimer tm(c, "expupdate", c->stream);
+  k_exp_update<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P, t);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// reunit: g.projectSU (gaugeUtils.nim:1333-1334)
+__global__ void __launch_bounds__(256) k_reunit(size_t nlinks_tiles, double2 *G) {
+  size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t tile = j >> 6;
+  if (tile >= nlinks_tiles) return;
+  size_t o = tile * 576 + (j & 63);
+  m3_store(G + o, 64, m3_projectSU(m3_load(G + o, 64)));
+}
+int gauge_reunit(qexhip_ctx *c) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  const size_t ltiles = (size_t)2 * c->g.ntile * 4;
+  k_reunit<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, c->gn->U);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// wline (gaugeUtils.nim:1079-1112): volume- and colour-averaged trace of a path product; path entries
+// +-(mu+1), any length (Polyakov loops: [mu+1] * L_mu, src/examples/staghmc_sh.nim:281-291)
+__global__ void __launch_bounds__(256) k_wline(Geom g, const double2 *__restrict__ G, const int *path, int n, double *partials) {
+  double sr = 0, si = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < g.V; i += gridDim.x * 256) {
+    int p = i >= g.Vh, c = i - p * g.Vh;
+    int x[4];
+    coords_of(g, c, p, x);
+    M3 m;
+    for (int k = 0; k < n; k++) {
+      const int s = path[k];
+      const int d = (s > 0 ? s : -s) - 1;
+      if (s > 0) {
+        M3 u = m3_load(G + link_off(g, x, d), 64);
+        x[d] = x[d] + 1 >= g.X[d] ? 0 : x[d] + 1;
+        m = k == 0 ? u : m3_mul(m, u);
+      } else {
+        x[d] = x[d] == 0 ? g.X[d] - 1 : x[d] - 1;
+        M3 u = m3_load(G + link_off(g, x, d), 64);
+        if (k == 0) { m = m3_zero(); m3_add_diag(m, 1.0); }
+        m = m3_mul_na(m, u);
+      }
+    }
+    sr += m.e[0].x + m.e[4].x + m.e[8].x;
+    si += m.e[0].y + m.e[4].y + m.e[8].y;
+  }
+  double r;
+  r = block_sum_256(sr); if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  r = block_sum_256(si); if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = r;
+  if (threadIdx.x == 0) partials[2 * gridDim.x + blockIdx.x] = 0.0;
+}
+int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  if (n < 1 || n > 4096) { qexhip_set_error("wline: path length out of range"); return -1; }
+  for (int k = 0; k < n; k++) if (path[k] == 0 || path[k] > 4 || path[k] < -4) { qexhip_set_error("wline: path entries are +-(mu+1)"); return -1; }
+  CHK(ensure_stage(c, 4096 * sizeof(int)));
+  HIPCHK(hipMemcpyAsync(c->stage, path, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  int nb = (c->g.V + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  k_wline<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, (const int *)c->stage, n, c->partials);
+  k_sum3<<<1, 256, 0, c->stream>>>(c->partials, nb, &c->dscal[24]);
+  HIPCHK(hipGetLastError());
+  double s[3];
+  CHK(read_scalars(c, &c->dscal[24], 3, s));
+  const double fac = 1.0 / ((double)c->g.V * 3.0);
+  out[0] = s[0] * fac; out[1] = s[1] * fac;
   return 0;
 }

@@ -86,50 +86,6 @@ __global__ void __launch_bounds__(256) k_mscale(Geom g, MViewW dst, double coef,
   m3_store(dst.p + od, 64, m);
 }
 
-// eigs3 + rsqrtPHM3f + rsqrtPHM3 + projectU (matrixFunctions.nim:79-182,279-313)
-// z = (x^+ x + 1e-20)^(-1/2)   (projectUrsqrt, matrixFunctions.nim:301-306)
-__device__ __forceinline__ M3 m3_rsqrt_xdx(const M3 &x) {
-  M3 t = m3_mul_an(x, x);
-  m3_add_diag(t, 1e-20);
-  const double tr = t.e[0].x + t.e[4].x + t.e[8].x;
-  M3 t2 = m3_mul(t, t);
-  const double p2 = t2.e[0].x + t2.e[4].x + t2.e[8].x;
-  // Re det (matrixFunctions.nim:72-75)
-  const double2 d01 = make_double2(t.e[0].x * t.e[4].x - t.e[0].y * t.e[4].y - (t.e[1].x * t.e[3].x - t.e[1].y * t.e[3].y),
-                                   t.e[0].x * t.e[4].y + t.e[0].y * t.e[4].x - (t.e[1].x * t.e[3].y + t.e[1].y * t.e[3].x));
-  const double2 d20 = make_double2(t.e[2].x * t.e[3].x - t.e[2].y * t.e[3].y - (t.e[0].x * t.e[5].x - t.e[0].y * t.e[5].y),
-                                   t.e[2].x * t.e[3].y + t.e[2].y * t.e[3].x - (t.e[0].x * t.e[5].y + t.e[0].y * t.e[5].x));
-  const double2 d12 = make_double2(t.e[1].x * t.e[5].x - t.e[1].y * t.e[5].y - (t.e[2].x * t.e[4].x - t.e[2].y * t.e[4].y),
-                                   t.e[1].x * t.e[5].y + t.e[1].y * t.e[5].x - (t.e[2].x * t.e[4].y + t.e[2].y * t.e[4].x));
-  const double det = (d01.x * t.e[8].x - d01.y * t.e[8].y) + (d20.x * t.e[7].x - d20.y * t.e[7].y) + (d12.x * t.e[6].x - d12.y * t.e[6].y);
-  // eigs3
-  const double tr3 = (1.0 / 3.0) * tr, p23 = (1.0 / 3.0) * p2, tr32 = tr3 * tr3;
-  const double q = fabs(0.5 * (p23 - tr32));
-  const double r = 0.25 * tr3 * (5 * tr32 - p2) - 0.5 * det;
-  const double sq = sqrt(q), sq3 = q * sq;
-  const double isq3c = fmin(3e38, fmax(-3e38, 1.0 / sq3));
-  const double rsq3 = fmin(1.0, fmax(-1.0, r * isq3c));
-  const double th = (1.0 / 3.0) * acos(rsq3);
-  const double st = sin(th), ct = cos(th);
-  const double sqc = sq * ct, sqs = 1.73205080756887729352 * sq * st;
-  const double ll = tr3 + sqc;
-  const double l0 = tr3 - 2 * sqc, l1 = ll + sqs, l2 = ll - sqs;
-  // rsqrtPHM3f
-  const double sl0 = sqrt(fabs(l0)), sl1 = sqrt(fabs(l1)), sl2 = sqrt(fabs(l2));
-  const double u = sl0 + sl1 + sl2, w = sl0 * sl1 * sl2;
-  const double d = w * (sl0 + sl1) * (sl0 + sl2) * (sl1 + sl2);
-  const double di = 1 / d;
-  const double c0 = (w * u * u + l0 * sl0 * (l1 + l2) + l1 * sl1 * (l0 + l2) + l2 * sl2 * (l0 + l1)) * di;
-  const double c1 = -(tr * u + w) * di;
-  const double c2 = u * di;
-  M3 rs;
-#pragma unroll
-  for (int k = 0; k < 9; k++) rs.e[k] = make_double2(c1 * t.e[k].x + c2 * t2.e[k].x, c1 * t.e[k].y + c2 * t2.e[k].y);
-  m3_add_diag(rs, c0);
-  return rs;
-}
-__device__ __forceinline__ M3 m3_projectU(const M3 &x) { return m3_mul(x, m3_rsqrt_xdx(x)); }
-
 // ---- projectUderiv and its pieces (matrixFunctions.nim:329-357, projUderiv.nim:8-38,96-147, matinv.nim:90-115)
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }

@@ -339,6 +339,39 @@ def flowEQ(ctx, loop=1, g=None):
     return out
 
 
+def gaugeAction(ctx, g=None, plaq=1.0, rect=0.0, adjplaq=0.0):
+    """gc.gaugeAction1(g) / gc.actionA(g) (gaugeAction.nim:61-142,614-681) of g (or of the resident field)"""
+    if g is not None:
+        check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+    out = C.c_double(0)
+    check(lib().qexhip_gauge_action(ctx._h, float(plaq), float(rect), float(adjplaq), C.byref(out)))
+    return out.value
+
+
+def gaugeUpdate(ctx, g, p, t):
+    """mdt: g := exp(t p) g in place (staghmc_sh.nim:429-435)"""
+    check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+    check(lib().qexhip_gauge_update(ctx._h, _p(p), float(t)))
+    check(lib().qexhip_gauge_get(ctx._h, _p(g)))
+
+
+def reunit(ctx, g):
+    """g.projectSU in place (gaugeUtils.nim:1333-1334)"""
+    check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+    check(lib().qexhip_gauge_reunit(ctx._h))
+    check(lib().qexhip_gauge_get(ctx._h, _p(g)))
+
+
+def wline(ctx, path, g=None):
+    """g.wline(path) (gaugeUtils.nim:1079-1112); path entries +-(mu+1)"""
+    if g is not None:
+        check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+    out = (C.c_double * 2)()
+    arr = (C.c_int * len(path))(*[int(v) for v in path])
+    check(lib().qexhip_wline(ctx._h, arr, len(path), out))
+    return complex(out[0], out[1])
+
+
 def gaugeFlow(ctx, g, steps, eps, measure=None, flow_act="Wilson", plaq=1.0, rect=0.0, adjplaq=0.0):
     """g.gaugeFlow(steps, eps): measure (wflow.nim:21-67), or the fork's
     gc.gaugeFlow(flow_act, g, steps, eps): measure (src/flow/flow.nim:22-90) with

@@ -79,8 +79,8 @@ class Replay:
          be.D(handle, x, m), be.solve(handle, b, m) -> (x, iterations)
          be.fermion_force(handle, g, fields, scales) -> f     fforce + smearedOneLinkForce (:387-427)
          be.gauge_force(g) -> gc.forceA(g);  be.gauge_action(g) -> gc.actionA(g)
-         be.plaq(g) -> 6 plaquettes
-       Everything else (RNG, exp update, reunit, Polyakov loop) is the driver's and uses the oracle."""
+         be.plaq(g) -> 6 plaquettes;  be.exp_update(g, p, t): g := exp(t p) g;  be.reunit(g);  be.wline(g, path)
+       Only the random numbers (momenta, pseudofermion and pbp sources) are the driver's, from the oracle's RngMilc6."""
 
     def __init__(self, o, be):
         self.o, self.be = o, be
@@ -129,7 +129,7 @@ class Replay:
 
     # ---- MD updates (staghmc_sh.nim:429-640) ----
     def mdt(self, t):
-        self.o.gauge_exp_update(self.lo, self.g, self.p, t)
+        self.be.exp_update(self.g, self.p, t)
 
     def fforce(self, h, g, ix, ts):
         """fields = the force solves (:394-404); scales = fscale(k, i, ts[j])"""
@@ -162,7 +162,7 @@ class Replay:
             gg = self.g.copy()                                             # fgsave
             h = be.smear_rephase(gg, True)
             f = self.fforce(h, gg, updateFG, [tg.get(k, 0.0) for k in range(3)])
-            o.gauge_exp_update(lo, self.g, f, 1.0)                         # fgvf: g := exp(f) g
+            be.exp_update(self.g, f, 1.0)                                  # fgvf: g := exp(f) g
             h = be.smear_rephase(self.g, True)
             self.p += self.fforce(h, self.g, updateFG, [tf.get(k, 0.0) for k in range(3)])
             self.g = gg                                                    # fgload
@@ -182,7 +182,7 @@ class Replay:
     # ---- measurements after ACCEPT (staghmc_sh.nim:774-789) ----
     def measure(self):
         o, lo, be = self.o, self.lo, self.be
-        o.gauge_projectSU(lo, self.g)                                      # g.reunit
+        be.reunit(self.g)                                                  # g.reunit
         h = be.smear_rephase(self.g, False)
         pbp, iters = [], []
         for _ in range(2):                                                 # pbpreps = 2
@@ -192,7 +192,7 @@ class Replay:
             iters.append(its)
         pl = be.plaq(self.g)
         ps, pt = 2.0 * sum(pl[:3]), 2.0 * sum(pl[3:])
-        loops = [o.wline(lo, self.g, [mu + 1] * LAT[mu]) for mu in range(4)]
+        loops = [be.wline(self.g, [mu + 1] * LAT[mu]) for mu in range(4)]
         pls = sum(loops[:3]) / 3.0
         return dict(pbp=pbp, pbp_iters=iters, plaq=(ps, pt, 0.5 * (ps + pt)),
                     ploop=(pls.real, pls.imag, loops[3].real, loops[3].imag))
@@ -235,13 +235,21 @@ class OracleBackend:
     def plaq(self, g):
         return self.o.plaq(self.lo, g)
 
+    def exp_update(self, g, p, t):
+        self.o.gauge_exp_update(self.lo, g, p, t)
+
+    def reunit(self, g):
+        self.o.gauge_projectSU(self.lo, g)
+
+    def wline(self, g, path):
+        return self.o.wline(self.lo, g, path)
+
 
 class HipBackend:
     """Every operator on the hot path runs through libqexhip (C ABI)."""
 
-    def __init__(self, q, lat, oracle):
+    def __init__(self, q, lat):
         self.q = q
-        self.oracle, self.oracle_lo = oracle, oracle.Layout(lat)
         self.ctx = q.Context(lat)
         self.hc = q.HypCoefs(*ALPHA)
 
@@ -269,8 +277,16 @@ class HipBackend:
         return self.q.gaugeForce(self.ctx, g, cplaq=BETA, adjplaq=BETA * ADJFAC)
 
     def gauge_action(self, g):
-        # the action is evaluated twice per trajectory by the driver, not on the hot path
-        return self.oracle.gauge_action(self.oracle_lo, g, BETA, BETA * ADJFAC, 1)
+        return self.q.gaugeAction(self.ctx, g, plaq=BETA, adjplaq=BETA * ADJFAC)
+
+    def exp_update(self, g, p, t):
+        self.q.gaugeUpdate(self.ctx, g, p, t)
+
+    def reunit(self, g):
+        self.q.reunit(self.ctx, g)
+
+    def wline(self, g, path):
+        return self.q.wline(self.ctx, path, g)
 
     def fermion_force(self, h, g, fields, scales):
         f = np.zeros_like(g)

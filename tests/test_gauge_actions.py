@@ -77,3 +77,33 @@ def test_gpu_flow_general(oracle, act, cp, c2):
     assert np.linalg.norm(g - gref) / np.linalg.norm(gref) < 1e-12
     p0, p1 = o.plaq(lo, gref).sum(), q.plaq(ctx, g).sum()
     assert abs(p0 - p1) < 1e-13
+
+
+@pytest.mark.gpu
+def test_gpu_md_building_blocks(oracle):
+    """gauge action (three kinds), mdt link update, reunit, Wilson / Polyakov lines on the device."""
+    import qex_amd as q
+
+    o = oracle
+    lat = [4, 6, 8, 4]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 19)
+    g = o.gauge_warm(lo, 0.4, rf)
+    p = o.gauge_random_tah(lo, rf)
+    ctx = q.Context(lat)
+    for cp, c2, kind in [(1.0, 0.0, 0), (5.0 / 3.0, -1.0 / 12.0, 0), (6.0, -1.5, 1)]:
+        a = q.gaugeAction(ctx, g, plaq=cp, rect=c2 if kind == 0 else 0.0, adjplaq=c2 if kind == 1 else 0.0)
+        ref = o.gauge_action(lo, g, cp, c2, kind)
+        assert abs(a - ref) < 1e-12 * max(1.0, abs(ref))
+    g1, g2 = g.copy(), g.copy()
+    q.gaugeUpdate(ctx, g1, p, 0.37)
+    o.gauge_exp_update(lo, g2, p, 0.37)
+    assert np.linalg.norm(g1 - g2) / np.linalg.norm(g2) < 1e-14
+    g1 *= 1.0 + 1e-9                                    # drift off the group, then reunit
+    g2 = g1.copy()
+    q.reunit(ctx, g1)
+    o.gauge_projectSU(lo, g2)
+    assert np.linalg.norm(g1 - g2) / np.linalg.norm(g2) < 1e-14
+    for path in ([4] * lat[3], [1] * lat[0], [1, 2, -1, -2], [-3, 4, 4, 3, -4, -4], [2]):
+        w = q.wline(ctx, path, g1)
+        assert abs(w - o.wline(lo, g1, path)) < 1e-14
