@@ -23,37 +23,100 @@ LAT = [8, 8, 8, 8]
 SEED = 987654321
 BETA, ADJFAC = 6.0, -0.25
 TAU = 1.0
-MASS, HMASSES = 0.1, [0.2, 0.4]
 RSQ = 9.999999999999999e-25          # arsq = frsq = hfrsq = pbprsq
-GSTEPS, GLAMBDA = 18, 0.19
-FSTEPS, FLAMBDA = 3, 0.2962962962962963
+PBPMASS = 0.1
 ALPHA = (0.4, 0.5, 0.5)
+XI = 0.005144032921810704            # VTV coefficient of 4MN3F1GP at lambda = 8/27 (ref.0:80)
+LAM = 0.2962962962962963
 
-# tests/extra/staghmc_sh/ref.0:117-128
-GOLD = {
-    "begin": dict(H=18451.47947589929, Sg=0.0, Sf=[6115.074514620805, 6296.481015505035, 6143.045791623304], T=-103.1218458498552),
-    "end": dict(H=18452.64279359589, Sg=18431.57360855611, Sf=[6127.428742650334, 6325.453215672831, 5587.471917645606], T=-18019.28469092899),
-    "pbp": [0.2117714665683549, 0.211234484887779],
-    "plaq": (0.7798927061684001, 0.7803495769561876, 0.7801211415622938),
-    "ploop": (0.1593085565961168, 0.004142883358352041, 0.1806483723808761, 0.003657953473352228),
-    "pbp_iters": 101,                      # ref.0:122 "stagSolve: 101"
+
+class Config:
+    """One run of tests/extra/staghmc_sh/run (test 0, 1 or 2)."""
+
+    def __init__(self, name, masses, hmasses, galg, gsteps, fsteps, hfsteps, gold):
+        self.name, self.masses, self.hmasses = name, masses, hmasses
+        self.galg, self.gsteps, self.fsteps, self.hfsteps = galg, gsteps, fsteps, hfsteps
+        self.gold = gold
+        # flattened pseudofermion fields: (species k, level i); level 0 = the light mass, i > 0 = Hasenbusch i-1
+        self.fields = [(k, i) for k in range(len(masses)) for i in range(len(hmasses[k]) + 1)]
+        self.steps = [[fsteps[k]] + list(hfsteps[k]) for k in range(len(masses))]
+
+
+def _E(H, Sg, Sf, T):
+    return dict(H=H, Sg=Sg, Sf=Sf, T=T)
+
+
+# tests/extra/staghmc_sh/ref.0:117-147, ref.1:158-197, ref.2:165-200
+CONFIGS = {
+    0: Config("ref.0", [0.1], [[0.2, 0.4]], ("2MN", 0.19), 18, [3], [[3, 3]], {
+        "begin": _E(18451.47947589929, 0.0, [6115.074514620805, 6296.481015505035, 6143.045791623304], -103.1218458498552),
+        "end": _E(18452.64279359589, 18431.57360855611, [6127.428742650334, 6325.453215672831, 5587.471917645606], -18019.28469092899),
+        "accept": True,
+        "pbp": [0.2117714665683549, 0.211234484887779],
+        "plaq": (0.7798927061684001, 0.7803495769561876, 0.7801211415622938),
+        "ploop": (0.1593085565961168, 0.004142883358352041, 0.1806483723808761, 0.003657953473352228),
+        "pbp_iters": 101,                                   # ref.0:122 "stagSolve: 101"
+        "force_stats": [(12, 80, 98), (12, 69, 82), (12, 49, 55)],      # Solver[force] count:avg:max (ref.0:134-136)
+        "action_max": [99, 82, 54],
+        "begin2": _E(36739.46806257457, 18431.57360855611, [6167.177355372508, 6207.772553312414, 6058.237942980893], -125.2933976473578),
+        "end2": _E(36740.43410254073, 29993.99458721639, [6176.234483849725, 6221.867671160123, 5713.001444448795], -11364.6640841343),
+        "reversed2": _E(36739.46806257457, 18431.57360855611, [6167.177355372508, 6207.772553312412, 6058.237942980893], -125.2933976473578),
+        "accept2": False,
+        "pbp2": [0.2118970809638824, 0.2101254523243145],
+        "plaq2": (0.7798927061684001, 0.7803495769561876, 0.7801211415622938),
+    }),
+    1: Config("ref.1", [0.1, 0.05], [[0.2, 0.4], [0.2, 0.4]], ("4MN3F1GP", LAM), 8, [4, 1], [[4, 4], [4, 4]], {
+        "begin": _E(37060.84273906729, 0.0, [6115.074514620805, 6306.389181751562, 6135.810117523342,
+                                             6295.354845031659, 6105.404747102119, 6205.931178887655], -103.1218458498552),
+        "end": _E(37059.74483704752, 18305.11759204451, [6126.510266887249, 6335.609427651825, 5601.461747229001,
+                                                        6310.501654586174, 6136.272325695626, 5669.590023510308], -17425.31820055717),
+        "accept": True,
+        "pbp": [0.2124987385567164, 0.2121777421850332],
+        "plaq": (0.7806760387002425, 0.7821946149314469, 0.7814353268158447),
+        "ploop": (0.1698385451622547, -0.0002273776499279601, 0.1893621803302616, 0.003975399375172897),
+        "pbp_iters": 99,
+        "force_stats": [(16, 79, 97), (16, 69, 82), (16, 49, 55), (4, 84, 101), (16, 69, 82), (16, 49, 54)],   # ref.1:178-183
+        "action_max": [98, 81, 55, 105, 82, 54],
+    }),
+    2: Config("ref.2", [0.1, 0.05], [[0.2, 0.4], [0.2, 0.4]], ("4MN3F1GP", LAM), 8, [4, 1], [[2, 8], [4, 4]], {
+        "begin": _E(37060.84273906728, 0.0, [6115.074514620805, 6306.389181751561, 6135.810117523342,
+                                             6295.35484503166, 6105.40474710212, 6205.931178887655], -103.1218458498624),
+        "end": _E(37059.67520145793, 18305.14306547379, [6126.509964414681, 6335.589195322854, 5601.206802025012,
+                                                        6310.501330347202, 6136.271596425377, 5669.6042640287], -17425.15101657969),
+        "accept": True,
+        "pbp": [0.212498005749541, 0.2121770649184098],
+        "plaq": (0.7806754017364743, 0.7821946737822517, 0.7814350377593631),
+        "ploop": (0.1698446687873951, -0.0002275802967509945, 0.1893696000700383, 0.003974432970409643),
+    }),
 }
+GOLD = CONFIGS[0].gold                      # kept for the Begin-H-only tests
 
 
-def schedule():
-    """[(time, [(member, t, g), ...])]: V updates on the common time axis, tau = 1."""
-    ev = []
-    dt = TAU / GSTEPS
-    for s in range(GSTEPS):
-        ev.append(((s + GLAMBDA) * dt, 0, 0.5 * dt, 0.0))
-        ev.append(((s + 1.0 - GLAMBDA) * dt, 0, 0.5 * dt, 0.0))
-    dt = TAU / FSTEPS
-    xi = 0.005144032921810704                       # ref.0:80
-    for m in (1, 2, 3):
-        for s in range(FSTEPS):
-            ev.append(((s + 0.125) * dt, m, FLAMBDA * dt, 0.0))
-            ev.append(((s + 0.5) * dt, m, 0.4074074074074074 * dt, xi * dt ** 3))
-            ev.append(((s + 0.875) * dt, m, FLAMBDA * dt, 0.0))
+def _member_events(alg, steps, member):
+    """V updates (time, member, t, g) of one Omelyan member over tau = 1 (coefficients: ref.0:67-113)"""
+    ev, dt = [], TAU / steps
+    if alg[0] == "2MN":
+        lam = alg[1]
+        for s in range(steps):
+            ev.append(((s + lam) * dt, member, 0.5 * dt, 0.0))
+            ev.append(((s + 1.0 - lam) * dt, member, 0.5 * dt, 0.0))
+    elif alg[0] == "4MN3F1GP":
+        lam = alg[1]
+        assert abs(lam - LAM) < 1e-15                # XI belongs to this lambda
+        for s in range(steps):
+            ev.append(((s + 0.125) * dt, member, lam * dt, 0.0))
+            ev.append(((s + 0.5) * dt, member, (1.0 - 2.0 * lam) * dt, XI * dt ** 3))
+            ev.append(((s + 0.875) * dt, member, lam * dt, 0.0))
+    else:
+        raise ValueError(alg)
+    return ev
+
+
+def schedule(cfg):
+    """[(time, [(member, t, g), ...])]: member 0 = gauge, member 1 + j = pseudofermion field j"""
+    ev = _member_events(cfg.galg, cfg.gsteps, 0)
+    for j, (k, i) in enumerate(cfg.fields):
+        ev += _member_events(("4MN3F1GP", LAM), cfg.steps[k][i], 1 + j)
     ev.sort(key=lambda e: (e[0], e[1]))
     out = []
     for t, m, ts, gs in ev:
@@ -62,15 +125,6 @@ def schedule():
         else:
             out.append((t, [(m, ts, gs)]))
     return out
-
-
-def fscale(i, t):
-    """staghmc_sh.nim:381-385 for one species with two Hasenbusch masses"""
-    if i == 0:
-        return 0.5 * t * (HMASSES[0] ** 2 - MASS ** 2) / MASS
-    if i < len(HMASSES):
-        return 0.5 * t * (HMASSES[i] ** 2 - HMASSES[i - 1] ** 2) / HMASSES[i - 1]
-    return 0.5 * t / HMASSES[i - 1]
 
 
 class Replay:
@@ -82,26 +136,46 @@ class Replay:
          be.plaq(g) -> 6 plaquettes;  be.exp_update(g, p, t): g := exp(t p) g;  be.reunit(g);  be.wline(g, path)
        Only the random numbers (momenta, pseudofermion and pbp sources) are the driver's, from the oracle's RngMilc6."""
 
-    def __init__(self, o, be):
+    def __init__(self, o, be, cfg=None):
         self.o, self.be = o, be
+        self.cfg = cfg or CONFIGS[0]
         self.lo = o.Layout(LAT)
         self.rf = o.RngField(self.lo, o.RNG_MILC6, SEED)
         self.g = o.gauge_unit(self.lo)
         self.p = None
-        self.phi = None
-        self.stats = {"force_iters": [], "action_iters": []}
+        self.phi = None                              # phi[j] for the flattened fields
+        self.stats = {"force_iters": [[] for _ in self.cfg.fields], "action_iters": [[] for _ in self.cfg.fields]}
+
+    def _m(self, j):
+        """mass the field j is solved with: light mass at level 0, else the previous Hasenbusch mass"""
+        k, i = self.cfg.fields[j]
+        return self.cfg.masses[k] if i == 0 else self.cfg.hmasses[k][i - 1]
+
+    def _last(self, j):
+        k, i = self.cfg.fields[j]
+        return i == len(self.cfg.hmasses[k])
+
+    def fscale(self, j, t):
+        """staghmc_sh.nim:381-385"""
+        k, i = self.cfg.fields[j]
+        hm, m = self.cfg.hmasses[k], self.cfg.masses[k]
+        if len(hm) == 0:
+            return 0.5 * t / m
+        if i == 0:
+            return 0.5 * t * (hm[0] ** 2 - m ** 2) / m
+        if i < len(hm):
+            return 0.5 * t * (hm[i] ** 2 - hm[i - 1] ** 2) / hm[i - 1]
+        return 0.5 * t / hm[i - 1]
 
     # ---- action pieces (staghmc_sh.nim:330-364) ----
     def faction(self, h):
-        be, n = self.be, len(self.phi)
+        be, cfg = self.be, self.cfg
         fa = []
-        for i in range(n - 1):
-            x, its = be.solve(h, be.D(h, self.phi[i], HMASSES[i]), MASS if i == 0 else HMASSES[i - 1])
-            self.stats["action_iters"].append(its)
+        for j, (k, i) in enumerate(cfg.fields):
+            src = self.phi[j] if self._last(j) else be.D(h, self.phi[j], cfg.hmasses[k][i])
+            x, its = be.solve(h, src, cfg.hmasses[k][-1] if self._last(j) and cfg.hmasses[k] else self._m(j))
+            self.stats["action_iters"][j].append(its)
             fa.append((x * x).sum())
-        x, its = be.solve(h, self.phi[-1], HMASSES[-1])
-        self.stats["action_iters"].append(its)
-        fa.append((x * x).sum())
         return fa
 
     def energies(self, h, g):
@@ -113,15 +187,22 @@ class Replay:
 
     def refresh(self):
         """staghmc_sh.nim:716-757"""
-        o, lo, be = self.o, self.lo, self.be
+        o, lo, be, cfg = self.o, self.lo, self.be, self.cfg
         self.p = o.gauge_random_tah(lo, self.rf)
         h = be.smear_rephase(self.g, False)
-        psi = [o.vector_gaussian(lo, self.rf) for _ in range(len(HMASSES) + 1)]
-        n = len(psi)
+        # psi[k][i].gaussian r, level by level across the species ("conforms to bsm.lua", :735-745)
+        psi = {}
+        for lvl in range(max(len(hm) for hm in cfg.hmasses) + 1):
+            for k in range(len(cfg.masses)):
+                if lvl <= len(cfg.hmasses[k]):
+                    psi[(k, lvl)] = o.vector_gaussian(lo, self.rf)
         self.phi = []
-        for i in range(n):
-            mi = -MASS if i == 0 else -HMASSES[i - 1]
-            ph = be.solve(h, be.D(h, psi[i], mi), -HMASSES[i])[0] if i != n - 1 else be.D(h, psi[i], mi)
+        for j, (k, i) in enumerate(cfg.fields):
+            mi = -self._m(j)
+            if self._last(j):
+                ph = be.D(h, psi[(k, i)], mi)
+            else:
+                ph = be.solve(h, be.D(h, psi[(k, i)], mi), -cfg.hmasses[k][i])[0]
             ph = ph.copy()
             ph[lo.vol // 2:] = 0
             self.phi.append(ph)
@@ -136,40 +217,50 @@ class Replay:
         be = self.be
         fields, scales = [], []
         for j in ix:
-            x, its = be.solve(h, self.phi[j], MASS if j == 0 else HMASSES[j - 1])
-            self.stats["force_iters"].append(its)
+            x, its = be.solve(h, self.phi[j], self._m(j))
+            self.stats["force_iters"][j].append(its)
             fields.append(x)
-            scales.append(fscale(j, ts[j]))
+            scales.append(self.fscale(j, ts[j]))
         return be.fermion_force(h, g, fields, scales)
 
     def mdv_all(self, group):
-        """mdvAllfga(ts, gs) (:505-640), first-order force-gradient approximation (useFG2 = 0)"""
-        o, lo, be = self.o, self.lo, self.be
-        ts, gs = [0.0] * 4, [0.0] * 4
+        """mdvAllfga(ts, gs) (:505-640), first-order force-gradient approximation (useFG2 = 0):
+        exp(t V + g [V,[T,V]]) ~ links shifted by exp(-(2g/t) F), force taken there with step t"""
+        be = self.be
+        nf = len(self.cfg.fields)
+        ts, gs = [0.0] * (nf + 1), [0.0] * (nf + 1)
         for m, t, g_ in group:
             ts[m], gs[m] = t, g_
-        assert gs[0] == 0.0                         # the gauge member is plain 2MN in this run
-        updateF = [k for k in range(3) if gs[k + 1] == 0.0 and ts[k + 1] != 0.0]
-        updateFG = [k for k in range(3) if gs[k + 1] != 0.0]
-        if ts[0] != 0.0:                            # mdv (:436-444): p -= t forceA(g)
-            self.p -= ts[0] * be.gauge_force(self.g)
-        if updateF:                                 # mdvf (:446-453): p += f
-            h = be.smear_rephase(self.g, True)
-            self.p += self.fforce(h, self.g, updateF, ts[1:])
-        if updateFG:
-            tf = {k: ts[k + 1] for k in updateFG}                          # approximateFGcoeff
-            tg = {k: 2.0 * gs[k + 1] / ts[k + 1] for k in updateFG}
+        updateGG = gs[0] != 0.0
+        updateG = (not updateGG) and ts[0] != 0.0
+        updateF = [k for k in range(nf) if gs[k + 1] == 0.0 and ts[k + 1] != 0.0]
+        updateFG = [k for k in range(nf) if gs[k + 1] != 0.0]
+        gg, hshared = None, None
+        if updateGG or updateFG:
             gg = self.g.copy()                                             # fgsave
-            h = be.smear_rephase(gg, True)
-            f = self.fforce(h, gg, updateFG, [tg.get(k, 0.0) for k in range(3)])
-            be.exp_update(self.g, f, 1.0)                                  # fgvf: g := exp(f) g
-            h = be.smear_rephase(self.g, True)
-            self.p += self.fforce(h, self.g, updateFG, [tf.get(k, 0.0) for k in range(3)])
+            if updateFG:
+                hshared = be.smear_rephase(gg, True)                       # sforceShared
+        if updateG:                                                        # mdv: p -= t forceA(g)
+            self.p -= ts[0] * be.gauge_force(self.g)
+        if updateF:                                                        # mdvf: p += f
+            h = hshared if updateFG else be.smear_rephase(self.g, True)
+            self.p += self.fforce(h, self.g, updateF, ts[1:])
+        if updateGG or updateFG:
+            if updateGG:                                                   # fgv: g := exp(-tg forceA(gg)) g
+                be.exp_update(self.g, be.gauge_force(gg), -2.0 * gs[0] / ts[0])
+            if updateFG:                                                   # fgvf: g := exp(f) g, f at gg with steps tg
+                tg = [2.0 * gs[k + 1] / ts[k + 1] if k in updateFG else 0.0 for k in range(nf)]
+                be.exp_update(self.g, self.fforce(hshared, gg, updateFG, tg), 1.0)
+            if updateGG:                                                   # FG mdv at the shifted links
+                self.p -= ts[0] * be.gauge_force(self.g)
+            if updateFG:                                                   # FG mdvf at the shifted links
+                h = be.smear_rephase(self.g, True)
+                self.p += self.fforce(h, self.g, updateFG, ts[1:])
             self.g = gg                                                    # fgload
 
     def evolve(self):
         now = 0.0
-        for t, group in schedule():
+        for t, group in schedule(self.cfg):
             self.mdt(t - now)
             now = t
             self.mdv_all(group)
@@ -179,16 +270,28 @@ class Replay:
         h = self.be.smear_rephase(self.g, False)
         return self.energies(h, self.g)
 
-    # ---- measurements after ACCEPT (staghmc_sh.nim:774-789) ----
-    def measure(self):
+    def reverse_check(self):
+        """revCheck (staghmc_sh.nim:642-680): flip the momenta, evolve again, report the energies, restore"""
+        g1, p1 = self.g.copy(), self.p.copy()
+        self.p = -self.p
+        self.evolve()
+        e = self.finish_energies()
+        self.g, self.p = g1, p1
+        return e
+
+    # ---- measurements after ACCEPT / REJECT (staghmc_sh.nim:774-789) ----
+    def measure(self, accepted=True, g0=None):
         o, lo, be = self.o, self.lo, self.be
-        be.reunit(self.g)                                                  # g.reunit
+        if accepted:
+            be.reunit(self.g)                                              # g.reunit
+        else:
+            self.g = g0.copy()                                             # g := g0; stag0.pbp uses sg0
         h = be.smear_rephase(self.g, False)
         pbp, iters = [], []
         for _ in range(2):                                                 # pbpreps = 2
             src = o.vector_u1(lo, self.rf)
-            x, its = be.solve(h, src, MASS)
-            pbp.append(MASS * (x * x).sum() / lo.vol)
+            x, its = be.solve(h, src, PBPMASS)
+            pbp.append(PBPMASS * (x * x).sum() / lo.vol)
             iters.append(its)
         pl = be.plaq(self.g)
         ps, pt = 2.0 * sum(pl[:3]), 2.0 * sum(pl[3:])
