@@ -205,6 +205,19 @@ int qexhip_fat7(qexhip_handle h, const double *g, const double coef[5], double *
 int qexhip_hisq_smear(qexhip_handle h, const double *g, double *fl, double *ll);
 int qexhip_nhyp_smear(qexhip_handle h, const double *g, double *fl, double alpha1, double alpha2, double alpha3);
 
+/* n (1..4) independent systems on the SAME links solved in lock-step, the links streamed once per sweep for all of
+ * them (the Dslash is HBM-bound and 89 % of its bytes are links).  This is how the back-to-back solves of QEX's HMC
+ * are meant to be issued: the Hasenbusch chain of faction / fforce (src/examples/staghmc_sh.nim:339-364,394-404), the
+ * pbp repetitions (:260-272), the fork's fforce loop (src/stagg_pv_hmc/staghmc_spv.nim:758-830).
+ *   solve_xx_batch: n x solveXX (qexhip_stag_solve_xx semantics per system: own mass, r2req, iteration count)
+ *   solve_batch:    n x Staggered.solve (qexhip_stag_solve semantics per system)
+ * Each system's arithmetic is that of the single-system call, so solutions and iteration counts are the same.
+ * x, b: arrays of n host fields [vol][3][2].  Single GPU. */
+int qexhip_stag_solve_xx_batch(qexhip_handle h, int n, double *const *x, const double *const *b, const double *mass,
+                               const double *r2req, int maxits, int par_even, int *iters, double *r2_over_b2);
+int qexhip_stag_solve_batch(qexhip_handle h, int n, double *const *x, const double *const *b, const double *mass,
+                            const double *r2req, int maxits, int *iters, double *r2_over_b2);
+
 /* Storage format the library chose for the operator's links at the last set_links call.  A unitary link is fixed
  * by rows 0,1 and its determinant (row2 = det * conj(row0 x row1)), and the sweep is HBM-bound, so:
  *   1: every link is SU(3) up to a sign (thin links with BC + staggered phases): rows 0,1 + a sign bit, 96 B/link

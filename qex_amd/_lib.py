@@ -58,6 +58,8 @@ SYMBOLS = [
     ("qexhip_fat7", _ci, [_vp, _vp, _pd, _vp, _vp, _cd]),
     ("qexhip_hisq_smear", _ci, [_vp, _vp, _vp, _vp]),
     ("qexhip_nhyp_smear", _ci, [_vp, _vp, _vp, _cd, _cd, _cd]),
+    ("qexhip_stag_solve_xx_batch", _ci, [_vp, _ci, _vp, _vp, _vp, _vp, _ci, _ci, _pi, _vp]),
+    ("qexhip_stag_solve_batch", _ci, [_vp, _ci, _vp, _vp, _vp, _vp, _ci, _pi, _vp]),
     ("qexhip_stag_links_info", _ci, [_vp, _pi, _pi, _vp]),
     ("qexhip_set_option", _ci, [_vp, C.c_char_p, _ci]),
     ("qexhip_stag_set_links_hisq", _ci, [_vp, _vp]),

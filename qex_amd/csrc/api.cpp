@@ -131,9 +131,13 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
   c->fields.clear();
   for (auto &kv : c->timers) for (auto e : kv.second.ev) (void)hipEventDestroy(e);
   nhyp_state_free(c);
+  batch_state_free(c);
   gauge_free(c);
   comm_destroy(c);
   if (c->W) (void)hipFree(c->W);
+  if (c->outer_F) (void)hipFree(c->outer_F);
+  if (c->obs_table) (void)hipFree(c->obs_table);
+  if (c->cgm_scal) (void)hipFree(c->cgm_scal);
   if (c->Wc) (void)hipFree(c->Wc);
   if (c->Ws) (void)hipFree(c->Ws);
   if (c->stage) (void)hipFree(c->stage);
@@ -469,6 +473,18 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "overlap") c->opt_overlap = value;
   else { qexhip_set_error("unknown option"); return QEXHIP_ERR_ARG; }
   return 0;
+}
+extern "C" int qexhip_stag_solve_xx_batch(qexhip_handle c, int n, double *const *x, const double *const *b, const double *mass,
+                                          const double *r2req, int maxits, int par_even, int *iters, double *r2_over_b2) {
+  if (!c || !x || !b || !mass || !r2req) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return solve_batch_host(c, n, x, b, mass, r2req, maxits, par_even ? 1 : 0, iters, r2_over_b2);
+}
+extern "C" int qexhip_stag_solve_batch(qexhip_handle c, int n, double *const *x, const double *const *b, const double *mass,
+                                       const double *r2req, int maxits, int *iters, double *r2_over_b2) {
+  if (!c || !x || !b || !mass || !r2req) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return solve_batch_host(c, n, x, b, mass, r2req, maxits, -1, iters, r2_over_b2);
 }
 extern "C" int qexhip_stag_links_info(qexhip_handle c, int *nlinks, int *compressed, double *max_dev) {
   if (!c) return QEXHIP_ERR_ARG;

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) k_redot(const double2 *x, const double2 *
   double acc = 0;
   for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     double2 xv = x[i], yv = y[i];
-    acc += xv.x * yv.x + xv.y * yv.y;
+    acc = fma(xv.x, yv.x, fma(xv.y, yv.y, acc));   // explicit fma: the same rounding in every kernel that forms this sum
   }
   double r = block_sum_256(acc);
   if (threadIdx.x == 0) partials[blockIdx.x] = r;
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_cg_update(double2 *x, double2 *r, const
     xv.x += alpha * pv.x; xv.y += alpha * pv.y;
     rv.x -= alpha * av.x; rv.y -= alpha * av.y;
     x[i] = xv; r[i] = rv;
-    acc += rv.x * rv.x + rv.y * rv.y;
+    acc = fma(rv.x, rv.x, fma(rv.y, rv.y, acc));
   }
   double t = block_sum_256(acc);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;

@@ -31,52 +31,7 @@ struct DslashArgs {
   int ntstore;           // 1: non-temporal stores of the output
 };
 
-typedef double d2v __attribute__((ext_vector_type(2)));
-
-// acc += U v  (SUB = false)  /  acc -= U v  (SUB = true); every term one v_fma_f64
-template <bool SUB>
-__device__ __forceinline__ void mv3(double2 acc[3], const double2 U[9], const double2 v[3]) {
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      if (!SUB) {
-        acc[i].x += U[3 * i + j].x * v[j].x;
-        acc[i].x -= U[3 * i + j].y * v[j].y;
-        acc[i].y += U[3 * i + j].x * v[j].y;
-        acc[i].y += U[3 * i + j].y * v[j].x;
-      } else {
-        acc[i].x -= U[3 * i + j].x * v[j].x;
-        acc[i].x += U[3 * i + j].y * v[j].y;
-        acc[i].y -= U[3 * i + j].x * v[j].y;
-        acc[i].y -= U[3 * i + j].y * v[j].x;
-      }
-    }
-  }
-}
-
-// rows 0,1 of a link -> full link: row 2 = det * conj(row0 x row1); det = +-1 (format 1) or U[6] (format 2)
-template <int FMT>
-__device__ __forceinline__ void recon_row2(double2 U[9], bool neg) {
-  const double2 ph = U[6];
-  double2 r2[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const int a = (k + 1) % 3, b = (k + 2) % 3;
-    double rx = U[a].x * U[3 + b].x;
-    rx -= U[a].y * U[3 + b].y;
-    rx -= U[b].x * U[3 + a].x;
-    rx += U[b].y * U[3 + a].y;
-    double ry = U[b].x * U[3 + a].y;
-    ry += U[b].y * U[3 + a].x;
-    ry -= U[a].x * U[3 + b].y;
-    ry -= U[a].y * U[3 + b].x;
-    if (FMT == 1) r2[k] = make_double2(neg ? -rx : rx, neg ? -ry : ry);
-    else r2[k] = make_double2(ph.x * rx - ph.y * ry, ph.x * ry + ph.y * rx);
-  }
-#pragma unroll
-  for (int k = 0; k < 3; k++) U[6 + k] = r2[k];
-}
+#include "dslash_core.h"
 
 template <int NDIR, bool HALO, bool INIT, bool DOT, int RECON>
 __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
@@ -183,7 +138,7 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
     }
     if (DOT) {
 #pragma unroll
-      for (int k = 0; k < 3; k++) dotv += xsv[k].x * acc[k].x + xsv[k].y * acc[k].y;
+      for (int k = 0; k < 3; k++) dotv = fma(xsv[k].x, acc[k].x, fma(xsv[k].y, acc[k].y, dotv));
     }
   }
   if (DOT) {

@@ -76,14 +76,14 @@ int stag_outer_host(qexhip_ctx *c, double *f_host, const double *x_host, double 
   DevField *fx;
   CHK(get_work(c, WK_IN, &fx));
   CHK(field_upload(c, *fx, x_host));
-  static double2 *Fd = nullptr;
-  static size_t Fn = 0;
   const size_t n2 = (size_t)2 * g.ntile * 4 * 576;
-  if (Fn < n2) {
-    if (Fd) HIPCHK(hipFree(Fd));
-    HIPCHK(hipMalloc((void **)&Fd, n2 * sizeof(double2)));
-    Fn = n2;
+  if (c->outer_Fn < n2) {
+    if (c->outer_F) HIPCHK(hipFree(c->outer_F));
+    c->outer_F = nullptr; c->outer_Fn = 0;
+    HIPCHK(hipMalloc((void **)&c->outer_F, n2 * sizeof(double2)));
+    c->outer_Fn = n2;
   }
+  double2 *Fd = c->outer_F;
   const size_t gbytes = (size_t)g.V * 72 * sizeof(double);
   if (accumulate) {
     CHK(ensure_stage(c, gbytes));

@@ -316,8 +316,8 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
     if (loop > 1 && c->g.X[d] < 4) { qexhip_set_error("improved fmunu needs extents >= 4"); return -1; }
   ObsTable T;
   CHK(obs_build_table(loop, T));
-  static ObsTable *dT = nullptr;
-  if (!dT) HIPCHK(hipMalloc((void **)&dT, sizeof(ObsTable)));
+  if (!c->obs_table) HIPCHK(hipMalloc(&c->obs_table, sizeof(ObsTable)));
+  ObsTable *dT = (ObsTable *)c->obs_table;
   HIPCHK(hipMemcpyAsync(dT, &T, sizeof(T), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));  // T is a stack object
   int nb = (c->g.V + 255) / 256;
@@ -498,8 +498,7 @@ int gauge_plaq(qexhip_ctx *c, double out[6]) {
 static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, double cpm = 0, double c2 = 0, int kind = 0) {
   CHK(gn_alloc_fp(c));
   ScopedTimer tm(c, "staple", c->stream);
-  static int mode = -1;
-  if (mode < 0) { const char *e = getenv("QEXHIP_FORCE_MODE"); mode = e ? atoi(e) : 1; }
+  static const int mode = [] { const char *e = getenv("QEXHIP_FORCE_MODE"); return e ? atoi(e) : 1; }();   // process-wide tuning switch
   int nb = mode == 0 ? (4 * c->g.V + 255) / 256 : 2 * c->g.ntile;
   if (c2 != 0.0) {
     // kind 0: cr = c.rect/nc ; kind 1: ca = 2 c.adjplaq/nc^2

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) k_cgm_base(double2 *x, double2 *r, const 
     rv.x -= alpha * av.x; rv.y -= alpha * av.y;
     xv.x += alpha * pv.x; xv.y += alpha * pv.y;
     x[i] = xv; r[i] = rv;
-    acc += rv.x * rv.x + rv.y * rv.y;
+    acc = fma(rv.x, rv.x, fma(rv.y, rv.y, acc));
   }
   double t = block_sum_256(acc);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
@@ -103,7 +103,6 @@ __global__ void k_cgm_init(CgScal *s, const double *dscal, double r2req, int max
   if (histcap > 0) hist[0] = (s->b2 != 0.0) ? 1.0 : 0.0;
 }
 
-static CgmScal *g_cgm_dev = nullptr;  // one per process is enough (single context per GPU)
 
 static int read_cg(qexhip_ctx *c, CgScal *host) {
   HIPCHK(hipMemcpyAsync(c->pinned, c->cg, sizeof(CgScal), hipMemcpyDeviceToHost, c->stream));
@@ -131,7 +130,8 @@ int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, 
   // search directions ps[k]: one-parity use of full fields
   std::vector<DevField> ps(nmass);
   for (int k = 0; k < nmass; k++) CHK(field_alloc(c, ps[k]));
-  if (!g_cgm_dev) HIPCHK(hipMalloc((void **)&g_cgm_dev, sizeof(CgmScal)));
+  if (!c->cgm_scal) HIPCHK(hipMalloc(&c->cgm_scal, sizeof(CgmScal)));
+  CgmScal *g_cgm_dev = (CgmScal *)c->cgm_scal;
   CgmScal hm;
   memset(&hm, 0, sizeof(hm));
   hm.nmass = nmass; hm.cont = 1;

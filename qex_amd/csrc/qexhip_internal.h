@@ -99,6 +99,11 @@ struct qexhip_ctx {
   // natural gauge (flow)
   GaugeNat *gn = nullptr;
   void *nhyp = nullptr;   // NhypState (smear.hip): the smearGetForce closure
+  // small per-context device scratch owned by single kernels' host wrappers
+  double2 *outer_F = nullptr; size_t outer_Fn = 0;   // force field of stag_outer_host (force.hip)
+  void *obs_table = nullptr;                         // ObsTable of gauge_flow_obs (gauge.hip)
+  void *batch = nullptr;                             // BatchState of the lock-step multi-system CG (batch.hip)
+  void *cgm_scal = nullptr;                          // CgmScal of the multi-shift solver (multishift.hip)
 };
 
 // work-field slots (get_work)
@@ -135,6 +140,10 @@ int links_upload(qexhip_ctx *c, const double *fat, const double *lng);
 int ensure_stage(qexhip_ctx *c, size_t bytes);
 int links_from_natural(qexhip_ctx *c, const double2 *fat, const double2 *lng);
 int links_compress(qexhip_ctx *c);
+int op_eo_reconstruct_pub(qexhip_ctx *c, DevField &r, DevField &b, double m);
+void batch_state_free(qexhip_ctx *c);
+int solve_batch_host(qexhip_ctx *c, int n, double *const *x, const double *const *b, const double *mass,
+                     const double *r2req, int maxits, int xx_parity, int *iters, double *r2);
 
 // ---- comm.cpp ----
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready, records ev_halo

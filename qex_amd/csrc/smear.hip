@@ -310,8 +310,7 @@ struct Smear {
   }
   int staple(MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef) {
     ScopedTimer tm(c, "smear", c->stream);
-    static int swz = -1;
-    if (swz < 0) { const char *e = getenv("QEXHIP_SMEAR_SWZ"); swz = e ? atoi(e) : 1; }
+    static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
     k_gen_staple<<<nb(), 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz);
     HIPCHK(hipGetLastError());
     return 0;
@@ -459,12 +458,9 @@ int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, doub
 }
 // smearedForce(f, chain) on the device field st->F (in: chain, out: f)   (hypsmear.nim:146-245)
 static int staple_deriv(qexhip_ctx *c, const Geom &g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu) {
-  static int variant = -1, swz = 0;
-  if (variant < 0) {
-    const char *e = getenv("QEXHIP_SDERIV");
-    variant = e ? atoi(e) % 10 : 0;
-    swz = e ? atoi(e) / 10 : 1;
-  }
+  // QEXHIP_SDERIV = 10*swizzle + variant (variant 1: f1 and f2 in separate launches); default 10
+  static const int sel = [] { const char *e = getenv("QEXHIP_SDERIV"); return e ? atoi(e) : 10; }();
+  const int variant = sel % 10, swz = sel / 10;
   const int nblk = (g.V + 255) / 256;
   if (variant == 0) {
     k_staple_deriv<0><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz);

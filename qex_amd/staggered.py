@@ -285,6 +285,42 @@ class Staggered:
         if sp.verbosity > 1:
             print("stagSolve(HIP): " + sp.getStats())
 
+    def _batch(self, fn_name, xs, bs, ms, r2req, maxits, parEven=None):
+        n = len(xs)
+        if not (1 <= n <= 4 and len(bs) == n and len(ms) == n):
+            raise ValueError("batch solve: 1..4 systems, one source and one mass each")
+        rq = [float(r2req)] * n if np.isscalar(r2req) else [float(v) for v in r2req]
+        xp = (C.c_void_p * n)(*[_p(a).value for a in xs])
+        bp = (C.c_void_p * n)(*[_p(a).value for a in bs])
+        mv, rv = (C.c_double * n)(*[float(v) for v in ms]), (C.c_double * n)(*rq)
+        its, fin = (C.c_int * n)(), (C.c_double * n)()
+        if parEven is None:
+            check(lib().qexhip_stag_solve_batch(self.ctx._h, n, xp, bp, mv, rv, int(maxits), its, fin))
+        else:
+            check(lib().qexhip_stag_solve_xx_batch(self.ctx._h, n, xp, bp, mv, rv, int(maxits), 1 if parEven else 0, its, fin))
+        return list(its), list(fin)
+
+    def solve_batch(self, xs, bs, ms, sps):
+        """n (<= 4) x Staggered.solve on these links in lock-step: the links are streamed once per sweep for
+        all systems.  sps: one SolverParams (shared r2req / maxits) or one per system; each gets the
+        statistics of its own system, exactly as n calls of solve would record them."""
+        sl = [sps] * len(xs) if isinstance(sps, SolverParams) else list(sps)
+        t0 = time.time()
+        its, fin = self._batch("solve", xs, bs, ms, [sp.r2req for sp in sl], min(sp.maxits for sp in sl))
+        dt = (time.time() - t0) / len(xs)
+        for sp, i, f in zip(sl, its, fin):
+            sp.calls += 1
+            sp.iterations += i
+            sp.iterationsMax = max(sp.iterationsMax, i)
+            sp.seconds += dt
+            sp.flops += self._flops(i)
+            sp.r2 = f
+        return its
+
+    def solveXX_batch(self, xs, bs, ms, r2req, maxits, parEven=True):
+        """n (<= 4) x solveEE / solveOO in lock-step; returns (iterations, r2/b2) per system"""
+        return self._batch("xx", xs, bs, ms, r2req, maxits, parEven)
+
     def solveXX_multi(self, xs, b, shifts, sp, parEven=True, histcap=0):
         """Staggered.solveXX(xs, b, ms, sp, subset) (stagSolve.nim:296-345): shifts[0] = base mass."""
         its = C.c_int(0)

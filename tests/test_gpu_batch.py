@@ -1,0 +1,75 @@
+"""Lock-step solves of several systems on the same links (qexhip_stag_solve_xx_batch / solve_batch): the
+Hasenbusch chains and pbp repetitions of the HMC drivers (staghmc_sh.nim:260-272,339-364,394-404) issued so
+that the links are streamed once for all systems.  Every system must come out as the single-system call
+delivers it: same iteration count, same solution."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300)
+
+
+def _setup(o, lat, kind):
+    import qex_amd as q
+
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 4711)
+    ctx = q.Context(lat)
+    if kind == "random":            # 18-real links
+        g = o.gauge_random(lo, rf); o.rephase(lo, g); s = q.newStag(ctx, g); fmt = 0
+    elif kind == "warm":            # rows 0,1 + sign
+        g = o.gauge_warm(lo, 0.5, rf); o.rephase(lo, g); s = q.newStag(ctx, g); fmt = 1
+    elif kind == "nhyp":            # rows 0,1 + determinant
+        g = o.gauge_warm(lo, 0.5, rf); s = q.Staggered(ctx, g, smear=q.HypCoefs(), bc="pppa"); fmt = 2
+    else:                           # Naik: 16 links
+        g = o.gauge_warm(lo, 0.5, rf); o.rephase(lo, g)
+        g3 = 0.3 * o.gauge_warm(lo, 0.6, rf); o.rephase(lo, g3)
+        s = q.newStag3(ctx, g, g3); fmt = 2
+    assert s.links_info()[1] == fmt
+    return q, lo, rf, s
+
+
+@pytest.mark.parametrize("kind", ["random", "warm", "nhyp", "naik"])
+@pytest.mark.parametrize("par_even", [True, False])
+def test_solveXX_batch_equals_single(oracle, kind, par_even):
+    q, lo, rf, s = _setup(oracle, [8, 4, 6, 4] if kind != "naik" else [4, 8, 6, 4], kind)
+    ms = [0.1, 0.2, 0.4, 0.05]
+    bs = [oracle.vector_gaussian(lo, rf) for _ in ms]
+    bs[3][:] = 0.0                                           # a zero source finishes at once (cg.nim:155,174)
+    for n in (4, 3, 1):
+        xs = [np.zeros_like(b) for b in bs[:n]]
+        its, fin = s.solveXX_batch(xs, bs[:n], ms[:n], [1e-14, 1e-12, 1e-16, 1e-12][:n], 5000, par_even)
+        for j in range(n):
+            sp = q.SolverParams(r2req=[1e-14, 1e-12, 1e-16, 1e-12][j], maxits=5000, verbosity=0)
+            x1 = np.zeros_like(bs[j])
+            s.solveXX(x1, bs[j], ms[j], sp, par_even)
+            assert its[j] == sp.iterations
+            assert np.array_equal(xs[j], x1) or relerr(xs[j], x1) < 1e-13
+    # a shared iteration cap stops every system at that count
+    xs = [np.zeros_like(b) for b in bs[:2]]
+    its, _ = s.solveXX_batch(xs, bs[:2], ms[:2], 0.0, 7, par_even)
+    assert its == [7, 7]
+
+
+@pytest.mark.parametrize("kind", ["warm", "nhyp"])
+def test_solve_batch_equals_single_and_oracle(oracle, kind):
+    q, lo, rf, s = _setup(oracle, [8, 4, 6, 4], kind)
+    ms = [0.1, 0.2, 0.4]
+    bs = [oracle.vector_gaussian(lo, rf) for _ in ms]
+    bs[0][lo.vol // 2:] = 0                                  # phi.odd := 0 (staghmc_sh.nim:753): reconstruct-right
+    bs[1][:lo.vol // 2] = 0                                  # odd-only source
+    sps = [q.SolverParams(r2req=1e-20, maxits=10000, verbosity=0) for _ in ms]
+    xs = [np.zeros_like(b) for b in bs]
+    its = s.solve_batch(xs, bs, ms, sps)
+    for j in range(3):
+        sp = q.SolverParams(r2req=1e-20, maxits=10000, verbosity=0)
+        x1 = np.zeros_like(bs[j])
+        s.solve(x1, bs[j], ms[j], sp)
+        assert its[j] == sp.iterations == sps[j].iterations
+        assert relerr(xs[j], x1) < 1e-13
+        r = np.zeros_like(x1)
+        s.D(r, xs[j], ms[j])
+        assert ((r - bs[j]) ** 2).sum() / (bs[j] ** 2).sum() <= 1e-20
