@@ -131,6 +131,7 @@ class Replay:
     """`be` supplies the operators under test:
          be.smear_rephase(g, want_force) -> handle     smearGetForce / smear, then setBC + stagPhase
          be.D(handle, x, m), be.solve(handle, b, m) -> (x, iterations)
+         be.solve_many(handle, [b], [m]) -> [(x, iterations)]   independent systems on the same links
          be.fermion_force(handle, g, fields, scales) -> f     fforce + smearedOneLinkForce (:387-427)
          be.gauge_force(g) -> gc.forceA(g);  be.gauge_action(g) -> gc.actionA(g)
          be.plaq(g) -> 6 plaquettes;  be.exp_update(g, p, t): g := exp(t p) g;  be.reunit(g);  be.wline(g, path)
@@ -170,10 +171,12 @@ class Replay:
     # ---- action pieces (staghmc_sh.nim:330-364) ----
     def faction(self, h):
         be, cfg = self.be, self.cfg
-        fa = []
+        srcs, ms = [], []
         for j, (k, i) in enumerate(cfg.fields):
-            src = self.phi[j] if self._last(j) else be.D(h, self.phi[j], cfg.hmasses[k][i])
-            x, its = be.solve(h, src, cfg.hmasses[k][-1] if self._last(j) and cfg.hmasses[k] else self._m(j))
+            srcs.append(self.phi[j] if self._last(j) else be.D(h, self.phi[j], cfg.hmasses[k][i]))
+            ms.append(cfg.hmasses[k][-1] if self._last(j) and cfg.hmasses[k] else self._m(j))
+        fa = []
+        for j, (x, its) in enumerate(be.solve_many(h, srcs, ms)):     # the chain's solves share the links
             self.stats["action_iters"][j].append(its)
             fa.append((x * x).sum())
         return fa
@@ -216,8 +219,7 @@ class Replay:
         """fields = the force solves (:394-404); scales = fscale(k, i, ts[j])"""
         be = self.be
         fields, scales = [], []
-        for j in ix:
-            x, its = be.solve(h, self.phi[j], self._m(j))
+        for j, (x, its) in zip(ix, be.solve_many(h, [self.phi[j] for j in ix], [self._m(j) for j in ix])):
             self.stats["force_iters"][j].append(its)
             fields.append(x)
             scales.append(self.fscale(j, ts[j]))
@@ -288,9 +290,8 @@ class Replay:
             self.g = g0.copy()                                             # g := g0; stag0.pbp uses sg0
         h = be.smear_rephase(self.g, False)
         pbp, iters = [], []
-        for _ in range(2):                                                 # pbpreps = 2
-            src = o.vector_u1(lo, self.rf)
-            x, its = be.solve(h, src, PBPMASS)
+        srcs = [o.vector_u1(lo, self.rf) for _ in range(2)]                # pbpreps = 2
+        for x, its in be.solve_many(h, srcs, [PBPMASS, PBPMASS]):
             pbp.append(PBPMASS * (x * x).sum() / lo.vol)
             iters.append(its)
         pl = be.plaq(self.g)
@@ -317,6 +318,9 @@ class OracleBackend:
     def solve(self, h, b, m):
         x, its, _ = self.o.solve(self.lo, h["sg"], None, b, m, RSQ, 1000000)
         return x, its
+
+    def solve_many(self, h, bs, ms):
+        return [self.solve(h, b, m) for b, m in zip(bs, ms)]
 
     def gauge_force(self, g):
         return self.o.gauge_force_general(self.lo, g, BETA, BETA * ADJFAC, 1)
@@ -375,6 +379,17 @@ class HipBackend:
         x = np.zeros_like(b)
         h["s"].solve(x, b, m, sp)
         return x, sp.iterations
+
+    def solve_many(self, h, bs, ms):
+        """lock-step batches of up to four systems (qexhip_stag_solve_batch): same result per system"""
+        out = []
+        for i0 in range(0, len(bs), 4):
+            b4, m4 = bs[i0:i0 + 4], ms[i0:i0 + 4]
+            xs = [np.zeros_like(b) for b in b4]
+            sps = [self.q.SolverParams(r2req=RSQ, maxits=1000000, verbosity=0) for _ in b4]
+            h["s"].solve_batch(xs, b4, m4, sps)
+            out += [(x, sp.iterations) for x, sp in zip(xs, sps)]
+        return out
 
     def gauge_force(self, g):
         return self.q.gaugeForce(self.ctx, g, cplaq=BETA, adjplaq=BETA * ADJFAC)
