@@ -11,11 +11,13 @@
 #include "qexhip_internal.h"
 #include "reduce.h"
 #include "su3.h"
+#include <utility>
 #include <cstdlib>
 #include <initializer_list>
 
 struct GaugeNat {
   double2 *U = nullptr, *F = nullptr, *P = nullptr;
+  double2 *U2 = nullptr;   // second link buffer: the fused flow stage reads U and writes exp(v) U here, then they swap
   size_t n2 = 0;  // double2 elements per field
 };
 
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(256) k_plaq_final(const double *partials, int 
 // flow mode (Pm != nullptr): the RK3 combination v = cf*f + cpm*p (wflow.nim:39,48,57) is formed here
 // and written over the momentum field, so the exp kernel reads one field less and F is not needed.
 __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict__ G, double2 *F, double cp, int mode,
-                                               double2 *Pm, double cf, double cpm) {
+                                               double2 *Pm, double cf, double cpm, double2 *Uout) {
   int mu, p, c;
   if (mode == 0) {
     int j = blockIdx.x * 256 + threadIdx.x;
@@ -153,6 +155,9 @@ __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict
       for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x, cf * f.e[k].y);
     }
     m3_store(Pm + o, 64, v);
+    // fused second half of the RK3 stage (wflow.nim:40-43): U <- exp(v) U into the other buffer, so the
+    // compute-bound exp overlaps the L2-bound staple gathers of other waves and v, U are not re-read
+    if (Uout) m3_store(Uout + o, 64, m3_mul(m3_exp(v), m3_load(G + o, 64)));
   } else {
     m3_store(F + o, 64, f);
   }
@@ -340,7 +345,7 @@ __device__ const signed char RECT_STEPS[6][5] = {
     {2, 2, 1, -2, -2}, {2, 1, 1, -2, -1}, {-1, 2, 1, 1, -2},          // +nu
     {-2, -2, 1, 2, 2}, {-2, 1, 1, 2, -1}, {-1, -2, 1, 1, 2}};         // -nu
 __global__ void __launch_bounds__(256) k_force_gen(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
-                                                   double c2, int kind, double2 *Pm, double cf, double cpm, int raw) {
+                                                   double c2, int kind, double2 *Pm, double cf, double cpm, int raw, double2 *Uout) {
   const int bid = blockIdx.x;
   const int mu = threadIdx.x >> 6;
   const int p = bid >= g.ntile;
@@ -414,6 +419,9 @@ __global__ void __launch_bounds__(256) k_force_gen(Geom g, const double2 *__rest
       for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x, cf * f.e[k].y);
     }
     m3_store(Pm + o, 64, v);
+    // fused second half of the RK3 stage (wflow.nim:40-43): U <- exp(v) U into the other buffer, so the
+    // compute-bound exp overlaps the L2-bound staple gathers of other waves and v, U are not re-read
+    if (Uout) m3_store(Uout + o, 64, m3_mul(m3_exp(v), m3_load(G + o, 64)));
   } else {
     m3_store(F + o, 64, f);
   }
@@ -425,7 +433,7 @@ int gauge_deriv_dev(qexhip_ctx *c, const double2 *G, double2 *F, double cplaq, d
   if (kind == 0 && c2 != 0.0) for (int d = 0; d < 4; d++) if (c->g.X[d] < 4) { qexhip_set_error("rectangle action needs extents >= 4"); return -1; }
   const double k2 = kind == 0 ? c2 / 3.0 : 2.0 * c2 / 9.0;
   ScopedTimer tm(c, "staple", c->stream);
-  k_force_gen<<<2 * c->g.ntile, 256, 0, c->stream>>>(c->g, G, F, cplaq / 3.0, k2, kind, nullptr, 0.0, 0.0, 1);
+  k_force_gen<<<2 * c->g.ntile, 256, 0, c->stream>>>(c->g, G, F, cplaq / 3.0, k2, kind, nullptr, 0.0, 0.0, 1, nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -451,6 +459,7 @@ void gauge_free(qexhip_ctx *c) {
   if (c->gn->U) (void)hipFree(c->gn->U);
   if (c->gn->F) (void)hipFree(c->gn->F);
   if (c->gn->P) (void)hipFree(c->gn->P);
+  if (c->gn->U2) (void)hipFree(c->gn->U2);
   delete c->gn;
   c->gn = nullptr;
 }
@@ -495,7 +504,8 @@ int gauge_plaq(qexhip_ctx *c, double out[6]) {
   return read_scalars(c, &c->dscal[16], 6, out);
 }
 
-static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, double cpm = 0, double c2 = 0, int kind = 0) {
+static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, double cpm = 0, double c2 = 0, int kind = 0,
+                     double2 *Uout = nullptr) {
   CHK(gn_alloc_fp(c));
   ScopedTimer tm(c, "staple", c->stream);
   static const int mode = [] { const char *e = getenv("QEXHIP_FORCE_MODE"); return e ? atoi(e) : 1; }();   // process-wide tuning switch
@@ -504,9 +514,10 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
     // kind 0: cr = c.rect/nc ; kind 1: ca = 2 c.adjplaq/nc^2
     const double k2 = kind == 0 ? c2 / 3.0 : 2.0 * c2 / 9.0;
     k_force_gen<<<2 * c->g.ntile, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind,
-                                                       flow ? c->gn->P : nullptr, cf, cpm, 0);
+                                                       flow ? c->gn->P : nullptr, cf, cpm, 0, Uout);
   } else {
-    k_force<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, flow ? c->gn->P : nullptr, cf, cpm);
+    // (capping the registers for 3 or 4 waves/SIMD spills: 1460 / 2370 us against 1310 us fused at 2 waves/SIMD)
+    k_force<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, flow ? c->gn->P : nullptr, cf, cpm, Uout);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -527,12 +538,22 @@ int gauge_wflow(qexhip_ctx *c, int nsteps, double eps, double cplaq, double c2, 
   const int nb = (int)((ltiles * 64 + 255) / 256);
   const double cf[3] = {(-1.0 / 4.0) * epsnc, (-8.0 / 9.0) * epsnc, (-3.0 / 4.0) * epsnc};
   const double cpm[3] = {0.0, -17.0 / 9.0, -1.0};
+  static const int fused = [] { const char *e = getenv("QEXHIP_FLOW_FUSED"); return e ? atoi(e) : 1; }();
+  if (fused && !c->gn->U2) {
+    HIPCHK(hipMalloc((void **)&c->gn->U2, c->gn->n2 * sizeof(double2)));
+    HIPCHK(hipMemsetAsync(c->gn->U2, 0, c->gn->n2 * sizeof(double2), c->stream));
+  }
   for (int s = 0; s < nsteps; s++)
     for (int st = 0; st < 3; st++) {
-      CHK(force_dev(c, cplaq, 1, cf[st], cpm[st], c2, kind));
-      ScopedTimer tm(c, "expupdate", c->stream);
-      k_exp_update<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P, 1.0);
-      HIPCHK(hipGetLastError());
+      if (fused) {
+        CHK(force_dev(c, cplaq, 1, cf[st], cpm[st], c2, kind, c->gn->U2));
+        std::swap(c->gn->U, c->gn->U2);
+      } else {
+        CHK(force_dev(c, cplaq, 1, cf[st], cpm[st], c2, kind));
+        ScopedTimer tm(c, "expupdate", c->stream);
+        k_exp_update<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P, 1.0);
+        HIPCHK(hipGetLastError());
+      }
     }
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
