@@ -120,6 +120,14 @@ class Staggered {
  public:
   Staggered(Context &c, const Field &g) : c_(c), nlinks_(4) { check(qexhip_stag_set_links(c.h, g.data(), nullptr)); }
   Staggered(Context &c, const Field &g, const Field &g3) : c_(c), nlinks_(8) { check(qexhip_stag_set_links(c.h, g.data(), g3.data())); }
+  struct FromHisq {};   // links = HisqCoefs.smear(g) built on the device (hisqLinks.nim:32-43)
+  struct FromNhyp { double alpha1, alpha2, alpha3; std::array<int, 4> antiperiodic{0, 0, 0, 1}; };   // rephase(nHYP(g))
+  Staggered(Context &c, const Field &g, FromHisq) : c_(c), nlinks_(8) { check(qexhip_stag_set_links_hisq(c.h, g.data())); }
+  Staggered(Context &c, const Field &g, const FromNhyp &h) : c_(c), nlinks_(4) {
+    check(qexhip_stag_set_links_nhyp(c.h, g.data(), h.alpha1, h.alpha2, h.alpha3, h.antiperiodic.data(), nullptr));
+  }
+  // storage format chosen for the links: 0 = 18 reals, 1 = 2 rows + sign, 2 = 2 rows + determinant
+  int linkFormat() const { int n = 0, f = 0; double d = 0; check(qexhip_stag_links_info(c_.h, &n, &f, &d)); return f; }
   void D(Field &r, const Field &x, double m) { check(qexhip_stag_D(c_.h, r.data(), x.data(), m, 1.0)); }
   void Ddag(Field &r, const Field &x, double m) { check(qexhip_stag_D(c_.h, r.data(), x.data(), m, -1.0)); }
   void eoReconstruct(Field &r, const Field &b, double m) { check(qexhip_stag_eo_reconstruct(c_.h, r.data(), b.data(), m)); }
@@ -148,6 +156,22 @@ class Staggered {
   void solve(Field &x, const Field &b, double m, double res) {
     SolverParams sp; sp.r2req = res * res; sp.maxits = 100000;
     solve(x, b, m, sp);
+  }
+  // n <= 4 independent solves on these links in lock-step (one stream of the links per sweep for all of them);
+  // per system the result of solve(x[j], b[j], m[j], sps[j])
+  void solveBatch(std::vector<Field> &xs, const std::vector<Field> &bs, const std::vector<double> &ms, std::vector<SolverParams> &sps) {
+    const int n = (int)xs.size();
+    std::vector<double *> xp; std::vector<const double *> bp; std::vector<double> rq, fin(n); std::vector<int> its(n);
+    int maxits = sps.at(0).maxits;
+    for (int j = 0; j < n; j++) { xp.push_back(xs[j].data()); bp.push_back(bs.at(j).data()); rq.push_back(sps.at(j).r2req); maxits = std::min(maxits, sps[j].maxits); }
+    auto t0 = std::chrono::steady_clock::now();
+    check(qexhip_stag_solve_batch(c_.h, n, xp.data(), bp.data(), ms.data(), rq.data(), maxits, its.data(), fin.data()));
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / n;
+    for (int j = 0; j < n; j++) {
+      SolverParams &sp = sps[j];
+      sp.seconds += dt; sp.calls += 1; sp.iterations += its[j]; sp.iterationsMax = std::max(sp.iterationsMax, its[j]);
+      sp.flops += flops(its[j]); sp.r2 = fin[j];
+    }
   }
   // multi-mass Staggered.solve(xs, b, ms, sp) (stagSolve.nim:347-446)
   void solve(std::vector<Field> &xs, const Field &b, const std::vector<double> &ms, SolverParams &sp) {
@@ -182,6 +206,38 @@ inline void gaugeFlow(Context &c, Field &g, int steps, double eps) {
   check(qexhip_gauge_set(c.h, g.data()));
   check(qexhip_wflow(c.h, steps, eps));
   check(qexhip_gauge_get(c.h, g.data()));
+}
+
+// HypCoefs (hypsmear.nim:15-18): smear, and smearGetForce as an object holding the device-resident closure
+struct HypCoefs {
+  double alpha1 = 0.4, alpha2 = 0.5, alpha3 = 0.5;
+  void smear(Context &c, const Field &g, Field &fl) const { check(qexhip_nhyp_smear(c.h, g.data(), fl.data(), alpha1, alpha2, alpha3)); }
+  class SmearedForce {
+    Context &c_;
+   public:
+    SmearedForce(Context &c, const HypCoefs &h, const Field &g, Field *fl) : c_(c) {
+      check(qexhip_nhyp_prepare(c.h, g.data(), h.alpha1, h.alpha2, h.alpha3, fl ? fl->data() : nullptr));
+    }
+    ~SmearedForce() { qexhip_nhyp_release(c_.h); }
+    SmearedForce(const SmearedForce &) = delete;
+    void operator()(Field &f, const Field &chain) { check(qexhip_nhyp_force(c_.h, f.data(), chain.data())); }   // smearedForce(f, chain)
+    void gforce(Field &f, double plaq, double rect = 0, double adjplaq = 0) { check(qexhip_nhyp_gauge_force(c_.h, f.data(), plaq, rect, adjplaq)); }
+    void fforce(Field &f, const std::vector<Field> &psi, const std::vector<double> &scale, const std::array<int, 4> &antiperiodic = {0, 0, 0, 1}) {
+      std::vector<const double *> p;
+      for (auto &v : psi) p.push_back(v.data());
+      check(qexhip_nhyp_fermion_force(c_.h, f.data(), p.data(), scale.data(), (int)p.size(), antiperiodic.data(), nullptr));
+    }
+  };
+};
+// HisqCoefs.smear(g, fl, ll) (hisqLinks.nim:32-43)
+inline void hisqSmear(Context &c, const Field &g, Field &fl, Field &ll) { check(qexhip_hisq_smear(c.h, g.data(), fl.data(), ll.data())); }
+// loadGauge / saveGauge (gaugeUtils.nim:87-122)
+inline void saveGauge(const Layout &lo, const Field &g, const std::string &fn, char prec = 'D') {
+  check(qexhip_io_write_gauge(fn.c_str(), lo.physGeom.data(), g.data(), prec, nullptr, nullptr));
+}
+inline void loadGauge(const Layout &lo, Field &g, const std::string &fn) {
+  unsigned a = 0, b = 0;
+  check(qexhip_io_read_gauge(fn.c_str(), lo.physGeom.data(), g.data(), &a, &b));
 }
 
 // field algebra used by the reference's tests (fieldET.nim:605-625)

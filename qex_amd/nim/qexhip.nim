@@ -38,6 +38,27 @@ proc qexhip_wflow(h: QexhipHandle; nsteps: cint; eps: cdouble): cint {.qh.}
 proc qexhip_gauge_set(h: QexhipHandle; g: ptr cdouble): cint {.qh.}
 proc qexhip_gauge_get(h: QexhipHandle; g: ptr cdouble): cint {.qh.}
 proc qexhip_plaq(h: QexhipHandle; o: ptr cdouble): cint {.qh.}
+# the HMC-side entry points (INTEGRATION.md 5b): smearing closure, MD forces, batched solves, gauge-sector pieces
+proc qexhip_stag_solve(h: QexhipHandle; x, b: ptr cdouble; mass, r2req: cdouble; maxits: cint;
+                       iters: ptr cint; r2: ptr cdouble): cint {.qh.}
+proc qexhip_stag_solve_batch(h: QexhipHandle; n: cint; x, b: ptr ptr cdouble; mass, r2req: ptr cdouble;
+                             maxits: cint; iters: ptr cint; r2: ptr cdouble): cint {.qh.}
+proc qexhip_stag_set_links_nhyp(h: QexhipHandle; g: ptr cdouble; a1, a2, a3: cdouble;
+                                antiperiodic, phases: ptr cint): cint {.qh.}
+proc qexhip_stag_set_links_hisq(h: QexhipHandle; g: ptr cdouble): cint {.qh.}
+proc qexhip_nhyp_prepare(h: QexhipHandle; g: ptr cdouble; a1, a2, a3: cdouble; fl: ptr cdouble): cint {.qh.}
+proc qexhip_nhyp_force(h: QexhipHandle; f, chain: ptr cdouble): cint {.qh.}
+proc qexhip_nhyp_gauge_force(h: QexhipHandle; f: ptr cdouble; cplaq, crect, cadjplaq: cdouble): cint {.qh.}
+proc qexhip_nhyp_fermion_force(h: QexhipHandle; f: ptr cdouble; psi: ptr ptr cdouble; scale: ptr cdouble;
+                               n: cint; antiperiodic, phases: ptr cint): cint {.qh.}
+proc qexhip_nhyp_release(h: QexhipHandle): cint {.qh.}
+proc qexhip_gauge_action(h: QexhipHandle; cplaq, crect, cadjplaq: cdouble; o: ptr cdouble): cint {.qh.}
+proc qexhip_gauge_update(h: QexhipHandle; p: ptr cdouble; t: cdouble): cint {.qh.}
+proc qexhip_gauge_reunit(h: QexhipHandle): cint {.qh.}
+proc qexhip_wline(h: QexhipHandle; path: ptr cint; n: cint; o: ptr cdouble): cint {.qh.}
+proc qexhip_flow_EQ(h: QexhipHandle; loop: cint; o: ptr cdouble): cint {.qh.}
+proc qexhip_io_read_gauge(path: cstring; lat: ptr cint; g: ptr cdouble; suma, sumb: ptr cuint): cint {.qh.}
+proc qexhip_io_write_gauge(path: cstring; lat: ptr cint; g: ptr cdouble; prec: cchar; fileMd, recMd: cstring): cint {.qh.}
 
 template chk(e: untyped) =
   ## libqexhip reports errors by return code; QEX aborts (base/qexInternal.nim:37-45)

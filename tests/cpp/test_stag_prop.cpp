@@ -121,6 +121,53 @@ int main() {
     CHECK(std::abs(its - spe.iterations) <= 1 && dev100 < 1e-10 && dev < 0.1, "CG residual history vs CPU path");
   }
 
+  // --- the HMC-side pieces: nHYP closure (hypsmear.nim:49-247), links from smeared fields, batched solves, file I/O
+  {
+    Field gw = lo.newGauge(), sg = lo.newGauge(), sgo = lo.newGauge(), f = lo.newGauge(), fo = lo.newGauge(), chain = lo.newGauge();
+    qo_rngfield *rf2 = qo_rngfield_new(olo, QO_RNG_MILC6, 77ull);
+    qo_gauge_warm(olo, rf2, 0.5, gw.data());
+    qo_gauge_random_tah(olo, rf2, chain.data());
+    HypCoefs hc;                                          // 0.4, 0.5, 0.5
+    {
+      HypCoefs::SmearedForce sf(ctx, hc, gw, &sg);
+      sf(f, chain);
+    }
+    qo_nhyp_force(olo, gw.data(), sgo.data(), fo.data(), chain.data(), 0.4, 0.5, 0.5);
+    printf("nHYP: smeared links rel err %g, force chain rel err %g\n", relerr(sg, sgo), relerr(f, fo));
+    CHECK(relerr(sg, sgo) < 1e-12 && relerr(f, fo) < 1e-11, "nHYP smearing / force chain vs oracle");
+    // operator on device-smeared links; thin warm links are stored compressed, the U(3) ones with their determinant
+    Staggered sn(ctx, gw, Staggered::FromNhyp{0.4, 0.5, 0.5});
+    CHECK(sn.linkFormat() == 2, "nHYP links use the 2 rows + determinant format");
+    qo_setBC(olo, sgo.data());
+    const int ph2[4] = {8, 9, 11, 0};
+    qo_stagPhase(olo, sgo.data(), ph2);
+    Field b1 = lo.ColorVector(), b2 = lo.ColorVector(), y = lo.ColorVector(), yo = lo.ColorVector();
+    qo_vector_gaussian(olo, rf2, b1.data());
+    qo_vector_gaussian(olo, rf2, b2.data());
+    sn.D(y, b1, 0.05);
+    qo_D(olo, sgo.data(), nullptr, yo.data(), b1.data(), 0.05);
+    CHECK(relerr(y, yo) < 1e-12, "D on device-smeared links");
+    // two systems in lock-step == the same two solved one after the other
+    std::vector<Field> xs(2, lo.ColorVector()), bs{b1, b2};
+    std::vector<SolverParams> sps(2);
+    for (auto &p : sps) { p.r2req = 1e-20; p.maxits = 100000; }
+    sn.solveBatch(xs, bs, {0.1, 0.2}, sps);
+    for (int j = 0; j < 2; j++) {
+      SolverParams s1; s1.r2req = 1e-20; s1.maxits = 100000;
+      Field x1 = lo.ColorVector();
+      sn.solve(x1, bs[j], j ? 0.2 : 0.1, s1);
+      CHECK(s1.iterations == sps[j].iterations && relerr(xs[j], x1) < 1e-13, "batched solve equals the single solve");
+    }
+    // SciDAC file round trip
+    const std::string fn = "/tmp/qexhip_cpp_test.lime";
+    saveGauge(lo, gw, fn);
+    Field gr = lo.newGauge();
+    loadGauge(lo, gr, fn);
+    CHECK(gr == gw, "saveGauge / loadGauge round trip");
+    std::remove(fn.c_str());
+    qo_rngfield_free(rf2);
+  }
+
   // --- error behaviour: bad arguments raise, non-convergence does not
   {
     SolverParams sp2;
