@@ -211,6 +211,28 @@ def main():
                 "frac_streamed": round(streamed_gbs / HBM_PEAK_GBS, 4),
             },
         }
+        if N == 1 and not args.halo:
+            # three systems (the Hasenbusch chain 0.1 / 0.2 / 0.4 of tests/extra/staghmc_sh) in lock-step on the same
+            # links: the links are streamed once per sweep for all of them (csrc/batch.hip); host fields, so the
+            # figure is taken from the kernel timers of the iterations, not from the wall clock (PCIe in and out)
+            ms3 = [0.1, 0.2, 0.4]
+            bs3 = [b] + [q.synthetic_gaussian_vector(lo, seed=977 + k) for k in range(2)]
+            xs3 = [np.zeros_like(v) for v in bs3]
+            kb = max(args.steps // 4, 10)
+            s.solveXX_batch(xs3, bs3, ms3, 0.0, 5, True)
+            ctx.timers_enable(1)
+            ctx.timers_reset()
+            s.solveXX_batch(xs3, bs3, ms3, 0.0, kb, True)
+            nd3, msd3 = ctx.timer("dslash_batch")
+            _, msb3 = ctx.timer("blas")
+            _, msr3 = ctx.timer("reduce")
+            ctx.timers_enable(0)
+            per = (msd3 + msb3 + msr3) / kb / 3.0           # ms per system-iteration (kernel time)
+            out["batched_cg_3_systems"] = {
+                "us_per_system_iteration": round(per * 1e3, 2), "cg_iters_per_s_per_system_kernel_time": round(1e3 / per / 1.0, 1),
+                "sweep_us": round(1e3 * msd3 / max(nd3, 1), 2),
+                "note": "kernel time of the lock-step iteration / 3; compare ms_per_step",
+            }
         if N == 1 and compressed and not args.halo:
             # the same workload with link compression switched off (all 18 reals streamed)
             ctx.set_option("recon", 0)
@@ -224,6 +246,7 @@ def main():
                 "roofline_frac": round(b_alg / (ms2 / max(n2, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             }
             ctx.set_option("recon", 2)
+            s = q.newStag3(ctx, g, g3) if args.naik else q.newStag(ctx, g)     # back to the default format
         if N == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(lat_loc, g, g3 if args.naik else None, b, args.mass, args.cpu_seconds)
     barrier()
