@@ -264,6 +264,12 @@ int qexhip_nhyp_release(qexhip_handle h);
  *            (psi_k full-volume vectors, host), f.rephase (setBC_cust + stagPhase), odd sites *= -1,
  *            smearedForce, projTAH(gf) = TAH(f g^+).  antiperiodic / phases as qexhip_stag_set_links_nhyp. */
 int qexhip_nhyp_gauge_force(qexhip_handle h, double *f, double cplaq, double crect, double cadjplaq);
+/*   fforce, solves included (src/examples/staghmc_sh.nim:387-427): psi_k = D(mass[k])^-1 phi_k for the n pseudofermion
+ *            fields (Staggered.solve semantics, lock-step batches of four on the operator's CURRENT links -- set them
+ *            from this closure first: qexhip_stag_set_links_nhyp(h, NULL, ...)), then the fermion force above with
+ *            scale[k] = fscale(k, i, t).  Solutions never leave the GPU; iters[k] (nullable) = iterations of system k. */
+int qexhip_nhyp_fforce(qexhip_handle h, double *f, int n, const double *const *phi, const double *mass, const double *scale,
+                       const double *r2req, int maxits, const int antiperiodic[4], const int phases[4], int *iters);
 int qexhip_nhyp_fermion_force(qexhip_handle h, double *f, const double *const *psi, const double *scale, int n,
                               const int antiperiodic[4], const int phases[4]);
 

@@ -67,6 +67,7 @@ SYMBOLS = [
     ("qexhip_nhyp_prepare", _ci, [_vp, _vp, _cd, _cd, _cd, _vp]),
     ("qexhip_nhyp_force", _ci, [_vp, _vp, _vp]),
     ("qexhip_nhyp_release", _ci, [_vp]),
+    ("qexhip_nhyp_fforce", _ci, [_vp, _vp, _ci, _vp, _vp, _vp, _vp, _ci, _pi, _pi, _pi]),
     ("qexhip_nhyp_gauge_force", _ci, [_vp, _vp, _cd, _cd, _cd]),
     ("qexhip_nhyp_fermion_force", _ci, [_vp, _vp, _vp, _vp, _ci, _pi, _pi]),
     ("qexhip_gauge_action", _ci, [_vp, _cd, _cd, _cd, _vp]),

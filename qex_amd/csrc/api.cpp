@@ -533,6 +533,16 @@ extern "C" int qexhip_nhyp_fermion_force(qexhip_handle c, double *f, const doubl
   for (int mu = 0; mu < 4; mu++) if (antiperiodic ? antiperiodic[mu] : (mu == 3)) mask |= 1 << mu;
   return nhyp_fermion_force(c, f, psi, scale, n, mask, phases ? phases : defph);
 }
+extern "C" int qexhip_nhyp_fforce(qexhip_handle c, double *f, int n, const double *const *phi, const double *mass,
+                                  const double *scale, const double *r2req, int maxits, const int antiperiodic[4],
+                                  const int phases[4], int *iters) {
+  if (!c || !f || !phi || !mass || !scale || !r2req) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  static const int defph[4] = {8, 9, 11, 0};
+  int mask = 0;
+  for (int mu = 0; mu < 4; mu++) if (antiperiodic ? antiperiodic[mu] : (mu == 3)) mask |= 1 << mu;
+  return nhyp_fforce(c, f, n, phi, mass, scale, r2req, maxits, mask, phases ? phases : defph, iters);
+}
 extern "C" int qexhip_nhyp_release(qexhip_handle c) {
   if (!c) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));

@@ -462,22 +462,27 @@ int solve_full_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const
   return 0;
 }
 
-// host-field entry points
-int solve_batch_host(qexhip_ctx *c, int n, double *const *x, const double *const *b, const double *mass,
-                     const double *r2req, int maxits, int xx_parity, int *iters, double *r2) {
+// device fields for the systems' sources and solutions (slots of the batch state)
+int batch_io_fields(qexhip_ctx *c, int n, DevField **xs, DevField **bs) {
   if (n < 1 || n > QX_MAXRHS) { qexhip_set_error("batch solve: 1 <= n <= %d", QX_MAXRHS); return -1; }
   BatchState *B = (BatchState *)c->batch;
   if (!B) { B = new BatchState(); c->batch = B; }
-  while ((int)B->f.size() < 9 * QX_MAXRHS) {     // + x, b per system
+  while ((int)B->f.size() < 9 * QX_MAXRHS) {     // 4 CG fields + r, y, d + x, b per system
     DevField nf;
     CHK(field_alloc(c, nf));
     B->f.push_back(nf);
   }
+  for (int j = 0; j < n; j++) { xs[j] = &B->f[7 * QX_MAXRHS + 2 * j]; bs[j] = &B->f[7 * QX_MAXRHS + 2 * j + 1]; }
+  return 0;
+}
+
+// host-field entry points
+int solve_batch_host(qexhip_ctx *c, int n, double *const *x, const double *const *b, const double *mass,
+                     const double *r2req, int maxits, int xx_parity, int *iters, double *r2) {
+  if (n < 1 || n > QX_MAXRHS) { qexhip_set_error("batch solve: 1 <= n <= %d", QX_MAXRHS); return -1; }
   DevField *xs[QX_MAXRHS], *bs[QX_MAXRHS];
-  for (int j = 0; j < n; j++) {
-    xs[j] = &B->f[7 * QX_MAXRHS + 2 * j]; bs[j] = &B->f[7 * QX_MAXRHS + 2 * j + 1];
-    CHK(field_upload(c, *bs[j], b[j]));
-  }
+  CHK(batch_io_fields(c, n, xs, bs));
+  for (int j = 0; j < n; j++) CHK(field_upload(c, *bs[j], b[j]));
   if (xx_parity >= 0) CHK(solve_xx_batch_dev(c, n, xs, bs, mass, r2req, maxits, xx_parity, iters, r2));
   else CHK(solve_full_batch_dev(c, n, xs, bs, mass, r2req, maxits, iters, r2));
   for (int j = 0; j < n; j++) CHK(field_download(c, *xs[j], x[j]));

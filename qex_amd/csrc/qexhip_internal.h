@@ -142,6 +142,11 @@ int links_from_natural(qexhip_ctx *c, const double2 *fat, const double2 *lng);
 int links_compress(qexhip_ctx *c);
 int op_eo_reconstruct_pub(qexhip_ctx *c, DevField &r, DevField &b, double m);
 void batch_state_free(qexhip_ctx *c);
+int batch_io_fields(qexhip_ctx *c, int n, DevField **xs, DevField **bs);
+int solve_full_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const double *mass, const double *r2req,
+                         int maxits, int *iters, double *r2_final);
+int nhyp_fforce(qexhip_ctx *c, double *f_host, int n, const double *const *phi, const double *mass, const double *scale,
+                const double *r2req, int maxits, int bcmask, const int ph[4], int *iters);
 int solve_batch_host(qexhip_ctx *c, int n, double *const *x, const double *const *b, const double *mass,
                      const double *r2req, int maxits, int xx_parity, int *iters, double *r2);
 

@@ -16,6 +16,7 @@
 #include "qexhip_internal.h"
 #include "su3.h"
 #include <cmath>
+#include <algorithm>
 
 struct MView {        // read-only matrix field view
   const double2 *p;
@@ -670,6 +671,28 @@ int nhyp_fermion_force(qexhip_ctx *c, double *f_host, const double *const *psi, 
   for (int k = 0; k < n; k++) {
     CHK(field_upload(c, *fx, psi[k]));
     CHK(stag_outer_dev(c, *fx, st->F, scale[k], -scale[k], k > 0));
+  }
+  k_rephase<<<st->S.nb(), 256, 0, c->stream>>>(st->S.g, st->F, bcmask, ph[0], ph[1], ph[2], ph[3]);
+  HIPCHK(hipGetLastError());
+  return nhyp_finish(c, st, 0, f_host);
+}
+
+// the whole fforce (src/examples/staghmc_sh.nim:387-427, src/stagg_pv_hmc/staghmc_spv.nim:758-865) on the device:
+// solve D(m_k) psi_k = phi_k for the n fields (lock-step batches of four on the operator's current links, which
+// the caller has set from this closure: qexhip_stag_set_links_nhyp(g = NULL)), outer products straight from the
+// device solutions, rephase, chain, TAH.  Only phi goes in and f comes out over PCIe.
+int nhyp_fforce(qexhip_ctx *c, double *f_host, int n, const double *const *phi, const double *mass, const double *scale,
+                const double *r2req, int maxits, int bcmask, const int ph[4], int *iters) {
+  NhypState *st = (NhypState *)c->nhyp;
+  if (!st) { qexhip_set_error("nhyp_fforce: call qexhip_nhyp_prepare first (smearGetForce)"); return -1; }
+  if (n < 1) { qexhip_set_error("nhyp_fforce: n < 1"); return -1; }
+  for (int k0 = 0; k0 < n; k0 += 4) {
+    const int k = std::min(4, n - k0);
+    DevField *xs[4], *bs[4];
+    CHK(batch_io_fields(c, k, xs, bs));
+    for (int j = 0; j < k; j++) CHK(field_upload(c, *bs[j], phi[k0 + j]));
+    CHK(solve_full_batch_dev(c, k, xs, bs, mass + k0, r2req + k0, maxits, iters ? iters + k0 : nullptr, nullptr));
+    for (int j = 0; j < k; j++) CHK(stag_outer_dev(c, *xs[j], st->F, scale[k0 + j], -scale[k0 + j], (k0 + j) > 0));
   }
   k_rephase<<<st->S.nb(), 256, 0, c->stream>>>(st->S.g, st->F, bcmask, ph[0], ph[1], ph[2], ph[3]);
   HIPCHK(hipGetLastError());

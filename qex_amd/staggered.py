@@ -465,7 +465,20 @@ class HypCoefs:
             ap = (C.c_int * 4)(*[1 if ch == "a" else 0 for ch in bc])
             check(lib().qexhip_nhyp_fermion_force(ctx._h, _p(f), arr, sc, n, ap, None))
 
-        smearedForce.gforce, smearedForce.fforce = gforce, fforce
+        def fforce_solve(f, phis, masses, scales, r2req, maxits=1000000, bc="aaaa"):
+            """the whole fforce incl. its solves (staghmc_sh.nim:387-427) on the operator's current links
+            (build them from this closure: Staggered(ctx, None, smear=...)); returns the iteration counts"""
+            n = len(phis)
+            arr = (C.c_void_p * n)(*[p.ctypes.data for p in phis])
+            ms = (C.c_double * n)(*[float(v) for v in masses])
+            sc = (C.c_double * n)(*[float(v) for v in scales])
+            rq = (C.c_double * n)(*([float(r2req)] * n if np.isscalar(r2req) else [float(v) for v in r2req]))
+            ap = (C.c_int * 4)(*[1 if ch == "a" else 0 for ch in bc])
+            its = (C.c_int * n)()
+            check(lib().qexhip_nhyp_fforce(ctx._h, _p(f), n, arr, ms, sc, rq, int(maxits), ap, None, its))
+            return list(its)
+
+        smearedForce.gforce, smearedForce.fforce, smearedForce.fforce_solve = gforce, fforce, fforce_solve
         smearedForce.release = lambda: check(lib().qexhip_nhyp_release(ctx._h))
         return smearedForce
 

@@ -218,6 +218,12 @@ class Replay:
     def fforce(self, h, g, ix, ts):
         """fields = the force solves (:394-404); scales = fscale(k, i, ts[j])"""
         be = self.be
+        if hasattr(be, "fforce_solve"):               # solves + outer products + chain in one call
+            f, its = be.fforce_solve(h, g, [self.phi[j] for j in ix], [self._m(j) for j in ix],
+                                     [self.fscale(j, ts[j]) for j in ix])
+            for j, n in zip(ix, its):
+                self.stats["force_iters"][j].append(n)
+            return f
         fields, scales = [], []
         for j, (x, its) in zip(ix, be.solve_many(h, [self.phi[j] for j in ix], [self._m(j) for j in ix])):
             self.stats["force_iters"][j].append(its)
@@ -410,6 +416,11 @@ class HipBackend:
         f = np.zeros_like(g)
         h["sf"].fforce(f, fields, scales, bc="pppa")
         return f
+
+    def fforce_solve(self, h, g, phis, masses, scales):
+        f = np.zeros_like(g)
+        its = h["sf"].fforce_solve(f, phis, masses, scales, RSQ, bc="pppa")
+        return f, its
 
     def plaq(self, g):
         return self.q.plaq(self.ctx, g)

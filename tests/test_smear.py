@@ -245,6 +245,24 @@ def test_gpu_nhyp_md_forces(oracle):
         _, ref = o.nhyp_force(lo, g, ref, 0.4, 0.5, 0.5)
         o.force_projTAH(lo, ref, g, adj=False)
         assert np.linalg.norm(f - ref) / np.linalg.norm(ref) < 1e-11
+        if bc == "pppa":
+            # fforce incl. its solves in one call == solve each field, then fforce (staghmc_sh.nim:387-427)
+            s_op = q.Staggered(ctx, None, smear=q.HypCoefs(0.4, 0.5, 0.5), bc=bc)      # links from the closure
+            phis = [p.copy() for p in psis]
+            for p in phis:
+                p[lo.vol // 2:] = 0
+            f1 = np.zeros_like(g)
+            its = sf.fforce_solve(f1, phis, [0.1, 0.2], scales, 1e-20, bc=bc)
+            sols = []
+            for p, m in zip(phis, [0.1, 0.2]):
+                x = np.zeros_like(p)
+                sp = q.SolverParams(r2req=1e-20, maxits=100000, verbosity=0)
+                s_op.solve(x, p, m, sp)
+                sols.append(x)
+                assert sp.iterations == its[len(sols) - 1]
+            f2 = np.zeros_like(g)
+            sf.fforce(f2, sols, scales, bc=bc)
+            assert np.linalg.norm(f1 - f2) / np.linalg.norm(f2) < 1e-13
         # the force is in the algebra
         fc = cx(f)
         assert np.abs(fc + np.conj(np.swapaxes(fc, -1, -2))).max() < 1e-12
