@@ -47,8 +47,12 @@ __device__ __forceinline__ void shift_sm(const Geom &g, const int x[4], int mu, 
   y[mu] = v >= g.X[mu] ? v - g.X[mu] : (v < 0 ? v + g.X[mu] : v);
 }
 
-// staple field (optional) and acc += coef * staple (optional)
-__global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, int swz) {
+// staple field (optional) and acc (+)= coef * staple (optional).  Two fusions for the nHYP levels
+// (hypsmear.nim:98-143): with `init` the accumulator STARTS as cinit * init(x) instead of being read
+// (the `l := ma * g[mu]` assignment), with `proj` the finished sum is also projected, proj(x) = projectU(acc(x))
+// (the `l.proj lx` that follows the last staple of a level).
+__global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, int swz,
+                                                    MView init, double cinit, MViewW proj) {
   int bid = blockIdx.x;
   if (swz && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // contiguous site range per XCD
   int i = bid * 256 + threadIdx.x;
@@ -69,9 +73,17 @@ __global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, in
   if (st.p) m3_store(st.p + site_off(g, x, st.tstride), 64, s);
   if (acc.p) {
     double2 *a = acc.p + site_off(g, x, acc.tstride);
-    M3 o = m3_load(a, 64);
+    M3 o;
+    if (init.p) {
+      o = m3_load(init.p + site_off(g, x, init.tstride), 64);
+#pragma unroll
+      for (int k = 0; k < 9; k++) { o.e[k].x *= cinit; o.e[k].y *= cinit; }
+    } else {
+      o = m3_load(a, 64);
+    }
     m3_axpy(o, coef, s);
     m3_store(a, 64, o);
+    if (proj.p) m3_store(proj.p + site_off(g, x, proj.tstride), 64, m3_projectU(o));
   }
 }
 // dst = coef * src
@@ -149,8 +161,11 @@ __device__ __forceinline__ M3 m3_projectUderiv(const M3 &u, const M3 &x, const M
   for (int k = 0; k < 9; k++) r.e[k] = csub(r.e[k], xt.e[k]);
   return r;
 }
-// dst = projectUderiv(U or projectU(X), X, C); dst may alias C
-__global__ void __launch_bounds__(256) k_projUderiv(Geom g, MViewW dst, MView U, MView X, MView C) {
+// r = projectUderiv(U or projectU(X), X, C);  f (=|+=) ma * r;  dst = alp * r      (dst may alias C)
+// -- the projection's chain rule fused with the bookkeeping that follows it at every level
+// (hypsmear.nim:166-173,196-205,224-233: `f[mu] += ma*fl; fl *= alp`)
+__global__ void __launch_bounds__(256) k_projUderiv(Geom g, MViewW dst, MView U, MView X, MView C, MViewW f, double ma, double alp,
+                                                    int accumulate) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= g.V) return;
   const int p = i >= g.Vh, c = i - p * g.Vh;
@@ -159,28 +174,20 @@ __global__ void __launch_bounds__(256) k_projUderiv(Geom g, MViewW dst, MView U,
   const M3 x = m3_load(X.p + t * X.tstride + l, 64);
   const M3 u = U.p ? m3_load(U.p + t * U.tstride + l, 64) : m3_projectU(x);
   const M3 ch = m3_load(C.p + t * C.tstride + l, 64);
-  m3_store(dst.p + t * dst.tstride + l, 64, m3_projectUderiv(u, x, ch));
-}
-// f (=|+=) ma * src ; src *= alp       (hypsmear.nim:171-173,201-205,229-233)
-__global__ void __launch_bounds__(256) k_acc_scale(Geom g, MViewW f, double ma, MViewW src, double alp, int accumulate) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= g.V) return;
-  const int p = i >= g.Vh, c = i - p * g.Vh;
-  const size_t t = (size_t)p * g.ntile + (c >> 6);
-  const int l = c & 63;
-  M3 s = m3_load(src.p + t * src.tstride + l, 64);
+  M3 r = m3_projectUderiv(u, x, ch);
   M3 o = accumulate ? m3_load(f.p + t * f.tstride + l, 64) : m3_zero();
-  m3_axpy(o, ma, s);
+  m3_axpy(o, ma, r);
   m3_store(f.p + t * f.tstride + l, 64, o);
 #pragma unroll
-  for (int k = 0; k < 9; k++) { s.e[k].x *= alp; s.e[k].y *= alp; }
-  m3_store(src.p + t * src.tstride + l, 64, s);
+  for (int k = 0; k < 9; k++) { r.e[k].x *= alp; r.e[k].y *= alp; }
+  m3_store(dst.p + t * dst.tstride + l, 64, r);
 }
 // symStapleDeriv (smearutil.nim:22-50) gathered per site:
 //   f1(x) += g2(x) g1(x+mu) c(x+nu)^+ + c(x) g1(x+mu) g2(x+nu)^+ + [g2^+ g1 c(+nu) + c^+ g1 g2(+nu)](x-mu)
 //   f2(x) += g1(x) c(x+nu) g1(x+mu)^+ + [g1^+ c g1(+mu)](x-nu)
 template <int PART>   // 0: f1 and f2, 1: f1 only, 2: f2 only
-__global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu, int swz) {
+__global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu, int swz,
+                                                      int z1, int z2) {   // z1 / z2: f1 / f2 start from zero (first contribution)
   int bid = blockIdx.x;
   if (swz && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // contiguous site range per XCD
   int i = bid * 256 + threadIdx.x;
@@ -197,7 +204,7 @@ __global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW 
   const size_t o0 = ((size_t)p * g.ntile + (c >> 6));
   const int l = c & 63;
   if (PART != 2) {
-    M3 a = m3_load(f1.p + o0 * f1.tstride + l, 64);
+    M3 a = z1 ? m3_zero() : m3_load(f1.p + o0 * f1.tstride + l, 64);
     {
       const M3 g1pm = m3_load(g1.p + site_off(g, xpm, g1.tstride), 64);
       M3 t = m3_mul_na(g1pm, m3_load(cf.p + site_off(g, xpn, cf.tstride), 64));
@@ -215,7 +222,7 @@ __global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW 
     m3_store(f1.p + o0 * f1.tstride + l, 64, a);
   }
   if (PART != 1) {
-    M3 a = m3_load(f2.p + o0 * f2.tstride + l, 64);
+    M3 a = z2 ? m3_zero() : m3_load(f2.p + o0 * f2.tstride + l, 64);
     M3 t = m3_mul_na(m3_load(cf.p + site_off(g, xpn, cf.tstride), 64), m3_load(g1.p + site_off(g, xpm, g1.tstride), 64));
     m3_mac(a, m3_load(g1.p + o0 * g1.tstride + l, 64), t);
     t = m3_mul(m3_load(cf.p + site_off(g, xmn, cf.tstride), 64), m3_load(g1.p + site_off(g, xmnpm, g1.tstride), 64));
@@ -309,10 +316,11 @@ struct Smear {
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
   }
-  int staple(MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef) {
+  int staple(MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, MView init = MView{nullptr, 0}, double cinit = 0.0,
+             MViewW proj = MViewW{nullptr, 0}) {
     ScopedTimer tm(c, "smear", c->stream);
     static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
-    k_gen_staple<<<nb(), 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz);
+    k_gen_staple<<<nb(), 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -385,36 +393,35 @@ struct Smear {
     if (keep && !reuse) CHK(alloc(&K.flx, gsz));
     const double alp1 = a1 / 2.0, alp2 = a2 / 4.0, alp3 = a3 / 6.0;
     const MViewW none{nullptr, 0};
-    const int nblk = nb();
+    const MView noinit{nullptr, 0};
+    // every level: first staple starts the sum from ma * U_mu, last staple projects it (fused, see k_gen_staple)
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
-        k_mscale<<<nblk, 256, 0, c->stream>>>(g, fvw(K.l1x[mu][nu]), 1 - a1, gv(G, mu));
-        CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(K.l1x[mu][nu]), alp1));
-        k_projectU<<<nblk, 256, 0, c->stream>>>(g, fvw(K.l1[mu][nu]), fv(K.l1x[mu][nu]));
-        HIPCHK(hipGetLastError());
+        CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(K.l1x[mu][nu]), alp1, gv(G, mu), 1 - a1, fvw(K.l1[mu][nu])));
       }
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
-        k_mscale<<<nblk, 256, 0, c->stream>>>(g, fvw(K.l2x[mu][nu]), 1 - a2, gv(G, mu));
+        int cnt = 0;
         for (int a = 0; a < 4; a++) {
           if (a == mu || a == nu) continue;
           const int b = 6 - mu - nu - a;
-          CHK(staple(fv(K.l1[a][b]), fv(K.l1[mu][b]), mu, a, none, fvw(K.l2x[mu][nu]), alp2));
+          const bool first = cnt == 0, last = cnt == 1;
+          CHK(staple(fv(K.l1[a][b]), fv(K.l1[mu][b]), mu, a, none, fvw(K.l2x[mu][nu]), alp2, first ? gv(G, mu) : noinit, 1 - a2,
+                     last ? fvw(K.l2[mu][nu]) : none));
+          cnt++;
         }
-        k_projectU<<<nblk, 256, 0, c->stream>>>(g, fvw(K.l2[mu][nu]), fv(K.l2x[mu][nu]));
-        HIPCHK(hipGetLastError());
       }
     for (int mu = 0; mu < 4; mu++) {
       const MViewW x3 = keep ? gvw(K.flx, mu) : fvw(tmp);
-      k_mscale<<<nblk, 256, 0, c->stream>>>(g, x3, 1 - a3, gv(G, mu));
+      int cnt = 0;
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
-        CHK(staple(fv(K.l2[nu][mu]), fv(K.l2[mu][nu]), mu, nu, none, x3, alp3));
+        CHK(staple(fv(K.l2[nu][mu]), fv(K.l2[mu][nu]), mu, nu, none, x3, alp3, cnt == 0 ? gv(G, mu) : noinit, 1 - a3,
+                   cnt == 2 ? gvw(FL, mu) : none));
+        cnt++;
       }
-      k_projectU<<<nblk, 256, 0, c->stream>>>(g, gvw(FL, mu), MView{x3.p, x3.tstride});
-      HIPCHK(hipGetLastError());
     }
     return 0;
   }
@@ -458,16 +465,17 @@ int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, doub
   return 0;
 }
 // smearedForce(f, chain) on the device field st->F (in: chain, out: f)   (hypsmear.nim:146-245)
-static int staple_deriv(qexhip_ctx *c, const Geom &g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu) {
+static int staple_deriv(qexhip_ctx *c, const Geom &g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu,
+                        int z1 = 0, int z2 = 0) {
   // QEXHIP_SDERIV = 10*swizzle + variant (variant 1: f1 and f2 in separate launches); default 10
   static const int sel = [] { const char *e = getenv("QEXHIP_SDERIV"); return e ? atoi(e) : 10; }();
   const int variant = sel % 10, swz = sel / 10;
   const int nblk = (g.V + 255) / 256;
   if (variant == 0) {
-    k_staple_deriv<0><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz);
+    k_staple_deriv<0><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2);
   } else {
-    k_staple_deriv<1><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz);
-    k_staple_deriv<2><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz);
+    k_staple_deriv<1><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2);
+    k_staple_deriv<2><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -480,29 +488,26 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
   const double ma1 = 1 - st->a1, ma2 = 1 - st->a2, ma3 = 1 - st->a3;
   const MView noU{nullptr, 0};
   ScopedTimer tm(c, "nhyp_force", c->stream);
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++)
-      if (mu != nu) {
-        HIPCHK(hipMemsetAsync(st->fl1[mu][nu], 0, S.fsz * sizeof(double2), c->stream));
-        HIPCHK(hipMemsetAsync(st->fl2[mu][nu], 0, S.fsz * sizeof(double2), c->stream));
-      }
+  // fl1 / fl2 are sums of several staple derivatives: the first contribution to each writes, the rest accumulate
+  bool t1[4][4] = {}, t2[4][4] = {};
   for (int mu = 0; mu < 4; mu++) {
-    k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->fc, mu), noU, S.gv(st->K.flx, mu), S.gv(st->F, mu));
-    k_acc_scale<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->F, mu), ma3, S.gvw(st->fc, mu), alp3, 0);
+    k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->fc, mu), noU, S.gv(st->K.flx, mu), S.gv(st->F, mu),
+                                              S.gvw(st->F, mu), ma3, alp3, 0);
   }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
     for (int nu = 0; nu < 4; nu++) {
       if (nu == mu) continue;
-      CHK(staple_deriv(c, g, S.fvw(st->fl2[nu][mu]), S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[nu][mu]),
-                                                  S.fv(st->K.l2[mu][nu]), S.gv(st->fc, mu), mu, nu));
+      CHK(staple_deriv(c, g, S.fvw(st->fl2[nu][mu]), S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[nu][mu]), S.fv(st->K.l2[mu][nu]),
+                       S.gv(st->fc, mu), mu, nu, !t2[nu][mu], !t2[mu][nu]));
+      t2[nu][mu] = t2[mu][nu] = true;
     }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
     for (int nu = 0; nu < 4; nu++) {
       if (nu == mu) continue;
-      k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[mu][nu]), S.fv(st->K.l2x[mu][nu]), S.fv(st->fl2[mu][nu]));
-      k_acc_scale<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->F, mu), ma2, S.fvw(st->fl2[mu][nu]), alp2, 1);
+      k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[mu][nu]), S.fv(st->K.l2x[mu][nu]),
+                                                S.fv(st->fl2[mu][nu]), S.gvw(st->F, mu), ma2, alp2, 1);
     }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
@@ -511,16 +516,17 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
       for (int a = 0; a < 4; a++) {
         if (a == mu || a == nu) continue;
         const int b = 6 - mu - nu - a;
-        CHK(staple_deriv(c, g, S.fvw(st->fl1[a][b]), S.fvw(st->fl1[mu][b]), S.fv(st->K.l1[a][b]),
-                                                    S.fv(st->K.l1[mu][b]), S.fv(st->fl2[mu][nu]), mu, a));
+        CHK(staple_deriv(c, g, S.fvw(st->fl1[a][b]), S.fvw(st->fl1[mu][b]), S.fv(st->K.l1[a][b]), S.fv(st->K.l1[mu][b]),
+                         S.fv(st->fl2[mu][nu]), mu, a, !t1[a][b], !t1[mu][b]));
+        t1[a][b] = t1[mu][b] = true;
       }
     }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
     for (int nu = 0; nu < 4; nu++) {
       if (nu == mu) continue;
-      k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl1[mu][nu]), S.fv(st->K.l1[mu][nu]), S.fv(st->K.l1x[mu][nu]), S.fv(st->fl1[mu][nu]));
-      k_acc_scale<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->F, mu), ma1, S.fvw(st->fl1[mu][nu]), alp1, 1);
+      k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl1[mu][nu]), S.fv(st->K.l1[mu][nu]), S.fv(st->K.l1x[mu][nu]),
+                                                S.fv(st->fl1[mu][nu]), S.gvw(st->F, mu), ma1, alp1, 1);
     }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
