@@ -48,6 +48,10 @@ def main():
                          "(rehearses the sharded code path and its host overhead on one GPU)")
     ap.add_argument("--naik", action="store_true", help="add synthetic 3-hop (Naik) links: 16 links per site")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--rehearse-no-rccl", action="store_true",
+                    help="N>1 control-flow rehearsal on a box with fewer GPUs than ranks: every rank uses GPU 0 and wraps "
+                         "its own slab periodically instead of talking to its neighbours (RCCL refuses duplicate GPUs); "
+                         "the numbers are meaningless, only the launch / barrier / reporting path is exercised")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,11 +95,16 @@ def main():
     q.rephase(lo, g, t_offset=rank * lt, t_global=lat[3])
     b = q.synthetic_gaussian_vector(lo, seed=4321 + rank)
 
-    ctx = q.Context(lat_loc, device=local_rank, rank_geom=(1, 1, 1, N), rank_coord=(0, 0, 0, rank))
+    if args.rehearse_no_rccl:
+        ctx = q.Context(lat_loc, device=0)
+        ctx.force_halo(True)
+    else:
+        ctx = q.Context(lat_loc, device=local_rank, rank_geom=(1, 1, 1, N), rank_coord=(0, 0, 0, rank))
     if N > 1:
         uid = [q.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], N, rank)
+        if not args.rehearse_no_rccl:
+            ctx.comm_init(uid[0], N, rank)
     elif args.halo:
         ctx.comm_init(q.Context.unique_id(), 1, 0)
         ctx.force_halo(True)
