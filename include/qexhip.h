@@ -273,6 +273,27 @@ int qexhip_nhyp_fforce(qexhip_handle h, double *f, int n, const double *const *p
 int qexhip_nhyp_fermion_force(qexhip_handle h, double *f, const double *const *psi, const double *scale, int n,
                               const int antiperiodic[4], const int phases[4]);
 
+/* ---------------- random number fields and configuration generation (host only, no handle) ----------------
+ * newRNGField (src/rng/distributionUtils.nim:306-331): one generator per site of the LOCAL lattice, seeded with
+ * (seed, global lexicographic site index, x fastest); kind 0 = RngMilc6 (src/rng/milcrng.nim), 1 = MRG32k3a
+ * (src/rng/mrg32k3a.nim).  glat NULL = lat, t_offset = first global t of this rank's slab.  The deviates are produced
+ * with the host's libm so that they are bit-identical to QEX's.  Fields in the library's host format:
+ *   uniform:          x.uniform r, ncomp reals per site           (distributionUtils.nim:23-44)
+ *   gaussian_vector:  v.gaussian r, colour vector                  (:64-97)
+ *   u1_vector:        v.u1 r                                       (:182-211)
+ *   random_tah:       p.randomTAH r (randTah3)                     (src/gauge/gaugeUtils.nim:1356-1383)
+ *   gauge_random:     g.random r = gaussian + projectSU            (:1348-1354,1424-1429)
+ *   gauge_warm:       g.warm s, r = exp(s randTah3)                (:1384-1388,1431-1441) */
+typedef struct qexhip_rng qexhip_rng;
+int qexhip_rng_new(qexhip_rng **rng, int kind, unsigned long long seed, const int lat[4], const int glat[4], int t_offset);
+int qexhip_rng_free(qexhip_rng *rng);
+int qexhip_rng_uniform(qexhip_rng *rng, int ncomp, double *v);
+int qexhip_rng_gaussian_vector(qexhip_rng *rng, double *v);
+int qexhip_rng_u1_vector(qexhip_rng *rng, double *v);
+int qexhip_rng_random_tah(qexhip_rng *rng, double *p);
+int qexhip_rng_gauge_random(qexhip_rng *rng, double *g);
+int qexhip_rng_gauge_warm(qexhip_rng *rng, double s, double *g);
+
 /* ---------------- SciDAC/LIME gauge files (host only, no handle) ----------------
  * loadGauge / saveGauge (src/gauge/gaugeUtils.nim:87-122) via Reader / Writer (src/io/readerQiolite.nim:37-239,
  * src/io/writerQiolite.nim:28-187): one record of 4 x QDP_{F,D}3_ColorMatrix per site, sites x-fastest, big-endian,

@@ -11,3 +11,4 @@ from .staggered import (  # noqa: F401
     Context, Staggered, SolverParams, newStag, newStag3, plaq, gaugeForce, gaugeFlow, flowEQ, gaugeAction, gaugeUpdate, reunit, wline, HisqCoefs, HypCoefs, makeImpLinks, EVEN, ODD, ALL,
 )
 from .io import loadGauge, saveGauge, getFileLattice, gaugeFileInfo  # noqa: F401
+from .rng import RngField, RngMilc6, MRG32k3a  # noqa: F401

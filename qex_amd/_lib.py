@@ -74,6 +74,14 @@ SYMBOLS = [
     ("qexhip_gauge_update", _ci, [_vp, _vp, _cd]),
     ("qexhip_gauge_reunit", _ci, [_vp]),
     ("qexhip_wline", _ci, [_vp, _pi, _ci, _vp]),
+    ("qexhip_rng_new", _ci, [_vp, _ci, C.c_ulonglong, _pi, _pi, _ci]),
+    ("qexhip_rng_free", _ci, [_vp]),
+    ("qexhip_rng_uniform", _ci, [_vp, _ci, _vp]),
+    ("qexhip_rng_gaussian_vector", _ci, [_vp, _vp]),
+    ("qexhip_rng_u1_vector", _ci, [_vp, _vp]),
+    ("qexhip_rng_random_tah", _ci, [_vp, _vp]),
+    ("qexhip_rng_gauge_random", _ci, [_vp, _vp]),
+    ("qexhip_rng_gauge_warm", _ci, [_vp, _cd, _vp]),
     ("qexhip_io_gauge_info", _ci, [C.c_char_p, _pi, C.c_char_p, _pi]),
     ("qexhip_io_read_gauge", _ci, [C.c_char_p, _pi, _vp, _vp, _vp]),
     ("qexhip_io_write_gauge", _ci, [C.c_char_p, _pi, _vp, C.c_char, C.c_char_p, C.c_char_p]),

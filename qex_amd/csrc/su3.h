@@ -11,17 +11,17 @@ struct M3 {
   double2 e[9];
 };
 
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ double2 cmulc(double2 a, double2 b) { /* a * conj(b) */ return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
-__device__ __forceinline__ double2 ccmul(double2 a, double2 b) { /* conj(a) * b */ return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x); }
+__host__ __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__host__ __device__ __forceinline__ double2 cmulc(double2 a, double2 b) { /* a * conj(b) */ return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+__host__ __device__ __forceinline__ double2 ccmul(double2 a, double2 b) { /* conj(a) * b */ return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x); }
 
-__device__ __forceinline__ M3 m3_load(const double2 *p, int stride) {
+__host__ __device__ __forceinline__ M3 m3_load(const double2 *p, int stride) {
   M3 r;
 #pragma unroll
   for (int k = 0; k < 9; k++) r.e[k] = p[(size_t)k * stride];
   return r;
 }
-__device__ __forceinline__ void m3_store(double2 *p, int stride, const M3 &a) {
+__host__ __device__ __forceinline__ void m3_store(double2 *p, int stride, const M3 &a) {
 #pragma unroll
   for (int k = 0; k < 9; k++) p[(size_t)k * stride] = a.e[k];
 }
@@ -31,7 +31,7 @@ __device__ __forceinline__ void m3_store(double2 *p, int stride, const M3 &a) {
 #define M3_MAC(sx, sy, ax, ay, bx, by) \
   do { sx += (ax) * (bx); sx -= (ay) * (by); sy += (ax) * (by); sy += (ay) * (bx); } while (0)
 // a*b
-__device__ __forceinline__ M3 m3_mul(const M3 &a, const M3 &b) {
+__host__ __device__ __forceinline__ M3 m3_mul(const M3 &a, const M3 &b) {
   M3 r;
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -45,7 +45,7 @@ __device__ __forceinline__ M3 m3_mul(const M3 &a, const M3 &b) {
   return r;
 }
 // a*b^dagger
-__device__ __forceinline__ M3 m3_mul_na(const M3 &a, const M3 &b) {
+__host__ __device__ __forceinline__ M3 m3_mul_na(const M3 &a, const M3 &b) {
   M3 r;
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -59,7 +59,7 @@ __device__ __forceinline__ M3 m3_mul_na(const M3 &a, const M3 &b) {
   return r;
 }
 // a^dagger*b
-__device__ __forceinline__ M3 m3_mul_an(const M3 &a, const M3 &b) {
+__host__ __device__ __forceinline__ M3 m3_mul_an(const M3 &a, const M3 &b) {
   M3 r;
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -73,7 +73,7 @@ __device__ __forceinline__ M3 m3_mul_an(const M3 &a, const M3 &b) {
   return r;
 }
 // r += a*b, r += a*b^dagger, r += a^dagger*b  (accumulating forms: no temporary product matrix)
-__device__ __forceinline__ void m3_mac(M3 &r, const M3 &a, const M3 &b) {
+__host__ __device__ __forceinline__ void m3_mac(M3 &r, const M3 &a, const M3 &b) {
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -84,7 +84,7 @@ __device__ __forceinline__ void m3_mac(M3 &r, const M3 &a, const M3 &b) {
       r.e[3 * i + j] = make_double2(sx, sy);
     }
 }
-__device__ __forceinline__ void m3_mac_na(M3 &r, const M3 &a, const M3 &b) {
+__host__ __device__ __forceinline__ void m3_mac_na(M3 &r, const M3 &a, const M3 &b) {
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -95,7 +95,7 @@ __device__ __forceinline__ void m3_mac_na(M3 &r, const M3 &a, const M3 &b) {
       r.e[3 * i + j] = make_double2(sx, sy);
     }
 }
-__device__ __forceinline__ void m3_mac_an(M3 &r, const M3 &a, const M3 &b) {
+__host__ __device__ __forceinline__ void m3_mac_an(M3 &r, const M3 &a, const M3 &b) {
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -106,26 +106,26 @@ __device__ __forceinline__ void m3_mac_an(M3 &r, const M3 &a, const M3 &b) {
       r.e[3 * i + j] = make_double2(sx, sy);
     }
 }
-__device__ __forceinline__ void m3_axpy(M3 &r, double a, const M3 &x) {
+__host__ __device__ __forceinline__ void m3_axpy(M3 &r, double a, const M3 &x) {
 #pragma unroll
   for (int k = 0; k < 9; k++) { r.e[k].x += a * x.e[k].x; r.e[k].y += a * x.e[k].y; }
 }
-__device__ __forceinline__ void m3_add_diag(M3 &r, double s) { r.e[0].x += s; r.e[4].x += s; r.e[8].x += s; }
-__device__ __forceinline__ M3 m3_zero() {
+__host__ __device__ __forceinline__ void m3_add_diag(M3 &r, double s) { r.e[0].x += s; r.e[4].x += s; r.e[8].x += s; }
+__host__ __device__ __forceinline__ M3 m3_zero() {
   M3 r;
 #pragma unroll
   for (int k = 0; k < 9; k++) r.e[k] = make_double2(0, 0);
   return r;
 }
 // Re tr(a^dagger b)
-__device__ __forceinline__ double m3_redot(const M3 &a, const M3 &b) {
+__host__ __device__ __forceinline__ double m3_redot(const M3 &a, const M3 &b) {
   double s = 0;
 #pragma unroll
   for (int k = 0; k < 9; k++) s += a.e[k].x * b.e[k].x + a.e[k].y * b.e[k].y;
   return s;
 }
 // traceless anti-Hermitian part
-__device__ __forceinline__ M3 m3_tah(const M3 &x) {
+__host__ __device__ __forceinline__ M3 m3_tah(const M3 &x) {
   M3 t;
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -139,7 +139,7 @@ __device__ __forceinline__ M3 m3_tah(const M3 &x) {
   t.e[8].x -= dr; t.e[8].y -= di;
   return t;
 }
-__device__ __forceinline__ M3 m3_exp(const M3 &m) {
+__host__ __device__ __forceinline__ M3 m3_exp(const M3 &m) {
   const double s = 1.0 / (double)(1 << 20);
   M3 ms, a;
 #pragma unroll
@@ -164,7 +164,7 @@ __device__ __forceinline__ M3 m3_exp(const M3 &m) {
 
 // eigs3 + rsqrtPHM3f + rsqrtPHM3 + projectU (matrixFunctions.nim:79-182,279-313)
 // z = (x^+ x + 1e-20)^(-1/2)   (projectUrsqrt, matrixFunctions.nim:301-306)
-__device__ __forceinline__ M3 m3_rsqrt_xdx(const M3 &x) {
+__host__ __device__ __forceinline__ M3 m3_rsqrt_xdx(const M3 &x) {
   M3 t = m3_mul_an(x, x);
   m3_add_diag(t, 1e-20);
   const double tr = t.e[0].x + t.e[4].x + t.e[8].x;
@@ -204,10 +204,10 @@ __device__ __forceinline__ M3 m3_rsqrt_xdx(const M3 &x) {
   m3_add_diag(rs, c0);
   return rs;
 }
-__device__ __forceinline__ M3 m3_projectU(const M3 &x) { return m3_mul(x, m3_rsqrt_xdx(x)); }
+__host__ __device__ __forceinline__ M3 m3_projectU(const M3 &x) { return m3_mul(x, m3_rsqrt_xdx(x)); }
 
 // projectSU (matrixFunctions.nim:359-370): projectU, then remove the determinant's phase
-__device__ __forceinline__ M3 m3_projectSU(const M3 &x) {
+__host__ __device__ __forceinline__ M3 m3_projectSU(const M3 &x) {
   const M3 m = m3_projectU(x);
   const double2 *e = m.e;
   const double2 d01 = make_double2(e[0].x * e[4].x - e[0].y * e[4].y - (e[1].x * e[3].x - e[1].y * e[3].y),

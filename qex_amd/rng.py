@@ -1,0 +1,62 @@
+"""Per-site random number fields and the configuration generators on them: the host mirror of
+newRNGField / gaussian / uniform / u1 (src/rng/distributionUtils.nim) and random / warm / randomTAH
+(src/gauge/gaugeUtils.nim:1348-1446) over qexhip_rng_* (csrc/rng.hip).  Host only, no GPU needed."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+RngMilc6, MRG32k3a = 0, 1
+
+
+class RngField:
+    """lo.newRNGField(RngMilc6 | MRG32k3a, seed); for a t-sharded rank pass the global lattice and t_offset."""
+
+    def __init__(self, lat, kind=RngMilc6, seed=987654321, glat=None, t_offset=0):
+        self.lat = [int(v) for v in lat]
+        self.vol = int(np.prod(self.lat))
+        self._h = C.c_void_p()
+        gl = (C.c_int * 4)(*[int(v) for v in glat]) if glat is not None else None
+        check(lib().qexhip_rng_new(C.byref(self._h), int(kind), C.c_ulonglong(int(seed) & (2 ** 64 - 1)), (C.c_int * 4)(*self.lat),
+                                   gl, int(t_offset)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().qexhip_rng_free(self._h)
+        except Exception:
+            pass
+
+    def _new(self, *shape):
+        return np.zeros((self.vol,) + shape)
+
+    def uniform(self, ncomp):
+        v = self._new(ncomp)
+        check(lib().qexhip_rng_uniform(self._h, int(ncomp), v.ctypes.data_as(C.c_void_p)))
+        return v
+
+    def gaussian_vector(self):
+        v = self._new(3, 2)
+        check(lib().qexhip_rng_gaussian_vector(self._h, v.ctypes.data_as(C.c_void_p)))
+        return v
+
+    def u1_vector(self):
+        v = self._new(3, 2)
+        check(lib().qexhip_rng_u1_vector(self._h, v.ctypes.data_as(C.c_void_p)))
+        return v
+
+    def randomTAH(self):
+        p = self._new(4, 3, 3, 2)
+        check(lib().qexhip_rng_random_tah(self._h, p.ctypes.data_as(C.c_void_p)))
+        return p
+
+    def random(self):
+        g = self._new(4, 3, 3, 2)
+        check(lib().qexhip_rng_gauge_random(self._h, g.ctypes.data_as(C.c_void_p)))
+        return g
+
+    def warm(self, s):
+        g = self._new(4, 3, 3, 2)
+        check(lib().qexhip_rng_gauge_warm(self._h, float(s), g.ctypes.data_as(C.c_void_p)))
+        return g

@@ -135,13 +135,15 @@ class Replay:
          be.fermion_force(handle, g, fields, scales) -> f     fforce + smearedOneLinkForce (:387-427)
          be.gauge_force(g) -> gc.forceA(g);  be.gauge_action(g) -> gc.actionA(g)
          be.plaq(g) -> 6 plaquettes;  be.exp_update(g, p, t): g := exp(t p) g;  be.reunit(g);  be.wline(g, path)
-       Only the random numbers (momenta, pseudofermion and pbp sources) are the driver's, from the oracle's RngMilc6."""
+       The random numbers (momenta, pseudofermion and pbp sources) come from `rng` (see __init__)."""
 
-    def __init__(self, o, be, cfg=None):
+    def __init__(self, o, be, cfg=None, rng=None):
+        """rng: object with randomTAH() / gaussian_vector() / u1_vector() drawing from newRNGField(RngMilc6, SEED);
+        default = the oracle's; the GPU replay passes the product's own (qex_amd.RngField)."""
         self.o, self.be = o, be
         self.cfg = cfg or CONFIGS[0]
         self.lo = o.Layout(LAT)
-        self.rf = o.RngField(self.lo, o.RNG_MILC6, SEED)
+        self.rng = rng or OracleRng(o, self.lo)
         self.g = o.gauge_unit(self.lo)
         self.p = None
         self.phi = None                              # phi[j] for the flattened fields
@@ -191,14 +193,14 @@ class Replay:
     def refresh(self):
         """staghmc_sh.nim:716-757"""
         o, lo, be, cfg = self.o, self.lo, self.be, self.cfg
-        self.p = o.gauge_random_tah(lo, self.rf)
+        self.p = self.rng.randomTAH()
         h = be.smear_rephase(self.g, False)
         # psi[k][i].gaussian r, level by level across the species ("conforms to bsm.lua", :735-745)
         psi = {}
         for lvl in range(max(len(hm) for hm in cfg.hmasses) + 1):
             for k in range(len(cfg.masses)):
                 if lvl <= len(cfg.hmasses[k]):
-                    psi[(k, lvl)] = o.vector_gaussian(lo, self.rf)
+                    psi[(k, lvl)] = self.rng.gaussian_vector()
         self.phi = []
         for j, (k, i) in enumerate(cfg.fields):
             mi = -self._m(j)
@@ -296,7 +298,7 @@ class Replay:
             self.g = g0.copy()                                             # g := g0; stag0.pbp uses sg0
         h = be.smear_rephase(self.g, False)
         pbp, iters = [], []
-        srcs = [o.vector_u1(lo, self.rf) for _ in range(2)]                # pbpreps = 2
+        srcs = [self.rng.u1_vector() for _ in range(2)]                    # pbpreps = 2
         for x, its in be.solve_many(h, srcs, [PBPMASS, PBPMASS]):
             pbp.append(PBPMASS * (x * x).sum() / lo.vol)
             iters.append(its)
@@ -306,6 +308,20 @@ class Replay:
         pls = sum(loops[:3]) / 3.0
         return dict(pbp=pbp, pbp_iters=iters, plaq=(ps, pt, 0.5 * (ps + pt)),
                     ploop=(pls.real, pls.imag, loops[3].real, loops[3].imag))
+
+
+class OracleRng:
+    def __init__(self, o, lo):
+        self.o, self.lo, self.rf = o, lo, o.RngField(lo, o.RNG_MILC6, SEED)
+
+    def randomTAH(self):
+        return self.o.gauge_random_tah(self.lo, self.rf)
+
+    def gaussian_vector(self):
+        return self.o.vector_gaussian(self.lo, self.rf)
+
+    def u1_vector(self):
+        return self.o.vector_u1(self.lo, self.rf)
 
 
 class OracleBackend:

@@ -143,9 +143,10 @@ def test_oracle_replays_reference_trajectory(oracle, run):
 @pytest.mark.parametrize("run", [0, 1])
 def test_gpu_replays_reference_trajectory(oracle, run):
     """The same trajectories with every operator -- smearing, solves, forces, link update, action,
-    reunitarisation, plaquettes, Polyakov loops -- running through libqexhip; only the random
-    numbers come from the oracle's RngMilc6."""
+    reunitarisation, plaquettes, Polyakov loops -- AND the random numbers (momenta, pseudofermions,
+    pbp sources: qex_amd.RngField) coming from libqexhip; the oracle supplies nothing but the unit start."""
     import qex_amd as q
     import hmc_replay as R
 
-    _check_trajectory(R.Replay(oracle, R.HipBackend(q, R.LAT), R.CONFIGS[run]), second=(run == 0))
+    rng = q.RngField(R.LAT, q.RngMilc6, R.SEED)          # the product's own newRNGField
+    _check_trajectory(R.Replay(oracle, R.HipBackend(q, R.LAT), R.CONFIGS[run], rng=rng), second=(run == 0))
