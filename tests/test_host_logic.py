@@ -154,3 +154,34 @@ def test_sharded_dslash_two_ranks_gloo(naik):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert "SHARDED_OK" in o, o
+
+
+def test_index_arithmetic_random_lattices(oracle):
+    """hypothesis: any even extents (incl. 2, where +mu and -mu are the same site, and Vh % 64 != 0):
+    site coordinates and 1-/3-hop neighbours of the closed-form device arithmetic == the oracle's tables."""
+    from hypothesis import given, settings, strategies as st
+    import qex_amd
+
+    L = qex_amd.lib()
+    ext = st.integers(min_value=1, max_value=5).map(lambda v: 2 * v)
+
+    @settings(max_examples=25, deadline=None)
+    @given(st.tuples(ext, ext, ext, ext), st.integers(min_value=0, max_value=2 ** 31 - 1))
+    def check(lat, seed):
+        lat = list(lat)
+        lo = oracle.Layout(lat)
+        vh = lo.vol // 2
+        i4 = (C.c_int * 4)(*lat)
+        x = (C.c_int * 4)()
+        rng = np.random.default_rng(seed)
+        for idx in rng.integers(0, lo.vol, size=40):
+            idx = int(idx)
+            p, c = idx // vh, idx % vh
+            assert L.qexhip_debug_site_coord(i4, c, p, x) == 0 and list(x) == lo.coord(idx)
+            for mu in range(4):
+                for hop in (1, -1, 3, -3):
+                    if abs(hop) == 3 and lat[mu] < 4:
+                        continue
+                    assert _nbr(lat, 1, 0, c, p, mu, hop) == lo.neighbor(idx, mu, hop) - (1 - p) * vh
+
+    check()
