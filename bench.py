@@ -253,6 +253,8 @@ def main():
                 "cg_iters_per_s": round(k2 / dt2, 2), "value": round(flop_cg * (V // 2) * k2 / dt2 / 1e9, 2),
                 "dslash_us_per_sweep": round(1e3 * ms2 / max(n2, 1), 2),
                 "roofline_frac": round(b_alg / (ms2 / max(n2, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "same links, compression off; also what the library picks by itself for QEX's g.random hot start "
+                        "(projectSU of gaussians, unitary only to 1e-11) and for non-unitary (HISQ fat) links",
             }
             ctx.set_option("recon", 2)
             s = q.newStag3(ctx, g, g3) if args.naik else q.newStag(ctx, g)     # back to the default format
