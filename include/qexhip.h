@@ -204,6 +204,13 @@ int qexhip_wline(qexhip_handle h, const int *path, int n, double out[2]);
 int qexhip_fat7(qexhip_handle h, const double *g, const double coef[5], double *fl, double *ll, double naik);
 int qexhip_hisq_smear(qexhip_handle h, const double *g, double *fl, double *ll);
 int qexhip_nhyp_smear(qexhip_handle h, const double *g, double *fl, double alpha1, double alpha2, double alpha3);
+/* The chain rule through those link constructions (HISQ molecular dynamics):
+ *   fat7_deriv: fat7lDeriv (src/gauge/fat7lderiv.nim): d = d/dU^+ of sum Re tr(dfl^+ fl(g)) + sum Re tr(dll^+ ll(g)) for
+ *               (fl, ll) = makeImpLinks(g, coef, naik); dll NULL = no long links
+ *   hisq_force: HisqCoefs.smearGetForce's smearedForce(dsdu, dsdsu, dsdsul) (src/gauge/hisqsmear.nim:55-90): second fat7 +
+ *               Naik, projectUderiv, first fat7, in reverse; dsdsu / dsdsul = the action's derivative w.r.t. the fat / long links */
+int qexhip_fat7_deriv(qexhip_handle h, const double *g, const double *dfl, const double coef[5], const double *dll, double naik, double *d);
+int qexhip_hisq_force(qexhip_handle h, const double *g, const double *dsdsu, const double *dsdsul, double *f);
 
 /* n (1..4) independent systems on the SAME links solved in lock-step, the links streamed once per sweep for all of
  * them (the Dslash is HBM-bound and 89 % of its bytes are links).  This is how the back-to-back solves of QEX's HMC

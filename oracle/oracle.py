@@ -73,6 +73,8 @@ def lib():
         L.qo_force_projTAH.argtypes = [vp, vp, vp, ci]
         L.qo_gauge_exp_update.argtypes = [vp, vp, vp, cd]
         L.qo_gauge_projectSU.argtypes = [vp, vp]
+        L.qo_fat7_deriv.argtypes = [vp, vp, vp, vp, vp, vp, cd]
+        L.qo_hisq_force.argtypes = [vp, vp, vp, vp, vp]
         L.qo_field_uniform.argtypes = [vp, vp, ci, vp, ci]
         L.qo_stag_outer.argtypes = [vp, vp, vp, cd, cd, ci]
         L.qo_solve_prev.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp]
@@ -369,6 +371,21 @@ def projectUderiv(x, chain):
     lib().qo_projectU(_p(u), _p(x))
     lib().qo_projectUderiv(_p(r), _p(u), _p(x), _p(chain))
     return r
+
+
+def fat7_deriv(lo, g, cfl, coef, cll=None, naik=0.0):
+    """d/dU^+ of sum Re tr(cfl^+ fl) + sum Re tr(cll^+ ll), (fl, ll) = fat7(g, coef, naik)"""
+    d = lo.new_gauge()
+    lib().qo_fat7_deriv(lo._h, _p(d), _p(g), _p(np.ascontiguousarray(cfl)), (C.c_double * 5)(*coef),
+                        _p(np.ascontiguousarray(cll)) if cll is not None else None, float(naik))
+    return d
+
+
+def hisq_force(lo, g, dsdsu, dsdsul):
+    """HisqCoefs.smearGetForce(...)'s smearedForce(dsdu, dsdsu, dsdsul) (hisqsmear.nim:55-90)"""
+    f = lo.new_gauge()
+    lib().qo_hisq_force(lo._h, _p(g), _p(np.ascontiguousarray(dsdsu)), _p(np.ascontiguousarray(dsdsul)), _p(f))
+    return f
 
 
 def gauge_exp_update(lo, g, p, t):

@@ -1586,25 +1586,31 @@ void qo_projectUderiv(double *r, const double *u, const double *x, const double 
  *          + [g2^+ g1 c(+nu) + c^+ g1 g2(+nu)](x-mu)
  *   f2(x) += g1(x) c(x+nu) g1(x+mu)^+ + [g1^+ c g1(+mu)](x-nu)
  * g1: side links (direction nu), g2: middle links (direction mu), c: chain of the staple sum */
-static void staple_deriv(const qo_layout *lo, double *f1, size_t f1s, double *f2, size_t f2s,
-                         mview g1, mview g2, const double *c, int mu, int nu) {
+static void staple_deriv_c(const qo_layout *lo, double *f1, size_t f1s, double *f2, size_t f2s,
+                           mview g1, mview g2, const double *c, size_t cs, int mu, int nu, double coef) {
 #pragma omp parallel for schedule(static)
   for (int x = 0; x < lo->vol; x++) {
     const int xpm = lo->nb[mu][0][x], xpn = lo->nb[nu][0][x], xmm = lo->nb[mu][1][x], xmn = lo->nb[nu][1][x];
     const int xmmpn = lo->nb[nu][0][xmm], xmnpm = lo->nb[mu][0][xmn];
     const double *C = c;
     double t[18], u[18], a1[18], a2[18];
+#define CC(site) (&C[(size_t)(site) * cs])
     m_zero(a1); m_zero(a2);
-    m_mul_na(t, MV(g1, xpm), &C[(size_t)xpn * 18]); m_mul(u, MV(g2, x), t); m_axpy(a1, 1.0, u);
-    m_mul_na(t, MV(g1, xpm), MV(g2, xpn)); m_mul(u, &C[(size_t)x * 18], t); m_axpy(a1, 1.0, u);
-    m_mul(t, MV(g1, xmm), &C[(size_t)xmmpn * 18]); m_mul_an(u, MV(g2, xmm), t); m_axpy(a1, 1.0, u);
-    m_mul(t, MV(g1, xmm), MV(g2, xmmpn)); m_mul_an(u, &C[(size_t)xmm * 18], t); m_axpy(a1, 1.0, u);
-    m_mul_na(t, &C[(size_t)xpn * 18], MV(g1, xpm)); m_mul(u, MV(g1, x), t); m_axpy(a2, 1.0, u);
-    m_mul(t, &C[(size_t)xmn * 18], MV(g1, xmnpm)); m_mul_an(u, MV(g1, xmn), t); m_axpy(a2, 1.0, u);
+    m_mul_na(t, MV(g1, xpm), CC(xpn)); m_mul(u, MV(g2, x), t); m_axpy(a1, 1.0, u);
+    m_mul_na(t, MV(g1, xpm), MV(g2, xpn)); m_mul(u, CC(x), t); m_axpy(a1, 1.0, u);
+    m_mul(t, MV(g1, xmm), CC(xmmpn)); m_mul_an(u, MV(g2, xmm), t); m_axpy(a1, 1.0, u);
+    m_mul(t, MV(g1, xmm), MV(g2, xmmpn)); m_mul_an(u, CC(xmm), t); m_axpy(a1, 1.0, u);
+    m_mul_na(t, CC(xpn), MV(g1, xpm)); m_mul(u, MV(g1, x), t); m_axpy(a2, 1.0, u);
+    m_mul(t, CC(xmn), MV(g1, xmnpm)); m_mul_an(u, MV(g1, xmn), t); m_axpy(a2, 1.0, u);
     /* f1 and f2 may be the same gauge field (different mu) but never the same matrix */
-    m_axpy(&f1[(size_t)x * f1s], 1.0, a1);
-    m_axpy(&f2[(size_t)x * f2s], 1.0, a2);
+    m_axpy(&f1[(size_t)x * f1s], coef, a1);
+    m_axpy(&f2[(size_t)x * f2s], coef, a2);
   }
+#undef CC
+}
+static void staple_deriv(const qo_layout *lo, double *f1, size_t f1s, double *f2, size_t f2s,
+                         mview g1, mview g2, const double *c, int mu, int nu) {
+  staple_deriv_c(lo, f1, f1s, f2, f2s, g1, g2, c, 18, mu, nu, 1.0);
 }
 
 /* smearGetForce + smearedForce(f, chain) with keepProj (gauge/hypsmear.nim:49-247).
@@ -1762,4 +1768,92 @@ void qo_gauge_exp_update(const qo_layout *lo, double *g, const double *p, double
 void qo_gauge_projectSU(const qo_layout *lo, double *g) {
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < lo->vol * 4; i++) qo_projectSU(&g[(size_t)i * 18], &g[(size_t)i * 18]);
+}
+
+/* ------------------------------------------------------------------ */
+/* HISQ force: reverse of makeImpLinks and of HisqCoefs.smear           */
+/* (gauge/fat7lderiv.nim, gauge/hisqsmear.nim:16-90)                    */
+/* ------------------------------------------------------------------ */
+/* d(gauge-format, accumulated): derivative w.r.t. gf of  sum Re tr(cfl^+ fl(gf)) + sum Re tr(cll^+ ll(gf)),
+ * fl, ll = makeImpLinks(gf, coef, naik) as in qo_fat7.  Reverse accumulation over the same staple graph:
+ * every generic staple S(A; B) is differentiated by symStapleDeriv (staple_deriv_c above). */
+static void fat7_deriv(const qo_layout *lo, double *d, const double *gf, const double *cfl, const double coef[5],
+                       const double *cll, double naik) {
+  const double c3 = coef[1], c5 = coef[2], c7 = coef[3], cL = coef[4];
+  const double c1 = coef[0] - 6.0 * cL;
+  const int have5 = (c5 != 0.0) || (c7 != 0.0) || (cL != 0.0);
+  const int have3 = (c3 != 0.0) || have5;
+  const size_t n = (size_t)lo->vol * 18;
+  double *st1 = (double *)malloc(sizeof(double) * n), *tmp = (double *)malloc(sizeof(double) * n);
+  double *ast1 = (double *)malloc(sizeof(double) * n), *atmp = (double *)malloc(sizeof(double) * n);
+  for (int dir = 0; dir < 4; dir++) {
+    const double *ch = cfl + (size_t)dir * 18;                      /* chain of fl[dir], stride 72 */
+    for (int x = 0; x < lo->vol; x++) m_axpy(&d[((size_t)x * 4 + dir) * 18], c1, &ch[(size_t)x * 72]);
+    if (!have3) continue;
+    for (int nu = 0; nu < 4; nu++) {
+      if (nu == dir) continue;
+      /* forward: st1 = S(gf_nu; gf_dir) */
+      gen_staple(lo, st1, NULL, 0, 0.0, gauge_view(gf, nu), gauge_view(gf, dir), dir, nu);
+      /* adjoint of st1 starts with the direct term c3 * chain */
+      for (int x = 0; x < lo->vol; x++) m_scale(&ast1[(size_t)x * 18], c3, &ch[(size_t)x * 72]);
+      if (cL != 0.0)   /* fl += cL S(gf_nu; st1) */
+        staple_deriv_c(lo, d + (size_t)nu * 18, 72, ast1, 18, gauge_view(gf, nu), field_view(st1), ch, 72, dir, nu, cL);
+      if (c5 != 0.0 || c7 != 0.0)
+        for (int rho = 0; rho < 4; rho++) {
+          if (rho == dir || rho == nu) continue;
+          gen_staple(lo, tmp, NULL, 0, 0.0, gauge_view(gf, rho), field_view(st1), dir, rho);     /* tmp = S(gf_rho; st1) */
+          for (int x = 0; x < lo->vol; x++) m_scale(&atmp[(size_t)x * 18], c5, &ch[(size_t)x * 72]);
+          if (c7 != 0.0)
+            for (int sig = 0; sig < 4; sig++) {
+              if (sig == dir || sig == nu || sig == rho) continue;
+              staple_deriv_c(lo, d + (size_t)sig * 18, 72, atmp, 18, gauge_view(gf, sig), field_view(tmp), ch, 72, dir, sig, c7);
+            }
+          staple_deriv_c(lo, d + (size_t)rho * 18, 72, ast1, 18, gauge_view(gf, rho), field_view(st1), atmp, 18, dir, rho, 1.0);
+        }
+      staple_deriv_c(lo, d + (size_t)nu * 18, 72, d + (size_t)dir * 18, 72, gauge_view(gf, nu), gauge_view(gf, dir), ast1, 18, dir, nu, 1.0);
+    }
+  }
+  if (naik != 0.0 && cll) {
+    /* ll[dir](x) = naik U(x) U(x+d) U(x+2d): the three places a link occupies */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < lo->vol * 4; i++) {
+      const int x = i / 4, dir = i % 4;
+      const int xp = lo->nb[dir][0][x], xpp = lo->nb[dir][0][xp], xm = lo->nb[dir][1][x], xmm = lo->nb[dir][1][xm];
+      double t[18], u[18], acc[18];
+      /* first:  C(x) U(x+2d)^+ U(x+d)^+ */
+      m_mul_na(t, GLINK(cll, x, dir), GLINK(gf, xpp, dir)); m_mul_na(acc, t, GLINK(gf, xp, dir));
+      /* middle: U(x-d)^+ C(x-d) U(x+d)^+ */
+      m_mul_an(t, GLINK(gf, xm, dir), GLINK(cll, xm, dir)); m_mul_na(u, t, GLINK(gf, xp, dir)); m_axpy(acc, 1.0, u);
+      /* last:   U(x-d)^+ U(x-2d)^+ C(x-2d) */
+      m_mul_an(t, GLINK(gf, xmm, dir), GLINK(cll, xmm, dir)); m_mul_an(u, GLINK(gf, xm, dir), t); m_axpy(acc, 1.0, u);
+      m_axpy(&d[(size_t)i * 18], naik, acc);
+    }
+  }
+  free(st1); free(tmp); free(ast1); free(atmp);
+}
+
+/* derivative of makeImpLinks alone (test hook) */
+void qo_fat7_deriv(const qo_layout *lo, double *d, const double *gf, const double *cfl, const double coef[5],
+                   const double *cll, double naik) {
+  memset(d, 0, sizeof(double) * (size_t)lo->vol * 72);
+  fat7_deriv(lo, d, gf, cfl, coef, cll, naik);
+}
+
+/* HisqCoefs.smearGetForce -> smearedForce(dsdu, dsdsu, dsdsul) (gauge/hisqsmear.nim:55-90):
+ * f = d/dU^+ of  sum Re tr(dsdsu^+ fl(U)) + sum Re tr(dsdsul^+ ll(U)),  fl, ll = HISQ links of U */
+void qo_hisq_force(const qo_layout *lo, const double *g, const double *dsdsu, const double *dsdsul, double *f) {
+  const double f7lf = 0.0, naik = 1.0, f2 = 2.0 - f7lf;
+  const double c_first[5] = {(1.0 + 3.0 * f7lf + 0.0) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f7lf / 16.0};
+  const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
+  const size_t n = (size_t)lo->vol * 72;
+  double *v = (double *)malloc(sizeof(double) * n), *w = (double *)malloc(sizeof(double) * n), *t = (double *)calloc(n, sizeof(double));
+  qo_fat7(lo, v, g, c_first, NULL, g, 0.0);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < lo->vol * 4; i++) qo_projectU(&w[(size_t)i * 18], &v[(size_t)i * 18]);
+  fat7_deriv(lo, t, w, dsdsu, c_second, dsdsul, -naik / 24.0);          /* second fat7 + Naik */
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < lo->vol * 4; i++) qo_projectUderiv(&t[(size_t)i * 18], &w[(size_t)i * 18], &v[(size_t)i * 18], &t[(size_t)i * 18]);
+  memset(f, 0, sizeof(double) * n);
+  fat7_deriv(lo, f, g, t, c_first, NULL, 0.0);                          /* first fat7 */
+  free(v); free(w); free(t);
 }

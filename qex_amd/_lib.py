@@ -62,6 +62,8 @@ SYMBOLS = [
     ("qexhip_stag_solve_batch", _ci, [_vp, _ci, _vp, _vp, _vp, _vp, _ci, _pi, _vp]),
     ("qexhip_stag_links_info", _ci, [_vp, _pi, _pi, _vp]),
     ("qexhip_set_option", _ci, [_vp, C.c_char_p, _ci]),
+    ("qexhip_fat7_deriv", _ci, [_vp, _vp, _vp, _vp, _vp, _cd, _vp]),
+    ("qexhip_hisq_force", _ci, [_vp, _vp, _vp, _vp, _vp]),
     ("qexhip_stag_set_links_hisq", _ci, [_vp, _vp]),
     ("qexhip_stag_set_links_nhyp", _ci, [_vp, _vp, _cd, _cd, _cd, _pi, _pi]),
     ("qexhip_nhyp_prepare", _ci, [_vp, _vp, _cd, _cd, _cd, _vp]),

@@ -493,6 +493,17 @@ extern "C" int qexhip_stag_links_info(qexhip_handle c, int *nlinks, int *compres
   if (max_dev) *max_dev = c->recon_dev;
   return 0;
 }
+extern "C" int qexhip_hisq_force(qexhip_handle c, const double *g, const double *dsdsu, const double *dsdsul, double *f) {
+  if (!c || !g || !dsdsu || !dsdsul || !f) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return smear_hisq_force_host(c, g, dsdsu, dsdsul, f);
+}
+extern "C" int qexhip_fat7_deriv(qexhip_handle c, const double *g, const double *dfl, const double coef[5], const double *dll,
+                                 double naik, double *d) {
+  if (!c || !g || !dfl || !coef || !d) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return smear_fat7_deriv_host(c, g, dfl, coef, dll, naik, d);
+}
 extern "C" int qexhip_stag_set_links_hisq(qexhip_handle c, const double *g) {
   if (!c || !g) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));

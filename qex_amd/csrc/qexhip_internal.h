@@ -210,6 +210,9 @@ int smear_fat7_host(qexhip_ctx *c, const double *g_host, const double coef[5], d
 int smear_hisq_host(qexhip_ctx *c, const double *g_host, double *fl_host, double *ll_host);
 int smear_nhyp_host(qexhip_ctx *c, const double *g_host, double *fl_host, double a1, double a2, double a3);
 int smear_set_links_hisq(qexhip_ctx *c, const double *g_host);
+int smear_hisq_force_host(qexhip_ctx *c, const double *g_host, const double *dfl_host, const double *dll_host, double *f_host);
+int smear_fat7_deriv_host(qexhip_ctx *c, const double *g_host, const double *dfl_host, const double coef[5], const double *dll_host,
+                          double naik, double *d_host);
 void nhyp_state_free(qexhip_ctx *c);
 int gauge_deriv_dev(qexhip_ctx *c, const double2 *G, double2 *F, double cplaq, double c2, int kind);
 int stag_outer_dev(qexhip_ctx *c, DevField &fx, double2 *F, double se, double so, int accumulate);

@@ -86,6 +86,17 @@ __global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, in
     if (proj.p) m3_store(proj.p + site_off(g, x, proj.tstride), 64, m3_projectU(o));
   }
 }
+// dst += coef * src
+__global__ void __launch_bounds__(256) k_maxpy(Geom g, MViewW dst, double coef, MView src) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  const size_t od = ((size_t)p * g.ntile + (c >> 6)) * dst.tstride + (c & 63);
+  const size_t os = ((size_t)p * g.ntile + (c >> 6)) * src.tstride + (c & 63);
+  M3 o = m3_load(dst.p + od, 64);
+  m3_axpy(o, coef, m3_load(src.p + os, 64));
+  m3_store(dst.p + od, 64, o);
+}
 // dst = coef * src
 __global__ void __launch_bounds__(256) k_mscale(Geom g, MViewW dst, double coef, MView src) {
   int i = blockIdx.x * 256 + threadIdx.x;
@@ -175,9 +186,11 @@ __global__ void __launch_bounds__(256) k_projUderiv(Geom g, MViewW dst, MView U,
   const M3 u = U.p ? m3_load(U.p + t * U.tstride + l, 64) : m3_projectU(x);
   const M3 ch = m3_load(C.p + t * C.tstride + l, 64);
   M3 r = m3_projectUderiv(u, x, ch);
-  M3 o = accumulate ? m3_load(f.p + t * f.tstride + l, 64) : m3_zero();
-  m3_axpy(o, ma, r);
-  m3_store(f.p + t * f.tstride + l, 64, o);
+  if (f.p) {
+    M3 o = accumulate ? m3_load(f.p + t * f.tstride + l, 64) : m3_zero();
+    m3_axpy(o, ma, r);
+    m3_store(f.p + t * f.tstride + l, 64, o);
+  }
 #pragma unroll
   for (int k = 0; k < 9; k++) { r.e[k].x *= alp; r.e[k].y *= alp; }
   m3_store(dst.p + t * dst.tstride + l, 64, r);
@@ -185,9 +198,10 @@ __global__ void __launch_bounds__(256) k_projUderiv(Geom g, MViewW dst, MView U,
 // symStapleDeriv (smearutil.nim:22-50) gathered per site:
 //   f1(x) += g2(x) g1(x+mu) c(x+nu)^+ + c(x) g1(x+mu) g2(x+nu)^+ + [g2^+ g1 c(+nu) + c^+ g1 g2(+nu)](x-mu)
 //   f2(x) += g1(x) c(x+nu) g1(x+mu)^+ + [g1^+ c g1(+mu)](x-nu)
-template <int PART>   // 0: f1 and f2, 1: f1 only, 2: f2 only
+template <int PART, bool SCALED = false>   // PART 0: f1 and f2, 1: f1 only, 2: f2 only; SCALED: f += coef * (derivative)
 __global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu, int swz,
-                                                      int z1, int z2) {   // z1 / z2: f1 / f2 start from zero (first contribution)
+                                                      int z1, int z2,      // z1 / z2: f1 / f2 start from zero (first contribution)
+                                                      double coef = 1.0) {
   int bid = blockIdx.x;
   if (swz && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // contiguous site range per XCD
   int i = bid * 256 + threadIdx.x;
@@ -204,7 +218,7 @@ __global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW 
   const size_t o0 = ((size_t)p * g.ntile + (c >> 6));
   const int l = c & 63;
   if (PART != 2) {
-    M3 a = z1 ? m3_zero() : m3_load(f1.p + o0 * f1.tstride + l, 64);
+    M3 a = (z1 || SCALED) ? m3_zero() : m3_load(f1.p + o0 * f1.tstride + l, 64);
     {
       const M3 g1pm = m3_load(g1.p + site_off(g, xpm, g1.tstride), 64);
       M3 t = m3_mul_na(g1pm, m3_load(cf.p + site_off(g, xpn, cf.tstride), 64));
@@ -219,14 +233,24 @@ __global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW 
       t = m3_mul(g1mm, m3_load(g2.p + site_off(g, xmmpn, g2.tstride), 64));
       m3_mac_an(a, m3_load(cf.p + site_off(g, xmm, cf.tstride), 64), t);
     }
+    if (SCALED) {
+      M3 o = z1 ? m3_zero() : m3_load(f1.p + o0 * f1.tstride + l, 64);
+      m3_axpy(o, coef, a);
+      a = o;
+    }
     m3_store(f1.p + o0 * f1.tstride + l, 64, a);
   }
   if (PART != 1) {
-    M3 a = z2 ? m3_zero() : m3_load(f2.p + o0 * f2.tstride + l, 64);
+    M3 a = (z2 || SCALED) ? m3_zero() : m3_load(f2.p + o0 * f2.tstride + l, 64);
     M3 t = m3_mul_na(m3_load(cf.p + site_off(g, xpn, cf.tstride), 64), m3_load(g1.p + site_off(g, xpm, g1.tstride), 64));
     m3_mac(a, m3_load(g1.p + o0 * g1.tstride + l, 64), t);
     t = m3_mul(m3_load(cf.p + site_off(g, xmn, cf.tstride), 64), m3_load(g1.p + site_off(g, xmnpm, g1.tstride), 64));
     m3_mac_an(a, m3_load(g1.p + site_off(g, xmn, g1.tstride), 64), t);
+    if (SCALED) {
+      M3 o = z2 ? m3_zero() : m3_load(f2.p + o0 * f2.tstride + l, 64);
+      m3_axpy(o, coef, a);
+      a = o;
+    }
     m3_store(f2.p + o0 * f2.tstride + l, 64, a);
   }
 }
@@ -272,6 +296,28 @@ __global__ void __launch_bounds__(256) k_sm_from_tiles(Geom g, double2 *__restri
     const double2 *w = G + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
     for (int k = 0; k < 9; k++) host[((size_t)i * 4 + mu) * 9 + k] = w[k * 64];
   }
+}
+
+// derivative of ll(x) = naik U(x) U(x+d) U(x+2d) (fat7l.nim:146-156) w.r.t. the three places of a link:
+//   F(x) += naik [ C(x) U(x+2d)^+ U(x+d)^+ + U(x-d)^+ C(x-d) U(x+d)^+ + U(x-d)^+ U(x-2d)^+ C(x-2d) ]
+__global__ void __launch_bounds__(256) k_naik_deriv(Geom g, MViewW F, MView U, MView Cl, int dir, double naik) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  int x[4], xp[4], xpp[4], xm[4], xmm[4];
+  coords_sm(g, c, p, x);
+  shift_sm(g, x, dir, 1, xp);
+  shift_sm(g, xp, dir, 1, xpp);
+  shift_sm(g, x, dir, -1, xm);
+  shift_sm(g, xm, dir, -1, xmm);
+  const M3 up = m3_load(U.p + site_off(g, xp, U.tstride), 64), um = m3_load(U.p + site_off(g, xm, U.tstride), 64);
+  M3 acc = m3_mul_na(m3_mul_na(m3_load(Cl.p + site_off(g, x, Cl.tstride), 64), m3_load(U.p + site_off(g, xpp, U.tstride), 64)), up);
+  m3_mac_na(acc, m3_mul_an(um, m3_load(Cl.p + site_off(g, xm, Cl.tstride), 64)), up);
+  m3_mac_an(acc, um, m3_mul_an(m3_load(U.p + site_off(g, xmm, U.tstride), 64), m3_load(Cl.p + site_off(g, xmm, Cl.tstride), 64)));
+  double2 *f = F.p + site_off(g, x, F.tstride);
+  M3 o = m3_load(f, 64);
+  m3_axpy(o, naik, acc);
+  m3_store(f, 64, o);
 }
 
 namespace {
@@ -360,6 +406,73 @@ struct Smear {
         HIPCHK(hipGetLastError());
       }
     return 0;
+  }
+  int sderiv(MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu, double coef) {
+    static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
+    ScopedTimer tm(c, "smear_deriv", c->stream);
+    k_staple_deriv<0, true><<<nb(), 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, 0, 0, coef);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  // reverse of fat7 (gauge/fat7lderiv.nim): d += d/dU^+ of sum Re tr(cfl^+ fl) + sum Re tr(cll^+ ll), over the same
+  // staple graph as fat7() above, every generic staple differentiated by k_staple_deriv (symStapleDeriv)
+  int fat7_deriv(double2 *d, const double2 *gf, const double2 *cfl, const double coef[5], const double2 *cll, double naik) {
+    const double c3 = coef[1], c5 = coef[2], c7 = coef[3], cL = coef[4];
+    const double c1 = coef[0] - 6.0 * cL;
+    const bool have5 = (c5 != 0.0) || (c7 != 0.0) || (cL != 0.0);
+    const bool have3 = (c3 != 0.0) || have5;
+    double2 *st1, *tmp, *ast1, *atmp;
+    CHK(alloc(&st1, fsz)); CHK(alloc(&tmp, fsz)); CHK(alloc(&ast1, fsz)); CHK(alloc(&atmp, fsz));
+    const MViewW none{nullptr, 0};
+    for (int dir = 0; dir < 4; dir++) {
+      const MView ch = gv(cfl, dir);
+      // d[dir] += c1 * chain: an accumulate with the generic scale kernel's twin
+      k_maxpy<<<nb(), 256, 0, c->stream>>>(g, gvw(d, dir), c1, ch);
+      HIPCHK(hipGetLastError());
+      if (!have3) continue;
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == dir) continue;
+        CHK(staple(gv(gf, nu), gv(gf, dir), dir, nu, fvw(st1), none, 0.0));
+        k_mscale<<<nb(), 256, 0, c->stream>>>(g, fvw(ast1), c3, ch);
+        if (cL != 0.0) CHK(sderiv(gvw(d, nu), fvw(ast1), gv(gf, nu), fv(st1), ch, dir, nu, cL));
+        if (c5 != 0.0 || c7 != 0.0)
+          for (int rho = 0; rho < 4; rho++) {
+            if (rho == dir || rho == nu) continue;
+            CHK(staple(gv(gf, rho), fv(st1), dir, rho, fvw(tmp), none, 0.0));
+            k_mscale<<<nb(), 256, 0, c->stream>>>(g, fvw(atmp), c5, ch);
+            if (c7 != 0.0)
+              for (int sig = 0; sig < 4; sig++) {
+                if (sig == dir || sig == nu || sig == rho) continue;
+                CHK(sderiv(gvw(d, sig), fvw(atmp), gv(gf, sig), fv(tmp), ch, dir, sig, c7));
+              }
+            CHK(sderiv(gvw(d, rho), fvw(ast1), gv(gf, rho), fv(st1), fv(atmp), dir, rho, 1.0));
+          }
+        CHK(sderiv(gvw(d, nu), gvw(d, dir), gv(gf, nu), gv(gf, dir), fv(ast1), dir, nu, 1.0));
+      }
+    }
+    if (naik != 0.0 && cll)
+      for (int dir = 0; dir < 4; dir++) {
+        k_naik_deriv<<<nb(), 256, 0, c->stream>>>(g, gvw(d, dir), gv(gf, dir), gv(cll, dir), dir, naik);
+        HIPCHK(hipGetLastError());
+      }
+    return 0;
+  }
+  // HisqCoefs.smearGetForce's smearedForce (gauge/hisqsmear.nim:55-90): second fat7 + Naik, projectU, first fat7, in reverse
+  int hisq_force(const double2 *G, const double2 *CF, const double2 *CL, double2 *F) {
+    const double f7lf = 0.0, naik = 1.0, f2 = 2.0 - f7lf;
+    const double c_first[5] = {(1.0 + 3.0 * f7lf + 0.0) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f7lf / 16.0};
+    const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
+    double2 *V, *W, *T;
+    CHK(alloc(&V, gsz)); CHK(alloc(&W, gsz)); CHK(alloc(&T, gsz));     // alloc zero-fills
+    CHK(fat7(V, G, c_first, nullptr, G, 0.0));
+    for (int mu = 0; mu < 4; mu++) k_projectU<<<nb(), 256, 0, c->stream>>>(g, gvw(W, mu), gv(V, mu));
+    HIPCHK(hipGetLastError());
+    CHK(fat7_deriv(T, W, CF, c_second, CL, -naik / 24.0));
+    for (int mu = 0; mu < 4; mu++)
+      k_projUderiv<<<nb(), 256, 0, c->stream>>>(g, gvw(T, mu), gv(W, mu), gv(V, mu), gv(T, mu), MViewW{nullptr, 0}, 0.0, 1.0, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(F, 0, gsz * sizeof(double2), c->stream));
+    return fat7_deriv(F, G, T, c_first, nullptr, 0.0);
   }
   // HisqCoefs.init + smear (hisqLinks.nim:9-43) on device fields
   int hisq(const double2 *G, double2 *FL, double2 *LL) {
@@ -597,6 +710,27 @@ int smear_hisq_host(qexhip_ctx *c, const double *g_host, double *fl_host, double
   CHK(S.hisq(G, FL, LL));
   CHK(S.download(fl_host, FL));
   return S.download(ll_host, LL);
+}
+
+int smear_hisq_force_host(qexhip_ctx *c, const double *g_host, const double *dfl_host, const double *dll_host, double *f_host) {
+  CHK(smear_check(c, 4));
+  Smear S(c);
+  double2 *G, *CF, *CL, *F;
+  CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&CF, S.gsz)); CHK(S.alloc(&CL, S.gsz)); CHK(S.alloc(&F, S.gsz));
+  CHK(S.upload(G, g_host)); CHK(S.upload(CF, dfl_host)); CHK(S.upload(CL, dll_host));
+  CHK(S.hisq_force(G, CF, CL, F));
+  return S.download(f_host, F);
+}
+int smear_fat7_deriv_host(qexhip_ctx *c, const double *g_host, const double *dfl_host, const double coef[5], const double *dll_host,
+                          double naik, double *d_host) {
+  CHK(smear_check(c, dll_host && naik != 0.0 ? 4 : 2));
+  Smear S(c);
+  double2 *G, *CF, *CL = nullptr, *D;
+  CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&CF, S.gsz)); CHK(S.alloc(&D, S.gsz));
+  CHK(S.upload(G, g_host)); CHK(S.upload(CF, dfl_host));
+  if (dll_host) { CHK(S.alloc(&CL, S.gsz)); CHK(S.upload(CL, dll_host)); }
+  CHK(S.fat7_deriv(D, G, CF, coef, CL, naik));
+  return S.download(d_host, D);
 }
 
 int smear_nhyp_host(qexhip_ctx *c, const double *g_host, double *fl_host, double a1, double a2, double a3) {

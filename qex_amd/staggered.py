@@ -431,8 +431,22 @@ class HisqCoefs:
     def init(self):
         return self
 
+    def force(self, ctx, g, dsdsu, dsdsul):
+        """smearGetForce(...)'s smearedForce(dsdu, dsdsu, dsdsul) (hisqsmear.nim:55-90); returns dsdu"""
+        f = np.zeros_like(g)
+        check(lib().qexhip_hisq_force(ctx._h, _p(g), _p(dsdsu), _p(dsdsul), _p(f)))
+        return f
+
     def smear(self, ctx, g, fl, ll):
         check(lib().qexhip_hisq_smear(ctx._h, _p(g), _p(fl), _p(ll)))
+
+
+def fat7lDeriv(ctx, g, dfl, coef, dll=None, naik=0.0):
+    """fat7lDeriv (fat7lderiv.nim): derivative through makeImpLinks(g, coef, naik) of the chains dfl (, dll)"""
+    d = np.zeros_like(g)
+    cf = (C.c_double * 5)(*[float(v) for v in coef])
+    check(lib().qexhip_fat7_deriv(ctx._h, _p(g), _p(dfl), cf, _p(dll), float(naik), _p(d)))
+    return d
 
 
 class HypCoefs:

@@ -267,3 +267,52 @@ def test_gpu_nhyp_md_forces(oracle):
         fc = cx(f)
         assert np.abs(fc + np.conj(np.swapaxes(fc, -1, -2))).max() < 1e-12
         assert np.abs(np.trace(fc, axis1=-2, axis2=-1)).max() < 1e-12
+
+
+def test_oracle_hisq_force_is_the_gradient(oracle):
+    """fat7lDeriv / the HISQ chain (fat7lderiv.nim, hisqsmear.nim:55-90) restated as reverse accumulation over the
+    oracle's own staple graph, held to the definition  d[sum Re tr(C^+ links(U))] = sum Re tr(dU^+ F)."""
+    o = oracle
+    lo = o.Layout([4, 4, 4, 6])
+    g = o.gauge_warm(lo, 0.5, o.RngField(lo, o.RNG_MILC6, 3))
+    o.rephase(lo, g)
+    rng = np.random.default_rng(2)
+    Cf, Cl = rng.standard_normal(g.shape), rng.standard_normal(g.shape)
+    coef = (0.9, -0.11, 0.021, -0.0043, -0.07)                    # every term on, incl. Lepage
+    cases = [
+        (lambda u: sum((c * f).sum() for c, f in zip((Cf, Cl), o.fat7(lo, u, coef, naik=-0.05))), o.fat7_deriv(lo, g, Cf, coef, Cl, -0.05)),
+        (lambda u: sum((c * f).sum() for c, f in zip((Cf, Cl), o.hisq_smear(lo, u))), o.hisq_force(lo, g, Cf, Cl)),
+    ]
+    for S, F in cases:
+        for t in range(3):
+            d = np.zeros_like(g)
+            if t == 0:
+                d = 1e-6 * rng.standard_normal(g.shape)
+            else:
+                d[int(rng.integers(lo.vol)), int(rng.integers(4))] = 1e-5 * rng.standard_normal((3, 3, 2))
+            num, ana = (S(g + d) - S(g - d)) / 2, (d * F).sum()
+            assert abs(num - ana) < 1e-6 * abs(ana)
+
+
+@pytest.mark.gpu
+def test_gpu_hisq_force(oracle):
+    import qex_amd as q
+
+    o = oracle
+    lat = [4, 6, 8, 4]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 8)
+    g = o.gauge_warm(lo, 0.5, rf)
+    o.rephase(lo, g)
+    dfl, dll = o.gauge_random_tah(lo, rf) + 0.2 * o.gauge_random(lo, rf), o.gauge_random_tah(lo, rf)
+    ctx = q.Context(lat)
+    coef = (0.9, -0.11, 0.021, -0.0043, -0.07)
+    d = q.fat7lDeriv(ctx, g, dfl, coef, dll, naik=-0.05)
+    ref = o.fat7_deriv(lo, g, dfl, coef, dll, -0.05)
+    assert np.linalg.norm(d - ref) / np.linalg.norm(ref) < 1e-13
+    d = q.fat7lDeriv(ctx, g, dfl, (0.7, -0.1, 0, 0, 0))            # 3-staple only, no long links
+    ref = o.fat7_deriv(lo, g, dfl, (0.7, -0.1, 0, 0, 0))
+    assert np.linalg.norm(d - ref) / np.linalg.norm(ref) < 1e-13
+    f = q.HisqCoefs().init().force(ctx, g, dfl, dll)
+    ref = o.hisq_force(lo, g, dfl, dll)
+    assert np.linalg.norm(f - ref) / np.linalg.norm(ref) < 1e-12
