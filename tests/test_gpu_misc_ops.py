@@ -93,3 +93,41 @@ def test_fermion_force_outer_product(oracle, halo):
         want = (0.37 - 1.9) * np.vdot(xc[nb], xc)
         got = np.trace(fc[:, mu], axis1=1, axis2=2).sum()
         assert abs(got - want) < 1e-9 * abs(want)
+
+
+def test_error_behaviour_of_the_abi(oracle):
+    """Bad arguments and out-of-order calls come back as error codes with a message (the host mirror raises);
+    nothing aborts, nothing falls back."""
+    import ctypes as C
+    import qex_amd as q
+
+    L = q.lib()
+    lat = [4, 4, 4, 4]
+    lo = oracle.Layout(lat)
+    ctx = q.Context(lat)
+    x = np.zeros((lo.vol, 3, 2))
+    from qex_amd._lib import check
+
+    with pytest.raises(q.QexHipError, match="links not set"):            # operator before set_links
+        rc = L.qexhip_stag_D(ctx._h, x.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_double(0.1), C.c_double(1.0))
+        assert rc != 0
+        check(rc)
+    with pytest.raises(q.QexHipError):                                   # odd extent
+        q.Context([4, 4, 3, 4])
+    g = oracle.gauge_unit(lo)
+    s = q.newStag(ctx, g)
+    with pytest.raises(q.QexHipError, match="Naik|extents"):             # 3-hop links need extents >= 4
+        q.newStag3(q.Context([2, 4, 4, 4]), oracle.gauge_unit(oracle.Layout([2, 4, 4, 4])), oracle.gauge_unit(oracle.Layout([2, 4, 4, 4])))
+    with pytest.raises(q.QexHipError, match="prepare"):                  # closure used before smearGetForce
+        f = np.zeros_like(g)
+        check(L.qexhip_nhyp_force(ctx._h, f.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p)))
+    with pytest.raises(ValueError):                                      # batch sizes
+        s.solveXX_batch([x] * 5, [x] * 5, [0.1] * 5, 1e-10, 10)
+    with pytest.raises(q.QexHipError, match="mass"):
+        s.solveXX_batch([x.copy()], [x], [0.0], 1e-10, 10)
+    with pytest.raises(ValueError):                                      # wrong dtype / layout
+        s.D(x.astype(np.float32), x, 0.1)
+    with pytest.raises(q.QexHipError, match="unknown option"):
+        ctx.set_option("nonsense", 1)
+    # null handle
+    assert L.qexhip_sync(None) != 0
