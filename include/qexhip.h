@@ -219,7 +219,8 @@ int qexhip_hisq_force(qexhip_handle h, const double *g, const double *dsdsu, con
  *   solve_xx_batch: n x solveXX (qexhip_stag_solve_xx semantics per system: own mass, r2req, iteration count)
  *   solve_batch:    n x Staggered.solve (qexhip_stag_solve semantics per system)
  * Each system's arithmetic is that of the single-system call, so solutions and iteration counts are the same.
- * x, b: arrays of n host fields [vol][3][2].  Single GPU. */
+ * x, b: arrays of n host fields [vol][3][2].  Works t-sharded as well (faces of all systems exchanged per sweep, one
+ * all-reduce for the n scalars of a reduction). */
 int qexhip_stag_solve_xx_batch(qexhip_handle h, int n, double *const *x, const double *const *b, const double *mass,
                                const double *r2req, int maxits, int par_even, int *iters, double *r2_over_b2);
 int qexhip_stag_solve_batch(qexhip_handle h, int n, double *const *x, const double *const *b, const double *mass,

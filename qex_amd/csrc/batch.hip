@@ -9,7 +9,8 @@
 // system keeps its own CG state (alpha, beta, residual, iteration count, done flag) and its arithmetic
 // is, operation for operation, that of the single-system path (same per-site accumulation order, same
 // workgroup partials, same fixed-order final sums), so each solution and iteration count equals what
-// qexhip_stag_solve_xx returns for that system alone.  Single GPU (no t sharding).
+// qexhip_stag_solve_xx returns for that system alone.  t-sharded runs exchange the faces of all systems, then
+// sweep the slab in one launch, and all-reduce the n scalars of a reduction in ONE call.
 #include "qexhip_internal.h"
 #include "site_index.h"
 #include "reduce.h"
@@ -35,7 +36,7 @@ struct MrhsArgs {
 
 // SECOND = false: out_j = +sum_mu (U in_j(+mu) - U^+ in_j(-mu))              (stagDP, first half of stagD2ee)
 // SECOND = true : out_j = cb_j xs_j - sum_mu (...), partial <xs_j, out_j>   (stagDM + 4m^2 x + <p,Ap>)
-template <int NDIR, int RECON, bool SECOND>
+template <int NDIR, int RECON, bool SECOND, bool HALO>
 __global__ void __launch_bounds__(256) k_dslash_mrhs(MrhsArgs A) {
   bool act[QX_MAXRHS];
   bool any = false;
@@ -74,8 +75,8 @@ __global__ void __launch_bounds__(256) k_dslash_mrhs(MrhsArgs A) {
     for (int pr = 0; pr < NDIR / 2; pr++) {
       const int mu = pr & 3;
       const int hop = pr >= 4 ? 3 : 1;
-      const int pf = nbr_pos<false>(g, c, s, mu, hop);
-      const int pb = nbr_pos<false>(g, c, s, mu, -hop);
+      const int pf = nbr_pos<HALO>(g, c, s, mu, hop);
+      const int pb = nbr_pos<HALO>(g, c, s, mu, -hop);
       const double2 *wp = w + (size_t)pr * (2 * LROW);
       double2 U[9], Wm[9];
 #pragma unroll
@@ -141,7 +142,8 @@ struct BatchBlas {
   double2 *x[QX_MAXRHS], *r[QX_MAXRHS], *p[QX_MAXRHS], *Ap[QX_MAXRHS];
   double *dotp[QX_MAXRHS], *r2p[QX_MAXRHS];
   CgScal *st;
-  int ndot;
+  double *glob;      // multi-rank: [0..4) rank-summed <p,Ap>, [4..8) rank-summed |r|^2 (contiguous for one all-reduce)
+  int ndot;          // > 0: deferred <p,Ap> partial sum inside k_cgb_update; 0: pAp from the state; -1: from glob
 };
 // the three CG kernels of blas.hip (k_cg_xpay, k_cg_update, k_cg_reduce_finish), system = blockIdx.y
 __global__ void __launch_bounds__(256) k_cgb_xpay(BatchBlas B, size_t n) {
@@ -165,7 +167,7 @@ __global__ void __launch_bounds__(256) k_cgb_update(BatchBlas B, size_t n) {
   const int j = blockIdx.y;
   const CgScal *s = &B.st[j];
   if (s->done) return;
-  double pAp = s->pAp;
+  double pAp = B.ndot < 0 ? B.glob[j] : s->pAp;
   if (B.ndot > 0) {
     double a = 0;
     for (int i = threadIdx.x; i < B.ndot; i += 256) a += B.dotp[j][i];
@@ -196,6 +198,26 @@ __global__ void __launch_bounds__(256) k_cgb_reduce_dot(BatchBlas B, int n) {
   double r = block_sum_256(acc);
   if (threadIdx.x == 0) s->pAp = r;
 }
+// multi-rank pieces: local sums into the contiguous buffer (then ONE ncclAllReduce for all systems), bookkeeping from it
+__global__ void __launch_bounds__(256) k_cgb_local_sum(BatchBlas B, int n, int which) {   // which 0: <p,Ap>, 1: |r|^2
+  const int j = blockIdx.x;
+  if (B.st[j].done) { if (threadIdx.x == 0) B.glob[4 * which + j] = 0.0; return; }
+  const double *src = which ? B.r2p[j] : B.dotp[j];
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += src[i];
+  double r = block_sum_256(acc);
+  if (threadIdx.x == 0) B.glob[4 * which + j] = r;
+}
+__global__ void k_cgb_finish_glob(BatchBlas B, int n) {
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    CgScal *s = &B.st[j];
+    if (s->done) continue;
+    s->rzo = s->r2;
+    s->r2 = B.glob[4 + j];
+    s->itn += 1;
+    if (!(s->itn < s->maxits && s->r2 > s->r2stop)) s->done = 1;
+  }
+}
 __global__ void __launch_bounds__(256) k_cgb_reduce_finish(BatchBlas B, int n) {
   const int j = blockIdx.x;
   CgScal *s = &B.st[j];
@@ -214,6 +236,7 @@ __global__ void __launch_bounds__(256) k_cgb_reduce_finish(BatchBlas B, int n) {
 struct BatchState {
   std::vector<DevField> f;     // r, p, Ap, t per system
   CgScal *st = nullptr;
+  double *glob = nullptr;
   double *partials = nullptr;
   size_t npart = 0;
 };
@@ -222,6 +245,7 @@ void batch_state_free(qexhip_ctx *c) {
   if (!b) return;
   for (auto &f : b->f) (void)hipFree(f.d);
   if (b->st) (void)hipFree(b->st);
+  if (b->glob) (void)hipFree(b->glob);
   if (b->partials) (void)hipFree(b->partials);
   delete b;
   c->batch = nullptr;
@@ -229,10 +253,19 @@ void batch_state_free(qexhip_ctx *c) {
 
 template <int NDIR, int RECON>
 static void launch_mrhs(qexhip_ctx *c, MrhsArgs &A, bool second, int nb) {
-  if (second) hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, true>), dim3(nb), dim3(256), 0, c->stream, A);
-  else hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, false>), dim3(nb), dim3(256), 0, c->stream, A);
+  if (c->g.halo) {
+    if (second) hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, true, true>), dim3(nb), dim3(256), 0, c->stream, A);
+    else hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, false, true>), dim3(nb), dim3(256), 0, c->stream, A);
+  } else {
+    if (second) hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, true, false>), dim3(nb), dim3(256), 0, c->stream, A);
+    else hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, false, false>), dim3(nb), dim3(256), 0, c->stream, A);
+  }
 }
-static int sweep_mrhs(qexhip_ctx *c, MrhsArgs &A, bool second) {
+// t-sharded: the faces of every system's input field are exchanged first (on the compute stream), then ONE launch
+// covers the slab -- the exchange-then-sweep order of dslash_sweep's non-overlapped branch
+static int sweep_mrhs(qexhip_ctx *c, MrhsArgs &A, bool second, DevField *const *infield = nullptr, int inpar = 0) {
+  if (c->g.halo)
+    for (int j = 0; j < A.nrhs; j++) CHK(comm_halo_exchange(c, *infield[j], inpar, 0));
   const int nb = (c->g.Vh + 255) / 256;
   const int swz = c->opt_swz >= 0 ? c->opt_swz : (c->recon != 0);
   A.swz = (swz && nb >= 64 && (nb & 7) == 0) ? nb : 0;
@@ -256,7 +289,6 @@ int solve_xx_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const d
                        int maxits, int par_even, int *iters, double *r2_over_b2) {
   const Geom &g = c->g;
   if (n < 1 || n > QX_MAXRHS) { qexhip_set_error("batch solve: 1 <= n <= %d", QX_MAXRHS); return -1; }
-  if (g.halo || c->nranks > 1) { qexhip_set_error("batch solve: single GPU only"); return -3; }
   if (!c->W) { qexhip_set_error("staggered links not set (qexhip_stag_set_links)"); return -3; }
   for (int j = 0; j < n; j++) if (mass[j] == 0.0) { qexhip_set_error("batch solve: mass must be non-zero"); return -1; }
   BatchState *B = (BatchState *)c->batch;
@@ -267,6 +299,7 @@ int solve_xx_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const d
     B->f.push_back(nf);
   }
   if (!B->st) HIPCHK(hipMalloc((void **)&B->st, sizeof(CgScal) * QX_MAXRHS));
+  if (!B->glob) { HIPCHK(hipMalloc((void **)&B->glob, sizeof(double) * 8)); HIPCHK(hipMemsetAsync(B->glob, 0, sizeof(double) * 8, c->stream)); }
   const int nbd = (g.Vh + 255) / 256;                 // Dslash workgroups = <p,Ap> partials per system
   const size_t nvec = (size_t)g.ntile * 192;
   const int nbb = (int)std::min<size_t>((nvec + 255) / 256, 2048);
@@ -280,6 +313,7 @@ int solve_xx_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const d
   const int par = par_even ? 0 : 1;
   MrhsArgs A1, A2;
   BatchBlas L;
+  DevField *pf[QX_MAXRHS], *tf[QX_MAXRHS];
   memset(&A1, 0, sizeof A1); memset(&A2, 0, sizeof A2); memset(&L, 0, sizeof L);
   for (int j = 0; j < n; j++) {
     DevField &r = B->f[4 * j], &p = B->f[4 * j + 1], &Ap = B->f[4 * j + 2], &t = B->f[4 * j + 3];
@@ -290,6 +324,7 @@ int solve_xx_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const d
     CHK(blas_norm2(c, r, par, &c->dscal[1]));
     CHK(cg_init(c, r2req[j], maxits));
     HIPCHK(hipMemcpyAsync(&B->st[j], c->cg, sizeof(CgScal), hipMemcpyDeviceToDevice, c->stream));
+    pf[j] = &p; tf[j] = &t;
     A1.in[j] = p.par(par); A1.out[j] = t.par(1 - par);
     A2.in[j] = t.par(1 - par); A2.out[j] = Ap.par(par); A2.xs[j] = p.par(par);
     A2.cb[j] = 4.0 * mass[j] * mass[j];
@@ -297,8 +332,9 @@ int solve_xx_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const d
     L.x[j] = x[j]->par(par); L.r[j] = r.par(par); L.p[j] = p.par(par); L.Ap[j] = Ap.par(par);
     L.dotp[j] = B->partials + per * j; L.r2p[j] = B->partials + per * j + nbd;
   }
-  const bool deferred = nbd <= 4096;          // same switch as dslash_sweep / k_cg_update
-  L.st = B->st; L.ndot = deferred ? nbd : 0;
+  const bool multi = c->nranks > 1 || c->opt_batch_multi;
+  const bool deferred = !multi && nbd <= 4096;          // same switch as dslash_sweep / k_cg_update
+  L.st = B->st; L.glob = B->glob; L.ndot = multi ? -1 : (deferred ? nbd : 0);
   for (MrhsArgs *A : {&A1, &A2}) {
     A->g = g; A->st = B->st; A->nrhs = n;
     if (c->recon) {
@@ -328,14 +364,25 @@ int solve_xx_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const d
         ScopedTimer tm(c, "blas", c->stream);
         k_cgb_xpay<<<dim3(nbb, n), 256, 0, c->stream>>>(L, nvec);
       }
-      CHK(sweep_mrhs(c, A1, false));
-      CHK(sweep_mrhs(c, A2, true));
-      if (!deferred) k_cgb_reduce_dot<<<n, 256, 0, c->stream>>>(L, nbd);
+      CHK(sweep_mrhs(c, A1, false, pf, par));
+      CHK(sweep_mrhs(c, A2, true, tf, 1 - par));
+      if (multi) {
+        k_cgb_local_sum<<<n, 256, 0, c->stream>>>(L, nbd, 0);
+        CHK(comm_allreduce(c, B->glob, n));
+      } else if (!deferred) {
+        k_cgb_reduce_dot<<<n, 256, 0, c->stream>>>(L, nbd);
+      }
       {
         ScopedTimer tm(c, "blas", c->stream);
         k_cgb_update<<<dim3(nbb, n), 256, 0, c->stream>>>(L, nvec);
       }
-      k_cgb_reduce_finish<<<n, 256, 0, c->stream>>>(L, nbb);
+      if (multi) {
+        k_cgb_local_sum<<<n, 256, 0, c->stream>>>(L, nbb, 1);
+        CHK(comm_allreduce(c, B->glob + 4, n));
+        k_cgb_finish_glob<<<1, 64, 0, c->stream>>>(L, n);
+      } else {
+        k_cgb_reduce_finish<<<n, 256, 0, c->stream>>>(L, nbb);
+      }
       HIPCHK(hipGetLastError());
     }
     CHK(read_states());

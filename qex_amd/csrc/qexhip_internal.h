@@ -94,6 +94,7 @@ struct qexhip_ctx {
   int opt_swz = -1, opt_ntstore = 1;   // swz: -1 = on for compressed links, off for 18-real links (measured)
   // compressed links (recon = 1: rows 0,1 + sign mask; 2: rows 0,1 + det; row 2 rebuilt in the kernel)
   double2 *Wc = nullptr; unsigned long long *Ws = nullptr; size_t Wc_rows = 0; int recon = 0; double recon_dev = 0;
+  int opt_batch_multi = 0; // test hook: take the multi-rank reduction branch of the batched CG on one rank
   int opt_recon = 2;      // QEXHIP_RECON: 0 keeps the 18-real links always, 1 sign format only, 2 also the U(3) format
   int opt_overlap = -1;  // QEXHIP_OVERLAP: 1 always use the comm stream, 0 never, -1 by interior size
   // natural gauge (flow)

@@ -12,12 +12,14 @@ def relerr(a, b):
     return np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300)
 
 
-def _setup(o, lat, kind):
+def _setup(o, lat, kind, halo=False):
     import qex_amd as q
 
     lo = o.Layout(lat)
     rf = o.RngField(lo, o.RNG_MILC6, 4711)
     ctx = q.Context(lat)
+    if halo:
+        ctx.force_halo(True)          # the kernels and the face exchange of a t-sharded rank, on one GPU
     if kind == "random":            # 18-real links
         g = o.gauge_random(lo, rf); o.rephase(lo, g); s = q.newStag(ctx, g); fmt = 0
     elif kind == "warm":            # rows 0,1 + sign
@@ -73,3 +75,32 @@ def test_solve_batch_equals_single_and_oracle(oracle, kind):
         r = np.zeros_like(x1)
         s.D(r, xs[j], ms[j])
         assert ((r - bs[j]) ** 2).sum() / (bs[j] ** 2).sum() <= 1e-20
+
+
+@pytest.mark.parametrize("kind", ["random", "warm", "naik"])
+@pytest.mark.parametrize("multi", [False, True])
+def test_batch_on_the_sharded_path(oracle, kind, multi):
+    """ghost-zone kernels + face exchange of all systems (what each rank of a t-sharded job runs); `multi` also takes
+    the multi-rank reduction branch (local sums -> one all-reduce for all systems -> bookkeeping)."""
+    q, lo, rf, s = _setup(oracle, [8, 8, 8, 8], kind, halo=True)
+    s.ctx.set_option("batch_multi", 1 if multi else 0)
+    ms = [0.1, 0.2, 0.4]
+    bs = [oracle.vector_gaussian(lo, rf) for _ in ms]
+    xs = [np.zeros_like(b) for b in bs]
+    its, _ = s.solveXX_batch(xs, bs, ms, 1e-14, 5000, True)
+    for j in range(3):
+        sp = q.SolverParams(r2req=1e-14, maxits=5000, verbosity=0)
+        x1 = np.zeros_like(bs[j])
+        s.solveXX(x1, bs[j], ms[j], sp, True)
+        assert abs(its[j] - sp.iterations) <= (1 if multi else 0)
+        assert relerr(xs[j], x1) < (1e-7 if multi else 1e-13)
+    # and the full solve with reconstruction
+    bs[0][lo.vol // 2:] = 0
+    xs = [np.zeros_like(b) for b in bs]
+    sps = [q.SolverParams(r2req=1e-18, maxits=10000, verbosity=0) for _ in ms]
+    s.solve_batch(xs, bs, ms, sps)
+    for j in range(3):
+        r = np.zeros_like(bs[j])
+        s.D(r, xs[j], ms[j])
+        assert ((r - bs[j]) ** 2).sum() / (bs[j] ** 2).sum() <= 1e-18
+    s.ctx.set_option("batch_multi", 0)
