@@ -105,6 +105,31 @@ int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, 
   return 0;
 }
 
+// faces of up to two buffers (the two parity halves of a matrix field) in ONE group, both directions:
+// bottom[k] -> lower neighbour's ghost_hi, top[k] -> upper neighbour's ghost_lo   (same message order as above)
+int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double *const top[], double *const ghost_hi[],
+                        double *const ghost_lo[], size_t ndoubles) {
+  if (c->comm) {
+    ncclComm_t comm = (ncclComm_t)c->comm;
+    NCCLCHK(ncclGroupStart());
+    for (int k = 0; k < nbuf; k++) {
+      NCCLCHK(ncclSend(bottom[k], ndoubles, ncclDouble, lower(c), comm, c->stream));
+      NCCLCHK(ncclSend(top[k], ndoubles, ncclDouble, upper(c), comm, c->stream));
+    }
+    for (int k = 0; k < nbuf; k++) {
+      NCCLCHK(ncclRecv(ghost_hi[k], ndoubles, ncclDouble, upper(c), comm, c->stream));
+      NCCLCHK(ncclRecv(ghost_lo[k], ndoubles, ncclDouble, lower(c), comm, c->stream));
+    }
+    NCCLCHK(ncclGroupEnd());
+  } else {
+    for (int k = 0; k < nbuf; k++) {
+      HIPCHK(hipMemcpyAsync(ghost_hi[k], bottom[k], ndoubles * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(ghost_lo[k], top[k], ndoubles * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+  }
+  return 0;
+}
+
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
   if (c->nranks <= 1 || !c->comm) return 0;
   NCCLCHK(ncclAllReduce(dptr, dptr, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));

@@ -7,7 +7,11 @@
 //   contractProjectTAH         src/gauge/gaugeUtils.nim:389-398
 //   gaugeFlow (RK3)            src/gauge/wflow.nim:21-67
 // Layout: natural links G[parity][tile][mu][9][64] double2 (one 16-byte load per lane and entry).
-// Single GPU (BASELINE.json config 3); the staggered path above is the sharded one.
+// t-sharded runs: every parity half is [body ntile | ghost_hi 3F/64 tiles | ghost_lo 3F/64 tiles]; ghost_hi holds
+// the upper neighbour's slices t = Xt, Xt+1, Xt+2, ghost_lo the lower neighbour's t = -3, -2, -1 ("virtual slices":
+// a t-hop never wraps, link_off() maps the virtual slice to its ghost tile).  The ghosts of U are refreshed after
+// every change of U to the depth the next kernel needs (1: plaquette action, 2: rectangles, 3: 3x3 clover loops);
+// reductions end in an all-reduce.  Wilson lines that wind around t are not available sharded.
 #include "qexhip_internal.h"
 #include "reduce.h"
 #include "su3.h"
@@ -18,8 +22,12 @@
 struct GaugeNat {
   double2 *U = nullptr, *F = nullptr, *P = nullptr;
   double2 *U2 = nullptr;   // second link buffer: the fused flow stage reads U and writes exp(v) U here, then they swap
-  size_t n2 = 0;  // double2 elements per field
+  size_t n2 = 0;  // double2 elements per field (incl. ghost tiles when t is sharded)
+  int ghost_valid = 0;   // depth to which the ghost slices of U are current
 };
+
+static int gauge_ghosts(qexhip_ctx *c, int depth);
+static int read_global(qexhip_ctx *c, double *dev, int n, double *host);
 
 __device__ __forceinline__ void coords_of(const Geom &g, int c, int p, int x[4]) {
   unsigned r = (unsigned)c;
@@ -30,14 +38,17 @@ __device__ __forceinline__ void coords_of(const Geom &g, int c, int p, int x[4])
   x[0] = 2 * xh + ((x[1] + x[2] + x[3] + p) & 1);
 }
 __device__ __forceinline__ size_t link_off(const Geom &g, const int x[4], int mu) {
-  int lex = x[0] + g.X[0] * (x[1] + g.X[1] * (x[2] + g.X[2] * x[3]));
+  int t = x[3];
+  if (g.halo) t = t >= g.X[3] ? t + 0 : (t < 0 ? t + g.X[3] + 6 : t);     // virtual slices: Xt..Xt+2 -> ghost_hi, -3..-1 -> ghost_lo
+  int lex = x[0] + g.X[0] * (x[1] + g.X[1] * (x[2] + g.X[2] * t));
   int p = (x[0] + x[1] + x[2] + x[3]) & 1;
   int c = lex >> 1;
-  return (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+  return (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
 }
 __device__ __forceinline__ void shifted(const Geom &g, const int x[4], int mu, int d, int y[4]) {
   y[0] = x[0]; y[1] = x[1]; y[2] = x[2]; y[3] = x[3];
   int v = y[mu] + d;
+  if (g.halo && mu == 3) { y[3] = v; return; }                              // t sharded: no wrap, ghosts
   y[mu] = v >= g.X[mu] ? v - g.X[mu] : (v < 0 ? v + g.X[mu] : v);
 }
 
@@ -47,7 +58,7 @@ __global__ void __launch_bounds__(256) k_gauge_to_tiles(Geom g, const double2 *_
   if (i >= g.V) return;
   int p = i >= g.Vh, c = i - p * g.Vh;
   for (int mu = 0; mu < 4; mu++) {
-    double2 *w = G + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    double2 *w = G + (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
     for (int k = 0; k < 9; k++) w[k * 64] = host[((size_t)i * 4 + mu) * 9 + k];
   }
 }
@@ -56,7 +67,7 @@ __global__ void __launch_bounds__(256) k_gauge_from_tiles(Geom g, double2 *__res
   if (i >= g.V) return;
   int p = i >= g.Vh, c = i - p * g.Vh;
   for (int mu = 0; mu < 4; mu++) {
-    const double2 *w = G + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    const double2 *w = G + (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
     for (int k = 0; k < 9; k++) host[((size_t)i * 4 + mu) * 9 + k] = w[k * 64];
   }
 }
@@ -164,11 +175,16 @@ __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict
 }
 
 // RK3 stage, second half: U <- exp(v) U with v already in the momentum field (wflow.nim:40-43)
-__global__ void __launch_bounds__(256) k_exp_update(size_t nlinks_tiles, double2 *G, const double2 *V, double t) {
+// body link-tiles of both parity halves: linear index -> offset (skips the ghost tiles of a sharded field)
+__device__ __forceinline__ size_t body_tile_off(size_t tile, size_t ntile4, size_t etile4) {
+  const size_t p = tile >= ntile4;
+  return (p * etile4 + (tile - p * ntile4)) * 576;
+}
+__global__ void __launch_bounds__(256) k_exp_update(size_t nlinks_tiles, double2 *G, const double2 *V, double t, size_t ntile4, size_t etile4) {
   size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;  // (tile-of-links, lane)
   size_t tile = j >> 6;
   if (tile >= nlinks_tiles) return;
-  size_t o = tile * 576 + (j & 63);
+  size_t o = body_tile_off(tile, ntile4, etile4) + (j & 63);
   M3 v = m3_load(V + o, 64);
   if (t != 1.0) {
 #pragma unroll
@@ -199,10 +215,10 @@ __device__ __forceinline__ M3 path_prod(const Geom &g, const double2 *__restrict
     M3 u;
     if (s > 0) {
       u = m3_load(G + link_off(g, x, d), 64);
-      x[d] = x[d] + 1 >= g.X[d] ? 0 : x[d] + 1;
+      x[d] = (g.halo && d == 3) ? x[d] + 1 : (x[d] + 1 >= g.X[d] ? 0 : x[d] + 1);
       m = first ? u : m3_mul(m, u);
     } else {
-      x[d] = x[d] == 0 ? g.X[d] - 1 : x[d] - 1;
+      x[d] = (g.halo && d == 3) ? x[d] - 1 : (x[d] == 0 ? g.X[d] - 1 : x[d] - 1);
       u = m3_load(G + link_off(g, x, d), 64);
       if (first) {
 #pragma unroll
@@ -263,7 +279,7 @@ __global__ void __launch_bounds__(256) k_obs_final(const double *partials, int n
     double acc = 0;
     for (int i = threadIdx.x; i < nb; i += 256) acc += partials[(size_t)k * nb + i];
     double r = block_sum_256(acc);
-    if (threadIdx.x == 0) out[k] = (k < 2) ? -r / vol : -r / (4.0 * 3.14159265358979323846 * 3.14159265358979323846);
+    if (threadIdx.x == 0) out[k] = r;          // raw sums: rank-summed and normalised by the caller
   }
 }
 
@@ -319,6 +335,7 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
   for (int d = 0; d < 4; d++)
     if (loop > 1 && c->g.X[d] < 4) { qexhip_set_error("improved fmunu needs extents >= 4"); return -1; }
+  CHK(gauge_ghosts(c, loop > 1 ? 3 : 1));      // the improved clover reaches three sites from x (3x3, 1x3 loops)
   ObsTable T;
   CHK(obs_build_table(loop, T));
   if (!c->obs_table) HIPCHK(hipMalloc(&c->obs_table, sizeof(ObsTable)));
@@ -334,7 +351,11 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
   }
   k_obs_final<<<1, 256, 0, c->stream>>>(c->partials, nb, (double)c->g.V, &c->dscal[24]);
   HIPCHK(hipGetLastError());
-  return read_scalars(c, &c->dscal[24], 3, out);
+  CHK(read_global(c, &c->dscal[24], 3, out));
+  const double vol = (double)c->g.V * (double)c->nranks;
+  out[0] = -out[0] / vol; out[1] = -out[1] / vol;
+  out[2] = -out[2] / (4.0 * 3.14159265358979323846 * 3.14159265358979323846);
+  return 0;
 }
 
 // ---------------- general gauge actions: plaq + rect, plaq + adjplaq (completes row a14) ----------------
@@ -440,9 +461,8 @@ int gauge_deriv_dev(qexhip_ctx *c, const double2 *G, double2 *F, double cplaq, d
 
 static int gn_alloc(qexhip_ctx *c) {
   if (c->gn) return 0;
-  if (c->g.halo) { qexhip_set_error("gauge/flow kernels are single-GPU (no t sharding)"); return -3; }
   c->gn = new GaugeNat();
-  c->gn->n2 = (size_t)2 * c->g.ntile * 4 * 576;
+  c->gn->n2 = (size_t)2 * c->g.etile * 4 * 576;
   size_t bytes = c->gn->n2 * sizeof(double2);
   HIPCHK(hipMalloc((void **)&c->gn->U, bytes));
   HIPCHK(hipMemsetAsync(c->gn->U, 0, bytes, c->stream));
@@ -454,6 +474,33 @@ static int gn_alloc_fp(qexhip_ctx *c) {
   if (!c->gn->P) { HIPCHK(hipMalloc((void **)&c->gn->P, bytes)); HIPCHK(hipMemsetAsync(c->gn->P, 0, bytes, c->stream)); }
   return 0;
 }
+// refresh the ghost slices of the resident links to at least `depth` (1..3); no-op unless t is sharded
+static int gauge_ghosts(qexhip_ctx *c, int depth) {
+  const Geom &g = c->g;
+  if (!g.halo || c->gn->ghost_valid >= depth) return 0;
+  if (g.X[3] < depth) { qexhip_set_error("local t extent %d < ghost depth %d needed by this kernel", g.X[3], depth); return -1; }
+  const size_t tile2 = (size_t)4 * 576 * 2;                 // doubles per link-tile
+  const size_t ft = (size_t)g.F / 64;                       // tiles per t-slice
+  double *bottom[2], *top[2], *ghi[2], *glo[2];
+  for (int p = 0; p < 2; p++) {
+    double *base = (double *)c->gn->U + (size_t)p * g.etile * tile2;
+    bottom[p] = base;
+    top[p] = base + ((size_t)g.ntile - depth * ft) * tile2;
+    ghi[p] = base + (size_t)g.ntile * tile2;
+    glo[p] = base + ((size_t)g.ntile + 3 * ft + (3 - depth) * ft) * tile2;
+  }
+  ScopedTimer tm(c, "gauge_halo", c->stream);
+  CHK(comm_faces_exchange(c, 2, bottom, top, ghi, glo, (size_t)depth * ft * tile2));
+  c->gn->ghost_valid = depth;
+  return 0;
+}
+// rank-sum of n device scalars, then read back
+static int read_global(qexhip_ctx *c, double *dev, int n, double *host) {
+  if (c->nranks > 1) CHK(comm_allreduce(c, dev, n));
+  return read_scalars(c, dev, n, host);
+}
+static inline int ghost_depth_for(double c2, int kind) { return (kind == 0 && c2 != 0.0) ? 2 : 1; }
+
 void gauge_free(qexhip_ctx *c) {
   if (!c->gn) return;
   if (c->gn->U) (void)hipFree(c->gn->U);
@@ -472,6 +519,7 @@ int gauge_set(qexhip_ctx *c, const double *g) {
   HIPCHK(hipMemcpyAsync(c->stage, g, bytes, hipMemcpyHostToDevice, c->stream));
   k_gauge_to_tiles<<<(c->g.V + 255) / 256, 256, 0, c->stream>>>(c->g, (const double2 *)c->stage, c->gn->U);
   HIPCHK(hipGetLastError());
+  c->gn->ghost_valid = 0;
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -491,6 +539,7 @@ int gauge_get(qexhip_ctx *c, double *g) {
 
 int gauge_plaq(qexhip_ctx *c, double out[6]) {
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  CHK(gauge_ghosts(c, 1));
   int nb = (c->g.V + 255) / 256;
   if (nb > 1024) nb = 1024;
   {
@@ -498,15 +547,19 @@ int gauge_plaq(qexhip_ctx *c, double out[6]) {
     k_plaq<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->partials);
     HIPCHK(hipGetLastError());
   }
-  // pl[i]/(physVol*np*nc)  (gaugeUtils.nim:277)
-  k_plaq_final<<<1, 256, 0, c->stream>>>(c->partials, nb, (double)c->g.V * 18.0, &c->dscal[16]);
+  // pl[i]/(physVol*np*nc)  (gaugeUtils.nim:277); rankSum before the normalisation (:275-279)
+  k_plaq_final<<<1, 256, 0, c->stream>>>(c->partials, nb, 1.0, &c->dscal[16]);
   HIPCHK(hipGetLastError());
-  return read_scalars(c, &c->dscal[16], 6, out);
+  CHK(read_global(c, &c->dscal[16], 6, out));
+  const double norm = (double)c->g.V * (double)c->nranks * 18.0;
+  for (int k = 0; k < 6; k++) out[k] = out[k] / norm;
+  return 0;
 }
 
 static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, double cpm = 0, double c2 = 0, int kind = 0,
                      double2 *Uout = nullptr) {
   CHK(gn_alloc_fp(c));
+  CHK(gauge_ghosts(c, ghost_depth_for(c2, kind)));
   ScopedTimer tm(c, "staple", c->stream);
   static const int mode = [] { const char *e = getenv("QEXHIP_FORCE_MODE"); return e ? atoi(e) : 1; }();   // process-wide tuning switch
   int nb = mode == 0 ? (4 * c->g.V + 255) / 256 : 2 * c->g.ntile;
@@ -548,11 +601,13 @@ int gauge_wflow(qexhip_ctx *c, int nsteps, double eps, double cplaq, double c2, 
       if (fused) {
         CHK(force_dev(c, cplaq, 1, cf[st], cpm[st], c2, kind, c->gn->U2));
         std::swap(c->gn->U, c->gn->U2);
+        c->gn->ghost_valid = 0;
       } else {
         CHK(force_dev(c, cplaq, 1, cf[st], cpm[st], c2, kind));
         ScopedTimer tm(c, "expupdate", c->stream);
-        k_exp_update<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P, 1.0);
+        k_exp_update<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P, 1.0, (size_t)c->g.ntile * 4, (size_t)c->g.etile * 4);
         HIPCHK(hipGetLastError());
+        c->gn->ghost_valid = 0;
       }
     }
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -606,16 +661,17 @@ int gauge_action(qexhip_ctx *c, double cplaq, double c2, int kind, double *out) 
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
   const int rect = (kind == 0 && c2 != 0.0);
   if (rect) for (int d = 0; d < 4; d++) if (c->g.X[d] < 4) { qexhip_set_error("rectangle action needs extents >= 4"); return -1; }
+  CHK(gauge_ghosts(c, rect ? 2 : 1));
   int nb = (c->g.V + 255) / 256;
   if (nb > 1024) nb = 1024;
   k_action<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, rect, c->partials);
   k_sum3<<<1, 256, 0, c->stream>>>(c->partials, nb, &c->dscal[24]);
   HIPCHK(hipGetLastError());
   double s[3];
-  CHK(read_scalars(c, &c->dscal[24], 3, s));
+  CHK(read_global(c, &c->dscal[24], 3, s));
   if (kind == 0) *out = (-1.0 / 3.0) * (cplaq * s[0] + c2 * s[2]);
   else {
-    const double a0 = 0.5 * 12.0 * (double)c->g.V;
+    const double a0 = 0.5 * 12.0 * (double)c->g.V * (double)c->nranks;
     *out = cplaq * (a0 - s[0] / 3.0) + c2 * (a0 - s[1] / 9.0);
   }
   return 0;
@@ -630,23 +686,25 @@ int gauge_md_update(qexhip_ctx *c, const double *p_host, double t) {
   k_gauge_to_tiles<<<(c->g.V + 255) / 256, 256, 0, c->stream>>>(c->g, (const double2 *)c->stage, c->gn->P);
   const size_t ltiles = (size_t)2 * c->g.ntile * 4;
   ScopedTimer tm(c, "expupdate", c->stream);
-  k_exp_update<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P, t);
+  k_exp_update<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P, t, (size_t)c->g.ntile * 4, (size_t)c->g.etile * 4);
   HIPCHK(hipGetLastError());
+  c->gn->ghost_valid = 0;
   return 0;
 }
 // reunit: g.projectSU (gaugeUtils.nim:1333-1334)
-__global__ void __launch_bounds__(256) k_reunit(size_t nlinks_tiles, double2 *G) {
+__global__ void __launch_bounds__(256) k_reunit(size_t nlinks_tiles, double2 *G, size_t ntile4, size_t etile4) {
   size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
   size_t tile = j >> 6;
   if (tile >= nlinks_tiles) return;
-  size_t o = tile * 576 + (j & 63);
+  size_t o = body_tile_off(tile, ntile4, etile4) + (j & 63);
   m3_store(G + o, 64, m3_projectSU(m3_load(G + o, 64)));
 }
 int gauge_reunit(qexhip_ctx *c) {
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
   const size_t ltiles = (size_t)2 * c->g.ntile * 4;
-  k_reunit<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, c->gn->U);
+  k_reunit<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, c->gn->U, (size_t)c->g.ntile * 4, (size_t)c->g.etile * 4);
   HIPCHK(hipGetLastError());
+  c->gn->ghost_valid = 0;
   return 0;
 }
 // wline (gaugeUtils.nim:1079-1112): volume- and colour-averaged trace of a path product; path entries
@@ -663,10 +721,10 @@ __global__ void __launch_bounds__(256) k_wline(Geom g, const double2 *__restrict
       const int d = (s > 0 ? s : -s) - 1;
       if (s > 0) {
         M3 u = m3_load(G + link_off(g, x, d), 64);
-        x[d] = x[d] + 1 >= g.X[d] ? 0 : x[d] + 1;
+        x[d] = (g.halo && d == 3) ? x[d] + 1 : (x[d] + 1 >= g.X[d] ? 0 : x[d] + 1);
         m = k == 0 ? u : m3_mul(m, u);
       } else {
-        x[d] = x[d] == 0 ? g.X[d] - 1 : x[d] - 1;
+        x[d] = (g.halo && d == 3) ? x[d] - 1 : (x[d] == 0 ? g.X[d] - 1 : x[d] - 1);
         M3 u = m3_load(G + link_off(g, x, d), 64);
         if (k == 0) { m = m3_zero(); m3_add_diag(m, 1.0); }
         m = m3_mul_na(m, u);
@@ -682,6 +740,7 @@ __global__ void __launch_bounds__(256) k_wline(Geom g, const double2 *__restrict
 }
 int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]) {
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  if (c->g.halo) { qexhip_set_error("wline: not available on a t-sharded field (lines may wind around t)"); return -3; }
   if (n < 1 || n > 4096) { qexhip_set_error("wline: path length out of range"); return -1; }
   for (int k = 0; k < n; k++) if (path[k] == 0 || path[k] > 4 || path[k] < -4) { qexhip_set_error("wline: path entries are +-(mu+1)"); return -1; }
   CHK(ensure_stage(c, 4096 * sizeof(int)));

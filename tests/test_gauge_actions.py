@@ -107,3 +107,47 @@ def test_gpu_md_building_blocks(oracle):
     for path in ([4] * lat[3], [1] * lat[0], [1, 2, -1, -2], [-3, 4, 4, 3, -4, -4], [2]):
         w = q.wline(ctx, path, g1)
         assert abs(w - o.wline(lo, g1, path)) < 1e-14
+
+
+@pytest.mark.gpu
+def test_gpu_gauge_sector_on_the_sharded_path(oracle):
+    """t-sharded gauge-sector kernels (ghost slices of the links, virtual-slice indexing, face exchange to depth
+    1 / 2 / 3, rank reductions), exercised on one GPU with forced ghost zones: plaquettes, the three actions and
+    forces, Wilson / Symanzik / adjoint flow, clover observables, MD update, reunit == the periodic kernels."""
+    import qex_amd as q
+
+    o = oracle
+    lat = [8, 8, 8, 8]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 23)
+    g = o.gauge_warm(lo, 0.4, rf)
+    p = o.gauge_random_tah(lo, rf)
+    A, B = q.Context(lat), q.Context(lat)
+    B.force_halo(True)
+    assert "halo=1" in B.info()
+    assert np.array_equal(q.plaq(A, g), q.plaq(B, g))
+    for cp, c2, kind in [(1.0, 0.0, 0), (5.0 / 3.0, -1.0 / 12.0, 0), (6.0, -1.5, 1)]:
+        kw = dict(plaq=cp, rect=c2 if kind == 0 else 0.0, adjplaq=c2 if kind == 1 else 0.0)
+        assert q.gaugeAction(A, g, **kw) == q.gaugeAction(B, g, **kw)
+        fa = q.gaugeForce(A, g, cplaq=cp, rect=kw["rect"], adjplaq=kw["adjplaq"])
+        fb = q.gaugeForce(B, g, cplaq=cp, rect=kw["rect"], adjplaq=kw["adjplaq"])
+        assert np.array_equal(fa, fb)
+        ga, gb = g.copy(), g.copy()
+        act = {0: "rect" if c2 else "Wilson", 1: "adj"}[kind]
+        q.gaugeFlow(A, ga, 2, 0.01, flow_act=act, **kw)
+        q.gaugeFlow(B, gb, 2, 0.01, flow_act=act, **kw)
+        assert np.array_equal(ga, gb)
+        for loop in (1, 3, 4, 5):
+            ea, eb = q.flowEQ(A, loop), q.flowEQ(B, loop)          # of the resident (flowed) fields
+            assert np.allclose(ea, eb, rtol=0, atol=0)
+    ga, gb = g.copy(), g.copy()
+    q.gaugeUpdate(A, ga, p, 0.3)
+    q.gaugeUpdate(B, gb, p, 0.3)
+    assert np.array_equal(ga, gb)
+    ga *= 1 + 1e-9
+    gb = ga.copy()
+    q.reunit(A, ga)
+    q.reunit(B, gb)
+    assert np.array_equal(ga, gb) and np.array_equal(q.plaq(A, ga), q.plaq(B, gb))
+    with pytest.raises(q.QexHipError, match="wline"):
+        q.wline(B, [4] * 8, gb)
