@@ -37,19 +37,29 @@ __device__ __forceinline__ void coords_of(const Geom &g, int c, int p, int x[4])
   x[3] = r / (unsigned)g.X[2];
   x[0] = 2 * xh + ((x[1] + x[2] + x[3] + p) & 1);
 }
-__device__ __forceinline__ size_t link_off(const Geom &g, const int x[4], int mu) {
+// HALO as a template parameter for the kernels whose register allocation is tight (k_plaq spills with a runtime
+// flag); the runtime-flag forms below serve everything else
+template <bool HALO>
+__device__ __forceinline__ size_t link_off_t(const Geom &g, const int x[4], int mu) {
   int t = x[3];
-  if (g.halo) t = t >= g.X[3] ? t + 0 : (t < 0 ? t + g.X[3] + 6 : t);     // virtual slices: Xt..Xt+2 -> ghost_hi, -3..-1 -> ghost_lo
+  if (HALO) t = t < 0 ? t + g.X[3] + 6 : t;          // virtual slices: Xt..Xt+2 -> ghost_hi (in place), -3..-1 -> ghost_lo
   int lex = x[0] + g.X[0] * (x[1] + g.X[1] * (x[2] + g.X[2] * t));
   int p = (x[0] + x[1] + x[2] + x[3]) & 1;
   int c = lex >> 1;
   return (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
 }
-__device__ __forceinline__ void shifted(const Geom &g, const int x[4], int mu, int d, int y[4]) {
+template <bool HALO>
+__device__ __forceinline__ void shifted_t(const Geom &g, const int x[4], int mu, int d, int y[4]) {
   y[0] = x[0]; y[1] = x[1]; y[2] = x[2]; y[3] = x[3];
   int v = y[mu] + d;
-  if (g.halo && mu == 3) { y[3] = v; return; }                              // t sharded: no wrap, ghosts
+  if (HALO && mu == 3) { y[3] = v; return; }         // t sharded: no wrap, ghosts
   y[mu] = v >= g.X[mu] ? v - g.X[mu] : (v < 0 ? v + g.X[mu] : v);
+}
+__device__ __forceinline__ size_t link_off(const Geom &g, const int x[4], int mu) {
+  return g.halo ? link_off_t<true>(g, x, mu) : link_off_t<false>(g, x, mu);
+}
+__device__ __forceinline__ void shifted(const Geom &g, const int x[4], int mu, int d, int y[4]) {
+  if (g.halo) shifted_t<true>(g, x, mu, d, y); else shifted_t<false>(g, x, mu, d, y);
 }
 
 // host [idx][mu][9] <-> tiles
@@ -73,6 +83,7 @@ __global__ void __launch_bounds__(256) k_gauge_from_tiles(Geom g, double2 *__res
 }
 
 // plaquette: per site six Re tr[(U_mu(x)U_nu(x+mu))^+ (U_nu(x)U_mu(x+nu))], ip = mu(mu-1)/2+nu
+template <bool HALO>
 __global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict__ G, double *partials) {
   double pl[6] = {0, 0, 0, 0, 0, 0};
   for (int i = blockIdx.x * 256 + threadIdx.x; i < g.V; i += gridDim.x * 256) {
@@ -81,15 +92,15 @@ __global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict_
     coords_of(g, c, p, x);
     M3 U[4];
 #pragma unroll
-    for (int mu = 0; mu < 4; mu++) U[mu] = m3_load(G + link_off(g, x, mu), 64);
+    for (int mu = 0; mu < 4; mu++) U[mu] = m3_load(G + link_off_t<HALO>(g, x, mu), 64);
 #pragma unroll
     for (int mu = 1; mu < 4; mu++) {
 #pragma unroll
       for (int nu = 0; nu < mu; nu++) {
-        shifted(g, x, nu, 1, y);
-        M3 unumu = m3_mul(U[nu], m3_load(G + link_off(g, y, mu), 64));
-        shifted(g, x, mu, 1, y);
-        M3 umunu = m3_mul(U[mu], m3_load(G + link_off(g, y, nu), 64));
+        shifted_t<HALO>(g, x, nu, 1, y);
+        M3 unumu = m3_mul(U[nu], m3_load(G + link_off_t<HALO>(g, y, mu), 64));
+        shifted_t<HALO>(g, x, mu, 1, y);
+        M3 umunu = m3_mul(U[mu], m3_load(G + link_off_t<HALO>(g, y, nu), 64));
         pl[(mu * (mu - 1)) / 2 + nu] += m3_redot(umunu, unumu);
       }
     }
@@ -544,7 +555,8 @@ int gauge_plaq(qexhip_ctx *c, double out[6]) {
   if (nb > 1024) nb = 1024;
   {
     ScopedTimer tm(c, "plaq", c->stream);
-    k_plaq<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->partials);
+    if (c->g.halo) k_plaq<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->partials);
+    else k_plaq<false><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->partials);
     HIPCHK(hipGetLastError());
   }
   // pl[i]/(physVol*np*nc)  (gaugeUtils.nim:277); rankSum before the normalisation (:275-279)
