@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) k_outer(Geom g, const double2 *__restrict
     double2 b[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) b[k] = xn[vec_off(pos, k)];
-    double2 *w = F + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    double2 *w = F + (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) k_force_to_tiles(Geom g, const double2 *_
   if (i >= g.V) return;
   int p = i >= g.Vh, c = i - p * g.Vh;
   for (int mu = 0; mu < 4; mu++) {
-    double2 *w = F + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    double2 *w = F + (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
     for (int k = 0; k < 9; k++) w[k * 64] = host[((size_t)i * 4 + mu) * 9 + k];
   }
 }
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) k_force_from_tiles(Geom g, double2 *__res
   if (i >= g.V) return;
   int p = i >= g.Vh, c = i - p * g.Vh;
   for (int mu = 0; mu < 4; mu++) {
-    const double2 *w = F + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    const double2 *w = F + (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
     for (int k = 0; k < 9; k++) host[((size_t)i * 4 + mu) * 9 + k] = w[k * 64];
   }
 }
@@ -63,7 +63,13 @@ __global__ void __launch_bounds__(256) k_force_from_tiles(Geom g, double2 *__res
 // f (:= | +=) scale * x (x) x(+mu)^+ on a DEVICE force field in the natural layout (single GPU)
 int stag_outer_dev(qexhip_ctx *c, DevField &fx, double2 *F, double se, double so, int accumulate) {
   const Geom &g = c->g;
-  if (g.halo) { qexhip_set_error("stag_outer_dev: single GPU only"); return -3; }
+  if (g.halo) {
+    for (int par = 0; par < 2; par++) CHK(comm_halo_exchange(c, fx, par, 0));      // x(s + t) across the slab boundary
+    ScopedTimer tm(c, "outer", c->stream);
+    k_outer<true><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fx.par(0), fx.par(1), F, se, so, accumulate);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   ScopedTimer tm(c, "outer", c->stream);
   k_outer<false><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fx.par(0), fx.par(1), F, se, so, accumulate);
   HIPCHK(hipGetLastError());
@@ -76,7 +82,7 @@ int stag_outer_host(qexhip_ctx *c, double *f_host, const double *x_host, double 
   DevField *fx;
   CHK(get_work(c, WK_IN, &fx));
   CHK(field_upload(c, *fx, x_host));
-  const size_t n2 = (size_t)2 * g.ntile * 4 * 576;
+  const size_t n2 = (size_t)2 * g.etile * 4 * 576;
   if (c->outer_Fn < n2) {
     if (c->outer_F) HIPCHK(hipFree(c->outer_F));
     c->outer_F = nullptr; c->outer_Fn = 0;

@@ -253,11 +253,19 @@ __global__ void __launch_bounds__(256) k_links_from_nat(Geom g, const double2 *_
   SiteXYZT s = site_coord(g, c, p);
   double2 *w = W + ((size_t)p * g.ntile + (c >> 6)) * ndir * 576 + (c & 63);
   for (int mu = 0; mu < 4; mu++) {
-    const double2 *U = N + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    const double2 *U = N + (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
     double2 *wf = w + (size_t)(dbase + 2 * mu) * 576;
     for (int k = 0; k < 9; k++) wf[k * 64] = U[k * 64];
-    int cb = nbr_pos<false>(g, c, s, mu, -hop);
-    const double2 *B = N + (((size_t)(1 - p) * g.ntile + (cb >> 6)) * 4 + mu) * 576 + (cb & 63);
+    // the backward neighbour x - hop*mu; t-sharded: below the slab it lives in the ghost_lo slices of N
+    // (virtual slice t < 0 -> Xt + 6 + t, the ghost layout of gauge.hip / smear.hip)
+    int cb;
+    if (g.halo && mu == 3) {
+      const int t = c / g.F, tn = t - hop;
+      cb = (tn < 0 ? tn + g.X[3] + 6 : tn) * g.F + (c - t * g.F);
+    } else {
+      cb = nbr_pos<false>(g, c, s, mu, -hop);
+    }
+    const double2 *B = N + (((size_t)(1 - p) * g.etile + (cb >> 6)) * 4 + mu) * 576 + (cb & 63);
     double2 *wb = w + (size_t)(dbase + 2 * mu + 1) * 576;
     for (int r = 0; r < 3; r++)
       for (int q = 0; q < 3; q++) {
@@ -268,9 +276,9 @@ __global__ void __launch_bounds__(256) k_links_from_nat(Geom g, const double2 *_
 }
 int links_from_natural(qexhip_ctx *c, const double2 *fat, const double2 *lng) {
   const Geom &g = c->g;
-  if (g.halo) { qexhip_set_error("links_from_natural: single GPU only"); return -3; }
   int ndir = lng ? 16 : 8;
   if (lng) for (int i = 0; i < 4; i++) if (g.X[i] < 4) { qexhip_set_error("Naik links need local extents >= 4"); return -1; }
+  if (g.halo) c->g.depth = lng ? 3 : 1;      // vector ghost depth in use (as qexhip_stag_set_links does)
   size_t wbytes = (size_t)2 * g.ntile * ndir * 576 * sizeof(double2);
   if (c->W && c->ndir != ndir) { HIPCHK(hipFree(c->W)); c->W = nullptr; }
   if (!c->W) { HIPCHK(hipMalloc((void **)&c->W, wbytes)); }

@@ -35,22 +35,37 @@ __device__ __forceinline__ void coords_sm(const Geom &g, int c, int p, int x[4])
   x[3] = r / (unsigned)g.X[2];
   x[0] = 2 * xh + ((x[1] + x[2] + x[3] + p) & 1);
 }
-__device__ __forceinline__ size_t site_off(const Geom &g, const int x[4], int tstride) {
-  int lex = x[0] + g.X[0] * (x[1] + g.X[1] * (x[2] + g.X[2] * x[3]));
+// t-sharded runs: every parity half of a matrix field is [body ntile | ghost_hi 3F/64 tiles | ghost_lo 3F/64 tiles]
+// (the layout of gauge.hip); a t-hop never wraps, virtual slices Xt..Xt+2 / -3..-1 map to the ghost tiles.  HALO is a
+// template parameter for the two register-tight staple kernels, a runtime flag (g.halo) everywhere else.
+template <bool HALO>
+__device__ __forceinline__ size_t site_off_t(const Geom &g, const int x[4], int tstride) {
+  int t = x[3];
+  if (HALO) t = t < 0 ? t + g.X[3] + 6 : t;
+  int lex = x[0] + g.X[0] * (x[1] + g.X[1] * (x[2] + g.X[2] * t));
   int p = (x[0] + x[1] + x[2] + x[3]) & 1;
   int c = lex >> 1;
-  return ((size_t)p * g.ntile + (c >> 6)) * tstride + (c & 63);
+  return ((size_t)p * g.etile + (c >> 6)) * tstride + (c & 63);
 }
-__device__ __forceinline__ void shift_sm(const Geom &g, const int x[4], int mu, int d, int y[4]) {
+template <bool HALO>
+__device__ __forceinline__ void shift_sm_t(const Geom &g, const int x[4], int mu, int d, int y[4]) {
   y[0] = x[0]; y[1] = x[1]; y[2] = x[2]; y[3] = x[3];
   int v = y[mu] + d;
+  if (HALO && mu == 3) { y[3] = v; return; }
   y[mu] = v >= g.X[mu] ? v - g.X[mu] : (v < 0 ? v + g.X[mu] : v);
+}
+__device__ __forceinline__ size_t site_off(const Geom &g, const int x[4], int tstride) {
+  return g.halo ? site_off_t<true>(g, x, tstride) : site_off_t<false>(g, x, tstride);
+}
+__device__ __forceinline__ void shift_sm(const Geom &g, const int x[4], int mu, int d, int y[4]) {
+  if (g.halo) shift_sm_t<true>(g, x, mu, d, y); else shift_sm_t<false>(g, x, mu, d, y);
 }
 
 // staple field (optional) and acc (+)= coef * staple (optional).  Two fusions for the nHYP levels
 // (hypsmear.nim:98-143): with `init` the accumulator STARTS as cinit * init(x) instead of being read
 // (the `l := ma * g[mu]` assignment), with `proj` the finished sum is also projected, proj(x) = projectU(acc(x))
 // (the `l.proj lx` that follows the last staple of a level).
+template <bool HALO>
 __global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, int swz,
                                                     MView init, double cinit, MViewW proj) {
   int bid = blockIdx.x;
@@ -60,22 +75,22 @@ __global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, in
   const int p = i >= g.Vh, c = i - p * g.Vh;
   int x[4], xpn[4], xpm[4], xmn[4], xmnpm[4];
   coords_sm(g, c, p, x);
-  shift_sm(g, x, nu, 1, xpn);
-  shift_sm(g, x, mu, 1, xpm);
-  shift_sm(g, x, nu, -1, xmn);
-  shift_sm(g, xmn, mu, 1, xmnpm);
-  M3 t = m3_mul_na(m3_load(B.p + site_off(g, xpn, B.tstride), 64), m3_load(A.p + site_off(g, xpm, A.tstride), 64));
-  M3 s = m3_mul(m3_load(A.p + site_off(g, x, A.tstride), 64), t);
-  t = m3_mul_an(m3_load(A.p + site_off(g, xmn, A.tstride), 64), m3_load(B.p + site_off(g, xmn, B.tstride), 64));
-  M3 u = m3_mul(t, m3_load(A.p + site_off(g, xmnpm, A.tstride), 64));
+  shift_sm_t<HALO>(g, x, nu, 1, xpn);
+  shift_sm_t<HALO>(g, x, mu, 1, xpm);
+  shift_sm_t<HALO>(g, x, nu, -1, xmn);
+  shift_sm_t<HALO>(g, xmn, mu, 1, xmnpm);
+  M3 t = m3_mul_na(m3_load(B.p + site_off_t<HALO>(g, xpn, B.tstride), 64), m3_load(A.p + site_off_t<HALO>(g, xpm, A.tstride), 64));
+  M3 s = m3_mul(m3_load(A.p + site_off_t<HALO>(g, x, A.tstride), 64), t);
+  t = m3_mul_an(m3_load(A.p + site_off_t<HALO>(g, xmn, A.tstride), 64), m3_load(B.p + site_off_t<HALO>(g, xmn, B.tstride), 64));
+  M3 u = m3_mul(t, m3_load(A.p + site_off_t<HALO>(g, xmnpm, A.tstride), 64));
 #pragma unroll
   for (int k = 0; k < 9; k++) { s.e[k].x += u.e[k].x; s.e[k].y += u.e[k].y; }
-  if (st.p) m3_store(st.p + site_off(g, x, st.tstride), 64, s);
+  if (st.p) m3_store(st.p + site_off_t<HALO>(g, x, st.tstride), 64, s);
   if (acc.p) {
-    double2 *a = acc.p + site_off(g, x, acc.tstride);
+    double2 *a = acc.p + site_off_t<HALO>(g, x, acc.tstride);
     M3 o;
     if (init.p) {
-      o = m3_load(init.p + site_off(g, x, init.tstride), 64);
+      o = m3_load(init.p + site_off_t<HALO>(g, x, init.tstride), 64);
 #pragma unroll
       for (int k = 0; k < 9; k++) { o.e[k].x *= cinit; o.e[k].y *= cinit; }
     } else {
@@ -83,7 +98,7 @@ __global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, in
     }
     m3_axpy(o, coef, s);
     m3_store(a, 64, o);
-    if (proj.p) m3_store(proj.p + site_off(g, x, proj.tstride), 64, m3_projectU(o));
+    if (proj.p) m3_store(proj.p + site_off_t<HALO>(g, x, proj.tstride), 64, m3_projectU(o));
   }
 }
 // dst += coef * src
@@ -91,8 +106,8 @@ __global__ void __launch_bounds__(256) k_maxpy(Geom g, MViewW dst, double coef, 
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= g.V) return;
   const int p = i >= g.Vh, c = i - p * g.Vh;
-  const size_t od = ((size_t)p * g.ntile + (c >> 6)) * dst.tstride + (c & 63);
-  const size_t os = ((size_t)p * g.ntile + (c >> 6)) * src.tstride + (c & 63);
+  const size_t od = ((size_t)p * g.etile + (c >> 6)) * dst.tstride + (c & 63);
+  const size_t os = ((size_t)p * g.etile + (c >> 6)) * src.tstride + (c & 63);
   M3 o = m3_load(dst.p + od, 64);
   m3_axpy(o, coef, m3_load(src.p + os, 64));
   m3_store(dst.p + od, 64, o);
@@ -102,8 +117,8 @@ __global__ void __launch_bounds__(256) k_mscale(Geom g, MViewW dst, double coef,
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= g.V) return;
   const int p = i >= g.Vh, c = i - p * g.Vh;
-  const size_t od = ((size_t)p * g.ntile + (c >> 6)) * dst.tstride + (c & 63);
-  const size_t os = ((size_t)p * g.ntile + (c >> 6)) * src.tstride + (c & 63);
+  const size_t od = ((size_t)p * g.etile + (c >> 6)) * dst.tstride + (c & 63);
+  const size_t os = ((size_t)p * g.etile + (c >> 6)) * src.tstride + (c & 63);
   M3 m = m3_load(src.p + os, 64);
 #pragma unroll
   for (int k = 0; k < 9; k++) { m.e[k].x *= coef; m.e[k].y *= coef; }
@@ -180,7 +195,7 @@ __global__ void __launch_bounds__(256) k_projUderiv(Geom g, MViewW dst, MView U,
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= g.V) return;
   const int p = i >= g.Vh, c = i - p * g.Vh;
-  const size_t t = (size_t)p * g.ntile + (c >> 6);
+  const size_t t = (size_t)p * g.etile + (c >> 6);
   const int l = c & 63;
   const M3 x = m3_load(X.p + t * X.tstride + l, 64);
   const M3 u = U.p ? m3_load(U.p + t * U.tstride + l, 64) : m3_projectU(x);
@@ -198,7 +213,7 @@ __global__ void __launch_bounds__(256) k_projUderiv(Geom g, MViewW dst, MView U,
 // symStapleDeriv (smearutil.nim:22-50) gathered per site:
 //   f1(x) += g2(x) g1(x+mu) c(x+nu)^+ + c(x) g1(x+mu) g2(x+nu)^+ + [g2^+ g1 c(+nu) + c^+ g1 g2(+nu)](x-mu)
 //   f2(x) += g1(x) c(x+nu) g1(x+mu)^+ + [g1^+ c g1(+mu)](x-nu)
-template <int PART, bool SCALED = false>   // PART 0: f1 and f2, 1: f1 only, 2: f2 only; SCALED: f += coef * (derivative)
+template <bool SCALED, bool HALO>   // SCALED: f += coef * (derivative) instead of accumulating in place
 __global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu, int swz,
                                                       int z1, int z2,      // z1 / z2: f1 / f2 start from zero (first contribution)
                                                       double coef = 1.0) {
@@ -209,29 +224,29 @@ __global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW 
   const int p = i >= g.Vh, c = i - p * g.Vh;
   int x[4], xpm[4], xpn[4], xmm[4], xmn[4], xmmpn[4], xmnpm[4];
   coords_sm(g, c, p, x);
-  shift_sm(g, x, mu, 1, xpm);
-  shift_sm(g, x, nu, 1, xpn);
-  shift_sm(g, x, mu, -1, xmm);
-  shift_sm(g, x, nu, -1, xmn);
-  shift_sm(g, xmm, nu, 1, xmmpn);
-  shift_sm(g, xmn, mu, 1, xmnpm);
-  const size_t o0 = ((size_t)p * g.ntile + (c >> 6));
+  shift_sm_t<HALO>(g, x, mu, 1, xpm);
+  shift_sm_t<HALO>(g, x, nu, 1, xpn);
+  shift_sm_t<HALO>(g, x, mu, -1, xmm);
+  shift_sm_t<HALO>(g, x, nu, -1, xmn);
+  shift_sm_t<HALO>(g, xmm, nu, 1, xmmpn);
+  shift_sm_t<HALO>(g, xmn, mu, 1, xmnpm);
+  const size_t o0 = ((size_t)p * g.etile + (c >> 6));
   const int l = c & 63;
-  if (PART != 2) {
+  {
     M3 a = (z1 || SCALED) ? m3_zero() : m3_load(f1.p + o0 * f1.tstride + l, 64);
     {
-      const M3 g1pm = m3_load(g1.p + site_off(g, xpm, g1.tstride), 64);
-      M3 t = m3_mul_na(g1pm, m3_load(cf.p + site_off(g, xpn, cf.tstride), 64));
+      const M3 g1pm = m3_load(g1.p + site_off_t<HALO>(g, xpm, g1.tstride), 64);
+      M3 t = m3_mul_na(g1pm, m3_load(cf.p + site_off_t<HALO>(g, xpn, cf.tstride), 64));
       m3_mac(a, m3_load(g2.p + o0 * g2.tstride + l, 64), t);
-      t = m3_mul_na(g1pm, m3_load(g2.p + site_off(g, xpn, g2.tstride), 64));
+      t = m3_mul_na(g1pm, m3_load(g2.p + site_off_t<HALO>(g, xpn, g2.tstride), 64));
       m3_mac(a, m3_load(cf.p + o0 * cf.tstride + l, 64), t);
     }
     {
-      const M3 g1mm = m3_load(g1.p + site_off(g, xmm, g1.tstride), 64);
-      M3 t = m3_mul(g1mm, m3_load(cf.p + site_off(g, xmmpn, cf.tstride), 64));
-      m3_mac_an(a, m3_load(g2.p + site_off(g, xmm, g2.tstride), 64), t);
-      t = m3_mul(g1mm, m3_load(g2.p + site_off(g, xmmpn, g2.tstride), 64));
-      m3_mac_an(a, m3_load(cf.p + site_off(g, xmm, cf.tstride), 64), t);
+      const M3 g1mm = m3_load(g1.p + site_off_t<HALO>(g, xmm, g1.tstride), 64);
+      M3 t = m3_mul(g1mm, m3_load(cf.p + site_off_t<HALO>(g, xmmpn, cf.tstride), 64));
+      m3_mac_an(a, m3_load(g2.p + site_off_t<HALO>(g, xmm, g2.tstride), 64), t);
+      t = m3_mul(g1mm, m3_load(g2.p + site_off_t<HALO>(g, xmmpn, g2.tstride), 64));
+      m3_mac_an(a, m3_load(cf.p + site_off_t<HALO>(g, xmm, cf.tstride), 64), t);
     }
     if (SCALED) {
       M3 o = z1 ? m3_zero() : m3_load(f1.p + o0 * f1.tstride + l, 64);
@@ -240,12 +255,12 @@ __global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW 
     }
     m3_store(f1.p + o0 * f1.tstride + l, 64, a);
   }
-  if (PART != 1) {
+  {
     M3 a = (z2 || SCALED) ? m3_zero() : m3_load(f2.p + o0 * f2.tstride + l, 64);
-    M3 t = m3_mul_na(m3_load(cf.p + site_off(g, xpn, cf.tstride), 64), m3_load(g1.p + site_off(g, xpm, g1.tstride), 64));
+    M3 t = m3_mul_na(m3_load(cf.p + site_off_t<HALO>(g, xpn, cf.tstride), 64), m3_load(g1.p + site_off_t<HALO>(g, xpm, g1.tstride), 64));
     m3_mac(a, m3_load(g1.p + o0 * g1.tstride + l, 64), t);
-    t = m3_mul(m3_load(cf.p + site_off(g, xmn, cf.tstride), 64), m3_load(g1.p + site_off(g, xmnpm, g1.tstride), 64));
-    m3_mac_an(a, m3_load(g1.p + site_off(g, xmn, g1.tstride), 64), t);
+    t = m3_mul(m3_load(cf.p + site_off_t<HALO>(g, xmn, cf.tstride), 64), m3_load(g1.p + site_off_t<HALO>(g, xmnpm, g1.tstride), 64));
+    m3_mac_an(a, m3_load(g1.p + site_off_t<HALO>(g, xmn, g1.tstride), 64), t);
     if (SCALED) {
       M3 o = z2 ? m3_zero() : m3_load(f2.p + o0 * f2.tstride + l, 64);
       m3_axpy(o, coef, a);
@@ -258,8 +273,8 @@ __global__ void __launch_bounds__(256) k_projectU(Geom g, MViewW dst, MView src)
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= g.V) return;
   const int p = i >= g.Vh, c = i - p * g.Vh;
-  const size_t od = ((size_t)p * g.ntile + (c >> 6)) * dst.tstride + (c & 63);
-  const size_t os = ((size_t)p * g.ntile + (c >> 6)) * src.tstride + (c & 63);
+  const size_t od = ((size_t)p * g.etile + (c >> 6)) * dst.tstride + (c & 63);
+  const size_t os = ((size_t)p * g.etile + (c >> 6)) * src.tstride + (c & 63);
   m3_store(dst.p + od, 64, m3_projectU(m3_load(src.p + os, 64)));
 }
 // ll(x) = naik * U(x) U(x+d) U(x+2d)   (fat7l.nim:146-156)
@@ -284,7 +299,7 @@ __global__ void __launch_bounds__(256) k_sm_to_tiles(Geom g, const double2 *__re
   if (i >= g.V) return;
   int p = i >= g.Vh, c = i - p * g.Vh;
   for (int mu = 0; mu < 4; mu++) {
-    double2 *w = G + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    double2 *w = G + (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
     for (int k = 0; k < 9; k++) w[k * 64] = host[((size_t)i * 4 + mu) * 9 + k];
   }
 }
@@ -293,7 +308,7 @@ __global__ void __launch_bounds__(256) k_sm_from_tiles(Geom g, double2 *__restri
   if (i >= g.V) return;
   int p = i >= g.Vh, c = i - p * g.Vh;
   for (int mu = 0; mu < 4; mu++) {
-    const double2 *w = G + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+    const double2 *w = G + (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
     for (int k = 0; k < 9; k++) host[((size_t)i * 4 + mu) * 9 + k] = w[k * 64];
   }
 }
@@ -330,7 +345,7 @@ struct Smear {
   size_t gsz, fsz;  // double2 per gauge field / per single matrix field
   std::vector<double2 *> owned;
   explicit Smear(qexhip_ctx *c_) : c(c_), g(c_->g) {
-    fsz = (size_t)2 * g.ntile * 576;
+    fsz = (size_t)2 * g.etile * 576;    // incl. the ghost tiles of a t-sharded field
     gsz = 4 * fsz;
   }
   ~Smear() { (void)hipStreamSynchronize(c->stream); for (auto p : owned) (void)hipFree(p); }
@@ -341,6 +356,24 @@ struct Smear {
     return 0;
   }
   int nb() const { return (g.V + 255) / 256; }
+  // t-sharded: refresh the ghost slices of a field (tstride 576: one matrix field, 2304: gauge-shaped) to `depth`;
+  // the caller does this for every field that is about to be read at shifted sites.  No-op on one GPU without ghosts.
+  int ghosts(const double2 *field, int tstride, int depth = 1) {
+    if (!g.halo) return 0;
+    const size_t tile2 = (size_t)tstride * 2, ft = (size_t)g.F / 64;
+    double *bottom[2], *top[2], *ghi[2], *glo[2];
+    for (int p = 0; p < 2; p++) {
+      double *base = (double *)field + (size_t)p * g.etile * tile2;
+      bottom[p] = base;
+      top[p] = base + ((size_t)g.ntile - depth * ft) * tile2;
+      ghi[p] = base + (size_t)g.ntile * tile2;
+      glo[p] = base + ((size_t)g.ntile + 3 * ft + (3 - depth) * ft) * tile2;
+    }
+    ScopedTimer tm(c, "smear_halo", c->stream);
+    return comm_faces_exchange(c, 2, bottom, top, ghi, glo, (size_t)depth * ft * tile2);
+  }
+  int ghosts_f(const double2 *f, int depth = 1) { return ghosts(f, 576, depth); }
+  int ghosts_g(const double2 *G, int depth = 1) { return ghosts(G, 4 * 576, depth); }
   MView gv(const double2 *G, int mu) const { return MView{G + (size_t)mu * 576, 4 * 576}; }
   MViewW gvw(double2 *G, int mu) const { return MViewW{G + (size_t)mu * 576, 4 * 576}; }
   MView fv(const double2 *F) const { return MView{F, 576}; }
@@ -366,7 +399,8 @@ struct Smear {
              MViewW proj = MViewW{nullptr, 0}) {
     ScopedTimer tm(c, "smear", c->stream);
     static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
-    k_gen_staple<<<nb(), 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj);
+    if (g.halo) k_gen_staple<true><<<nb(), 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj);
+    else k_gen_staple<false><<<nb(), 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -387,11 +421,13 @@ struct Smear {
       for (int nu = 0; nu < 4; nu++) {
         if (nu == dir) continue;
         CHK(staple(gv(gf, nu), gv(gf, dir), dir, nu, fvw(stp), gvw(fl, dir), c3));
+        if (have5) CHK(ghosts_f(stp));                      // the staple is the middle link of the next level
         if (cL != 0.0) CHK(staple(gv(gf, nu), fv(stp), dir, nu, none, gvw(fl, dir), cL));
         if (c5 != 0.0 || c7 != 0.0)
           for (int rho = 0; rho < 4; rho++) {
             if (rho == dir || rho == nu) continue;
             CHK(staple(gv(gf, rho), fv(stp), dir, rho, fvw(tmp), gvw(fl, dir), c5));
+            if (c7 != 0.0) CHK(ghosts_f(tmp));
             if (c7 != 0.0)
               for (int sig = 0; sig < 4; sig++) {
                 if (sig == dir || sig == nu || sig == rho) continue;
@@ -410,7 +446,8 @@ struct Smear {
   int sderiv(MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu, double coef) {
     static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
     ScopedTimer tm(c, "smear_deriv", c->stream);
-    k_staple_deriv<0, true><<<nb(), 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, 0, 0, coef);
+    if (g.halo) k_staple_deriv<true, true><<<nb(), 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, 0, 0, coef);
+    else k_staple_deriv<true, false><<<nb(), 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, 0, 0, coef);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -433,20 +470,24 @@ struct Smear {
       for (int nu = 0; nu < 4; nu++) {
         if (nu == dir) continue;
         CHK(staple(gv(gf, nu), gv(gf, dir), dir, nu, fvw(st1), none, 0.0));
+        if (have5) CHK(ghosts_f(st1));
         k_mscale<<<nb(), 256, 0, c->stream>>>(g, fvw(ast1), c3, ch);
         if (cL != 0.0) CHK(sderiv(gvw(d, nu), fvw(ast1), gv(gf, nu), fv(st1), ch, dir, nu, cL));
         if (c5 != 0.0 || c7 != 0.0)
           for (int rho = 0; rho < 4; rho++) {
             if (rho == dir || rho == nu) continue;
             CHK(staple(gv(gf, rho), fv(st1), dir, rho, fvw(tmp), none, 0.0));
+            if (c7 != 0.0) CHK(ghosts_f(tmp));
             k_mscale<<<nb(), 256, 0, c->stream>>>(g, fvw(atmp), c5, ch);
             if (c7 != 0.0)
               for (int sig = 0; sig < 4; sig++) {
                 if (sig == dir || sig == nu || sig == rho) continue;
                 CHK(sderiv(gvw(d, sig), fvw(atmp), gv(gf, sig), fv(tmp), ch, dir, sig, c7));
               }
+            CHK(ghosts_f(atmp));                            // adjoints are chains of the next derivative: read shifted
             CHK(sderiv(gvw(d, rho), fvw(ast1), gv(gf, rho), fv(st1), fv(atmp), dir, rho, 1.0));
           }
+        CHK(ghosts_f(ast1));
         CHK(sderiv(gvw(d, nu), gvw(d, dir), gv(gf, nu), gv(gf, dir), fv(ast1), dir, nu, 1.0));
       }
     }
@@ -464,14 +505,17 @@ struct Smear {
     const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
     double2 *V, *W, *T;
     CHK(alloc(&V, gsz)); CHK(alloc(&W, gsz)); CHK(alloc(&T, gsz));     // alloc zero-fills
+    CHK(ghosts_g(G));
     CHK(fat7(V, G, c_first, nullptr, G, 0.0));
     for (int mu = 0; mu < 4; mu++) k_projectU<<<nb(), 256, 0, c->stream>>>(g, gvw(W, mu), gv(V, mu));
     HIPCHK(hipGetLastError());
+    CHK(ghosts_g(W, 2)); CHK(ghosts_g(CF)); CHK(ghosts_g(CL, 2));
     CHK(fat7_deriv(T, W, CF, c_second, CL, -naik / 24.0));
     for (int mu = 0; mu < 4; mu++)
       k_projUderiv<<<nb(), 256, 0, c->stream>>>(g, gvw(T, mu), gv(W, mu), gv(V, mu), gv(T, mu), MViewW{nullptr, 0}, 0.0, 1.0, 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(F, 0, gsz * sizeof(double2), c->stream));
+    CHK(ghosts_g(T));
     return fat7_deriv(F, G, T, c_first, nullptr, 0.0);
   }
   // HisqCoefs.init + smear (hisqLinks.nim:9-43) on device fields
@@ -481,11 +525,13 @@ struct Smear {
     const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
     double2 *T1, *T2;
     CHK(alloc(&T1, gsz)); CHK(alloc(&T2, gsz));
+    CHK(ghosts_g(G));
     CHK(fat7(T1, G, c_first, nullptr, G, 0.0));
     for (int mu = 0; mu < 4; mu++) {
       k_projectU<<<nb(), 256, 0, c->stream>>>(g, gvw(T2, mu), gv(T1, mu));
       HIPCHK(hipGetLastError());
     }
+    CHK(ghosts_g(T2, 2));                                   // Naik: x+d, x+2d
     return fat7(FL, T2, c_second, LL, T2, -naik / 24.0);
   }
   // nHYP forward smearing (hypsmear.nim:49-144) on device fields; with `keep` the unprojected and
@@ -507,11 +553,14 @@ struct Smear {
     const double alp1 = a1 / 2.0, alp2 = a2 / 4.0, alp3 = a3 / 6.0;
     const MViewW none{nullptr, 0};
     const MView noinit{nullptr, 0};
-    // every level: first staple starts the sum from ma * U_mu, last staple projects it (fused, see k_gen_staple)
+    // every level: first staple starts the sum from ma * U_mu, last staple projects it (fused, see k_gen_staple);
+    // t-sharded: the projected links of a level get their ghost slices before the next level reads them shifted
+    CHK(ghosts_g(G));
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
         CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(K.l1x[mu][nu]), alp1, gv(G, mu), 1 - a1, fvw(K.l1[mu][nu])));
+        CHK(ghosts_f(K.l1[mu][nu]));
       }
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
@@ -525,6 +574,7 @@ struct Smear {
                      last ? fvw(K.l2[mu][nu]) : none));
           cnt++;
         }
+        CHK(ghosts_f(K.l2[mu][nu]));
       }
     for (int mu = 0; mu < 4; mu++) {
       const MViewW x3 = keep ? gvw(K.flx, mu) : fvw(tmp);
@@ -553,7 +603,7 @@ void nhyp_state_free(qexhip_ctx *c) {
   if (c->nhyp) { delete (NhypState *)c->nhyp; c->nhyp = nullptr; }
 }
 int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, double *fl_host) {
-  if (c->g.halo) { qexhip_set_error("nhyp force chain: single GPU only"); return -3; }
+  if (c->g.halo && c->g.X[3] < 4) { qexhip_set_error("t-sharded smearing needs a local t extent >= 4"); return -1; }
   for (int i = 0; i < 4; i++) if (c->g.X[i] < 2) { qexhip_set_error("nhyp force chain needs local extents >= 2"); return -1; }
   NhypState *st = (NhypState *)c->nhyp;
   const bool fresh = !st;       // a second smearGetForce on this context reuses the ~70 device fields
@@ -580,16 +630,10 @@ int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, doub
 // smearedForce(f, chain) on the device field st->F (in: chain, out: f)   (hypsmear.nim:146-245)
 static int staple_deriv(qexhip_ctx *c, const Geom &g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu,
                         int z1 = 0, int z2 = 0) {
-  // QEXHIP_SDERIV = 10*swizzle + variant (variant 1: f1 and f2 in separate launches); default 10
-  static const int sel = [] { const char *e = getenv("QEXHIP_SDERIV"); return e ? atoi(e) : 10; }();
-  const int variant = sel % 10, swz = sel / 10;
+  static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
   const int nblk = (g.V + 255) / 256;
-  if (variant == 0) {
-    k_staple_deriv<0><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2);
-  } else {
-    k_staple_deriv<1><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2);
-    k_staple_deriv<2><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2);
-  }
+  if (g.halo) k_staple_deriv<false, true><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2);
+  else k_staple_deriv<false, false><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -608,6 +652,7 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
                                               S.gvw(st->F, mu), ma3, alp3, 0);
   }
   HIPCHK(hipGetLastError());
+  CHK(S.ghosts_g(st->fc));          // t-sharded: a chain field is read at shifted sites by the staple derivative
   for (int mu = 0; mu < 4; mu++)
     for (int nu = 0; nu < 4; nu++) {
       if (nu == mu) continue;
@@ -621,6 +666,7 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
       if (nu == mu) continue;
       k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[mu][nu]), S.fv(st->K.l2x[mu][nu]),
                                                 S.fv(st->fl2[mu][nu]), S.gvw(st->F, mu), ma2, alp2, 1);
+      CHK(S.ghosts_f(st->fl2[mu][nu]));
     }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
@@ -640,6 +686,7 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
       if (nu == mu) continue;
       k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl1[mu][nu]), S.fv(st->K.l1[mu][nu]), S.fv(st->K.l1x[mu][nu]),
                                                 S.fv(st->fl1[mu][nu]), S.gvw(st->F, mu), ma1, alp1, 1);
+      CHK(S.ghosts_f(st->fl1[mu][nu]));
     }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
@@ -661,7 +708,8 @@ int nhyp_force_host(qexhip_ctx *c, double *f_host, const double *chain_host) {
 
 // setBC_cust + stagPhase on a device gauge field (stagg_pv_hmc/staghmc_spv.nim:367-401,
 // gauge/gaugeUtils.nim:124-131, physics/stagD.nim:509-520): sign flips only
-__global__ void __launch_bounds__(256) k_rephase(Geom g, double2 *G, int bcmask, int ph0, int ph1, int ph2, int ph3) {
+__global__ void __launch_bounds__(256) k_rephase(Geom g, double2 *G, int bcmask, int ph0, int ph1, int ph2, int ph3, int tlast) {
+  // tlast: this rank holds the last global t slice (the t boundary condition lives there; local t parity = global)
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= g.V) return;
   const int p = i >= g.Vh, c = i - p * g.Vh;
@@ -671,9 +719,9 @@ __global__ void __launch_bounds__(256) k_rephase(Geom g, double2 *G, int bcmask,
   for (int mu = 0; mu < 4; mu++) {
     int s = 0;
     for (int k = 0; k < 4; k++) s += (ph[mu] >> k) & x[k];
-    if (((bcmask >> mu) & 1) && x[mu] == g.X[mu] - 1) s += 1;
+    if (((bcmask >> mu) & 1) && x[mu] == g.X[mu] - 1 && (mu != 3 || tlast)) s += 1;
     if (s & 1) {
-      double2 *w = G + (((size_t)p * g.ntile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+      double2 *w = G + (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
       for (int k = 0; k < 9; k++) { double2 v = w[k * 64]; w[k * 64] = make_double2(-v.x, -v.y); }
     }
   }
@@ -681,7 +729,7 @@ __global__ void __launch_bounds__(256) k_rephase(Geom g, double2 *G, int bcmask,
 
 
 static int smear_check(qexhip_ctx *c, int min_extent) {
-  if (c->g.halo) { qexhip_set_error("link smearing kernels are single-GPU (no t sharding)"); return -3; }
+  if (c->g.halo && c->g.X[3] < 4) { qexhip_set_error("t-sharded smearing needs a local t extent >= 4"); return -1; }
   for (int d = 0; d < 4; d++)
     if (c->g.X[d] < min_extent) { qexhip_set_error("smearing needs lattice extents >= %d", min_extent); return -1; }
   return 0;
@@ -695,6 +743,7 @@ int smear_fat7_host(qexhip_ctx *c, const double *g_host, const double coef[5], d
   CHK(S.alloc(&FL, S.gsz));
   if (ll_host && naik != 0.0) CHK(S.alloc(&LL, S.gsz));
   CHK(S.upload(G, g_host));
+  CHK(S.ghosts_g(G, 2));
   CHK(S.fat7(FL, G, coef, LL, G, naik));
   CHK(S.download(fl_host, FL));
   if (LL) CHK(S.download(ll_host, LL));
@@ -728,7 +777,8 @@ int smear_fat7_deriv_host(qexhip_ctx *c, const double *g_host, const double *dfl
   double2 *G, *CF, *CL = nullptr, *D;
   CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&CF, S.gsz)); CHK(S.alloc(&D, S.gsz));
   CHK(S.upload(G, g_host)); CHK(S.upload(CF, dfl_host));
-  if (dll_host) { CHK(S.alloc(&CL, S.gsz)); CHK(S.upload(CL, dll_host)); }
+  if (dll_host) { CHK(S.alloc(&CL, S.gsz)); CHK(S.upload(CL, dll_host)); CHK(S.ghosts_g(CL, 2)); }
+  CHK(S.ghosts_g(G, 2)); CHK(S.ghosts_g(CF));
   CHK(S.fat7_deriv(D, G, CF, coef, CL, naik));
   return S.download(d_host, D);
 }
@@ -752,6 +802,7 @@ int smear_set_links_hisq(qexhip_ctx *c, const double *g_host) {
   CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&FL, S.gsz)); CHK(S.alloc(&LL, S.gsz));
   CHK(S.upload(G, g_host));
   CHK(S.hisq(G, FL, LL));
+  CHK(S.ghosts_g(FL, 1)); CHK(S.ghosts_g(LL, 3));      // backward links x - mu, x - 3 mu below the slab
   return links_from_natural(c, FL, LL);
 }
 int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, int bcmask, const int ph[4]) {
@@ -761,8 +812,9 @@ int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double 
     NhypState *st = (NhypState *)c->nhyp;
     if (!st) { qexhip_set_error("set_links_nhyp(g = NULL) needs qexhip_nhyp_prepare first"); return -1; }
     HIPCHK(hipMemcpyAsync(st->F, st->FL, st->S.gsz * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
-    k_rephase<<<st->S.nb(), 256, 0, c->stream>>>(st->S.g, st->F, bcmask, ph[0], ph[1], ph[2], ph[3]);
+    k_rephase<<<st->S.nb(), 256, 0, c->stream>>>(st->S.g, st->F, bcmask, ph[0], ph[1], ph[2], ph[3], c->rankCoord[3] == c->rankGeom[3] - 1);
     HIPCHK(hipGetLastError());
+    CHK(st->S.ghosts_g(st->F, 1));
     return links_from_natural(c, st->F, nullptr);
   }
   Smear S(c);
@@ -770,8 +822,9 @@ int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double 
   CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&FL, S.gsz));
   CHK(S.upload(G, g_host));
   CHK(S.nhyp(G, FL, a1, a2, a3));
-  k_rephase<<<S.nb(), 256, 0, c->stream>>>(S.g, FL, bcmask, ph[0], ph[1], ph[2], ph[3]);
+  k_rephase<<<S.nb(), 256, 0, c->stream>>>(S.g, FL, bcmask, ph[0], ph[1], ph[2], ph[3], c->rankCoord[3] == c->rankGeom[3] - 1);
   HIPCHK(hipGetLastError());
+  CHK(S.ghosts_g(FL, 1));
   return links_from_natural(c, FL, nullptr);
 }
 
@@ -787,7 +840,7 @@ __global__ void __launch_bounds__(256) k_force_projtah(size_t nlinks_tiles, doub
 }
 static int nhyp_finish(qexhip_ctx *c, NhypState *st, int adj, double *f_host) {
   CHK(nhyp_backward_dev(c, st));
-  const size_t ltiles = (size_t)2 * c->g.ntile * 4;
+  const size_t ltiles = (size_t)2 * c->g.etile * 4;       // ghost tiles included: harmless, keeps the index linear
   k_force_projtah<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, st->F, st->G, adj);
   HIPCHK(hipGetLastError());
   return st->S.download(f_host, st->F);
@@ -797,6 +850,7 @@ static int nhyp_finish(qexhip_ctx *c, NhypState *st, int adj, double *f_host) {
 int nhyp_gauge_force(qexhip_ctx *c, double *f_host, double cplaq, double c2, int kind) {
   NhypState *st = (NhypState *)c->nhyp;
   if (!st) { qexhip_set_error("nhyp_gauge_force: call qexhip_nhyp_prepare first (smearGetForce)"); return -1; }
+  CHK(st->S.ghosts_g(st->FL, (kind == 0 && c2 != 0.0) ? 2 : 1));
   CHK(gauge_deriv_dev(c, st->FL, st->F, cplaq, c2, kind));
   return nhyp_finish(c, st, 1, f_host);
 }
@@ -812,7 +866,7 @@ int nhyp_fermion_force(qexhip_ctx *c, double *f_host, const double *const *psi, 
     CHK(field_upload(c, *fx, psi[k]));
     CHK(stag_outer_dev(c, *fx, st->F, scale[k], -scale[k], k > 0));
   }
-  k_rephase<<<st->S.nb(), 256, 0, c->stream>>>(st->S.g, st->F, bcmask, ph[0], ph[1], ph[2], ph[3]);
+  k_rephase<<<st->S.nb(), 256, 0, c->stream>>>(st->S.g, st->F, bcmask, ph[0], ph[1], ph[2], ph[3], c->rankCoord[3] == c->rankGeom[3] - 1);
   HIPCHK(hipGetLastError());
   return nhyp_finish(c, st, 0, f_host);
 }
@@ -834,7 +888,7 @@ int nhyp_fforce(qexhip_ctx *c, double *f_host, int n, const double *const *phi, 
     CHK(solve_full_batch_dev(c, k, xs, bs, mass + k0, r2req + k0, maxits, iters ? iters + k0 : nullptr, nullptr));
     for (int j = 0; j < k; j++) CHK(stag_outer_dev(c, *xs[j], st->F, scale[k0 + j], -scale[k0 + j], (k0 + j) > 0));
   }
-  k_rephase<<<st->S.nb(), 256, 0, c->stream>>>(st->S.g, st->F, bcmask, ph[0], ph[1], ph[2], ph[3]);
+  k_rephase<<<st->S.nb(), 256, 0, c->stream>>>(st->S.g, st->F, bcmask, ph[0], ph[1], ph[2], ph[3], c->rankCoord[3] == c->rankGeom[3] - 1);
   HIPCHK(hipGetLastError());
   return nhyp_finish(c, st, 0, f_host);
 }

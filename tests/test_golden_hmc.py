@@ -140,8 +140,8 @@ def test_oracle_replays_reference_trajectory(oracle, run):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("run", [0, 1])
-def test_gpu_replays_reference_trajectory(oracle, run):
+@pytest.mark.parametrize("run,halo", [(0, False), (1, False), (0, True)])
+def test_gpu_replays_reference_trajectory(oracle, run, halo):
     """The same trajectories with every operator -- smearing, solves, forces, link update, action,
     reunitarisation, plaquettes, Polyakov loops -- AND the random numbers (momenta, pseudofermions,
     pbp sources: qex_amd.RngField) coming from libqexhip; the oracle supplies nothing but the unit start."""
@@ -149,4 +149,5 @@ def test_gpu_replays_reference_trajectory(oracle, run):
     import hmc_replay as R
 
     rng = q.RngField(R.LAT, q.RngMilc6, R.SEED)          # the product's own newRNGField
-    _check_trajectory(R.Replay(oracle, R.HipBackend(q, R.LAT), R.CONFIGS[run], rng=rng), second=(run == 0))
+    # halo: the same trajectory with every kernel in its t-sharded form (forced ghost zones on one GPU)
+    _check_trajectory(R.Replay(oracle, R.HipBackend(q, R.LAT, halo=halo), R.CONFIGS[run], rng=rng), second=(run == 0 and not halo))

@@ -316,3 +316,74 @@ def test_gpu_hisq_force(oracle):
     f = q.HisqCoefs().init().force(ctx, g, dfl, dll)
     ref = o.hisq_force(lo, g, dfl, dll)
     assert np.linalg.norm(f - ref) / np.linalg.norm(ref) < 1e-12
+
+
+@pytest.mark.gpu
+def test_gpu_smearing_and_forces_on_the_sharded_path(oracle):
+    """t-sharded link construction and force chains (ghost slices for every matrix field that is read at shifted
+    sites, face exchange after each such field is produced), on one GPU with forced ghost zones: must reproduce the
+    periodic kernels -- fat7 / HISQ links, their derivative, nHYP links, the nHYP closure and both MD forces, and
+    the operators built from device-smeared links."""
+    import qex_amd as q
+
+    o = oracle
+    lat = [8, 8, 8, 8]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 61)
+    g = o.gauge_warm(lo, 0.5, rf)
+    gp = g.copy()
+    o.rephase(lo, gp)
+    dfl, dll = o.gauge_random_tah(lo, rf) + 0.2 * o.gauge_random(lo, rf), o.gauge_random_tah(lo, rf)
+    x = o.vector_gaussian(lo, rf)
+    psis = [o.vector_gaussian(lo, rf), o.vector_gaussian(lo, rf)]
+    A, B = q.Context(lat), q.Context(lat)
+    B.force_halo(True)
+    eq = lambda a, b: np.linalg.norm(a - b) <= 1e-15 * np.linalg.norm(a)
+    coef = (0.9, -0.11, 0.021, -0.0043, -0.07)
+    out = {}
+    for name, ctx in (("A", A), ("B", B)):
+        r = {}
+        fl, ll = np.zeros_like(g), np.zeros_like(g)
+        q.makeImpLinks(ctx, fl, gp, coef, ll, naik=-0.05)
+        r["fat7"] = (fl.copy(), ll.copy())
+        q.HisqCoefs().init().smear(ctx, gp, fl, ll)
+        r["hisq"] = (fl.copy(), ll.copy())
+        r["fat7d"] = q.fat7lDeriv(ctx, gp, dfl, coef, dll, naik=-0.05)
+        r["hisqf"] = q.HisqCoefs().init().force(ctx, gp, dfl, dll)
+        sg = np.zeros_like(g)
+        hc = q.HypCoefs(0.4, 0.5, 0.5)
+        hc.smear(ctx, g, sg)
+        r["nhyp"] = sg.copy()
+        sf = hc.smearGetForce(ctx, g, sg)
+        r["nhyp2"] = sg.copy()
+        f = np.zeros_like(g)
+        sf(f, dfl)
+        r["chain"] = f.copy()
+        for k, kw in enumerate([dict(plaq=1.0), dict(plaq=5.0 / 3.0, rect=-1.0 / 12.0), dict(plaq=6.0, adjplaq=-1.5)]):
+            sf.gforce(f, **kw)
+            r["gforce%d" % k] = f.copy()
+        sf.fforce(f, psis, [0.37, -1.9], bc="aaaa")
+        r["fforce"] = f.copy()
+        s = q.Staggered(ctx, None, smear=hc, bc="pppa")               # operator on the closure's links
+        y = np.zeros_like(x)
+        s.D(y, x, 0.05)
+        r["D_nhyp"] = y.copy()
+        phis = [p.copy() for p in psis]
+        for p in phis:
+            p[lo.vol // 2:] = 0
+        its = sf.fforce_solve(f, phis, [0.1, 0.2], [0.37, -1.9], 1e-20, bc="pppa")
+        r["fsolve"], r["its"] = f.copy(), its
+        s = q.Staggered(ctx, gp, smear=q.HisqCoefs().init())
+        s.D(y, x, 0.05)
+        r["D_hisq"] = y.copy()
+        out[name] = r
+    a, b = out["A"], out["B"]
+    assert a["its"] == b["its"]
+    for k in a:
+        if k == "its":
+            continue
+        if isinstance(a[k], tuple):
+            assert all(eq(u, v) for u, v in zip(a[k], b[k])), k
+        else:
+            tol = 1e-9 if k == "fsolve" else 1e-15                     # solves: summation order of the slab reductions
+            assert np.linalg.norm(a[k] - b[k]) <= tol * np.linalg.norm(a[k]), k
