@@ -188,7 +188,8 @@ int qexhip_flow_EQ(qexhip_handle h, int loop, double out[3]);
  *   update: mdt, g[mu][s] := exp(t p[mu][s]) g[mu][s] (src/examples/staghmc_sh.nim:429-435); p host, [vol][4][3][3][2]
  *   reunit: g.projectSU (src/gauge/gaugeUtils.nim:1333-1334; `reunit` of the HMC examples, staghmc_sh.nim:247-258)
  *   wline:  g.wline(path) (gaugeUtils.nim:1079-1112): volume- and colour-averaged trace, out = {re, im}; path entries
- *           +-(mu+1); the Polyakov loops of `ploop` are path = [mu+1] * L_mu (staghmc_sh.nim:281-291) */
+ *           +-(mu+1); the Polyakov loops of `ploop` are path = [mu+1] * L_mu (staghmc_sh.nim:281-291).  On a t-sharded
+ *           field: paths that stray at most 3 slices in t, or the straight line [+-4] * L_t (global) */
 int qexhip_gauge_action(qexhip_handle h, double cplaq, double crect, double cadjplaq, double *out);
 int qexhip_gauge_update(qexhip_handle h, const double *p, double t);
 int qexhip_gauge_reunit(qexhip_handle h);

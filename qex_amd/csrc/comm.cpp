@@ -130,6 +130,16 @@ int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double 
   return 0;
 }
 
+// rank-ordered concatenation of `n` doubles per rank (one rank / no communicator: a copy)
+int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n) {
+  if (c->comm && c->nranks > 1) {
+    NCCLCHK(ncclAllGather(send, recv, n, ncclDouble, (ncclComm_t)c->comm, c->stream));
+  } else {
+    HIPCHK(hipMemcpyAsync(recv, send, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
+  return 0;
+}
+
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
   if (c->nranks <= 1 || !c->comm) return 0;
   NCCLCHK(ncclAllReduce(dptr, dptr, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));

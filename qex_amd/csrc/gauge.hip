@@ -16,6 +16,7 @@
 #include "reduce.h"
 #include "su3.h"
 #include <utility>
+#include <algorithm>
 #include <cstdlib>
 #include <initializer_list>
 
@@ -750,21 +751,91 @@ __global__ void __launch_bounds__(256) k_wline(Geom g, const double2 *__restrict
   r = block_sum_256(si); if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = r;
   if (threadIdx.x == 0) partials[2 * gridDim.x + blockIdx.x] = 0.0;
 }
+// t-sharded Polyakov line: every rank multiplies its own t-links, M_r(xs) = prod_{t local} U_t(xs, t) for the spatial
+// sites xs (both parities of the local t = 0 slice), the segments are all-gathered in rank order and every rank forms
+// tr(M_0 M_1 ... M_{N-1}) -- the trace is cyclic, so the line through (xs, t) has the same trace for every t.
+__global__ void __launch_bounds__(256) k_tline_segment(Geom g, const double2 *__restrict__ G, double2 *M) {
+  const int j = blockIdx.x * 256 + threadIdx.x;            // (parity, site of the t = 0 slice)
+  if (j >= 2 * g.F) return;
+  const int p = j >= g.F, c = j - p * g.F;
+  int x[4];
+  coords_of(g, c, p, x);
+  M3 m = m3_load(G + link_off(g, x, 3), 64);
+  for (int t = 1; t < g.X[3]; t++) {
+    x[3] = t;
+    m = m3_mul(m, m3_load(G + link_off(g, x, 3), 64));
+  }
+  for (int k = 0; k < 9; k++) M[(size_t)j * 9 + k] = m.e[k];
+}
+__global__ void __launch_bounds__(256) k_tline_trace(int nsites, int nranks, const double2 *__restrict__ M, double *partials) {
+  double sr = 0, si = 0;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < nsites; j += gridDim.x * 256) {
+    M3 m;
+    for (int k = 0; k < 9; k++) m.e[k] = M[(size_t)j * 9 + k];
+    for (int r = 1; r < nranks; r++) {
+      M3 u;
+      for (int k = 0; k < 9; k++) u.e[k] = M[((size_t)r * nsites + j) * 9 + k];
+      m = m3_mul(m, u);
+    }
+    sr += m.e[0].x + m.e[4].x + m.e[8].x;
+    si += m.e[0].y + m.e[4].y + m.e[8].y;
+  }
+  double r;
+  r = block_sum_256(sr); if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  r = block_sum_256(si); if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = r;
+  if (threadIdx.x == 0) partials[2 * gridDim.x + blockIdx.x] = 0.0;
+}
+
 int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]) {
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
-  if (c->g.halo) { qexhip_set_error("wline: not available on a t-sharded field (lines may wind around t)"); return -3; }
   if (n < 1 || n > 4096) { qexhip_set_error("wline: path length out of range"); return -1; }
   for (int k = 0; k < n; k++) if (path[k] == 0 || path[k] > 4 || path[k] < -4) { qexhip_set_error("wline: path entries are +-(mu+1)"); return -1; }
+  const Geom &g = c->g;
+  int nb = (g.V + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  double s[3];
+  if (g.halo) {
+    // how far the path strays in t: within the three ghost slices the generic walk works on the sharded field
+    int t = 0, tmin = 0, tmax = 0;
+    bool straight = true;
+    for (int k = 0; k < n; k++) {
+      if (path[k] == 4) t++; else if (path[k] == -4) t--;
+      if (path[k] != path[0]) straight = false;
+      tmin = std::min(tmin, t); tmax = std::max(tmax, t);
+    }
+    const int reach = std::max(-tmin, tmax);
+    if (reach > 3) {
+      const int Lt = g.X[3] * c->nranks;
+      if (!(straight && (path[0] == 4 || path[0] == -4) && n == Lt)) {
+        qexhip_set_error("wline on a t-sharded field: the path may stray at most 3 slices in t, or be the straight Polyakov line");
+        return -3;
+      }
+      const int ns = 2 * g.F;                                   // spatial sites
+      const size_t seg = (size_t)ns * 9 * 2;                    // doubles per rank
+      CHK(ensure_stage(c, seg * sizeof(double) * (1 + (size_t)c->nranks)));
+      double *mine = c->stage, *all = c->stage + seg;
+      k_tline_segment<<<(ns + 255) / 256, 256, 0, c->stream>>>(g, c->gn->U, (double2 *)mine);
+      HIPCHK(hipGetLastError());
+      CHK(comm_allgather(c, mine, all, seg));
+      int nbt = std::min((ns + 255) / 256, 1024);
+      k_tline_trace<<<nbt, 256, 0, c->stream>>>(ns, c->nranks, (const double2 *)all, c->partials);
+      k_sum3<<<1, 256, 0, c->stream>>>(c->partials, nbt, &c->dscal[24]);
+      HIPCHK(hipGetLastError());
+      CHK(read_scalars(c, &c->dscal[24], 3, s));               // identical on every rank: no reduction
+      const double fac = 1.0 / ((double)ns * 3.0);
+      out[0] = s[0] * fac;
+      out[1] = (path[0] == 4 ? 1.0 : -1.0) * s[1] * fac;       // the reversed line is the adjoint
+      return 0;
+    }
+    CHK(gauge_ghosts(c, std::max(reach, 1)));
+  }
   CHK(ensure_stage(c, 4096 * sizeof(int)));
   HIPCHK(hipMemcpyAsync(c->stage, path, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  int nb = (c->g.V + 255) / 256;
-  if (nb > 1024) nb = 1024;
-  k_wline<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, (const int *)c->stage, n, c->partials);
+  k_wline<<<nb, 256, 0, c->stream>>>(g, c->gn->U, (const int *)c->stage, n, c->partials);
   k_sum3<<<1, 256, 0, c->stream>>>(c->partials, nb, &c->dscal[24]);
   HIPCHK(hipGetLastError());
-  double s[3];
-  CHK(read_scalars(c, &c->dscal[24], 3, s));
-  const double fac = 1.0 / ((double)c->g.V * 3.0);
+  CHK(read_global(c, &c->dscal[24], 3, s));
+  const double fac = 1.0 / ((double)g.V * (double)c->nranks * 3.0);
   out[0] = s[0] * fac; out[1] = s[1] * fac;
   return 0;
 }

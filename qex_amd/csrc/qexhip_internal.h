@@ -154,6 +154,7 @@ int solve_batch_host(qexhip_ctx *c, int n, double *const *x, const double *const
 // ---- comm.cpp ----
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready, records ev_halo
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
+int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n);
 int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double *const top[], double *const ghost_hi[],
                         double *const ghost_lo[], size_t ndoubles);
 int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st);

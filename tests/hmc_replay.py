@@ -381,10 +381,8 @@ class HipBackend:
         """halo=True: every kernel runs in its t-sharded form (ghost zones, face exchanges, rank reductions) on one GPU"""
         self.q = q
         self.ctx = q.Context(lat)
-        self.wctx = self.ctx
         if halo:
             self.ctx.force_halo(True)
-            self.wctx = q.Context(lat)        # Wilson lines wind around t: measured on an unsharded copy
         self.hc = q.HypCoefs(*ALPHA)
 
     def smear_rephase(self, g, want_force):
@@ -431,7 +429,7 @@ class HipBackend:
         self.q.reunit(self.ctx, g)
 
     def wline(self, g, path):
-        return self.q.wline(self.wctx, path, g)
+        return self.q.wline(self.ctx, path, g)
 
     def fermion_force(self, h, g, fields, scales):
         f = np.zeros_like(g)

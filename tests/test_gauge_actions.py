@@ -149,5 +149,9 @@ def test_gpu_gauge_sector_on_the_sharded_path(oracle):
     q.reunit(A, ga)
     q.reunit(B, gb)
     assert np.array_equal(ga, gb) and np.array_equal(q.plaq(A, ga), q.plaq(B, gb))
+    # Wilson lines: loops that stay within the three ghost slices walk the sharded field directly, the straight
+    # Polyakov line in t is assembled from per-rank segments (all-gather); anything else is refused
+    for path in ([4] * 8, [-4] * 8, [1] * 8, [1, 4, -1, -4], [4, 4, 4, 1, -4, -4, -4, -1], [-4, -4, 2, 4, 4, -2]):
+        assert abs(q.wline(A, path, ga) - q.wline(B, path, gb)) < 1e-15
     with pytest.raises(q.QexHipError, match="wline"):
-        q.wline(B, [4] * 8, gb)
+        q.wline(B, [4] * 5 + [1] + [-4] * 5 + [-1], gb)
