@@ -312,6 +312,8 @@ int qexhip_rng_gauge_warm(qexhip_rng *rng, double s, double *g);
  *   write: precision 'F' | 'D' (saveGauge's prec); file_md / record_md NULL = QEX's defaults (gaugeUtils.nim:108-109) */
 int qexhip_io_gauge_info(const char *path, int lat[4], char *precision, int *checksums_present);
 int qexhip_io_read_gauge(const char *path, const int lat[4], double *g, unsigned *suma, unsigned *sumb);
+/* the slab t0 <= t < t0 + nt (both even) of a file with the GLOBAL lattice lat, into a rank-local field */
+int qexhip_io_read_gauge_slab(const char *path, const int lat[4], int t0, int nt, double *g);
 int qexhip_io_write_gauge(const char *path, const int lat[4], const double *g, char precision, const char *file_md,
                           const char *record_md);
 

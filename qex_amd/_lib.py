@@ -86,6 +86,7 @@ SYMBOLS = [
     ("qexhip_rng_gauge_warm", _ci, [_vp, _cd, _vp]),
     ("qexhip_io_gauge_info", _ci, [C.c_char_p, _pi, C.c_char_p, _pi]),
     ("qexhip_io_read_gauge", _ci, [C.c_char_p, _pi, _vp, _vp, _vp]),
+    ("qexhip_io_read_gauge_slab", _ci, [C.c_char_p, _pi, _ci, _ci, _vp]),
     ("qexhip_io_write_gauge", _ci, [C.c_char_p, _pi, _vp, C.c_char, C.c_char_p, C.c_char_p]),
     ("qexhip_timers_enable", _ci, [_vp, _ci]),
     ("qexhip_timers_reset", _ci, [_vp]),

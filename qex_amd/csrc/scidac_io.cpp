@@ -201,8 +201,18 @@ extern "C" int qexhip_io_gauge_info(const char *path, int lat[4], char *precisio
   return 0;
 }
 
+static int read_gauge_impl(const char *path, const int lat[4], int t0, int nt, double *g, unsigned *suma, unsigned *sumb);
 extern "C" int qexhip_io_read_gauge(const char *path, const int lat[4], double *g, unsigned *suma, unsigned *sumb) {
   if (!path || !lat || !g) return QEXHIP_ERR_ARG;
+  return read_gauge_impl(path, lat, 0, lat[3], g, suma, sumb);
+}
+// one rank's slab t0 <= t < t0 + nt of a file holding the GLOBAL lattice `lat`; g is the local field (its own
+// even-odd order).  The whole record is read, so the checksums are still verified.
+extern "C" int qexhip_io_read_gauge_slab(const char *path, const int lat[4], int t0, int nt, double *g) {
+  if (!path || !lat || !g || t0 < 0 || nt < 2 || (nt & 1) || (t0 & 1) || t0 + nt > lat[3]) return QEXHIP_ERR_ARG;
+  return read_gauge_impl(path, lat, t0, nt, g, nullptr, nullptr);
+}
+static int read_gauge_impl(const char *path, const int lat[4], int t0, int nt, double *g, unsigned *suma, unsigned *sumb) {
   FILE *f = fopen(path, "rb");
   if (!f) { qexhip_set_error("scidac: cannot open file"); return QEXHIP_ERR_ARG; }
   FileInfo I;
@@ -231,7 +241,9 @@ extern "C" int qexhip_io_read_gauge(const char *path, const int lat[4], double *
         for (x[0] = 0; x[0] < lat[0]; x[0]++, rank++) {
           const unsigned char *s = buf.data() + site_bytes * x[0];
           cs.add(s, site_bytes, rank);
-          double *d = g + eo_index(lat, x) * 72;
+          if (x[3] < t0 || x[3] >= t0 + nt) continue;
+          const int ll[4] = {lat[0], lat[1], lat[2], nt}, xl[4] = {x[0], x[1], x[2], x[3] - t0};
+          double *d = g + eo_index(ll, xl) * 72;
           if (wsz == 8) for (int k = 0; k < 72; k++) d[k] = from_be<double>(s + 8 * k);
           else for (int k = 0; k < 72; k++) d[k] = (double)from_be<float>(s + 4 * k);
         }

@@ -30,6 +30,15 @@ def loadGauge(fn, lat=None):
     return g, (a.value, b.value)
 
 
+def loadGaugeSlab(fn, glat, t0, nt):
+    """one rank's slab t0 <= t < t0 + nt of the global configuration in fn (local even-odd order)"""
+    lat = list(glat[:3]) + [int(nt)]
+    g = np.zeros((int(np.prod(lat)), 4, 3, 3, 2))
+    check(lib().qexhip_io_read_gauge_slab(str(fn).encode(), (C.c_int * 4)(*[int(v) for v in glat]), int(t0), int(nt),
+                                          g.ctypes.data_as(C.c_void_p)))
+    return g
+
+
 def saveGauge(g, lat, fn, prec="D", filemd=None, recordmd=None):
     if g.dtype != np.float64 or not g.flags["C_CONTIGUOUS"] or g.size != int(np.prod(lat)) * 72:
         raise ValueError("g must be a C-contiguous float64 [vol][4][3][3][2] array of this lattice")
