@@ -212,6 +212,13 @@ int qexhip_nhyp_smear(qexhip_handle h, const double *g, double *fl, double alpha
  *               Naik, projectUderiv, first fat7, in reverse; dsdsu / dsdsul = the action's derivative w.r.t. the fat / long links */
 int qexhip_fat7_deriv(qexhip_handle h, const double *g, const double *dfl, const double coef[5], const double *dll, double naik, double *d);
 int qexhip_hisq_force(qexhip_handle h, const double *g, const double *dsdsu, const double *dsdsul, double *f);
+/* the same as the closure the reference returns (hisqsmear.nim:55-90: it retains u and the intermediate v, w):
+ *   prepare: smear g, keep u, v = fat7_1(u), w = projectU(v) and the smeared su, sul on the device; fl / ll (nullable) receive
+ *            su / sul; qexhip_stag_set_links_hisq(h, NULL) afterwards hands su, sul to the operator without another smearing
+ *   closure_force: smearedForce(dsdu, dsdsu, dsdsul), the reverse pass only;  release: drop the state */
+int qexhip_hisq_prepare(qexhip_handle h, const double *g, double *fl, double *ll);
+int qexhip_hisq_closure_force(qexhip_handle h, const double *dsdsu, const double *dsdsul, double *f);
+int qexhip_hisq_release(qexhip_handle h);
 
 /* n (1..4) independent systems on the SAME links solved in lock-step, the links streamed once per sweep for all of
  * them (the Dslash is HBM-bound and 89 % of its bytes are links).  This is how the back-to-back solves of QEX's HMC

@@ -131,6 +131,7 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
   c->fields.clear();
   for (auto &kv : c->timers) for (auto e : kv.second.ev) (void)hipEventDestroy(e);
   nhyp_state_free(c);
+  hisq_state_free(c);
   batch_state_free(c);
   gauge_free(c);
   comm_destroy(c);
@@ -494,6 +495,22 @@ extern "C" int qexhip_stag_links_info(qexhip_handle c, int *nlinks, int *compres
   if (max_dev) *max_dev = c->recon_dev;
   return 0;
 }
+extern "C" int qexhip_hisq_prepare(qexhip_handle c, const double *g, double *fl, double *ll) {
+  if (!c || !g) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return hisq_prepare(c, g, fl, ll);
+}
+extern "C" int qexhip_hisq_closure_force(qexhip_handle c, const double *dsdsu, const double *dsdsul, double *f) {
+  if (!c || !dsdsu || !dsdsul || !f) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return hisq_closure_force(c, dsdsu, dsdsul, f);
+}
+extern "C" int qexhip_hisq_release(qexhip_handle c) {
+  if (!c) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  hisq_state_free(c);
+  return 0;
+}
 extern "C" int qexhip_hisq_force(qexhip_handle c, const double *g, const double *dsdsu, const double *dsdsul, double *f) {
   if (!c || !g || !dsdsu || !dsdsul || !f) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
@@ -506,7 +523,7 @@ extern "C" int qexhip_fat7_deriv(qexhip_handle c, const double *g, const double 
   return smear_fat7_deriv_host(c, g, dfl, coef, dll, naik, d);
 }
 extern "C" int qexhip_stag_set_links_hisq(qexhip_handle c, const double *g) {
-  if (!c || !g) return QEXHIP_ERR_ARG;
+  if (!c) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
   return smear_set_links_hisq(c, g);
 }

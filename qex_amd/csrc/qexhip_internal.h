@@ -100,6 +100,7 @@ struct qexhip_ctx {
   // natural gauge (flow)
   GaugeNat *gn = nullptr;
   void *nhyp = nullptr;   // NhypState (smear.hip): the smearGetForce closure
+  void *hisq = nullptr;   // HisqState (smear.hip): HisqCoefs.smearGetForce's closure
   // small per-context device scratch owned by single kernels' host wrappers
   double2 *outer_F = nullptr; size_t outer_Fn = 0;   // force field of stag_outer_host (force.hip)
   void *obs_table = nullptr;                         // ObsTable of gauge_flow_obs (gauge.hip)
@@ -218,6 +219,9 @@ int smear_hisq_force_host(qexhip_ctx *c, const double *g_host, const double *dfl
 int smear_fat7_deriv_host(qexhip_ctx *c, const double *g_host, const double *dfl_host, const double coef[5], const double *dll_host,
                           double naik, double *d_host);
 void nhyp_state_free(qexhip_ctx *c);
+void hisq_state_free(qexhip_ctx *c);
+int hisq_prepare(qexhip_ctx *c, const double *g_host, double *fl_host, double *ll_host);
+int hisq_closure_force(qexhip_ctx *c, const double *dfl_host, const double *dll_host, double *f_host);
 int gauge_deriv_dev(qexhip_ctx *c, const double2 *G, double2 *F, double cplaq, double c2, int kind);
 int stag_outer_dev(qexhip_ctx *c, DevField &fx, double2 *F, double se, double so, int accumulate);
 int nhyp_gauge_force(qexhip_ctx *c, double *f_host, double cplaq, double c2, int kind);

@@ -507,16 +507,28 @@ struct Smear {
   }
   // HisqCoefs.smearGetForce's smearedForce (gauge/hisqsmear.nim:55-90): second fat7 + Naik, projectU, first fat7, in reverse
   int hisq_force(const double2 *G, const double2 *CF, const double2 *CL, double2 *F) {
-    const double f7lf = 0.0, naik = 1.0, f2 = 2.0 - f7lf;
+    double2 *V, *W;
+    CHK(alloc(&V, gsz)); CHK(alloc(&W, gsz));
+    CHK(hisq_first(G, V, W));
+    return hisq_reverse(G, V, W, CF, CL, F);
+  }
+  // first half of the smearing, the part the reverse pass needs: V = fat7_1(G), W = projectU(V) (ghosts of G, W refreshed)
+  int hisq_first(const double2 *G, double2 *V, double2 *W) {
+    const double f7lf = 0.0;
     const double c_first[5] = {(1.0 + 3.0 * f7lf + 0.0) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f7lf / 16.0};
-    const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
-    double2 *V, *W, *T;
-    CHK(alloc(&V, gsz)); CHK(alloc(&W, gsz)); CHK(alloc(&T, gsz));     // alloc zero-fills
     CHK(ghosts_g(G));
     CHK(fat7(V, G, c_first, nullptr, G, 0.0));
     for (int mu = 0; mu < 4; mu++) k_projectU<<<nb(), 256, 0, c->stream>>>(g, gvw(W, mu), gv(V, mu));
     HIPCHK(hipGetLastError());
-    CHK(ghosts_g(W, 2)); CHK(ghosts_g(CF)); CHK(ghosts_g(CL, 2));
+    return ghosts_g(W, 2);
+  }
+  int hisq_reverse(const double2 *G, const double2 *V, const double2 *W, const double2 *CF, const double2 *CL, double2 *F) {
+    const double f7lf = 0.0, naik = 1.0, f2 = 2.0 - f7lf;
+    const double c_first[5] = {(1.0 + 3.0 * f7lf + 0.0) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f7lf / 16.0};
+    const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
+    double2 *T;
+    CHK(alloc(&T, gsz));                                               // alloc zero-fills
+    CHK(ghosts_g(CF)); CHK(ghosts_g(CL, 2));
     CHK(fat7_deriv(T, W, CF, c_second, CL, -naik / 24.0));
     for (int mu = 0; mu < 4; mu++)
       k_projUderiv<<<nb(), 256, 0, c->stream>>>(g, gvw(T, mu), gv(W, mu), gv(V, mu), gv(T, mu), MViewW{nullptr, 0}, 0.0, 1.0, 0);
@@ -715,6 +727,55 @@ int nhyp_force_host(qexhip_ctx *c, double *f_host, const double *chain_host) {
   return st->S.download(f_host, st->F);
 }
 
+// HisqCoefs.smearGetForce's closure (gauge/hisqsmear.nim:55-90): u, the intermediate v, w and the smeared su, sul stay on
+// the device; smearedForce(dsdu, dsdsu, dsdsul) only runs the reverse pass
+struct HisqState {
+  Smear S;
+  double2 *G = nullptr, *V = nullptr, *W = nullptr, *FL = nullptr, *LL = nullptr, *CF = nullptr, *CL = nullptr, *F = nullptr;
+  explicit HisqState(qexhip_ctx *c) : S(c) {}
+};
+void hisq_state_free(qexhip_ctx *c) {
+  if (c->hisq) { delete (HisqState *)c->hisq; c->hisq = nullptr; }
+}
+int hisq_prepare(qexhip_ctx *c, const double *g_host, double *fl_host, double *ll_host) {
+  for (int i = 0; i < 4; i++) if (c->g.X[i] < 4) { qexhip_set_error("HISQ smearing needs lattice extents >= 4"); return -1; }
+  HisqState *st = (HisqState *)c->hisq;
+  if (!st) {
+    st = new HisqState(c);
+    c->hisq = st;
+    Smear &S = st->S;
+    for (double2 **p : {&st->G, &st->V, &st->W, &st->FL, &st->LL, &st->CF, &st->CL, &st->F}) CHK(S.alloc(p, S.gsz));
+  }
+  Smear &S = st->S;
+  const double naik = 1.0, f2 = 2.0;
+  const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
+  CHK(S.upload(st->G, g_host));
+  CHK(S.hisq_first(st->G, st->V, st->W));
+  CHK(S.fat7(st->FL, st->W, c_second, st->LL, st->W, -naik / 24.0));
+  if (fl_host) CHK(S.download(fl_host, st->FL));
+  if (ll_host) CHK(S.download(ll_host, st->LL));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  while (S.owned.size() > 8) { (void)hipFree(S.owned.back()); S.owned.pop_back(); }     // scratch of the two fat7 passes
+  return 0;
+}
+int hisq_closure_force(qexhip_ctx *c, const double *dfl_host, const double *dll_host, double *f_host) {
+  HisqState *st = (HisqState *)c->hisq;
+  if (!st) { qexhip_set_error("hisq force: call qexhip_hisq_prepare first (smearGetForce)"); return -1; }
+  Smear &S = st->S;
+  CHK(S.upload(st->CF, dfl_host)); CHK(S.upload(st->CL, dll_host));
+  CHK(S.hisq_reverse(st->G, st->V, st->W, st->CF, st->CL, st->F));
+  CHK(S.download(f_host, st->F));
+  // the reverse pass parks its scratch in the closure's Smear: release what it allocated beyond the 8 fields
+  while (S.owned.size() > 8) { (void)hipFree(S.owned.back()); S.owned.pop_back(); }
+  return 0;
+}
+int hisq_set_links_from_closure(qexhip_ctx *c) {
+  HisqState *st = (HisqState *)c->hisq;
+  if (!st) { qexhip_set_error("set_links_hisq(g = NULL) needs qexhip_hisq_prepare first"); return -1; }
+  CHK(st->S.ghosts_g(st->FL, 1)); CHK(st->S.ghosts_g(st->LL, 3));
+  return links_from_natural(c, st->FL, st->LL);
+}
+
 // setBC_cust + stagPhase on a device gauge field (stagg_pv_hmc/staghmc_spv.nim:367-401,
 // gauge/gaugeUtils.nim:124-131, physics/stagD.nim:509-520): sign flips only
 __global__ void __launch_bounds__(256) k_rephase(Geom g, double2 *G, int bcmask, int ph0, int ph1, int ph2, int ph3, int tlast) {
@@ -806,6 +867,7 @@ int smear_nhyp_host(qexhip_ctx *c, const double *g_host, double *fl_host, double
 // smeared links): Staggered.g <- HISQ(g) / rephase(nHYP(g))
 int smear_set_links_hisq(qexhip_ctx *c, const double *g_host) {
   CHK(smear_check(c, 4));
+  if (!g_host) return hisq_set_links_from_closure(c);
   Smear S(c);
   double2 *G, *FL, *LL;
   CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&FL, S.gsz)); CHK(S.alloc(&LL, S.gsz));

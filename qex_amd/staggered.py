@@ -191,7 +191,7 @@ class Staggered:
             check(lib().qexhip_stag_set_links(ctx._h, _p(g), _p(g3)))
         elif isinstance(smear, HisqCoefs):
             self.nlinks = 8
-            check(lib().qexhip_stag_set_links_hisq(ctx._h, _p(g)))
+            check(lib().qexhip_stag_set_links_hisq(ctx._h, _p(g) if g is not None else None))
         else:
             self.nlinks = 4
             ap = (C.c_int * 4)(*[1 if ch == "a" else 0 for ch in bc])
@@ -439,6 +439,18 @@ class HisqCoefs:
 
     def smear(self, ctx, g, fl, ll):
         check(lib().qexhip_hisq_smear(ctx._h, _p(g), _p(fl), _p(ll)))
+
+    def smearGetForce(self, ctx, g, fl=None, ll=None):
+        """hisqsmear.nim:55-90: smear g (into fl, ll if given) and return the closure smearedForce(dsdu, dsdsu, dsdsul);
+        u, v, w, su, sul stay on the device until release().  Staggered(ctx, None, smear=HisqCoefs()) then builds the
+        operator from the closure's links."""
+        check(lib().qexhip_hisq_prepare(ctx._h, _p(g), _p(fl), _p(ll)))
+
+        def smearedForce(dsdu, dsdsu, dsdsul):
+            check(lib().qexhip_hisq_closure_force(ctx._h, _p(dsdsu), _p(dsdsul), _p(dsdu)))
+
+        smearedForce.release = lambda: check(lib().qexhip_hisq_release(ctx._h))
+        return smearedForce
 
 
 def fat7lDeriv(ctx, g, dfl, coef, dll=None, naik=0.0):

@@ -316,6 +316,23 @@ def test_gpu_hisq_force(oracle):
     f = q.HisqCoefs().init().force(ctx, g, dfl, dll)
     ref = o.hisq_force(lo, g, dfl, dll)
     assert np.linalg.norm(f - ref) / np.linalg.norm(ref) < 1e-12
+    # the closure form (hisqsmear.nim:55-90): smear once, reverse pass per call, operator from the closure's links
+    fl, ll = np.zeros_like(g), np.zeros_like(g)
+    sf = q.HisqCoefs().init().smearGetForce(ctx, g, fl, ll)
+    rfl, rll = o.hisq_smear(lo, g)
+    assert np.linalg.norm(fl - rfl) / np.linalg.norm(rfl) < 1e-13 and np.linalg.norm(ll - rll) / np.linalg.norm(rll) < 1e-13
+    for chains in ((dfl, dll), (dll, dfl)):
+        f2 = np.zeros_like(g)
+        sf(f2, *chains)
+        assert np.linalg.norm(f2 - o.hisq_force(lo, g, *chains)) / np.linalg.norm(ref) < 1e-12
+    s = q.Staggered(ctx, None, smear=q.HisqCoefs().init())
+    xv = o.vector_gaussian(lo, rf)
+    y = np.zeros_like(xv)
+    s.D(y, xv, 0.02)
+    assert np.linalg.norm(y - o.D(lo, rfl, rll, xv, 0.02)) / np.linalg.norm(y) < 1e-12
+    sf.release()
+    with pytest.raises(q.QexHipError, match="prepare"):
+        sf(f2, dfl, dll)
 
 
 @pytest.mark.gpu
