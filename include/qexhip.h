@@ -219,6 +219,10 @@ int qexhip_hisq_force(qexhip_handle h, const double *g, const double *dsdsu, con
 int qexhip_hisq_prepare(qexhip_handle h, const double *g, double *fl, double *ll);
 int qexhip_hisq_closure_force(qexhip_handle h, const double *dsdsu, const double *dsdsul, double *f);
 int qexhip_hisq_release(qexhip_handle h);
+/* fermionForce of the HISQ HMC (src/examples/hisqhmc.nim:496-541) through the closure (prepared with the PHASED links, as
+ * smearRephase does, :407-412): f1 = sum_k scale[k] p_k(x) (x) p_k(x+mu)^+, f3 the same with x+3mu, odd sites *= -1,
+ * smearedForce(ff, f1, f3), f = TAH(ff u^+) */
+int qexhip_hisq_fermion_force(qexhip_handle h, double *f, const double *const *psi, const double *scale, int n);
 
 /* n (1..4) independent systems on the SAME links solved in lock-step, the links streamed once per sweep for all of
  * them (the Dslash is HBM-bound and 89 % of its bytes are links).  This is how the back-to-back solves of QEX's HMC

@@ -77,6 +77,7 @@ def lib():
         L.qo_hisq_force.argtypes = [vp, vp, vp, vp, vp]
         L.qo_field_uniform.argtypes = [vp, vp, ci, vp, ci]
         L.qo_stag_outer.argtypes = [vp, vp, vp, cd, cd, ci]
+        L.qo_stag_outer_hop.argtypes = [vp, vp, vp, cd, cd, ci, ci]
         L.qo_solve_prev.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp]
         L.qo_solveXX_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, ci, vp, ci]
         L.qo_solve_multi.argtypes = [vp, vp, vp, vp, vp, vp, ci, cd, ci, vp]
@@ -409,8 +410,8 @@ def force_projTAH(lo, f, g, adj=False):
     lib().qo_force_projTAH(lo._h, _p(f), _p(g), 1 if adj else 0)
 
 
-def stag_outer(lo, f, x, scale_even, scale_odd, accumulate):
-    lib().qo_stag_outer(lo._h, _p(f), _p(x), scale_even, scale_odd, 1 if accumulate else 0)
+def stag_outer(lo, f, x, scale_even, scale_odd, accumulate, hop=1):
+    lib().qo_stag_outer_hop(lo._h, _p(f), _p(x), scale_even, scale_odd, 1 if accumulate else 0, int(hop))
 
 
 def solve_prev(lo, fat, lng, x0, b, m, r2req, maxits):

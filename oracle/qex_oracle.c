@@ -1366,11 +1366,17 @@ void qo_wflow_general(const qo_layout *lo, double *g, int nsteps, double eps, do
  *   fforce loop (stagg_pv_hmc/staghmc_spv.nim:831-854): the same scale on both parities,
  *                f := for the first field, f += afterwards */
 void qo_stag_outer(const qo_layout *lo, double *f, const double *x, double scale_even, double scale_odd, int accumulate) {
+  qo_stag_outer_hop(lo, f, x, scale_even, scale_odd, accumulate, 1);
+}
+/* hop = 3: the Naik part of the HISQ fermion force, p(x) (x) p(x+3mu)^+ (src/examples/hisqhmc.nim:496-516) */
+void qo_stag_outer_hop(const qo_layout *lo, double *f, const double *x, double scale_even, double scale_odd, int accumulate, int hop) {
 #pragma omp parallel for schedule(static)
   for (int s = 0; s < lo->vol; s++) {
     const double sc = s < lo->volh ? scale_even : scale_odd;
     for (int mu = 0; mu < 4; mu++) {
-      const double *a = &x[6 * (size_t)s], *b = &x[6 * (size_t)lo->nb[mu][0][s]];
+      int nb = s;
+      for (int h = 0; h < hop; h++) nb = lo->nb[mu][0][nb];
+      const double *a = &x[6 * (size_t)s], *b = &x[6 * (size_t)nb];
       double *m = &f[((size_t)s * 4 + mu) * 18];
       for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) {

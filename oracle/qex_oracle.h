@@ -92,6 +92,7 @@ void qo_nhyp_smear(const qo_layout *lo, const double *g, double *fl, double a1, 
 void qo_projectUderiv(double *r, const double *u, const double *x, const double *chain);
 void qo_nhyp_force(const qo_layout *lo, const double *g, double *fl, double *f, const double *chain, double a1, double a2, double a3);
 /* projTAH(f, g) of the fork (stagg_pv_hmc/staghmc_spv_gforce.nim:256-291): adj=0 TAH(f g^+), adj=1 TAH(g f^+) */
+void qo_stag_outer_hop(const qo_layout *lo, double *f, const double *x, double scale_even, double scale_odd, int accumulate, int hop);
 /* HISQ force: derivative of makeImpLinks (gauge/fat7lderiv.nim) and the HisqCoefs chain (gauge/hisqsmear.nim:55-90) */
 void qo_fat7_deriv(const qo_layout *lo, double *d, const double *gf, const double *cfl, const double coef[5], const double *cll, double naik);
 void qo_hisq_force(const qo_layout *lo, const double *g, const double *dsdsu, const double *dsdsul, double *f);

@@ -67,6 +67,7 @@ SYMBOLS = [
     ("qexhip_hisq_prepare", _ci, [_vp, _vp, _vp, _vp]),
     ("qexhip_hisq_closure_force", _ci, [_vp, _vp, _vp, _vp]),
     ("qexhip_hisq_release", _ci, [_vp]),
+    ("qexhip_hisq_fermion_force", _ci, [_vp, _vp, _vp, _vp, _ci]),
     ("qexhip_stag_set_links_hisq", _ci, [_vp, _vp]),
     ("qexhip_stag_set_links_nhyp", _ci, [_vp, _vp, _cd, _cd, _cd, _pi, _pi]),
     ("qexhip_nhyp_prepare", _ci, [_vp, _vp, _cd, _cd, _cd, _vp]),

@@ -505,6 +505,11 @@ extern "C" int qexhip_hisq_closure_force(qexhip_handle c, const double *dsdsu, c
   HIPCHK(hipSetDevice(c->device));
   return hisq_closure_force(c, dsdsu, dsdsul, f);
 }
+extern "C" int qexhip_hisq_fermion_force(qexhip_handle c, double *f, const double *const *psi, const double *scale, int n) {
+  if (!c || !f || !psi || !scale) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return hisq_fermion_force(c, f, psi, scale, n);
+}
 extern "C" int qexhip_hisq_release(qexhip_handle c) {
   if (!c) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));

@@ -12,7 +12,7 @@
 
 template <bool HALO>
 __global__ void __launch_bounds__(256) k_outer(Geom g, const double2 *__restrict__ x0, const double2 *__restrict__ x1,
-                                               double2 *F, double se, double so, int accumulate) {
+                                               double2 *F, double se, double so, int accumulate, int hop) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= g.V) return;
   const int p = i >= g.Vh, c = i - p * g.Vh;
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) k_outer(Geom g, const double2 *__restrict
   for (int k = 0; k < 3; k++) a[k] = xs[vec_off(c, k)];
 #pragma unroll
   for (int mu = 0; mu < 4; mu++) {
-    const int pos = nbr_pos<HALO>(g, c, s, mu, 1);
+    const int pos = nbr_pos<HALO>(g, c, s, mu, hop);
     double2 b[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) b[k] = xn[vec_off(pos, k)];
@@ -61,17 +61,19 @@ __global__ void __launch_bounds__(256) k_force_from_tiles(Geom g, double2 *__res
 }
 
 // f (:= | +=) scale * x (x) x(+mu)^+ on a DEVICE force field in the natural layout (single GPU)
-int stag_outer_dev(qexhip_ctx *c, DevField &fx, double2 *F, double se, double so, int accumulate) {
+int stag_outer_dev(qexhip_ctx *c, DevField &fx, double2 *F, double se, double so, int accumulate, int hop) {
   const Geom &g = c->g;
+  if (hop != 1 && hop != 3) { qexhip_set_error("outer product: hop must be 1 or 3"); return -1; }
   if (g.halo) {
-    for (int par = 0; par < 2; par++) CHK(comm_halo_exchange(c, fx, par, 0));      // x(s + t) across the slab boundary
+    if (g.depth < hop) { qexhip_set_error("outer product with hop 3 on a sharded field needs the Naik operator's ghost depth (set the links first)"); return -3; }
+    for (int par = 0; par < 2; par++) CHK(comm_halo_exchange(c, fx, par, 0));      // x(s + hop t) across the slab boundary
     ScopedTimer tm(c, "outer", c->stream);
-    k_outer<true><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fx.par(0), fx.par(1), F, se, so, accumulate);
+    k_outer<true><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fx.par(0), fx.par(1), F, se, so, accumulate, hop);
     HIPCHK(hipGetLastError());
     return 0;
   }
   ScopedTimer tm(c, "outer", c->stream);
-  k_outer<false><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fx.par(0), fx.par(1), F, se, so, accumulate);
+  k_outer<false><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fx.par(0), fx.par(1), F, se, so, accumulate, hop);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -101,10 +103,10 @@ int stag_outer_host(qexhip_ctx *c, double *f_host, const double *x_host, double 
     // neighbours across the t-faces: refresh the ghost zones of both parity halves
     for (int par = 0; par < 2; par++) CHK(comm_halo_exchange(c, *fx, par, 0));
     ScopedTimer tm(c, "outer", c->stream);
-    k_outer<true><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fx->par(0), fx->par(1), Fd, se, so, accumulate);
+    k_outer<true><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fx->par(0), fx->par(1), Fd, se, so, accumulate, 1);
   } else {
     ScopedTimer tm(c, "outer", c->stream);
-    k_outer<false><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fx->par(0), fx->par(1), Fd, se, so, accumulate);
+    k_outer<false><<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, fx->par(0), fx->par(1), Fd, se, so, accumulate, 1);
   }
   HIPCHK(hipGetLastError());
   CHK(ensure_stage(c, gbytes));

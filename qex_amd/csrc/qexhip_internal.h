@@ -223,7 +223,8 @@ void hisq_state_free(qexhip_ctx *c);
 int hisq_prepare(qexhip_ctx *c, const double *g_host, double *fl_host, double *ll_host);
 int hisq_closure_force(qexhip_ctx *c, const double *dfl_host, const double *dll_host, double *f_host);
 int gauge_deriv_dev(qexhip_ctx *c, const double2 *G, double2 *F, double cplaq, double c2, int kind);
-int stag_outer_dev(qexhip_ctx *c, DevField &fx, double2 *F, double se, double so, int accumulate);
+int stag_outer_dev(qexhip_ctx *c, DevField &fx, double2 *F, double se, double so, int accumulate, int hop = 1);
+int hisq_fermion_force(qexhip_ctx *c, double *f_host, const double *const *psi, const double *scale, int n);
 int nhyp_gauge_force(qexhip_ctx *c, double *f_host, double cplaq, double c2, int kind);
 int nhyp_fermion_force(qexhip_ctx *c, double *f_host, const double *const *psi, const double *scale, int n, int bcmask, const int ph[4]);
 int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, double *fl_host);

@@ -727,6 +727,8 @@ int nhyp_force_host(qexhip_ctx *c, double *f_host, const double *chain_host) {
   return st->S.download(f_host, st->F);
 }
 
+__global__ void k_force_projtah(size_t nlinks_tiles, double2 *F, const double2 *__restrict__ G, int adj);
+
 // HisqCoefs.smearGetForce's closure (gauge/hisqsmear.nim:55-90): u, the intermediate v, w and the smeared su, sul stay on
 // the device; smearedForce(dsdu, dsdsu, dsdsul) only runs the reverse pass
 struct HisqState {
@@ -766,6 +768,28 @@ int hisq_closure_force(qexhip_ctx *c, const double *dfl_host, const double *dll_
   CHK(S.hisq_reverse(st->G, st->V, st->W, st->CF, st->CL, st->F));
   CHK(S.download(f_host, st->F));
   // the reverse pass parks its scratch in the closure's Smear: release what it allocated beyond the 8 fields
+  while (S.owned.size() > 8) { (void)hipFree(S.owned.back()); S.owned.pop_back(); }
+  return 0;
+}
+// fermionForce of the HISQ HMC (src/examples/hisqhmc.nim:496-541) on the closure's fields: f1 = sum_k s_k p_k(x) (x) p_k(x+mu)^+,
+// f3 the same with x + 3 mu, odd sites *= -1, smearedForce, TAH(ff u^+) with the (phased) u of the closure
+int hisq_fermion_force(qexhip_ctx *c, double *f_host, const double *const *psi, const double *scale, int n) {
+  HisqState *st = (HisqState *)c->hisq;
+  if (!st) { qexhip_set_error("hisq fermion force: call qexhip_hisq_prepare first (smearGetForce)"); return -1; }
+  if (n < 1) { qexhip_set_error("hisq fermion force: n < 1"); return -1; }
+  Smear &S = st->S;
+  DevField *fx;
+  CHK(get_work(c, WK_IN, &fx));
+  for (int k = 0; k < n; k++) {
+    CHK(field_upload(c, *fx, psi[k]));
+    CHK(stag_outer_dev(c, *fx, st->CF, scale[k], -scale[k], k > 0, 1));
+    CHK(stag_outer_dev(c, *fx, st->CL, scale[k], -scale[k], k > 0, 3));
+  }
+  CHK(S.hisq_reverse(st->G, st->V, st->W, st->CF, st->CL, st->F));
+  const size_t ltiles = (size_t)2 * c->g.etile * 4;
+  k_force_projtah<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, st->F, st->G, 0);
+  HIPCHK(hipGetLastError());
+  CHK(S.download(f_host, st->F));
   while (S.owned.size() > 8) { (void)hipFree(S.owned.back()); S.owned.pop_back(); }
   return 0;
 }

@@ -449,6 +449,14 @@ class HisqCoefs:
         def smearedForce(dsdu, dsdsu, dsdsul):
             check(lib().qexhip_hisq_closure_force(ctx._h, _p(dsdsu), _p(dsdsul), _p(dsdu)))
 
+        def fermionForce(f, psis, scales):
+            """fermionForce (hisqhmc.nim:496-541) for the fields psis; the closure must hold the PHASED links"""
+            n = len(psis)
+            arr = (C.c_void_p * n)(*[p.ctypes.data for p in psis])
+            sc = (C.c_double * n)(*[float(v) for v in scales])
+            check(lib().qexhip_hisq_fermion_force(ctx._h, _p(f), arr, sc, n))
+
+        smearedForce.fermionForce = fermionForce
         smearedForce.release = lambda: check(lib().qexhip_hisq_release(ctx._h))
         return smearedForce
 

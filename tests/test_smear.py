@@ -330,6 +330,17 @@ def test_gpu_hisq_force(oracle):
     y = np.zeros_like(xv)
     s.D(y, xv, 0.02)
     assert np.linalg.norm(y - o.D(lo, rfl, rll, xv, 0.02)) / np.linalg.norm(y) < 1e-12
+    # fermionForce of hisqhmc.nim:496-541: 1-hop and 3-hop outer products, odd sign, chain, TAH(ff u^+)
+    psis, scales = [o.vector_gaussian(lo, rf), o.vector_gaussian(lo, rf)], [0.8, -0.3]
+    ff = np.zeros_like(g)
+    sf.fermionForce(ff, psis, scales)
+    f1, f3 = np.zeros_like(g), np.zeros_like(g)
+    for k, (p, sc) in enumerate(zip(psis, scales)):
+        o.stag_outer(lo, f1, p, sc, -sc, k > 0, hop=1)
+        o.stag_outer(lo, f3, p, sc, -sc, k > 0, hop=3)
+    rff = o.hisq_force(lo, g, f1, f3)
+    o.force_projTAH(lo, rff, g, adj=False)
+    assert np.linalg.norm(ff - rff) / np.linalg.norm(rff) < 1e-12
     sf.release()
     with pytest.raises(q.QexHipError, match="prepare"):
         sf(f2, dfl, dll)
