@@ -42,52 +42,62 @@ class Config:
         self.steps = [[fsteps[k]] + list(hfsteps[k]) for k in range(len(masses))]
 
 
-def _E(H, Sg, Sf, T):
-    return dict(H=H, Sg=Sg, Sf=Sf, T=T)
+def _parse_check(n):
+    """tests/golden/staghmc_sh/ref.N.check = the lines of the reference's golden log that its own harness compares
+    (tests/extra/staghmc_sh/run:43-44) plus the solver statistics; extracted by tests/golden/make_staghmc_fixtures.py"""
+    import os
+    import re
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "staghmc_sh", "ref.%d.check" % n)
+    num = r"[-+0-9.eE]+"
+    traj, cur = [], None
+    for line in open(path):
+        m = re.match(r"(Begin|End|Reversed) H: (%s)  Sg: (%s)  Sf: @\[(.*)\]  T: (%s)" % (num, num, num), line)
+        if m:
+            e = dict(H=float(m.group(2)), Sg=float(m.group(3)), T=float(m.group(5)),
+                     Sf=[float(v) for v in re.findall(num, m.group(4).replace("@", ""))])
+            if m.group(1) == "Begin":
+                cur = dict(begin=e, pbp=[], pbp_iters=[], force_stats=[], action_stats=[])
+                traj.append(cur)
+            else:
+                cur[{"End": "end", "Reversed": "reversed"}[m.group(1)]] = e
+            continue
+        if cur is None:
+            continue
+        if line.startswith(("ACCEPT", "REJECT")):
+            cur["accept"] = line.startswith("ACCEPT")
+        elif line.startswith("stagSolve:"):
+            cur["pbp_iters"].append(int(line.split()[1]))
+        elif line.startswith("MEASpbp"):
+            cur["pbp"].append(float(line.split(":")[1]))
+        elif line.startswith("MEASplaq"):
+            cur["plaq"] = tuple(float(v) for v in re.findall(r": +(%s)" % num, line))
+        elif line.startswith("MEASploop"):
+            cur["ploop"] = tuple(float(v) for v in re.findall(num, line.split("spatial:")[1].replace("temporal:", " ")))
+        elif line.startswith("Solver[pbp]:"):
+            m = re.match(r"Solver\[pbp\]: (\d+): (\d+):(\d+)", line)
+            cur["pbp_stats"] = (int(m.group(1)), int(m.group(2)), int(m.group(3)))
+        elif re.match(r"  [AF] m=", line):
+            m = re.match(r"  ([AF]) m=\S+ (\d+): (\d+):(\d+)", line)
+            cur["force_stats" if m.group(1) == "F" else "action_stats"].append((int(m.group(2)), int(m.group(3)), int(m.group(4))))
+    return traj
 
 
-# tests/extra/staghmc_sh/ref.0:117-147, ref.1:158-197, ref.2:165-200
+def _gold(n, second):
+    t = _parse_check(n)
+    g = dict(begin=t[0]["begin"], end=t[0]["end"], accept=t[0]["accept"], pbp=t[0]["pbp"], plaq=t[0]["plaq"], ploop=t[0]["ploop"],
+             pbp_iters=t[0]["pbp_stats"][2], force_stats=t[0]["force_stats"], action_max=[a[2] for a in t[0]["action_stats"]])
+    if second:
+        g.update(begin2=t[1]["begin"], end2=t[1]["end"], reversed2=t[1]["reversed"], accept2=t[1]["accept"], pbp2=t[1]["pbp"],
+                 plaq2=t[1]["plaq"])
+    return g
+
+
+# parameters of tests/extra/staghmc_sh/run:21-36 (tests 0, 1, 2); golden numbers from the committed log extracts
 CONFIGS = {
-    0: Config("ref.0", [0.1], [[0.2, 0.4]], ("2MN", 0.19), 18, [3], [[3, 3]], {
-        "begin": _E(18451.47947589929, 0.0, [6115.074514620805, 6296.481015505035, 6143.045791623304], -103.1218458498552),
-        "end": _E(18452.64279359589, 18431.57360855611, [6127.428742650334, 6325.453215672831, 5587.471917645606], -18019.28469092899),
-        "accept": True,
-        "pbp": [0.2117714665683549, 0.211234484887779],
-        "plaq": (0.7798927061684001, 0.7803495769561876, 0.7801211415622938),
-        "ploop": (0.1593085565961168, 0.004142883358352041, 0.1806483723808761, 0.003657953473352228),
-        "pbp_iters": 101,                                   # ref.0:122 "stagSolve: 101"
-        "force_stats": [(12, 80, 98), (12, 69, 82), (12, 49, 55)],      # Solver[force] count:avg:max (ref.0:134-136)
-        "action_max": [99, 82, 54],
-        "begin2": _E(36739.46806257457, 18431.57360855611, [6167.177355372508, 6207.772553312414, 6058.237942980893], -125.2933976473578),
-        "end2": _E(36740.43410254073, 29993.99458721639, [6176.234483849725, 6221.867671160123, 5713.001444448795], -11364.6640841343),
-        "reversed2": _E(36739.46806257457, 18431.57360855611, [6167.177355372508, 6207.772553312412, 6058.237942980893], -125.2933976473578),
-        "accept2": False,
-        "pbp2": [0.2118970809638824, 0.2101254523243145],
-        "plaq2": (0.7798927061684001, 0.7803495769561876, 0.7801211415622938),
-    }),
-    1: Config("ref.1", [0.1, 0.05], [[0.2, 0.4], [0.2, 0.4]], ("4MN3F1GP", LAM), 8, [4, 1], [[4, 4], [4, 4]], {
-        "begin": _E(37060.84273906729, 0.0, [6115.074514620805, 6306.389181751562, 6135.810117523342,
-                                             6295.354845031659, 6105.404747102119, 6205.931178887655], -103.1218458498552),
-        "end": _E(37059.74483704752, 18305.11759204451, [6126.510266887249, 6335.609427651825, 5601.461747229001,
-                                                        6310.501654586174, 6136.272325695626, 5669.590023510308], -17425.31820055717),
-        "accept": True,
-        "pbp": [0.2124987385567164, 0.2121777421850332],
-        "plaq": (0.7806760387002425, 0.7821946149314469, 0.7814353268158447),
-        "ploop": (0.1698385451622547, -0.0002273776499279601, 0.1893621803302616, 0.003975399375172897),
-        "pbp_iters": 99,
-        "force_stats": [(16, 79, 97), (16, 69, 82), (16, 49, 55), (4, 84, 101), (16, 69, 82), (16, 49, 54)],   # ref.1:178-183
-        "action_max": [98, 81, 55, 105, 82, 54],
-    }),
-    2: Config("ref.2", [0.1, 0.05], [[0.2, 0.4], [0.2, 0.4]], ("4MN3F1GP", LAM), 8, [4, 1], [[2, 8], [4, 4]], {
-        "begin": _E(37060.84273906728, 0.0, [6115.074514620805, 6306.389181751561, 6135.810117523342,
-                                             6295.35484503166, 6105.40474710212, 6205.931178887655], -103.1218458498624),
-        "end": _E(37059.67520145793, 18305.14306547379, [6126.509964414681, 6335.589195322854, 5601.206802025012,
-                                                        6310.501330347202, 6136.271596425377, 5669.6042640287], -17425.15101657969),
-        "accept": True,
-        "pbp": [0.212498005749541, 0.2121770649184098],
-        "plaq": (0.7806754017364743, 0.7821946737822517, 0.7814350377593631),
-        "ploop": (0.1698446687873951, -0.0002275802967509945, 0.1893696000700383, 0.003974432970409643),
-    }),
+    0: Config("ref.0", [0.1], [[0.2, 0.4]], ("2MN", 0.19), 18, [3], [[3, 3]], _gold(0, True)),
+    1: Config("ref.1", [0.1, 0.05], [[0.2, 0.4], [0.2, 0.4]], ("4MN3F1GP", LAM), 8, [4, 1], [[4, 4], [4, 4]], _gold(1, False)),
+    2: Config("ref.2", [0.1, 0.05], [[0.2, 0.4], [0.2, 0.4]], ("4MN3F1GP", LAM), 8, [4, 1], [[2, 8], [4, 4]], _gold(2, False)),
 }
 GOLD = CONFIGS[0].gold                      # kept for the Begin-H-only tests
 
