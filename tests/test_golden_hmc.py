@@ -151,3 +151,30 @@ def test_gpu_replays_reference_trajectory(oracle, run, halo):
     rng = q.RngField(R.LAT, q.RngMilc6, R.SEED)          # the product's own newRNGField
     # halo: the same trajectory with every kernel in its t-sharded form (forced ghost zones on one GPU)
     _check_trajectory(R.Replay(oracle, R.HipBackend(q, R.LAT, halo=halo), R.CONFIGS[run], rng=rng), second=(run == 0 and not halo))
+
+
+@pytest.mark.gpu
+def test_example_log_against_reference_log():
+    """The reference's own regression procedure (tests/extra/staghmc_sh/run:43-46): run the example, keep the
+    MEAS / Begin / End / Reversed lines, compare number by number with the golden log at 2e-11 -- here for
+    examples/staghmc_sh.py, which performs every field operation in libqexhip."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "staghmc_sh.py"), "-run", "0", "-trajs", "2"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
+    keep = re.compile(r"^MEASploop|^MEASplaq|^MEASpbp|(Begin|End|Reversed) H:|^(ACCEPT|REJECT)")
+    mine = [ln for ln in out.splitlines() if keep.search(ln)]
+    gold = [ln for ln in open(os.path.join(root, "tests", "golden", "staghmc_sh", "ref.0.check")).read().splitlines() if keep.search(ln)]
+    assert len(mine) == len(gold), out
+    num = re.compile(r"[-+]?\\d+\\.?\\d*(?:[eE][-+]?\\d+)?")
+    for a, b in zip(mine, gold):
+        assert a.split(":")[0].split()[0] == b.split(":")[0].split()[0], (a, b)     # same kind of line, same verdict
+        na, nb = [float(v) for v in num.findall(a)], [float(v) for v in num.findall(b)]
+        assert len(na) == len(nb), (a, b)
+        for x, y in zip(na, nb):
+            scale = max(abs(y), 16.0 * 4096 if " T: " in b or "dH" in b else 0.0, 0.1)
+            assert abs(x - y) <= RTOL * scale or "dH" in b and abs(x - y) <= 1e-6, (a, b)
