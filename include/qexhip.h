@@ -313,6 +313,11 @@ int qexhip_rng_u1_vector(qexhip_rng *rng, double *v);
 int qexhip_rng_random_tah(qexhip_rng *rng, double *p);
 int qexhip_rng_gauge_random(qexhip_rng *rng, double *g);
 int qexhip_rng_gauge_warm(qexhip_rng *rng, double s, double *g);
+/* generator state per site (RngMilc6: 9 uint32 = r0..r6, icState, multiplier, src/rng/milcrng.nim:12-14; MRG32k3a: 6),
+ * the payload of the fork's RNG checkpoints (src/stagg_pv_hmc/staghmc_spv_rng.nim:135-182) */
+int qexhip_rng_state_words(qexhip_rng *rng);
+int qexhip_rng_get_state(qexhip_rng *rng, unsigned *out);
+int qexhip_rng_set_state(qexhip_rng *rng, const unsigned *in);
 
 /* ---------------- SciDAC/LIME gauge files (host only, no handle) ----------------
  * loadGauge / saveGauge (src/gauge/gaugeUtils.nim:87-122) via Reader / Writer (src/io/readerQiolite.nim:37-239,
@@ -327,6 +332,13 @@ int qexhip_io_read_gauge(const char *path, const int lat[4], double *g, unsigned
 int qexhip_io_read_gauge_slab(const char *path, const int lat[4], int t0, int nt, double *g);
 int qexhip_io_write_gauge(const char *path, const int lat[4], const double *g, char precision, const char *file_md,
                           const char *record_md);
+/* any other field, as Writer.write / Reader.read handle it (src/io/writerQiolite.nim:96-166): site_bytes per site
+ * (library's even-odd order in memory, x-fastest in the file), every word_bytes-wide word big-endian in the file;
+ * datatype / precision / colors / datacount go into the record header (typesize = site_bytes / datacount).
+ * The fork's RNG checkpoint (staghmc_spv_rng.nim:135-182) is write_field(state, 36, 4, "QDP_RngMilc6", 'F', 0, 1, ...). */
+int qexhip_io_write_field(const char *path, const int lat[4], const void *data, int site_bytes, int word_bytes, const char *datatype,
+                          char precision, int colors, int datacount, const char *file_md, const char *record_md);
+int qexhip_io_read_field(const char *path, const int lat[4], void *data, int site_bytes, int word_bytes, char datatype[64]);
 
 /* ---------------- kernel timers ----------------
  * hipEvent pairs around launches of the named kernel class on the context stream

@@ -221,3 +221,24 @@ extern "C" int qexhip_rng_gauge_warm(qexhip_rng *R, double s, double *g) {
     });
   return 0;
 }
+
+// generator state of every site, for checkpoints (the fork writes the RngMilc6 field with the generic Writer,
+// src/stagg_pv_hmc/staghmc_spv_rng.nim:135-182): RngMilc6 = 9 uint32 per site in the struct's order
+// r0..r6, icState, multiplier (src/rng/milcrng.nim:12-14); MRG32k3a = 6 uint32 (s1[3], s2[3])
+extern "C" int qexhip_rng_state_words(qexhip_rng *R) { return R ? (R->kind == 0 ? 9 : 6) : 0; }
+extern "C" int qexhip_rng_get_state(qexhip_rng *R, unsigned *out) {
+  if (!R || !out) return QEXHIP_ERR_ARG;
+  for (size_t j = 0; j < R->vol; j++) {
+    if (R->kind == 0) { const Milc6 &m = R->m6[j]; const uint32_t w[9] = {m.r0, m.r1, m.r2, m.r3, m.r4, m.r5, m.r6, m.ic, m.mult}; memcpy(out + 9 * j, w, sizeof w); }
+    else { memcpy(out + 6 * j, R->mrg[j].s1, 12); memcpy(out + 6 * j + 3, R->mrg[j].s2, 12); }
+  }
+  return 0;
+}
+extern "C" int qexhip_rng_set_state(qexhip_rng *R, const unsigned *in) {
+  if (!R || !in) return QEXHIP_ERR_ARG;
+  for (size_t j = 0; j < R->vol; j++) {
+    if (R->kind == 0) { Milc6 &m = R->m6[j]; const unsigned *w = in + 9 * j; m.r0 = w[0]; m.r1 = w[1]; m.r2 = w[2]; m.r3 = w[3]; m.r4 = w[4]; m.r5 = w[5]; m.r6 = w[6]; m.ic = w[7]; m.mult = w[8]; }
+    else { memcpy(R->mrg[j].s1, in + 6 * j, 12); memcpy(R->mrg[j].s2, in + 6 * j + 3, 12); }
+  }
+  return 0;
+}

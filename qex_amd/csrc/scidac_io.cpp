@@ -319,3 +319,113 @@ extern "C" int qexhip_io_write_gauge(const char *path, const int lat[4], const d
   if (!ok) { qexhip_set_error("scidac: write failed"); return QEXHIP_ERR_ARG; }
   return 0;
 }
+
+// ---- generic site records: what Writer.write / Reader.read do for any field type (writerQiolite.nim:96-166,
+// readerQiolite.nim:120-200): `site_bytes` per site in x-fastest order, every `word_bytes`-wide word big-endian.
+// data: host array in the library's even-odd site order, words in host byte order.
+extern "C" int qexhip_io_write_field(const char *path, const int lat[4], const void *data, int site_bytes, int word_bytes,
+                                     const char *datatype, char precision, int colors, int datacount, const char *file_md,
+                                     const char *record_md) {
+  if (!path || !lat || !data || !datatype || site_bytes < 1 || (word_bytes != 4 && word_bytes != 8) || site_bytes % word_bytes ||
+      datacount < 1 || site_bytes % datacount)
+    return QEXHIP_ERR_ARG;
+  if (!file_md) file_md = "<?xml version=\"1.0\"?>\n<note>generated by QEX</note>\n";
+  if (!record_md) record_md = "<?xml version=\"1.0\"?>\n<note>field</note>\n";
+  FILE *f = fopen(path, "wb");
+  if (!f) { qexhip_set_error("scidac: cannot create file"); return QEXHIP_ERR_ARG; }
+  const size_t vol = (size_t)lat[0] * lat[1] * lat[2] * lat[3];
+  char xml[1024];
+  bool ok = true;
+  snprintf(xml, sizeof xml,
+           "<?xml version=\"1.0\" encoding=\"UTF-8\"?><scidacFile><version>1.1</version><spacetime>4</spacetime>"
+           "<dims>%d %d %d %d </dims><volfmt>0</volfmt></scidacFile>", lat[0], lat[1], lat[2], lat[3]);
+  ok = ok && write_record(f, "scidac-private-file-xml", true, false, xml, strlen(xml) + 1);
+  ok = ok && write_record(f, "scidac-file-xml", false, true, file_md, strlen(file_md) + 1);
+  char date[64];
+  time_t now = time(nullptr);
+  strftime(date, sizeof date, "%a %b %d %H:%M:%S %Y UTC", gmtime(&now));
+  snprintf(xml, sizeof xml,
+           "<?xml version=\"1.0\" encoding=\"UTF-8\"?><scidacRecord><version>1.1</version><date>%s</date>"
+           "<recordtype>0</recordtype><datatype>%s</datatype><precision>%c</precision>"
+           "<colors>%d</colors><typesize>%d</typesize><datacount>%d</datacount></scidacRecord>",
+           date, datatype, precision, colors, site_bytes / datacount, datacount);
+  ok = ok && write_record(f, "scidac-private-record-xml", true, false, xml, strlen(xml) + 1);
+  ok = ok && write_record(f, "scidac-record-xml", false, false, record_md, strlen(record_md) + 1);
+  {
+    unsigned char h[144];
+    memset(h, 0, sizeof h);
+    h[0] = 0x45; h[1] = 0x67; h[2] = 0x89; h[3] = 0xab; h[5] = 1;
+    put_be64(h + 8, (uint64_t)vol * site_bytes);
+    strncpy((char *)h + 16, "scidac-binary-data", 127);
+    ok = ok && fwrite(h, 1, 144, f) == 144;
+  }
+  std::vector<unsigned char> buf((size_t)site_bytes * lat[0]);
+  Checksum cs;
+  uint64_t rank = 0;
+  int x[4];
+  const uint16_t one = 1;
+  const bool little = *(const unsigned char *)&one == 1;
+  for (x[3] = 0; x[3] < lat[3] && ok; x[3]++)
+    for (x[2] = 0; x[2] < lat[2] && ok; x[2]++)
+      for (x[1] = 0; x[1] < lat[1] && ok; x[1]++) {
+        for (x[0] = 0; x[0] < lat[0]; x[0]++, rank++) {
+          unsigned char *s = buf.data() + (size_t)site_bytes * x[0];
+          const unsigned char *d = (const unsigned char *)data + eo_index(lat, x) * (size_t)site_bytes;
+          for (int w = 0; w < site_bytes; w += word_bytes)
+            for (int b = 0; b < word_bytes; b++) s[w + b] = little ? d[w + word_bytes - 1 - b] : d[w + b];
+          cs.add(s, site_bytes, rank);
+        }
+        ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+      }
+  {
+    static const unsigned char zero[8] = {0};
+    const size_t pad = (8 - ((size_t)vol * site_bytes) % 8) % 8;
+    ok = ok && (!pad || fwrite(zero, 1, pad, f) == pad);
+  }
+  snprintf(xml, sizeof xml,
+           "<?xml version=\"1.0\" encoding=\"UTF-8\"?><scidacChecksum><version>1.0</version><suma>%x</suma><sumb>%x</sumb>"
+           "</scidacChecksum>", cs.a, cs.b);
+  ok = ok && write_record(f, "scidac-checksum", false, true, xml, strlen(xml) + 1);
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) { qexhip_set_error("scidac: write failed"); return QEXHIP_ERR_ARG; }
+  return 0;
+}
+
+extern "C" int qexhip_io_read_field(const char *path, const int lat[4], void *data, int site_bytes, int word_bytes, char datatype[64]) {
+  if (!path || !lat || !data || site_bytes < 1 || (word_bytes != 4 && word_bytes != 8) || site_bytes % word_bytes) return QEXHIP_ERR_ARG;
+  FILE *f = fopen(path, "rb");
+  if (!f) { qexhip_set_error("scidac: cannot open file"); return QEXHIP_ERR_ARG; }
+  FileInfo I;
+  if (scan(f, I)) { fclose(f); return QEXHIP_ERR_ARG; }
+  const size_t vol = (size_t)lat[0] * lat[1] * lat[2] * lat[3];
+  for (int i = 0; i < 4; i++)
+    if (I.lat[i] != lat[i]) { fclose(f); qexhip_set_error("scidac: file lattice differs from the requested one"); return QEXHIP_ERR_ARG; }
+  if (I.data_len != vol * (size_t)site_bytes || (I.typesize && I.typesize * I.datacount != site_bytes)) {
+    fclose(f);
+    qexhip_set_error("scidac: record does not hold %d bytes per site", site_bytes);
+    return QEXHIP_ERR_ARG;
+  }
+  if (datatype) { strncpy(datatype, I.datatype.c_str(), 63); datatype[63] = 0; }
+  fseeko(f, I.data_off, SEEK_SET);
+  std::vector<unsigned char> buf((size_t)site_bytes * lat[0]);
+  Checksum cs;
+  uint64_t rank = 0;
+  int x[4];
+  const uint16_t one = 1;
+  const bool little = *(const unsigned char *)&one == 1;
+  for (x[3] = 0; x[3] < lat[3]; x[3]++)
+    for (x[2] = 0; x[2] < lat[2]; x[2]++)
+      for (x[1] = 0; x[1] < lat[1]; x[1]++) {
+        if (fread(buf.data(), 1, buf.size(), f) != buf.size()) { fclose(f); qexhip_set_error("scidac: short read"); return QEXHIP_ERR_ARG; }
+        for (x[0] = 0; x[0] < lat[0]; x[0]++, rank++) {
+          const unsigned char *s = buf.data() + (size_t)site_bytes * x[0];
+          cs.add(s, site_bytes, rank);
+          unsigned char *d = (unsigned char *)data + eo_index(lat, x) * (size_t)site_bytes;
+          for (int w = 0; w < site_bytes; w += word_bytes)
+            for (int b = 0; b < word_bytes; b++) d[w + b] = little ? s[w + word_bytes - 1 - b] : s[w + b];
+        }
+      }
+  fclose(f);
+  if (I.have_sum && (cs.a != I.suma || cs.b != I.sumb)) { qexhip_set_error("scidac: checksum mismatch"); return QEXHIP_ERR_IO; }
+  return 0;
+}

@@ -58,6 +58,11 @@ proc qexhip_gauge_reunit(h: QexhipHandle): cint {.qh.}
 proc qexhip_wline(h: QexhipHandle; path: ptr cint; n: cint; o: ptr cdouble): cint {.qh.}
 proc qexhip_flow_EQ(h: QexhipHandle; loop: cint; o: ptr cdouble): cint {.qh.}
 proc qexhip_io_read_gauge(path: cstring; lat: ptr cint; g: ptr cdouble; suma, sumb: ptr cuint): cint {.qh.}
+proc qexhip_rng_get_state(r: pointer; o: ptr cuint): cint {.qh.}
+proc qexhip_rng_set_state(r: pointer; i: ptr cuint): cint {.qh.}
+proc qexhip_io_write_field(path: cstring; lat: ptr cint; data: pointer; siteBytes, wordBytes: cint; datatype: cstring;
+                           prec: cchar; colors, datacount: cint; fileMd, recMd: cstring): cint {.qh.}
+proc qexhip_io_read_field(path: cstring; lat: ptr cint; data: pointer; siteBytes, wordBytes: cint; datatype: cstring): cint {.qh.}
 proc qexhip_io_write_gauge(path: cstring; lat: ptr cint; g: ptr cdouble; prec: cchar; fileMd, recMd: cstring): cint {.qh.}
 
 template chk(e: untyped) =

@@ -60,3 +60,30 @@ class RngField:
         g = self._new(4, 3, 3, 2)
         check(lib().qexhip_rng_gauge_warm(self._h, float(s), g.ctypes.data_as(C.c_void_p)))
         return g
+
+    # ---- checkpoints: write_rng / read_rng of the fork (src/stagg_pv_hmc/staghmc_spv_rng.nim:135-182) ----
+    def state(self):
+        n = lib().qexhip_rng_state_words(self._h)
+        w = np.zeros((self.vol, n), dtype=np.uint32)
+        check(lib().qexhip_rng_get_state(self._h, w.ctypes.data_as(C.c_void_p)))
+        return w
+
+    def set_state(self, w):
+        w = np.ascontiguousarray(w, dtype=np.uint32)
+        if w.shape != (self.vol, lib().qexhip_rng_state_words(self._h)):
+            raise ValueError("RNG state has the wrong shape")
+        check(lib().qexhip_rng_set_state(self._h, w.ctypes.data_as(C.c_void_p)))
+
+    def write(self, fn):
+        """the generator field as one SciDAC record of typesize 36 (`writer.write(r.milc, recordMd)`)"""
+        w = self.state()
+        name = b"QDP_RngMilc6" if w.shape[1] == 9 else b"QDP_MRG32k3a"
+        check(lib().qexhip_io_write_field(str(fn).encode(), (C.c_int * 4)(*self.lat), w.ctypes.data_as(C.c_void_p), 4 * w.shape[1], 4,
+                                          name, b"F", 0, 1, None, b'<?xml version="1.0"?>\n<note>RNG field</note>\n'))
+
+    def read(self, fn):
+        w = np.zeros((self.vol, lib().qexhip_rng_state_words(self._h)), dtype=np.uint32)
+        dt = C.create_string_buffer(64)
+        check(lib().qexhip_io_read_field(str(fn).encode(), (C.c_int * 4)(*self.lat), w.ctypes.data_as(C.c_void_p), 4 * w.shape[1], 4, dt))
+        self.set_state(w)
+        return dt.value.decode()
