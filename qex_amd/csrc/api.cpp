@@ -138,6 +138,7 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
   if (c->W) (void)hipFree(c->W);
   if (c->outer_F) (void)hipFree(c->outer_F);
   if (c->obs_table) (void)hipFree(c->obs_table);
+  if (c->tile_order) (void)hipFree(c->tile_order);
   if (c->cgm_scal) (void)hipFree(c->cgm_scal);
   if (c->Wc) (void)hipFree(c->Wc);
   if (c->Ws) (void)hipFree(c->Ws);

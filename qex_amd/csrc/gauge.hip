@@ -25,6 +25,7 @@ struct GaugeNat {
   double2 *U2 = nullptr;   // second link buffer: the fused flow stage reads U and writes exp(v) U here, then they swap
   size_t n2 = 0;  // double2 elements per field (incl. ghost tiles when t is sharded)
   int ghost_valid = 0;   // depth to which the ghost slices of U are current
+  double *pp = nullptr; int npp = 0;   // per-workgroup plaquette partials of k_plaq
 };
 
 static int gauge_ghosts(qexhip_ctx *c, int depth);
@@ -63,6 +64,46 @@ __device__ __forceinline__ void shifted(const Geom &g, const int x[4], int mu, i
   if (g.halo) shifted_t<true>(g, x, mu, d, y); else shifted_t<false>(g, x, mu, d, y);
 }
 
+// ---- visiting order of the gather kernels ----
+// Workgroups are dealt to the 8 XCDs round-robin by block id and start in id order, so block b runs on XCD b&7 as
+// that XCD's (b>>3)-th workgroup.  The table gives every XCD one contiguous (t,z) region of the lattice and walks
+// it in compact blocks of both parities, so that the ~64 workgroups an XCD has in flight share most of their
+// neighbour links through its 4 MB L2 instead of each fetching them from beyond it.
+// entry = 2*tile + parity, -1 = padding.  Layout: [8][chunk].
+static int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk_out) {
+  const Geom &g = c->g;
+  const int n = 2 * g.ntile, chunk = (n + 7) / 8;
+  if (c->tile_order && c->tile_order_n == 8 * chunk) { *tab = c->tile_order; *chunk_out = chunk; return 0; }
+  static const int by = [] { const char *e = getenv("QEXHIP_ORD_Y"); return e ? atoi(e) : 8; }();
+  static const int bz = [] { const char *e = getenv("QEXHIP_ORD_Z"); return e ? atoi(e) : 2; }();
+  static const int bt = [] { const char *e = getenv("QEXHIP_ORD_T"); return e ? atoi(e) : 4; }();
+  struct Ent { long key0, key1; int e; };
+  std::vector<Ent> v(n);
+  for (int p = 0; p < 2; p++)
+    for (int tile = 0; tile < g.ntile; tile++) {
+      unsigned r = (unsigned)tile * 64u / (unsigned)g.Xh;             // first site of the tile
+      const int y = r % g.X[1]; r /= g.X[1];
+      const int z = r % g.X[2], t = r / g.X[2];
+      Ent &a = v[(size_t)p * g.ntile + tile];
+      a.e = 2 * tile + p;
+      a.key0 = (((long)t * g.X[2] + z) * g.X[1] + y) * 2 + p;         // plain order: splits the lattice into 8 (t,z) regions
+      a.key1 = (((((long)(t / bt) * 4096 + z / bz) * 4096 + y / by) * 4096 + t % bt) * 4096 + z % bz) * 8192 + (y % by) * 2 + p;
+    }
+  std::sort(v.begin(), v.end(), [](const Ent &a, const Ent &b) { return a.key0 < b.key0; });
+  std::vector<int> h((size_t)8 * chunk, -1);
+  for (int k = 0; k < 8; k++) {
+    const int lo = std::min(n, k * chunk), hi = std::min(n, (k + 1) * chunk);
+    std::sort(v.begin() + lo, v.begin() + hi, [](const Ent &a, const Ent &b) { return a.key1 < b.key1; });
+    for (int j = lo; j < hi; j++) h[(size_t)k * chunk + (j - lo)] = v[j].e;
+  }
+  if (c->tile_order) { (void)hipFree(c->tile_order); c->tile_order = nullptr; }
+  HIPCHK(hipMalloc(&c->tile_order, h.size() * sizeof(int)));
+  HIPCHK(hipMemcpy(c->tile_order, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  c->tile_order_n = 8 * chunk;
+  *tab = c->tile_order; *chunk_out = chunk;
+  return 0;
+}
+
 // host [idx][mu][9] <-> tiles
 __global__ void __launch_bounds__(256) k_gauge_to_tiles(Geom g, const double2 *__restrict__ host, double2 *G) {
   int i = blockIdx.x * 256 + threadIdx.x;
@@ -84,11 +125,17 @@ __global__ void __launch_bounds__(256) k_gauge_from_tiles(Geom g, double2 *__res
 }
 
 // plaquette: per site six Re tr[(U_mu(x)U_nu(x+mu))^+ (U_nu(x)U_mu(x+nu))], ip = mu(mu-1)/2+nu
+// Visiting order from tile_order_table: wavefront w of workgroup b takes table slot 4*(b>>3)+w of XCD b&7.
+// The four local links stay in registers (16 link loads per site).  Walking the six planes one at a time instead
+// (24 loads, 8 of them L1 hits, 132 VGPR = 3 waves/SIMD instead of 1) measured 383 us against 277 us at 32^4: the
+// kernel is bound by the number of L2->L1 requests, not by occupancy.
 template <bool HALO>
-__global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict__ G, double *partials) {
+__global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict__ G, double *partials, const int *order, int chunk) {
   double pl[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < g.V; i += gridDim.x * 256) {
-    int p = i >= g.Vh, c = i - p * g.Vh;
+  const int slot = 4 * (blockIdx.x >> 3) + (threadIdx.x >> 6);
+  const int e = slot < chunk ? order[(blockIdx.x & 7) * chunk + slot] : -1;
+  const int p = e & 1, c = (e >> 1) * 64 + (threadIdx.x & 63);
+  if (e >= 0 && c < g.Vh) {
     int x[4], y[4];
     coords_of(g, c, p, x);
     M3 U[4];
@@ -112,6 +159,7 @@ __global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict_
     if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = r;
   }
 }
+
 __global__ void __launch_bounds__(256) k_plaq_final(const double *partials, int nb, double norm, double *out) {
   for (int k = 0; k < 6; k++) {
     double acc = 0;
@@ -130,9 +178,16 @@ __global__ void __launch_bounds__(256) k_plaq_final(const double *partials, int 
 // flow mode (Pm != nullptr): the RK3 combination v = cf*f + cpm*p (wflow.nim:39,48,57) is formed here
 // and written over the momentum field, so the exp kernel reads one field less and F is not needed.
 __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict__ G, double2 *F, double cp, int mode,
-                                               double2 *Pm, double cf, double cpm, double2 *Uout) {
+                                               double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk) {
   int mu, p, c;
-  if (mode == 0) {
+  if (mode == 3) {
+    const int e = order[(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)];
+    if (e < 0) return;
+    mu = threadIdx.x >> 6;
+    p = e & 1;
+    c = (e >> 1) * 64 + (threadIdx.x & 63);
+    if (c >= g.Vh) return;
+  } else if (mode == 0) {
     int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= 4 * g.V) return;
     mu = j / g.V;
@@ -378,11 +433,13 @@ __device__ const signed char RECT_STEPS[6][5] = {
     {2, 2, 1, -2, -2}, {2, 1, 1, -2, -1}, {-1, 2, 1, 1, -2},          // +nu
     {-2, -2, 1, 2, 2}, {-2, 1, 1, 2, -1}, {-1, -2, 1, 1, 2}};         // -nu
 __global__ void __launch_bounds__(256) k_force_gen(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
-                                                   double c2, int kind, double2 *Pm, double cf, double cpm, int raw, double2 *Uout) {
-  const int bid = blockIdx.x;
+                                                   double c2, int kind, double2 *Pm, double cf, double cpm, int raw, double2 *Uout,
+                                                   const int *order, int chunk) {
+  const int e = order[(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)];   // tile_order_table
+  if (e < 0) return;
   const int mu = threadIdx.x >> 6;
-  const int p = bid >= g.ntile;
-  const int c = (bid - p * g.ntile) * 64 + (threadIdx.x & 63);
+  const int p = e & 1;
+  const int c = (e >> 1) * 64 + (threadIdx.x & 63);
   if (c >= g.Vh) return;
   int x[4], xpm[4], y[4], z[4];
   coords_of(g, c, p, x);
@@ -466,7 +523,9 @@ int gauge_deriv_dev(qexhip_ctx *c, const double2 *G, double2 *F, double cplaq, d
   if (kind == 0 && c2 != 0.0) for (int d = 0; d < 4; d++) if (c->g.X[d] < 4) { qexhip_set_error("rectangle action needs extents >= 4"); return -1; }
   const double k2 = kind == 0 ? c2 / 3.0 : 2.0 * c2 / 9.0;
   ScopedTimer tm(c, "staple", c->stream);
-  k_force_gen<<<2 * c->g.ntile, 256, 0, c->stream>>>(c->g, G, F, cplaq / 3.0, k2, kind, nullptr, 0.0, 0.0, 1, nullptr);
+  const int *order = nullptr; int chunk = 0;
+  CHK(tile_order_table(c, &order, &chunk));
+  k_force_gen<<<8 * chunk, 256, 0, c->stream>>>(c->g, G, F, cplaq / 3.0, k2, kind, nullptr, 0.0, 0.0, 1, nullptr, order, chunk);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -519,6 +578,7 @@ void gauge_free(qexhip_ctx *c) {
   if (c->gn->F) (void)hipFree(c->gn->F);
   if (c->gn->P) (void)hipFree(c->gn->P);
   if (c->gn->U2) (void)hipFree(c->gn->U2);
+  if (c->gn->pp) (void)hipFree(c->gn->pp);
   delete c->gn;
   c->gn = nullptr;
 }
@@ -552,16 +612,24 @@ int gauge_get(qexhip_ctx *c, double *g) {
 int gauge_plaq(qexhip_ctx *c, double out[6]) {
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
   CHK(gauge_ghosts(c, 1));
-  int nb = (c->g.V + 255) / 256;
-  if (nb > 1024) nb = 1024;
+  const int *order = nullptr; int chunk = 0;
+  CHK(tile_order_table(c, &order, &chunk));
+  const int nb = 8 * ((chunk + 3) / 4);
+  if (c->gn->npp < 6 * nb) {
+    if (c->gn->pp) (void)hipFree(c->gn->pp);
+    c->gn->pp = nullptr; c->gn->npp = 0;
+    HIPCHK(hipMalloc((void **)&c->gn->pp, sizeof(double) * 6 * nb));
+    c->gn->npp = 6 * nb;
+  }
+  double *part = c->gn->pp;
   {
     ScopedTimer tm(c, "plaq", c->stream);
-    if (c->g.halo) k_plaq<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->partials);
-    else k_plaq<false><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->partials);
+    if (c->g.halo) k_plaq<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+    else k_plaq<false><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
     HIPCHK(hipGetLastError());
   }
   // pl[i]/(physVol*np*nc)  (gaugeUtils.nim:277); rankSum before the normalisation (:275-279)
-  k_plaq_final<<<1, 256, 0, c->stream>>>(c->partials, nb, 1.0, &c->dscal[16]);
+  k_plaq_final<<<1, 256, 0, c->stream>>>(part, nb, 1.0, &c->dscal[16]);
   HIPCHK(hipGetLastError());
   CHK(read_global(c, &c->dscal[16], 6, out));
   const double norm = (double)c->g.V * (double)c->nranks * 18.0;
@@ -574,16 +642,19 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
   CHK(gn_alloc_fp(c));
   CHK(gauge_ghosts(c, ghost_depth_for(c2, kind)));
   ScopedTimer tm(c, "staple", c->stream);
-  static const int mode = [] { const char *e = getenv("QEXHIP_FORCE_MODE"); return e ? atoi(e) : 1; }();   // process-wide tuning switch
+  static const int mode = [] { const char *e = getenv("QEXHIP_FORCE_MODE"); return e ? atoi(e) : 3; }();   // process-wide tuning switch
   int nb = mode == 0 ? (4 * c->g.V + 255) / 256 : 2 * c->g.ntile;
+  const int *order = nullptr; int chunk = 0;
+  CHK(tile_order_table(c, &order, &chunk));
+  if (mode == 3) nb = 8 * chunk;
   if (c2 != 0.0) {
     // kind 0: cr = c.rect/nc ; kind 1: ca = 2 c.adjplaq/nc^2
     const double k2 = kind == 0 ? c2 / 3.0 : 2.0 * c2 / 9.0;
-    k_force_gen<<<2 * c->g.ntile, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind,
-                                                       flow ? c->gn->P : nullptr, cf, cpm, 0, Uout);
+    k_force_gen<<<8 * chunk, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind,
+                                                  flow ? c->gn->P : nullptr, cf, cpm, 0, Uout, order, chunk);
   } else {
     // (capping the registers for 3 or 4 waves/SIMD spills: 1460 / 2370 us against 1310 us fused at 2 waves/SIMD)
-    k_force<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, flow ? c->gn->P : nullptr, cf, cpm, Uout);
+    k_force<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, flow ? c->gn->P : nullptr, cf, cpm, Uout, order, chunk);
   }
   HIPCHK(hipGetLastError());
   return 0;

@@ -103,6 +103,7 @@ struct qexhip_ctx {
   void *hisq = nullptr;   // HisqState (smear.hip): HisqCoefs.smearGetForce's closure
   // small per-context device scratch owned by single kernels' host wrappers
   double2 *outer_F = nullptr; size_t outer_Fn = 0;   // force field of stag_outer_host (force.hip)
+  int *tile_order = nullptr; int tile_order_n = 0;   // blocked (tile, parity) visiting order of the gather kernels (gauge.hip)
   void *obs_table = nullptr;                         // ObsTable of gauge_flow_obs (gauge.hip)
   void *batch = nullptr;                             // BatchState of the lock-step multi-system CG (batch.hip)
   void *cgm_scal = nullptr;                          // CgmScal of the multi-shift solver (multishift.hip)
