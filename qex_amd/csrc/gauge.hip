@@ -64,46 +64,6 @@ __device__ __forceinline__ void shifted(const Geom &g, const int x[4], int mu, i
   if (g.halo) shifted_t<true>(g, x, mu, d, y); else shifted_t<false>(g, x, mu, d, y);
 }
 
-// ---- visiting order of the gather kernels ----
-// Workgroups are dealt to the 8 XCDs round-robin by block id and start in id order, so block b runs on XCD b&7 as
-// that XCD's (b>>3)-th workgroup.  The table gives every XCD one contiguous (t,z) region of the lattice and walks
-// it in compact blocks of both parities, so that the ~64 workgroups an XCD has in flight share most of their
-// neighbour links through its 4 MB L2 instead of each fetching them from beyond it.
-// entry = 2*tile + parity, -1 = padding.  Layout: [8][chunk].
-static int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk_out) {
-  const Geom &g = c->g;
-  const int n = 2 * g.ntile, chunk = (n + 7) / 8;
-  if (c->tile_order && c->tile_order_n == 8 * chunk) { *tab = c->tile_order; *chunk_out = chunk; return 0; }
-  static const int by = [] { const char *e = getenv("QEXHIP_ORD_Y"); return e ? atoi(e) : 8; }();
-  static const int bz = [] { const char *e = getenv("QEXHIP_ORD_Z"); return e ? atoi(e) : 2; }();
-  static const int bt = [] { const char *e = getenv("QEXHIP_ORD_T"); return e ? atoi(e) : 4; }();
-  struct Ent { long key0, key1; int e; };
-  std::vector<Ent> v(n);
-  for (int p = 0; p < 2; p++)
-    for (int tile = 0; tile < g.ntile; tile++) {
-      unsigned r = (unsigned)tile * 64u / (unsigned)g.Xh;             // first site of the tile
-      const int y = r % g.X[1]; r /= g.X[1];
-      const int z = r % g.X[2], t = r / g.X[2];
-      Ent &a = v[(size_t)p * g.ntile + tile];
-      a.e = 2 * tile + p;
-      a.key0 = (((long)t * g.X[2] + z) * g.X[1] + y) * 2 + p;         // plain order: splits the lattice into 8 (t,z) regions
-      a.key1 = (((((long)(t / bt) * 4096 + z / bz) * 4096 + y / by) * 4096 + t % bt) * 4096 + z % bz) * 8192 + (y % by) * 2 + p;
-    }
-  std::sort(v.begin(), v.end(), [](const Ent &a, const Ent &b) { return a.key0 < b.key0; });
-  std::vector<int> h((size_t)8 * chunk, -1);
-  for (int k = 0; k < 8; k++) {
-    const int lo = std::min(n, k * chunk), hi = std::min(n, (k + 1) * chunk);
-    std::sort(v.begin() + lo, v.begin() + hi, [](const Ent &a, const Ent &b) { return a.key1 < b.key1; });
-    for (int j = lo; j < hi; j++) h[(size_t)k * chunk + (j - lo)] = v[j].e;
-  }
-  if (c->tile_order) { (void)hipFree(c->tile_order); c->tile_order = nullptr; }
-  HIPCHK(hipMalloc(&c->tile_order, h.size() * sizeof(int)));
-  HIPCHK(hipMemcpy(c->tile_order, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
-  c->tile_order_n = 8 * chunk;
-  *tab = c->tile_order; *chunk_out = chunk;
-  return 0;
-}
-
 // host [idx][mu][9] <-> tiles
 __global__ void __launch_bounds__(256) k_gauge_to_tiles(Geom g, const double2 *__restrict__ host, double2 *G) {
   int i = blockIdx.x * 256 + threadIdx.x;

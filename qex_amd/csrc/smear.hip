@@ -61,18 +61,37 @@ __device__ __forceinline__ void shift_sm(const Geom &g, const int x[4], int mu, 
   if (g.halo) shift_sm_t<true>(g, x, mu, d, y); else shift_sm_t<false>(g, x, mu, d, y);
 }
 
+// blocked visiting order for the gather kernels (tile_order_table, layout.hip); QEXHIP_SMEAR_ORD=0 falls back to the plain order
+static int smear_order(qexhip_ctx *c, const Geom &g, const int **order, int *chunk, int *nblk) {
+  static const int use = [] { const char *e = getenv("QEXHIP_SMEAR_ORD"); return e ? atoi(e) : 1; }();
+  *order = nullptr; *chunk = 0; *nblk = (g.V + 255) / 256;
+  if (!use) return 0;
+  CHK(tile_order_table(c, order, chunk));
+  *nblk = 8 * ((*chunk + 3) / 4);
+  return 0;
+}
+
 // staple field (optional) and acc (+)= coef * staple (optional).  Two fusions for the nHYP levels
 // (hypsmear.nim:98-143): with `init` the accumulator STARTS as cinit * init(x) instead of being read
 // (the `l := ma * g[mu]` assignment), with `proj` the finished sum is also projected, proj(x) = projectU(acc(x))
 // (the `l.proj lx` that follows the last staple of a level).
 template <bool HALO>
 __global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, int swz,
-                                                    MView init, double cinit, MViewW proj) {
-  int bid = blockIdx.x;
-  if (swz && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // contiguous site range per XCD
-  int i = bid * 256 + threadIdx.x;
-  if (i >= g.V) return;
-  const int p = i >= g.Vh, c = i - p * g.Vh;
+                                                    MView init, double cinit, MViewW proj, const int *order, int chunk) {
+  int p, c;
+  if (order) {   // blocked visiting order (tile_order_table): wavefront w takes slot 4*(b>>3)+w of XCD b&7
+    const int slot = 4 * (blockIdx.x >> 3) + (threadIdx.x >> 6);
+    const int e = slot < chunk ? order[(blockIdx.x & 7) * chunk + slot] : -1;
+    if (e < 0) return;
+    p = e & 1; c = (e >> 1) * 64 + (threadIdx.x & 63);
+    if (c >= g.Vh) return;
+  } else {
+    int bid = blockIdx.x;
+    if (swz && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // contiguous site range per XCD
+    int i = bid * 256 + threadIdx.x;
+    if (i >= g.V) return;
+    p = i >= g.Vh; c = i - p * g.Vh;
+  }
   int x[4], xpn[4], xpm[4], xmn[4], xmnpm[4];
   coords_sm(g, c, p, x);
   shift_sm_t<HALO>(g, x, nu, 1, xpn);
@@ -216,12 +235,21 @@ __global__ void __launch_bounds__(256) k_projUderiv(Geom g, MViewW dst, MView U,
 template <bool SCALED, bool HALO, bool SB>   // SCALED: f += coef * (derivative) instead of accumulating in place; SB: scheduling fences
 __global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu, int swz,
                                                       int z1, int z2,      // z1 / z2: f1 / f2 start from zero (first contribution)
-                                                      double coef = 1.0) {
-  int bid = blockIdx.x;
-  if (swz && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // contiguous site range per XCD
-  int i = bid * 256 + threadIdx.x;
-  if (i >= g.V) return;
-  const int p = i >= g.Vh, c = i - p * g.Vh;
+                                                      double coef, const int *order, int chunk) {
+  int p, c;
+  if (order) {   // blocked visiting order (tile_order_table): wavefront w takes slot 4*(b>>3)+w of XCD b&7
+    const int slot = 4 * (blockIdx.x >> 3) + (threadIdx.x >> 6);
+    const int e = slot < chunk ? order[(blockIdx.x & 7) * chunk + slot] : -1;
+    if (e < 0) return;
+    p = e & 1; c = (e >> 1) * 64 + (threadIdx.x & 63);
+    if (c >= g.Vh) return;
+  } else {
+    int bid = blockIdx.x;
+    if (swz && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);   // contiguous site range per XCD
+    int i = bid * 256 + threadIdx.x;
+    if (i >= g.V) return;
+    p = i >= g.Vh; c = i - p * g.Vh;
+  }
   int x[4], xpm[4], xpn[4], xmm[4], xmn[4], xmmpn[4], xmnpm[4];
   coords_sm(g, c, p, x);
   shift_sm_t<HALO>(g, x, mu, 1, xpm);
@@ -405,8 +433,10 @@ struct Smear {
              MViewW proj = MViewW{nullptr, 0}) {
     ScopedTimer tm(c, "smear", c->stream);
     static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
-    if (g.halo) k_gen_staple<true><<<nb(), 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj);
-    else k_gen_staple<false><<<nb(), 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj);
+    const int *order; int chunk, nblk;
+    CHK(smear_order(c, g, &order, &chunk, &nblk));
+    if (g.halo) k_gen_staple<true><<<nblk, 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk);
+    else k_gen_staple<false><<<nblk, 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -453,8 +483,10 @@ struct Smear {
     static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
     ScopedTimer tm(c, "smear_deriv", c->stream);
     // (scheduling fences cost 3 % here: 48.5 vs 46.9 ms per HISQ force, A/B on one GPU)
-    if (g.halo) k_staple_deriv<true, true, false><<<nb(), 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, 0, 0, coef);
-    else k_staple_deriv<true, false, false><<<nb(), 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, 0, 0, coef);
+    const int *order; int chunk, nblk;
+    CHK(smear_order(c, g, &order, &chunk, &nblk));
+    if (g.halo) k_staple_deriv<true, true, false><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, 0, 0, coef, order, chunk);
+    else k_staple_deriv<true, false, false><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, 0, 0, coef, order, chunk);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -650,11 +682,12 @@ int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, doub
 static int staple_deriv(qexhip_ctx *c, const Geom &g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu,
                         int z1 = 0, int z2 = 0) {
   static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
-  const int nblk = (g.V + 255) / 256;
+  const int *order; int chunk, nblk;
+  CHK(smear_order(c, g, &order, &chunk, &nblk));
   // in-place accumulating form: scheduling fences between the products bring it from 256 VGPRs / 1 wave per SIMD
   // to 216 / 2 and the nHYP chain from 24.2 to 23.2 ms (A/B on one GPU)
-  if (g.halo) k_staple_deriv<false, true, false><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2);
-  else k_staple_deriv<false, false, true><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2);
+  if (g.halo) k_staple_deriv<false, true, false><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2, 1.0, order, chunk);
+  else k_staple_deriv<false, false, true><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2, 1.0, order, chunk);
   HIPCHK(hipGetLastError());
   return 0;
 }
