@@ -30,6 +30,7 @@ struct GaugeNat {
 
 static int gauge_ghosts(qexhip_ctx *c, int depth);
 static int read_global(qexhip_ctx *c, double *dev, int n, double *host);
+static int ordered_sites(qexhip_ctx *c, const int **order, int *chunk, int *nb, double **part);
 
 __device__ __forceinline__ void coords_of(const Geom &g, int c, int p, int x[4]) {
   unsigned r = (unsigned)c;
@@ -278,10 +279,13 @@ __device__ __forceinline__ double m3_retr_mul(const M3 &a, const M3 &b) {
     for (int q = 0; q < 3; q++) s += a.e[3 * r + q].x * b.e[3 * q + r].x - a.e[3 * r + q].y * b.e[3 * q + r].y;
   return s;
 }
-__global__ void __launch_bounds__(256) k_flow_obs(Geom g, const double2 *__restrict__ G, const ObsTable *T, double *partials) {
+__global__ void __launch_bounds__(256) k_flow_obs(Geom g, const double2 *__restrict__ G, const ObsTable *T, double *partials,
+                                                  const int *order, int chunk) {
   double es = 0, et = 0, q = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < g.V; i += gridDim.x * 256) {
-    int p = i >= g.Vh, c = i - p * g.Vh;
+  const int slot = 4 * (blockIdx.x >> 3) + (threadIdx.x >> 6);     // visiting order: tile_order_table, as k_plaq
+  const int e = slot < chunk ? order[(blockIdx.x & 7) * chunk + slot] : -1;
+  const int p = e & 1, c = (e >> 1) * 64 + (threadIdx.x & 63);
+  if (e >= 0 && c < g.Vh) {
     int x[4];
     coords_of(g, c, p, x);
     // dual pairs and the sign of their term in Q = -(1/4pi^2) (F10 F32 - F20 F31 + F21 F30)
@@ -369,14 +373,15 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
   ObsTable *dT = (ObsTable *)c->obs_table;
   HIPCHK(hipMemcpyAsync(dT, &T, sizeof(T), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));  // T is a stack object
-  int nb = (c->g.V + 255) / 256;
-  if (nb > 2048) nb = 2048;
+  const int *order = nullptr; int chunk = 0, nb = 0;
+  double *part = nullptr;
+  CHK(ordered_sites(c, &order, &chunk, &nb, &part));
   {
     ScopedTimer tm(c, "flowobs", c->stream);
-    k_flow_obs<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, dT, c->partials);
+    k_flow_obs<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, dT, part, order, chunk);
     HIPCHK(hipGetLastError());
   }
-  k_obs_final<<<1, 256, 0, c->stream>>>(c->partials, nb, (double)c->g.V, &c->dscal[24]);
+  k_obs_final<<<1, 256, 0, c->stream>>>(part, nb, (double)c->g.V, &c->dscal[24]);
   HIPCHK(hipGetLastError());
   CHK(read_global(c, &c->dscal[24], 3, out));
   const double vol = (double)c->g.V * (double)c->nranks;
@@ -569,19 +574,25 @@ int gauge_get(qexhip_ctx *c, double *g) {
   return download_nat(c, c->gn->U, g);
 }
 
+// one lane per site in the blocked visiting order, 4 table slots per workgroup; `part` holds 6 doubles per workgroup
+static int ordered_sites(qexhip_ctx *c, const int **order, int *chunk, int *nb, double **part) {
+  CHK(tile_order_table(c, order, chunk));
+  *nb = 8 * ((*chunk + 3) / 4);
+  if (c->gn->npp < 6 * *nb) {
+    if (c->gn->pp) (void)hipFree(c->gn->pp);
+    c->gn->pp = nullptr; c->gn->npp = 0;
+    HIPCHK(hipMalloc((void **)&c->gn->pp, sizeof(double) * 6 * *nb));
+    c->gn->npp = 6 * *nb;
+  }
+  *part = c->gn->pp;
+  return 0;
+}
 int gauge_plaq(qexhip_ctx *c, double out[6]) {
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
   CHK(gauge_ghosts(c, 1));
-  const int *order = nullptr; int chunk = 0;
-  CHK(tile_order_table(c, &order, &chunk));
-  const int nb = 8 * ((chunk + 3) / 4);
-  if (c->gn->npp < 6 * nb) {
-    if (c->gn->pp) (void)hipFree(c->gn->pp);
-    c->gn->pp = nullptr; c->gn->npp = 0;
-    HIPCHK(hipMalloc((void **)&c->gn->pp, sizeof(double) * 6 * nb));
-    c->gn->npp = 6 * nb;
-  }
-  double *part = c->gn->pp;
+  const int *order = nullptr; int chunk = 0, nb = 0;
+  double *part = nullptr;
+  CHK(ordered_sites(c, &order, &chunk, &nb, &part));
   {
     ScopedTimer tm(c, "plaq", c->stream);
     if (c->g.halo) k_plaq<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
