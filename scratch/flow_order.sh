@@ -1,7 +1,6 @@
 set -e
 o=gpurun_out/flow_order.log; : > $o
-QEXHIP_FORCE_SYNC=0 python3 scratch/flow_order.py >> $o 2>&1
-QEXHIP_FORCE_SYNC=1 python3 scratch/flow_order.py >> $o 2>&1
-QEXHIP_FORCE_SYNC=0 python3 scratch/flow_order.py >> $o 2>&1
-QEXHIP_FORCE_SYNC=1 python3 scratch/flow_order.py >> $o 2>&1
+for m in 3 5 6 3 5 6; do
+QEXHIP_FORCE_MODE=$m python3 scratch/flow_order.py >> $o 2>&1
+done
 cat $o
