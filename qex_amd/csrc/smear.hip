@@ -685,8 +685,8 @@ static int staple_deriv(qexhip_ctx *c, const Geom &g, MViewW f1, MViewW f2, MVie
   const int *order; int chunk, nblk;
   CHK(smear_order(c, g, &order, &chunk, &nblk));
   // in-place accumulating form: scheduling fences between the products bring it from 256 VGPRs / 1 wave per SIMD
-  // to 216 / 2 and the nHYP chain from 24.2 to 23.2 ms (A/B on one GPU)
-  if (g.halo) k_staple_deriv<false, true, false><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2, 1.0, order, chunk);
+  // to 216 / 2 (192 in the sharded form) and the nHYP chain from 24.2 to 23.2 ms (sharded, 48^3x12: 31.2 -> 26.1 ms)
+  if (g.halo) k_staple_deriv<false, true, true><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2, 1.0, order, chunk);
   else k_staple_deriv<false, false, true><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2, 1.0, order, chunk);
   HIPCHK(hipGetLastError());
   return 0;
