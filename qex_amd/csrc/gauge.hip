@@ -132,10 +132,11 @@ __global__ void __launch_bounds__(256) k_plaq_final(const double *partials, int 
 
 // force: one lane per (mu, site).  F_mu(x) = TAH( U_mu(x) [cp * sum_nu (fwd + bwd staples)]^+ )
 // A workgroup = one 64-site tile x 4 directions (wavefront w handles mu = w), so the four
-// wavefronts that share most of their neighbour links run together; with `swz` the workgroups are
-// remapped so that each XCD sweeps a contiguous range of tiles (a contiguous t-range): every link
-// is used by 19 staple terms, and adjacent tiles on different XCDs would each re-fetch it from
-// beyond their own L2 (cdna_hip_programming.md T1).
+// wavefronts that share most of their neighbour links run together.  Which tile a workgroup takes comes from
+// tile_order_table (mode 3, the default: one contiguous (t,z) region per XCD, walked in compact blocks with both
+// parities adjacent -- every link is used by 19 staple terms, and tiles dealt round-robin over the XCDs would
+// each re-fetch it from beyond their own L2, cdna_hip_programming.md T1).  QEXHIP_FORCE_MODE keeps the older
+// mappings for A/B runs: 0 = mu-major lanes, 1 = tiles in storage order, 2 = storage order, contiguous per XCD.
 // flow mode (Pm != nullptr): the RK3 combination v = cf*f + cpm*p (wflow.nim:39,48,57) is formed here
 // and written over the momentum field, so the exp kernel reads one field less and F is not needed.
 __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict__ G, double2 *F, double cp, int mode,
