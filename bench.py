@@ -304,21 +304,10 @@ def leg_48x96(q, dist, torch, N, rank, local_rank, args):
     lt = lat[3] // N
     lat_loc = lat[:3] + [lt]
     lo = q.Layout(lat_loc)
-    # synthetic links: one random 48^3 x 12 block repeated along t (generating 10.6 M independent sites with numpy
-    # would take a minute); staggered phases repeat with period 2 in t, the antiperiodic boundary sits on the last
-    # global slice.  Local order = even sites then odd sites, t slowest within each half.
-    from qex_amd.gauge import stagPhase
-    t0 = 12
-    lob = q.Layout(lat[:3] + [t0])
-    gb = q.synthetic_random_su3(lob, seed=24680)
-    stagPhase(lob, gb)
-    vhb, n = lob.vol // 2, lt // t0
-    g = np.concatenate([np.tile(gb[:vhb], (n, 1, 1, 1, 1)), np.tile(gb[vhb:], (n, 1, 1, 1, 1))])
-    del gb
-    if rank == N - 1:
-        vh, f = lo.vol // 2, lat[0] * lat[1] * lat[2] // 2
-        for par in range(2):
-            g[par * vh + vh - f:(par + 1) * vh, 3] *= -1.0
+    # synthetic links: one random 48^3 x 12 block repeated along t (qex_amd/gauge.py: generating 10.6 M independent
+    # sites with numpy would take a minute), rephased for this slab
+    from qex_amd.gauge import synthetic_repeated_su3
+    g = synthetic_repeated_su3(lat_loc, 12, seed=24680, t_offset=rank * lt, t_global=lat[3])
     b = q.synthetic_gaussian_vector(lo, seed=1357 + rank)
     if args.rehearse_no_rccl:
         ctx = q.Context(lat_loc, device=0)

@@ -67,3 +67,34 @@ def synthetic_random_su3(lo, seed=987654321, spread=None, chunk=1 << 18):
 def synthetic_gaussian_vector(lo, seed=12345):
     rng = np.random.default_rng(seed)
     return rng.standard_normal((lo.vol, 3, 2))
+
+
+def repeat_in_t(lob, field, n):
+    """A field on the block lattice `lob` (even-odd site order, t slowest within each parity half, even t extent)
+    repeated n times along t: the same field on the lattice with n times the t extent, in that lattice's site order."""
+    if lob.lat[3] % 2:
+        raise ValueError("block t extent must be even (the site parity must repeat)")
+    vh = lob.vol // 2
+    reps = (n,) + (1,) * (field.ndim - 1)
+    return np.concatenate([np.tile(field[:vh], reps), np.tile(field[vh:], reps)])
+
+
+def synthetic_repeated_su3(lat, t_block, seed=987654321, t_offset=0, t_global=None):
+    """Benchmark configuration for large lattices: one random SU(3) block of `t_block` slices repeated along t
+    (numpy needs about a minute for 10 M independent sites), already rephased (antiperiodic boundary on the last
+    global slice + staggered phases, which have period 2 in t).  Returns the field of the local lattice `lat`."""
+    from .layout import Layout
+
+    if lat[3] % t_block or t_block % 2 or t_offset % 2:
+        raise ValueError("t extents must be even multiples of the block")
+    lob = Layout(list(lat[:3]) + [t_block])
+    gb = synthetic_random_su3(lob, seed=seed)
+    stagPhase(lob, gb)
+    g = repeat_in_t(lob, gb, lat[3] // t_block)
+    T = t_global if t_global is not None else lat[3]
+    if t_offset + lat[3] == T:                       # this slab holds the last global slice
+        vh = g.shape[0] // 2
+        f = lat[0] * lat[1] * lat[2] // 2
+        for par in range(2):
+            g[par * vh + vh - f:(par + 1) * vh, 3] *= -1.0
+    return g

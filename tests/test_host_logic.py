@@ -193,3 +193,27 @@ def test_index_arithmetic_random_lattices(oracle):
                     assert _nbr(lat, 1, 0, c, p, mu, hop) == lo.neighbor(idx, mu, hop) - (1 - p) * vh
 
     check()
+
+
+def test_repeated_block_configuration_is_the_periodic_one():
+    """bench.py's 48^3 x 96 leg builds its links from one block repeated along t: same field, same phases and
+    boundary as rephasing the repeated field directly, on a whole lattice and on the last slab of a split one."""
+    from qex_amd.gauge import repeat_in_t, synthetic_random_su3, synthetic_repeated_su3, rephase
+    from qex_amd.layout import Layout
+
+    lat, tb = [4, 6, 4, 8], 4
+    lob, lo = Layout(lat[:3] + [tb]), Layout(lat)
+    gb = synthetic_random_su3(lob, seed=3)
+    raw = repeat_in_t(lob, gb, lat[3] // tb)
+    for i in range(0, lo.vol, 7):                         # site order: x -> (x, y, z, t mod tb)
+        x = [int(v) for v in lo.coords[i]]
+        assert np.array_equal(raw[i], gb[lob.index(x[:3] + [x[3] % tb])])
+    direct = raw.copy()
+    rephase(lo, direct)
+    assert np.array_equal(synthetic_repeated_su3(lat, tb, seed=3), direct)
+    # second half of the same lattice split in two slabs of 4 slices
+    slab = synthetic_repeated_su3(lat[:3] + [4], tb, seed=3, t_offset=4, t_global=8)
+    los = Layout(lat[:3] + [4])
+    for i in range(0, los.vol, 5):
+        x = [int(v) for v in los.coords[i]]
+        assert np.array_equal(slab[i], direct[lo.index(x[:3] + [x[3] + 4])])
