@@ -15,7 +15,7 @@ t=time.time(); check(L.qexhip_wflow(ctx._h,2,0.01)); ctx.sync(); print("2 flow s
 for name in ("plaq","staple","expupdate"):
     n,ms=ctx.timer(name); print(name,n,"calls avg us",1e3*ms/max(n,1))
 pl2=q.plaq(ctx); print("plaq after flow",pl2)
-# size-independent property at full size (the parity tests hold the flow to the oracle at small sizes): unitarity preserved
+# size-independent property at full size (parity at small sizes is the job of tests/): unitarity preserved
 g2=np.zeros_like(g); check(L.qexhip_gauge_get(ctx._h, g2.ctypes.data_as(__import__('ctypes').c_void_p)))
 m=(g2[...,0]+1j*g2[...,1]).reshape(-1,3,3)[::1000]
 print("unitarity dev", np.abs(np.einsum('nij,nkj->nik',m,m.conj())-np.eye(3)).max(), "det dev", np.abs(np.linalg.det(m)-1).max())
