@@ -339,6 +339,11 @@ int qexhip_io_write_gauge(const char *path, const int lat[4], const double *g, c
 int qexhip_io_write_field(const char *path, const int lat[4], const void *data, int site_bytes, int word_bytes, const char *datatype,
                           char precision, int colors, int datacount, const char *file_md, const char *record_md);
 int qexhip_io_read_field(const char *path, const int lat[4], void *data, int site_bytes, int word_bytes, char datatype[64]);
+/* Reader.fileMetadata / Reader.recordMetadata (src/io/readerQiolite.nim:37-68,120-135; checked by tests/base/tfieldio.nim:
+ * 44-62): the user strings of the file and of its first record, 0-terminated, truncated to the capacities given;
+ * *file_len / *record_len = the sizes needed (incl. the 0). */
+int qexhip_io_metadata(const char *path, char *file_md, int file_cap, char *record_md, int record_cap, int *file_len,
+                       int *record_len);
 
 /* ---------------- kernel timers ----------------
  * hipEvent pairs around launches of the named kernel class on the context stream

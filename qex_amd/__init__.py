@@ -10,5 +10,5 @@ from .gauge import setBC, stagPhase, rephase, unit, synthetic_random_su3, synthe
 from .staggered import (  # noqa: F401
     Context, Staggered, SolverParams, newStag, newStag3, plaq, gaugeForce, gaugeFlow, flowEQ, gaugeAction, gaugeUpdate, reunit, wline, HisqCoefs, HypCoefs, makeImpLinks, fat7lDeriv, EVEN, ODD, ALL,
 )
-from .io import loadGauge, loadGaugeSlab, saveGauge, getFileLattice, gaugeFileInfo  # noqa: F401
+from .io import loadGauge, loadGaugeSlab, saveGauge, getFileLattice, gaugeFileInfo, writeField, readField, fileMetadata  # noqa: F401
 from .rng import RngField, RngMilc6, MRG32k3a  # noqa: F401

@@ -93,6 +93,7 @@ SYMBOLS = [
     ("qexhip_rng_set_state", _ci, [_vp, _vp]),
     ("qexhip_io_write_field", _ci, [C.c_char_p, _pi, _vp, _ci, _ci, C.c_char_p, C.c_char, _ci, _ci, C.c_char_p, C.c_char_p]),
     ("qexhip_io_read_field", _ci, [C.c_char_p, _pi, _vp, _ci, _ci, C.c_char_p]),
+    ("qexhip_io_metadata", _ci, [C.c_char_p, C.c_char_p, _ci, C.c_char_p, _ci, _pi, _pi]),
     ("qexhip_io_gauge_info", _ci, [C.c_char_p, _pi, C.c_char_p, _pi]),
     ("qexhip_io_read_gauge", _ci, [C.c_char_p, _pi, _vp, _vp, _vp]),
     ("qexhip_io_read_gauge_slab", _ci, [C.c_char_p, _pi, _ci, _ci, _vp]),

@@ -429,3 +429,24 @@ extern "C" int qexhip_io_read_field(const char *path, const int lat[4], void *da
   if (I.have_sum && (cs.a != I.suma || cs.b != I.sumb)) { qexhip_set_error("scidac: checksum mismatch"); return QEXHIP_ERR_IO; }
   return 0;
 }
+
+// Reader.fileMetadata / Reader.recordMetadata (src/io/readerQiolite.nim:37-68,120-135): the user strings of the first
+// record; returns the lengths needed (incl. the terminating 0) when a buffer is too small or NULL
+extern "C" int qexhip_io_metadata(const char *path, char *file_md, int file_cap, char *record_md, int record_cap, int *file_len,
+                                  int *record_len) {
+  if (!path) return QEXHIP_ERR_ARG;
+  FILE *f = fopen(path, "rb");
+  if (!f) { qexhip_set_error("scidac: cannot open file"); return QEXHIP_ERR_ARG; }
+  FileInfo I;
+  const int r = scan(f, I);
+  fclose(f);
+  if (r) return QEXHIP_ERR_ARG;
+  // the records hold C strings: drop the trailing 0 the writer adds
+  while (!I.file_md.empty() && I.file_md.back() == 0) I.file_md.pop_back();
+  while (!I.record_md.empty() && I.record_md.back() == 0) I.record_md.pop_back();
+  if (file_len) *file_len = (int)I.file_md.size() + 1;
+  if (record_len) *record_len = (int)I.record_md.size() + 1;
+  if (file_md && file_cap > 0) { strncpy(file_md, I.file_md.c_str(), file_cap - 1); file_md[file_cap - 1] = 0; }
+  if (record_md && record_cap > 0) { strncpy(record_md, I.record_md.c_str(), record_cap - 1); record_md[record_cap - 1] = 0; }
+  return 0;
+}

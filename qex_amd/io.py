@@ -45,3 +45,36 @@ def saveGauge(g, lat, fn, prec="D", filemd=None, recordmd=None):
     check(lib().qexhip_io_write_gauge(str(fn).encode(), (C.c_int * 4)(*lat), g.ctypes.data_as(C.c_void_p),
                                       prec.encode()[:1], filemd.encode() if filemd else None,
                                       recordmd.encode() if recordmd else None))
+
+
+# ---- any other field: Writer.write / Reader.read (src/io/writerQiolite.nim:96-187, src/io/readerQiolite.nim:120-239) ----
+def fileMetadata(fn):
+    """(Reader.fileMetadata, Reader.recordMetadata) of the file's first record"""
+    fl, rl = C.c_int(0), C.c_int(0)
+    check(lib().qexhip_io_metadata(str(fn).encode(), None, 0, None, 0, C.byref(fl), C.byref(rl)))
+    fb, rb = C.create_string_buffer(max(fl.value, 1)), C.create_string_buffer(max(rl.value, 1))
+    check(lib().qexhip_io_metadata(str(fn).encode(), fb, fl.value, rb, rl.value, None, None))
+    return fb.value.decode(), rb.value.decode()
+
+
+def writeField(f, lat, fn, filemd=None, recordmd=None, datatype=None, colors=3):
+    """One record holding the field f[vol, ...] (float64 -> precision D, float32 -> F; even-odd site order in memory)."""
+    if f.dtype not in (np.float64, np.float32) or not f.flags["C_CONTIGUOUS"] or f.shape[0] != int(np.prod(lat)):
+        raise ValueError("f must be a C-contiguous float32/float64 array [vol, ...] of this lattice")
+    word = f.dtype.itemsize
+    site = int(np.prod(f.shape[1:], dtype=np.int64)) * word
+    name = datatype or "QDP_%s_%dx%d" % ("D" if word == 8 else "F", site // word, word)
+    check(lib().qexhip_io_write_field(str(fn).encode(), (C.c_int * 4)(*lat), f.ctypes.data_as(C.c_void_p), site, word,
+                                      name.encode(), b"D" if word == 8 else b"F", colors, 1,
+                                      filemd.encode() if filemd is not None else None,
+                                      recordmd.encode() if recordmd is not None else None))
+
+
+def readField(fn, lat, site_shape, dtype=np.float64):
+    """Returns (f[vol, *site_shape], datatype); QexHipError if the record's site size or checksum does not fit."""
+    f = np.zeros((int(np.prod(lat)),) + tuple(site_shape), dtype=dtype)
+    word = f.dtype.itemsize
+    dt = C.create_string_buffer(64)
+    check(lib().qexhip_io_read_field(str(fn).encode(), (C.c_int * 4)(*lat), f.ctypes.data_as(C.c_void_p),
+                                     int(np.prod(site_shape, dtype=np.int64)) * word, word, dt))
+    return f, dt.value.decode()

@@ -63,6 +63,7 @@ proc qexhip_rng_set_state(r: pointer; i: ptr cuint): cint {.qh.}
 proc qexhip_io_write_field(path: cstring; lat: ptr cint; data: pointer; siteBytes, wordBytes: cint; datatype: cstring;
                            prec: cchar; colors, datacount: cint; fileMd, recMd: cstring): cint {.qh.}
 proc qexhip_io_read_field(path: cstring; lat: ptr cint; data: pointer; siteBytes, wordBytes: cint; datatype: cstring): cint {.qh.}
+proc qexhip_io_metadata(path: cstring; fileMd: cstring; fileCap: cint; recMd: cstring; recCap: cint; fileLen, recLen: ptr cint): cint {.qh.}
 proc qexhip_io_write_gauge(path: cstring; lat: ptr cint; g: ptr cdouble; prec: cchar; fileMd, recMd: cstring): cint {.qh.}
 
 template chk(e: untyped) =
