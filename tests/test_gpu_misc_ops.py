@@ -131,3 +131,42 @@ def test_error_behaviour_of_the_abi(oracle):
         ctx.set_option("nonsense", 1)
     # null handle
     assert L.qexhip_sync(None) != 0
+
+
+@pytest.mark.gpu
+def test_gpu_rsqrtPH_property_of_the_reference():
+    """tests/base/tmatfun.nim:33-77 on the device: projectSU of gaussian matrices (qexhip_gauge_reunit, the same
+    (x^+ x)^(-1/2) kernel code as projectU) is unitary to the reference's own bound 384 * 3 * eps (per element average)."""
+    import qex_amd as q
+    from test_oracle_golden import _tmatfun_bound
+
+    lat = [4, 4, 4, 8]
+    lo = q.Layout(lat)
+    g = q.unit(lo)
+    g.reshape(-1, 3, 3, 2)[:2000] = np.random.default_rng(13).standard_normal((2000, 3, 3, 2))   # the matrices of the oracle's test
+    ctx = q.Context(lat)
+    q.reunit(ctx, g)
+    s, bound = _tmatfun_bound(g.reshape(-1, 3, 3, 2)[:2000])
+    assert s.max() < bound
+    m = g.reshape(-1, 3, 3, 2)
+    det = np.linalg.det(m[..., 0] + 1j * m[..., 1])
+    assert np.abs(det - 1).max() < 1e-11
+
+
+@pytest.mark.gpu
+def test_gpu_action_and_plaquette_repeat_exactly():
+    """tests/base/tactionstress.nim:18-45 and tstressplaq.nim: the same field gives the same action / plaquette on every
+    one of many calls (the reference allows 1e-8 relative; the device reductions are ordered, so the bits repeat)."""
+    import qex_amd as q
+
+    lat = [8, 8, 8, 16]
+    lo = q.Layout(lat)
+    g = q.synthetic_random_su3(lo, seed=99)
+    ctx = q.Context(lat)
+    p0 = q.plaq(ctx, g)
+    a0 = q.gaugeAction(ctx, None, plaq=6.0)
+    for _ in range(64):
+        assert np.array_equal(q.plaq(ctx), p0)
+        assert q.gaugeAction(ctx, None, plaq=6.0) == a0
+    # gaugeAction1 = -(beta / 3) sum_P Re tr U_P (gaugeAction.nim:61-84) and plaq_i = sum Re tr / (18 V)
+    assert abs(a0 + 6.0 * 6.0 * lo.vol * p0.sum()) <= 1e-12 * abs(a0)

@@ -256,3 +256,22 @@ def test_solver_fixture(oracle):
     xs, its, fin = o.solve_multi(lo, g, None, b, fx["masses"], fx["r2req"], 10000)
     for k, v in enumerate(fx["multi_x2"]):
         assert abs((xs[k] * xs[k]).sum() / v - 1) < 1e-8
+
+
+def _tmatfun_bound(u):
+    """tests/base/tmatfun.nim:11-31 (chkzero / chkeq) for t = r y r against 1, y = x^+ x, r = rsqrtPH(y): with
+    W = x r (projectU), t = W^+ W.  The reference accepts max|t - 1| / max|1| / (rows * cols) < 384 * rows * eps."""
+    m = u[..., 0] + 1j * u[..., 1]
+    t = np.einsum("nki,nkj->nij", m.conj(), m)
+    md = np.abs(np.stack([(t - np.eye(3)).real, (t - np.eye(3)).imag])).max(axis=(0, 2, 3))
+    return md / 9.0, 384 * 3 * np.finfo(np.float64).eps
+
+
+def test_rsqrtPH_property_of_the_reference(oracle):
+    """`suite "Test matrix rsqrtPH"` (tests/base/tmatfun.nim:33-77) on complex 3x3 gaussian matrices: r y r = 1 to the
+    reference's own bound, through the restated projectU (= x (x^+ x)^(-1/2), matrixFunctions.nim:301-313)."""
+    o = oracle
+    x = np.random.default_rng(13).standard_normal((2000, 3, 3, 2))
+    u = np.stack([o.su3_fn("qo_projectU", xi) for xi in x])
+    s, bound = _tmatfun_bound(u)
+    assert s.max() < bound
