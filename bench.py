@@ -69,6 +69,12 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}")
 
+    # multi-process GPU work on this pool needs dmabuf IPC (without it RCCL fails with hipIpcGetMemHandle: invalid
+    # argument); RCCL problems should leave a trace in the log
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if N > 1:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+
     import torch
     import torch.distributed as dist
 
