@@ -60,16 +60,28 @@ ap = argparse.ArgumentParser()
 ap.add_argument("-run", type=int, default=0, choices=[0, 1, 2])
 ap.add_argument("-trajs", type=int, default=2)
 ap.add_argument("-halo", action="store_true")
+ap.add_argument("-lat", type=int, nargs=4, default=None, help="another lattice than the reference run's 8^4 (no golden log then)")
+ap.add_argument("-resident", action="store_true", help="MD evolution with links and momenta resident on the device (qexhip_md_*)")
+ap.add_argument("-time", action="store_true", help="print wall time and the kernel-time breakdown of every trajectory")
 a = ap.parse_args()
 
+if a.lat:
+    R.LAT = list(a.lat)
 cfg = R.CONFIGS[a.run]
-be = R.HipBackend(q, R.LAT, halo=a.halo)
+be = R.HipBackend(q, R.LAT, halo=a.halo, resident=a.resident)
 print(be.ctx.info())
 r = R.Replay(Host, be, cfg, rng=q.RngField(R.LAT, q.RngMilc6, R.SEED))
 G = GlobalRng(R.SEED)
 pl = be.plaq(r.g)
 print("MEASplaq ss: %r  st: %r  tot: %r" % (float(2 * sum(pl[:3])), float(2 * sum(pl[3:])), float(0.5 * (2 * sum(pl[:3]) + 2 * sum(pl[3:])))))
+import time  # noqa: E402
+
+TIMERS = ("expupdate", "dslash", "dslash_bnd", "dslash_batch", "blas", "reduce", "smear", "nhyp_force", "smear_deriv", "staple", "outer", "plaq")
 for n in range(1, a.trajs + 1):
+    if a.time:
+        be.ctx.timers_enable(1)
+        be.ctx.timers_reset()
+        t_traj = time.time()
     g0 = r.g.copy()
     b = r.refresh()
     print("Begin " + fmt(b))
@@ -82,6 +94,11 @@ for n in range(1, a.trajs + 1):
     acc, u = math.exp(-dH), G.uniform()
     ok = u <= acc
     print("%s:  dH: %r  exp(-dH): %r  r: %r" % ("ACCEPT" if ok else "REJECT", float(dH), acc, u))
+    if a.time:
+        parts = {k: be.ctx.timer(k) for k in TIMERS}
+        be.ctx.timers_enable(0)
+        print("TIME trajectory %d: wall %.2f s; kernel ms: %s" % (n, time.time() - t_traj, "  ".join(
+            "%s %.1f (%d)" % (k, ms, cnt) for k, (cnt, ms) in parts.items() if cnt)))
     m = r.measure(accepted=ok, g0=g0)
     for v, its in zip(m["pbp"], m["pbp_iters"]):
         print("stagSolve: %d" % its)

@@ -319,6 +319,25 @@ int qexhip_rng_state_words(qexhip_rng *rng);
 int qexhip_rng_get_state(qexhip_rng *rng, unsigned *out);
 int qexhip_rng_set_state(qexhip_rng *rng, const unsigned *in);
 
+/* ---------------- resident molecular dynamics ----------------
+ * The MD loop of QEX's HMC drivers -- mdt (U <- exp(t p) U), mdv (p -= t f), mdvAllfga with its force-gradient shifts
+ * (src/examples/staghmc_sh.nim:429-640, src/stagg_pv_hmc/staghmc_spv.nim:873-1061) -- with links and momenta left on the
+ * device between the updates.  Forces stay in a device buffer, the "source" of a later kick or shift:
+ *   source 0: qexhip_md_gauge_force (gc.forceA / gaugeForce of the resident thin links)
+ *   source 1: the last force of the nHYP closure: qexhip_nhyp_gauge_force / _fermion_force / _fforce called with f = NULL
+ * and qexhip_nhyp_prepare(g = NULL) smears the resident links.  begin uploads (g NULL: keep the resident links of
+ * qexhip_gauge_set), end downloads (either pointer may be NULL).  kick: p += t * f.  shift_links: U <- exp(t f) U
+ * (fgv / fgvf of the force-gradient update); save / restore bracket it (fgsave / fgload). */
+int qexhip_md_begin(qexhip_handle h, const double *g, const double *p);
+int qexhip_md_end(qexhip_handle h, double *g, double *p);
+int qexhip_md_momentum_norm2(qexhip_handle h, double *p2);
+int qexhip_md_update_links(qexhip_handle h, double t);
+int qexhip_md_gauge_force(qexhip_handle h, double cplaq, double crect, double cadj);
+int qexhip_md_kick(qexhip_handle h, int source, double t);
+int qexhip_md_shift_links(qexhip_handle h, int source, double t);
+int qexhip_md_save_links(qexhip_handle h);
+int qexhip_md_restore_links(qexhip_handle h);
+
 /* ---------------- SciDAC/LIME gauge files (host only, no handle) ----------------
  * loadGauge / saveGauge (src/gauge/gaugeUtils.nim:87-122) via Reader / Writer (src/io/readerQiolite.nim:37-239,
  * src/io/writerQiolite.nim:28-187): one record of 4 x QDP_{F,D}3_ColorMatrix per site, sites x-fastest, big-endian,

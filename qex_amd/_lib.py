@@ -93,6 +93,15 @@ SYMBOLS = [
     ("qexhip_rng_set_state", _ci, [_vp, _vp]),
     ("qexhip_io_write_field", _ci, [C.c_char_p, _pi, _vp, _ci, _ci, C.c_char_p, C.c_char, _ci, _ci, C.c_char_p, C.c_char_p]),
     ("qexhip_io_read_field", _ci, [C.c_char_p, _pi, _vp, _ci, _ci, C.c_char_p]),
+    ("qexhip_md_begin", _ci, [_vp, _vp, _vp]),
+    ("qexhip_md_end", _ci, [_vp, _vp, _vp]),
+    ("qexhip_md_momentum_norm2", _ci, [_vp, _pd]),
+    ("qexhip_md_update_links", _ci, [_vp, _cd]),
+    ("qexhip_md_gauge_force", _ci, [_vp, _cd, _cd, _cd]),
+    ("qexhip_md_kick", _ci, [_vp, _ci, _cd]),
+    ("qexhip_md_shift_links", _ci, [_vp, _ci, _cd]),
+    ("qexhip_md_save_links", _ci, [_vp]),
+    ("qexhip_md_restore_links", _ci, [_vp]),
     ("qexhip_io_metadata", _ci, [C.c_char_p, C.c_char_p, _ci, C.c_char_p, _ci, _pi, _pi]),
     ("qexhip_io_gauge_info", _ci, [C.c_char_p, _pi, C.c_char_p, _pi]),
     ("qexhip_io_read_gauge", _ci, [C.c_char_p, _pi, _vp, _vp, _vp]),

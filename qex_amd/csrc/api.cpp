@@ -507,7 +507,7 @@ extern "C" int qexhip_hisq_closure_force(qexhip_handle c, const double *dsdsu, c
   return hisq_closure_force(c, dsdsu, dsdsul, f);
 }
 extern "C" int qexhip_hisq_fermion_force(qexhip_handle c, double *f, const double *const *psi, const double *scale, int n) {
-  if (!c || !f || !psi || !scale) return QEXHIP_ERR_ARG;
+  if (!c || !psi || !scale) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
   return hisq_fermion_force(c, f, psi, scale, n);
 }
@@ -544,7 +544,7 @@ extern "C" int qexhip_stag_set_links_nhyp(qexhip_handle c, const double *g, doub
 }
 
 extern "C" int qexhip_nhyp_prepare(qexhip_handle c, const double *g, double a1, double a2, double a3, double *fl) {
-  if (!c || !g) return QEXHIP_ERR_ARG;
+  if (!c) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
   return nhyp_prepare(c, g, a1, a2, a3, fl);
 }
@@ -554,7 +554,7 @@ extern "C" int qexhip_nhyp_force(qexhip_handle c, double *f, const double *chain
   return nhyp_force_host(c, f, chain);
 }
 extern "C" int qexhip_nhyp_gauge_force(qexhip_handle c, double *f, double cplaq, double crect, double cadj) {
-  if (!c || !f) return QEXHIP_ERR_ARG;
+  if (!c) return QEXHIP_ERR_ARG;
   if (crect != 0.0 && cadj != 0.0) { qexhip_set_error("rect and adjplaq together are not a QEX action"); return QEXHIP_ERR_ARG; }
   HIPCHK(hipSetDevice(c->device));
   return nhyp_gauge_force(c, f, cplaq, cadj != 0.0 ? cadj : crect, cadj != 0.0 ? 1 : 0);
@@ -571,7 +571,7 @@ extern "C" int qexhip_nhyp_fermion_force(qexhip_handle c, double *f, const doubl
 extern "C" int qexhip_nhyp_fforce(qexhip_handle c, double *f, int n, const double *const *phi, const double *mass,
                                   const double *scale, const double *r2req, int maxits, const int antiperiodic[4],
                                   const int phases[4], int *iters) {
-  if (!c || !f || !phi || !mass || !scale || !r2req) return QEXHIP_ERR_ARG;
+  if (!c || !phi || !mass || !scale || !r2req) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
   static const int defph[4] = {8, 9, 11, 0};
   int mask = 0;
@@ -621,3 +621,23 @@ extern "C" int qexhip_wline(qexhip_handle c, const int *path, int n, double out[
   return gauge_wline(c, path, n, out);
 }
 extern "C" int qexhip_wflow(qexhip_handle c, int nsteps, double eps) { if (!c || nsteps < 0) return QEXHIP_ERR_ARG; return gauge_wflow(c, nsteps, eps); }
+
+// ---- resident molecular dynamics (gauge.hip) ----
+extern "C" int qexhip_md_begin(qexhip_handle c, const double *g, const double *p) {
+  if (!c || !p) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return md_begin(c, g, p);
+}
+extern "C" int qexhip_md_end(qexhip_handle c, double *g, double *p) { if (!c) return QEXHIP_ERR_ARG; HIPCHK(hipSetDevice(c->device)); return md_end(c, g, p); }
+extern "C" int qexhip_md_momentum_norm2(qexhip_handle c, double *p2) { if (!c || !p2) return QEXHIP_ERR_ARG; HIPCHK(hipSetDevice(c->device)); return md_momentum_norm2(c, p2); }
+extern "C" int qexhip_md_update_links(qexhip_handle c, double t) { if (!c) return QEXHIP_ERR_ARG; HIPCHK(hipSetDevice(c->device)); return md_update_links(c, t); }
+extern "C" int qexhip_md_gauge_force(qexhip_handle c, double cplaq, double crect, double cadj) {
+  if (!c) return QEXHIP_ERR_ARG;
+  if (crect != 0.0 && cadj != 0.0) { qexhip_set_error("rect and adjplaq together are not a QEX action"); return QEXHIP_ERR_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  return md_gauge_force(c, cplaq, cadj != 0.0 ? cadj : crect, cadj != 0.0 ? 1 : 0);
+}
+extern "C" int qexhip_md_kick(qexhip_handle c, int source, double t) { if (!c) return QEXHIP_ERR_ARG; HIPCHK(hipSetDevice(c->device)); return md_kick(c, source, t); }
+extern "C" int qexhip_md_shift_links(qexhip_handle c, int source, double t) { if (!c) return QEXHIP_ERR_ARG; HIPCHK(hipSetDevice(c->device)); return md_shift_links(c, source, t); }
+extern "C" int qexhip_md_save_links(qexhip_handle c) { if (!c) return QEXHIP_ERR_ARG; HIPCHK(hipSetDevice(c->device)); return md_save_links(c); }
+extern "C" int qexhip_md_restore_links(qexhip_handle c) { if (!c) return QEXHIP_ERR_ARG; HIPCHK(hipSetDevice(c->device)); return md_restore_links(c); }

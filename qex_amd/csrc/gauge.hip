@@ -26,6 +26,9 @@ struct GaugeNat {
   size_t n2 = 0;  // double2 elements per field (incl. ghost tiles when t is sharded)
   int ghost_valid = 0;   // depth to which the ghost slices of U are current
   double *pp = nullptr; int npp = 0;   // per-workgroup plaquette partials of k_plaq
+  double2 *M = nullptr;      // resident MD momenta (qexhip_md_*)
+  double2 *Usave = nullptr;  // links saved around a force-gradient shift
+  int save_ghost_valid = 0;
 };
 
 static int gauge_ghosts(qexhip_ctx *c, int depth);
@@ -545,6 +548,8 @@ void gauge_free(qexhip_ctx *c) {
   if (c->gn->P) (void)hipFree(c->gn->P);
   if (c->gn->U2) (void)hipFree(c->gn->U2);
   if (c->gn->pp) (void)hipFree(c->gn->pp);
+  if (c->gn->M) (void)hipFree(c->gn->M);
+  if (c->gn->Usave) (void)hipFree(c->gn->Usave);
   delete c->gn;
   c->gn = nullptr;
 }
@@ -745,6 +750,129 @@ int gauge_md_update(qexhip_ctx *c, const double *p_host, double t) {
   k_exp_update<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P, t, (size_t)c->g.ntile * 4, (size_t)c->g.etile * 4);
   HIPCHK(hipGetLastError());
   c->gn->ghost_valid = 0;
+  return 0;
+}
+// ---------------- resident molecular dynamics ----------------
+// The MD loop of QEX's HMC drivers (mdt / mdv / mdvAllfga, src/examples/staghmc_sh.nim:429-640,
+// src/stagg_pv_hmc/staghmc_spv.nim:873-1061) with links and momenta left on the device between the updates: through
+// the host-pointer entry points every update moves two or three 72-double-per-site fields over PCIe, which at 32^4 is
+// 8 of the 9.4 s of a trajectory.  Forces are left in a device buffer ("source": 0 = md_gauge_force, 1 = the nHYP
+// closure's last force) and applied by md_kick (p += t f) or md_shift_links (U <- exp(t f) U, the force-gradient shift).
+__global__ void __launch_bounds__(256) k_links_axpy(size_t nlinks_tiles, double2 *P, const double2 *__restrict__ F, double t, size_t ntile4, size_t etile4) {
+  size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t tile = j >> 6;
+  if (tile >= nlinks_tiles) return;
+  size_t o = body_tile_off(tile, ntile4, etile4) + (j & 63);
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    double2 a = P[o + k * 64];
+    const double2 f = F[o + k * 64];
+    a.x = fma(t, f.x, a.x); a.y = fma(t, f.y, a.y);
+    P[o + k * 64] = a;
+  }
+}
+__global__ void __launch_bounds__(256) k_links_norm2(size_t nlinks_tiles, const double2 *__restrict__ P, size_t ntile4, size_t etile4, double *partials) {
+  double acc = 0;
+  for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; (j >> 6) < nlinks_tiles; j += (size_t)gridDim.x * 256) {
+    size_t o = body_tile_off(j >> 6, ntile4, etile4) + (j & 63);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { const double2 a = P[o + k * 64]; acc = fma(a.x, a.x, fma(a.y, a.y, acc)); }
+  }
+  double r = block_sum_256(acc);
+  if (threadIdx.x == 0) { partials[blockIdx.x] = r; partials[gridDim.x + blockIdx.x] = 0; partials[2 * gridDim.x + blockIdx.x] = 0; }
+}
+double2 *nhyp_force_buffer(qexhip_ctx *c);      // smear.hip: the closure's force field (null without a closure)
+const double2 *gauge_resident_links(qexhip_ctx *c) { return c->gn ? c->gn->U : nullptr; }
+static int md_source(qexhip_ctx *c, int source, const double2 **F) {
+  *F = nullptr;
+  if (source == 0) *F = c->gn ? c->gn->F : nullptr;
+  else if (source == 1) *F = nhyp_force_buffer(c);
+  if (!*F) { qexhip_set_error("md: force source %d holds nothing yet", source); return -3; }
+  return 0;
+}
+static int md_ready(qexhip_ctx *c) {
+  if (!c->gn || !c->gn->M) { qexhip_set_error("md: call qexhip_md_begin first"); return -3; }
+  return 0;
+}
+static unsigned link_blocks(qexhip_ctx *c) { return (unsigned)(((size_t)2 * c->g.ntile * 4 * 64 + 255) / 256); }
+int md_begin(qexhip_ctx *c, const double *g, const double *p) {
+  if (g) CHK(gauge_set(c, g));
+  if (!c->gn) { qexhip_set_error("md_begin: no resident gauge field (pass g or call qexhip_gauge_set)"); return -3; }
+  CHK(gn_alloc_fp(c));
+  const size_t nbytes = c->gn->n2 * sizeof(double2);
+  if (!c->gn->M) { HIPCHK(hipMalloc((void **)&c->gn->M, nbytes)); HIPCHK(hipMemsetAsync(c->gn->M, 0, nbytes, c->stream)); }
+  const size_t bytes = (size_t)c->g.V * 72 * sizeof(double);
+  CHK(ensure_stage(c, bytes));
+  HIPCHK(hipMemcpyAsync(c->stage, p, bytes, hipMemcpyHostToDevice, c->stream));
+  k_gauge_to_tiles<<<(c->g.V + 255) / 256, 256, 0, c->stream>>>(c->g, (const double2 *)c->stage, c->gn->M);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int md_end(qexhip_ctx *c, double *g, double *p) {
+  CHK(md_ready(c));
+  if (g) CHK(download_nat(c, c->gn->U, g));
+  if (p) CHK(download_nat(c, c->gn->M, p));
+  return 0;
+}
+int md_momentum_norm2(qexhip_ctx *c, double *out) {
+  CHK(md_ready(c));
+  const size_t ltiles = (size_t)2 * c->g.ntile * 4;
+  const int nb = (int)std::min<size_t>(1024, (ltiles * 64 + 255) / 256);
+  k_links_norm2<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->M, (size_t)c->g.ntile * 4, (size_t)c->g.etile * 4, c->partials);
+  k_sum3<<<1, 256, 0, c->stream>>>(c->partials, nb, &c->dscal[24]);
+  HIPCHK(hipGetLastError());
+  double s[3];
+  CHK(read_global(c, &c->dscal[24], 3, s));
+  *out = s[0];
+  return 0;
+}
+int md_update_links(qexhip_ctx *c, double t) {
+  CHK(md_ready(c));
+  const size_t ltiles = (size_t)2 * c->g.ntile * 4;
+  ScopedTimer tm(c, "expupdate", c->stream);
+  k_exp_update<<<link_blocks(c), 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->M, t, (size_t)c->g.ntile * 4, (size_t)c->g.etile * 4);
+  HIPCHK(hipGetLastError());
+  c->gn->ghost_valid = 0;
+  return 0;
+}
+int md_gauge_force(qexhip_ctx *c, double cplaq, double c2, int kind) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  if (kind == 0 && c2 != 0.0) for (int d = 0; d < 4; d++) if (c->g.X[d] < 4) { qexhip_set_error("rectangle action needs extents >= 4"); return -1; }
+  return force_dev(c, cplaq, 0, 0, 0, c2, kind);
+}
+int md_kick(qexhip_ctx *c, int source, double t) {
+  CHK(md_ready(c));
+  const double2 *F;
+  CHK(md_source(c, source, &F));
+  const size_t ltiles = (size_t)2 * c->g.ntile * 4;
+  k_links_axpy<<<link_blocks(c), 256, 0, c->stream>>>(ltiles, c->gn->M, F, t, (size_t)c->g.ntile * 4, (size_t)c->g.etile * 4);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int md_shift_links(qexhip_ctx *c, int source, double t) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  const double2 *F;
+  CHK(md_source(c, source, &F));
+  const size_t ltiles = (size_t)2 * c->g.ntile * 4;
+  ScopedTimer tm(c, "expupdate", c->stream);
+  k_exp_update<<<link_blocks(c), 256, 0, c->stream>>>(ltiles, c->gn->U, F, t, (size_t)c->g.ntile * 4, (size_t)c->g.etile * 4);
+  HIPCHK(hipGetLastError());
+  c->gn->ghost_valid = 0;
+  return 0;
+}
+int md_save_links(qexhip_ctx *c) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  const size_t nbytes = c->gn->n2 * sizeof(double2);
+  if (!c->gn->Usave) HIPCHK(hipMalloc((void **)&c->gn->Usave, nbytes));
+  HIPCHK(hipMemcpyAsync(c->gn->Usave, c->gn->U, nbytes, hipMemcpyDeviceToDevice, c->stream));
+  c->gn->save_ghost_valid = c->gn->ghost_valid;
+  return 0;
+}
+int md_restore_links(qexhip_ctx *c) {
+  if (!c->gn || !c->gn->Usave) { qexhip_set_error("md_restore_links: nothing saved"); return -3; }
+  HIPCHK(hipMemcpyAsync(c->gn->U, c->gn->Usave, c->gn->n2 * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+  c->gn->ghost_valid = c->gn->save_ghost_valid;
   return 0;
 }
 // reunit: g.projectSU (gaugeUtils.nim:1333-1334)

@@ -243,5 +243,14 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]);
 int gauge_action(qexhip_ctx *c, double cplaq, double c2, int kind, double *out);
 int gauge_md_update(qexhip_ctx *c, const double *p_host, double t);
 int gauge_reunit(qexhip_ctx *c);
+int md_begin(qexhip_ctx *c, const double *g, const double *p);
+int md_end(qexhip_ctx *c, double *g, double *p);
+int md_momentum_norm2(qexhip_ctx *c, double *out);
+int md_update_links(qexhip_ctx *c, double t);
+int md_gauge_force(qexhip_ctx *c, double cplaq, double c2, int kind);
+int md_kick(qexhip_ctx *c, int source, double t);
+int md_shift_links(qexhip_ctx *c, int source, double t);
+int md_save_links(qexhip_ctx *c);
+int md_restore_links(qexhip_ctx *c);
 int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]);
 void gauge_free(qexhip_ctx *c);

@@ -650,6 +650,7 @@ struct NhypState {
   double a1 = 0, a2 = 0, a3 = 0;
   explicit NhypState(qexhip_ctx *c) : S(c) {}
 };
+const double2 *gauge_resident_links(qexhip_ctx *c);   // gauge.hip
 void nhyp_state_free(qexhip_ctx *c) {
   if (c->nhyp) { delete (NhypState *)c->nhyp; c->nhyp = nullptr; }
 }
@@ -672,7 +673,13 @@ int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, doub
         if (mu != nu) { CHK(S.alloc(&st->fl1[mu][nu], S.fsz)); CHK(S.alloc(&st->fl2[mu][nu], S.fsz)); }
       }
   }
-  CHK(S.upload(st->G, g_host));
+  if (g_host) {
+    CHK(S.upload(st->G, g_host));
+  } else {                                       // resident MD: the thin links are the device field of qexhip_gauge_set / md_*
+    const double2 *U = gauge_resident_links(c);
+    if (!U) { qexhip_set_error("nhyp_prepare(g = NULL) needs a resident gauge field (qexhip_gauge_set / qexhip_md_begin)"); return -3; }
+    HIPCHK(hipMemcpyAsync(st->G, U, S.gsz * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+  }
   CHK(S.nhyp(st->G, st->FL, a1, a2, a3, &st->K, !fresh));
   if (fl_host) CHK(S.download(fl_host, st->FL));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -971,8 +978,9 @@ static int nhyp_finish(qexhip_ctx *c, NhypState *st, int adj, double *f_host) {
   const size_t ltiles = (size_t)2 * c->g.etile * 4;       // ghost tiles included: harmless, keeps the index linear
   k_force_projtah<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, st->F, st->G, adj);
   HIPCHK(hipGetLastError());
-  return st->S.download(f_host, st->F);
+  return f_host ? st->S.download(f_host, st->F) : 0;      // f = NULL: left on the device for qexhip_md_kick / md_shift_links
 }
+double2 *nhyp_force_buffer(qexhip_ctx *c) { return c->nhyp ? ((NhypState *)c->nhyp)->F : nullptr; }
 // gforce(act, g, sg, f, smear_force) (stagg_pv_hmc/staghmc_spv.nim:217-228): derivative of the gauge
 // action on the SMEARED links -> smearedForce -> TAH(g f^+) with the thin links
 int nhyp_gauge_force(qexhip_ctx *c, double *f_host, double cplaq, double c2, int kind) {

@@ -63,6 +63,15 @@ proc qexhip_rng_set_state(r: pointer; i: ptr cuint): cint {.qh.}
 proc qexhip_io_write_field(path: cstring; lat: ptr cint; data: pointer; siteBytes, wordBytes: cint; datatype: cstring;
                            prec: cchar; colors, datacount: cint; fileMd, recMd: cstring): cint {.qh.}
 proc qexhip_io_read_field(path: cstring; lat: ptr cint; data: pointer; siteBytes, wordBytes: cint; datatype: cstring): cint {.qh.}
+proc qexhip_md_begin(h: pointer; g, p: ptr cdouble): cint {.qh.}
+proc qexhip_md_end(h: pointer; g, p: ptr cdouble): cint {.qh.}
+proc qexhip_md_momentum_norm2(h: pointer; p2: ptr cdouble): cint {.qh.}
+proc qexhip_md_update_links(h: pointer; t: cdouble): cint {.qh.}
+proc qexhip_md_gauge_force(h: pointer; cplaq, crect, cadj: cdouble): cint {.qh.}
+proc qexhip_md_kick(h: pointer; source: cint; t: cdouble): cint {.qh.}
+proc qexhip_md_shift_links(h: pointer; source: cint; t: cdouble): cint {.qh.}
+proc qexhip_md_save_links(h: pointer): cint {.qh.}
+proc qexhip_md_restore_links(h: pointer): cint {.qh.}
 proc qexhip_io_metadata(path: cstring; fileMd: cstring; fileCap: cint; recMd: cstring; recCap: cint; fileLen, recLen: ptr cint): cint {.qh.}
 proc qexhip_io_write_gauge(path: cstring; lat: ptr cint; g: ptr cdouble; prec: cchar; fileMd, recMd: cstring): cint {.qh.}
 

@@ -391,6 +391,51 @@ def gaugeUpdate(ctx, g, p, t):
     check(lib().qexhip_gauge_get(ctx._h, _p(g)))
 
 
+class ResidentMD:
+    """mdt / mdv / the force-gradient shifts of QEX's HMC drivers (staghmc_sh.nim:429-640) on links and momenta that
+    stay on the device between the updates (qexhip_md_*).  Forces are left on the device by `gauge_force()` (source 0)
+    and by the nHYP closure called with f = None (source 1: `sf.gforce(None, ...)`, `sf.fforce_solve(None, ...)` of
+    `HypCoefs.smearGetForce(ctx, None)`, which smears the resident links)."""
+
+    GAUGE, NHYP = 0, 1
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def begin(self, g, p):
+        """upload links (None: keep the resident ones) and momenta"""
+        check(lib().qexhip_md_begin(self.ctx._h, _p(g), _p(p)))
+
+    def end(self, g=None, p=None):
+        check(lib().qexhip_md_end(self.ctx._h, _p(g), _p(p)))
+
+    def momentum_norm2(self):
+        out = C.c_double(0)
+        check(lib().qexhip_md_momentum_norm2(self.ctx._h, C.byref(out)))
+        return out.value
+
+    def update_links(self, t):
+        """mdt: U <- exp(t p) U"""
+        check(lib().qexhip_md_update_links(self.ctx._h, float(t)))
+
+    def gauge_force(self, plaq=1.0, rect=0.0, adjplaq=0.0):
+        check(lib().qexhip_md_gauge_force(self.ctx._h, float(plaq), float(rect), float(adjplaq)))
+
+    def kick(self, source, t):
+        """mdv: p += t f"""
+        check(lib().qexhip_md_kick(self.ctx._h, int(source), float(t)))
+
+    def shift_links(self, source, t):
+        """fgv / fgvf: U <- exp(t f) U"""
+        check(lib().qexhip_md_shift_links(self.ctx._h, int(source), float(t)))
+
+    def save_links(self):
+        check(lib().qexhip_md_save_links(self.ctx._h))
+
+    def restore_links(self):
+        check(lib().qexhip_md_restore_links(self.ctx._h))
+
+
 def reunit(ctx, g):
     """g.projectSU in place (gaugeUtils.nim:1333-1334)"""
     check(lib().qexhip_gauge_set(ctx._h, _p(g)))

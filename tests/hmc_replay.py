@@ -278,7 +278,63 @@ class Replay:
                 self.p += self.fforce(h, self.g, updateFG, ts[1:])
             self.g = gg                                                    # fgload
 
+    # ---- the same MD with links and momenta resident on the device (backend.resident, qexhip_md_*) ----
+    def _fforce_resident(self, ix, ts):
+        its = self.be.md_fforce_solve([self.phi[j] for j in ix], [self._m(j) for j in ix], [self.fscale(j, ts[j]) for j in ix])
+        for j, n in zip(ix, its):
+            self.stats["force_iters"][j].append(n)
+
+    def _mdv_all_resident(self, group):
+        """mdv_all step for step; nothing crosses PCIe but the pseudofermion fields of the solves"""
+        be = self.be
+        nf = len(self.cfg.fields)
+        ts, gs = [0.0] * (nf + 1), [0.0] * (nf + 1)
+        for m, t, g_ in group:
+            ts[m], gs[m] = t, g_
+        updateGG = gs[0] != 0.0
+        updateG = (not updateGG) and ts[0] != 0.0
+        updateF = [k for k in range(nf) if gs[k + 1] == 0.0 and ts[k + 1] != 0.0]
+        updateFG = [k for k in range(nf) if gs[k + 1] != 0.0]
+        if updateGG or updateFG:
+            be.md_save()                                                   # fgsave
+            if updateFG:
+                be.md_smear()                                              # sforceShared (closure + operator from gg)
+        if updateG:
+            be.md_gauge_force()
+            be.md_kick(0, -ts[0])
+        if updateF:
+            if not updateFG:
+                be.md_smear()
+            self._fforce_resident(updateF, ts[1:])
+            be.md_kick(1, 1.0)
+        if updateGG or updateFG:
+            if updateGG:                                                   # fgv
+                be.md_gauge_force()
+                be.md_shift(0, -2.0 * gs[0] / ts[0])
+            if updateFG:                                                   # fgvf, closure still the one of gg
+                tg = [2.0 * gs[k + 1] / ts[k + 1] if k in updateFG else 0.0 for k in range(nf)]
+                self._fforce_resident(updateFG, tg)
+                be.md_shift(1, 1.0)
+            if updateGG:
+                be.md_gauge_force()
+                be.md_kick(0, -ts[0])
+            if updateFG:
+                be.md_smear()
+                self._fforce_resident(updateFG, ts[1:])
+                be.md_kick(1, 1.0)
+            be.md_restore()                                                # fgload
+
     def evolve(self):
+        if getattr(self.be, "resident", False):
+            self.be.md_begin(self.g, self.p)
+            now = 0.0
+            for t, group in schedule(self.cfg):
+                self.be.md_T(t - now)
+                now = t
+                self._mdv_all_resident(group)
+            self.be.md_T(TAU - now)
+            self.be.md_end(self.g, self.p)
+            return
         now = 0.0
         for t, group in schedule(self.cfg):
             self.mdt(t - now)
@@ -387,13 +443,50 @@ class OracleBackend:
 class HipBackend:
     """Every operator on the hot path runs through libqexhip (C ABI)."""
 
-    def __init__(self, q, lat, halo=False):
-        """halo=True: every kernel runs in its t-sharded form (ghost zones, face exchanges, rank reductions) on one GPU"""
+    def __init__(self, q, lat, halo=False, resident=False):
+        """halo=True: every kernel runs in its t-sharded form (ghost zones, face exchanges, rank reductions) on one GPU.
+        resident=True: the MD evolution keeps links and momenta on the device (qexhip_md_*, Replay.evolve)"""
         self.q = q
         self.ctx = q.Context(lat)
         if halo:
             self.ctx.force_halo(True)
         self.hc = q.HypCoefs(*ALPHA)
+        self.resident = resident
+        self.md = q.ResidentMD(self.ctx)
+        self._sf = None
+
+    # ---- resident MD (Replay._mdv_all_resident) ----
+    def md_begin(self, g, p):
+        self.md.begin(g, p)
+
+    def md_end(self, g, p):
+        self.md.end(g, p)
+
+    def md_T(self, t):
+        self.md.update_links(t)
+
+    def md_save(self):
+        self.md.save_links()
+
+    def md_restore(self):
+        self.md.restore_links()
+
+    def md_smear(self):
+        """smearRephase on the resident links: closure + operator links, nothing over PCIe"""
+        self._sf = self.hc.smearGetForce(self.ctx, None)
+        self._s = self.q.Staggered(self.ctx, None, smear=self.hc, bc="pppa")
+
+    def md_gauge_force(self):
+        self.md.gauge_force(plaq=BETA, adjplaq=BETA * ADJFAC)
+
+    def md_kick(self, source, t):
+        self.md.kick(source, t)
+
+    def md_shift(self, source, t):
+        self.md.shift_links(source, t)
+
+    def md_fforce_solve(self, phis, masses, scales):
+        return self._sf.fforce_solve(None, phis, masses, scales, RSQ, bc="pppa")
 
     def smear_rephase(self, g, want_force):
         q = self.q

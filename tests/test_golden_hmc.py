@@ -140,8 +140,9 @@ def test_oracle_replays_reference_trajectory(oracle, run):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("run,halo", [(0, False), (1, False), (0, True)])
-def test_gpu_replays_reference_trajectory(oracle, run, halo):
+@pytest.mark.parametrize("run,halo,resident", [(0, False, False), (1, False, False), (0, True, False), (0, False, True), (1, False, True),
+                                               (2, True, True)])
+def test_gpu_replays_reference_trajectory(oracle, run, halo, resident):
     """The same trajectories with every operator -- smearing, solves, forces, link update, action,
     reunitarisation, plaquettes, Polyakov loops -- AND the random numbers (momenta, pseudofermions,
     pbp sources: qex_amd.RngField) coming from libqexhip; the oracle supplies nothing but the unit start."""
@@ -150,7 +151,9 @@ def test_gpu_replays_reference_trajectory(oracle, run, halo):
 
     rng = q.RngField(R.LAT, q.RngMilc6, R.SEED)          # the product's own newRNGField
     # halo: the same trajectory with every kernel in its t-sharded form (forced ghost zones on one GPU)
-    _check_trajectory(R.Replay(oracle, R.HipBackend(q, R.LAT, halo=halo), R.CONFIGS[run], rng=rng), second=(run == 0 and not halo))
+    # resident: the MD evolution through qexhip_md_* (links, momenta and forces never leave the device)
+    _check_trajectory(R.Replay(oracle, R.HipBackend(q, R.LAT, halo=halo, resident=resident), R.CONFIGS[run], rng=rng),
+                      second=(run == 0 and not halo and not resident))
 
 
 @pytest.mark.gpu
