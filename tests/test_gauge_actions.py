@@ -155,3 +155,62 @@ def test_gpu_gauge_sector_on_the_sharded_path(oracle):
         assert abs(q.wline(A, path, ga) - q.wline(B, path, gb)) < 1e-15
     with pytest.raises(q.QexHipError, match="wline"):
         q.wline(B, [4] * 5 + [1] + [-4] * 5 + [-1], gb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("halo", [False, True])
+def test_gpu_resident_md_equals_the_host_field_path(halo):
+    """qexhip_md_*: a sequence of MD updates with links, momenta and forces resident on the device -- thin-link gauge force
+    (forceA), nHYP-smeared gauge force through the closure (gforce, staghmc_spv.nim:217-228), link update, a force-gradient
+    style shift bracketed by save / restore -- against the same sequence through the host-pointer entry points."""
+    import qex_amd as q
+
+    lat = [8, 4, 4, 8] if halo else [4, 6, 4, 8]          # sharding needs X*Y*Z/2 to be a multiple of 64
+    rf = q.RngField(lat, q.RngMilc6, 31)
+    g, p = rf.warm(0.4), rf.randomTAH()
+    hc = q.HypCoefs(0.4, 0.5, 0.5)
+    # --- host-field path
+    ch = q.Context(lat)
+    if halo:
+        ch.force_halo(True)
+    gh, ph = g.copy(), p.copy()
+    ph -= 0.1 * q.gaugeForce(ch, gh, cplaq=6.0, adjplaq=-1.5)
+    sf = hc.smearGetForce(ch, gh)
+    f = np.zeros_like(gh)
+    sf.gforce(f, plaq=1.3)
+    ph -= 0.2 * f
+    q.gaugeUpdate(ch, gh, ph, 0.05)
+    gshift = gh.copy()
+    q.gaugeUpdate(ch, gshift, q.gaugeForce(ch, gh, cplaq=6.0, adjplaq=-1.5), -0.03)
+    fshift = q.gaugeForce(ch, gshift, cplaq=6.0, adjplaq=-1.5)
+    ph -= 0.07 * fshift
+    # --- resident path
+    cd = q.Context(lat)
+    if halo:
+        cd.force_halo(True)
+    md = q.ResidentMD(cd)
+    md.begin(g, p)
+    assert abs(md.momentum_norm2() - (p * p).sum()) <= 1e-13 * (p * p).sum()
+    md.gauge_force(plaq=6.0, adjplaq=-1.5)
+    md.kick(md.GAUGE, -0.1)
+    sfd = hc.smearGetForce(cd, None)
+    sfd.gforce(None, plaq=1.3)
+    md.kick(md.NHYP, -0.2)
+    md.update_links(0.05)
+    md.save_links()
+    md.gauge_force(plaq=6.0, adjplaq=-1.5)
+    md.shift_links(md.GAUGE, -0.03)
+    md.gauge_force(plaq=6.0, adjplaq=-1.5)
+    md.kick(md.GAUGE, -0.07)
+    md.restore_links()
+    gd, pd = np.zeros_like(g), np.zeros_like(p)
+    md.end(gd, pd)
+    # p + t f is one fma on the device, two roundings in numpy: agreement to rounding, not to the bit
+    assert np.abs(pd - ph).max() <= 1e-14 * np.abs(ph).max()
+    assert np.abs(gd - gh).max() <= 1e-14
+    assert abs(md.momentum_norm2() - (pd * pd).sum()) <= 1e-13 * (pd * pd).sum()
+    cx = q.Context(lat)
+    with pytest.raises(q.QexHipError):                                    # nothing resident yet
+        q.ResidentMD(cx).update_links(0.1)
+    with pytest.raises(q.QexHipError):
+        hc.smearGetForce(cx, None)
