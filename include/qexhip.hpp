@@ -218,6 +218,18 @@ struct HypCoefs {
     SmearedForce(Context &c, const HypCoefs &h, const Field &g, Field *fl) : c_(c) {
       check(qexhip_nhyp_prepare(c.h, g.data(), h.alpha1, h.alpha2, h.alpha3, fl ? fl->data() : nullptr));
     }
+    // smear the links resident on the device (ResidentMD below); forces are then left there too: gforceResident / fforceResident
+    SmearedForce(Context &c, const HypCoefs &h) : c_(c) { check(qexhip_nhyp_prepare(c.h, nullptr, h.alpha1, h.alpha2, h.alpha3, nullptr)); }
+    void gforceResident(double plaq, double rect = 0, double adjplaq = 0) { check(qexhip_nhyp_gauge_force(c_.h, nullptr, plaq, rect, adjplaq)); }
+    std::vector<int> fforceResident(const std::vector<Field> &phi, const std::vector<double> &mass, const std::vector<double> &scale, double r2req,
+                                    int maxits = 1000000, const std::array<int, 4> &antiperiodic = {0, 0, 0, 1}) {
+      std::vector<const double *> p;
+      for (auto &v : phi) p.push_back(v.data());
+      std::vector<double> rq(p.size(), r2req);
+      std::vector<int> its(p.size(), 0);
+      check(qexhip_nhyp_fforce(c_.h, nullptr, (int)p.size(), p.data(), mass.data(), scale.data(), rq.data(), maxits, antiperiodic.data(), nullptr, its.data()));
+      return its;
+    }
     ~SmearedForce() { qexhip_nhyp_release(c_.h); }
     SmearedForce(const SmearedForce &) = delete;
     void operator()(Field &f, const Field &chain) { check(qexhip_nhyp_force(c_.h, f.data(), chain.data())); }   // smearedForce(f, chain)
@@ -228,6 +240,21 @@ struct HypCoefs {
       check(qexhip_nhyp_fermion_force(c_.h, f.data(), p.data(), scale.data(), (int)p.size(), antiperiodic.data(), nullptr));
     }
   };
+};
+// mdt / mdv / force-gradient shifts on device-resident links and momenta (staghmc_sh.nim:429-640; qexhip_md_*)
+class ResidentMD {
+  Context &c_;
+ public:
+  enum Source { Gauge = 0, Nhyp = 1 };                      // which device force buffer a kick / shift applies
+  ResidentMD(Context &c, const Field &g, const Field &p) : c_(c) { check(qexhip_md_begin(c.h, g.data(), p.data())); }
+  void end(Field *g, Field *p) { check(qexhip_md_end(c_.h, g ? g->data() : nullptr, p ? p->data() : nullptr)); }
+  double momentumNorm2() { double r = 0; check(qexhip_md_momentum_norm2(c_.h, &r)); return r; }
+  void updateLinks(double t) { check(qexhip_md_update_links(c_.h, t)); }                       // mdt
+  void gaugeForce(double plaq, double rect = 0, double adjplaq = 0) { check(qexhip_md_gauge_force(c_.h, plaq, rect, adjplaq)); }
+  void kick(Source s, double t) { check(qexhip_md_kick(c_.h, (int)s, t)); }                     // mdv: p += t f
+  void shiftLinks(Source s, double t) { check(qexhip_md_shift_links(c_.h, (int)s, t)); }        // fgv / fgvf
+  void saveLinks() { check(qexhip_md_save_links(c_.h)); }
+  void restoreLinks() { check(qexhip_md_restore_links(c_.h)); }
 };
 // HisqCoefs.smear(g, fl, ll) (hisqLinks.nim:32-43)
 inline void hisqSmear(Context &c, const Field &g, Field &fl, Field &ll) { check(qexhip_hisq_smear(c.h, g.data(), fl.data(), ll.data())); }
