@@ -272,7 +272,9 @@ int qexhip_stag_set_links_nhyp(qexhip_handle h, const double *g, double alpha1, 
  *            f = dS/dU^+ w.r.t. the thin links, through projectUderiv + symStapleDeriv
  *            (src/maths/matrixFunctions.nim:329-357, src/gauge/smearutil.nim:22-50); f may alias chain
  *            (the fork calls f.smeared_force(f), staghmc_spv.nim:740).
- *   release: drop the closure (QEX: GC of the closure, hypsmear.nim:249-263). */
+ *   release: drop the closure (QEX: GC of the closure, hypsmear.nim:249-263).
+ *   prepare with g == NULL smears the links resident on the device (qexhip_gauge_set / qexhip_md_begin); the three MD
+ *   forces below with f == NULL leave their result on the device for qexhip_md_kick / qexhip_md_shift_links (source 1). */
 int qexhip_nhyp_prepare(qexhip_handle h, const double *g, double alpha1, double alpha2, double alpha3, double *fl);
 int qexhip_nhyp_force(qexhip_handle h, double *f, const double *chain);
 int qexhip_nhyp_release(qexhip_handle h);
