@@ -157,7 +157,8 @@ def test_gpu_replays_reference_trajectory(oracle, run, halo, resident):
 
 
 @pytest.mark.gpu
-def test_example_log_against_reference_log():
+@pytest.mark.parametrize("extra", [[], ["-resident"]])
+def test_example_log_against_reference_log(extra):
     """The reference's own regression procedure (tests/extra/staghmc_sh/run:43-46): run the example, keep the
     MEAS / Begin / End / Reversed lines, compare number by number with the golden log at 2e-11 -- here for
     examples/staghmc_sh.py, which performs every field operation in libqexhip."""
@@ -167,7 +168,7 @@ def test_example_log_against_reference_log():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "examples", "staghmc_sh.py"), "-run", "0", "-trajs", "2"],
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "staghmc_sh.py"), "-run", "0", "-trajs", "2"] + extra,
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
     keep = re.compile(r"^MEASploop|^MEASplaq|^MEASpbp|(Begin|End|Reversed) H:|^(ACCEPT|REJECT)")
     mine = [ln for ln in out.splitlines() if keep.search(ln)]
