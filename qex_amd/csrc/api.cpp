@@ -507,7 +507,7 @@ extern "C" int qexhip_hisq_closure_force(qexhip_handle c, const double *dsdsu, c
   return hisq_closure_force(c, dsdsu, dsdsul, f);
 }
 extern "C" int qexhip_hisq_fermion_force(qexhip_handle c, double *f, const double *const *psi, const double *scale, int n) {
-  if (!c || !psi || !scale) return QEXHIP_ERR_ARG;
+  if (!c || !f || !psi || !scale) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
   return hisq_fermion_force(c, f, psi, scale, n);
 }
@@ -561,7 +561,7 @@ extern "C" int qexhip_nhyp_gauge_force(qexhip_handle c, double *f, double cplaq,
 }
 extern "C" int qexhip_nhyp_fermion_force(qexhip_handle c, double *f, const double *const *psi, const double *scale, int n,
                                          const int antiperiodic[4], const int phases[4]) {
-  if (!c || !f || !psi || !scale) return QEXHIP_ERR_ARG;
+  if (!c || !psi || !scale) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
   static const int defph[4] = {8, 9, 11, 0};
   int mask = 0;
