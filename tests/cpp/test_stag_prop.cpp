@@ -158,6 +158,35 @@ int main() {
       sn.solve(x1, bs[j], j ? 0.2 : 0.1, s1);
       CHECK(s1.iterations == sps[j].iterations && relerr(xs[j], x1) < 1e-13, "batched solve equals the single solve");
     }
+    // MD loop on resident fields (qexhip_md_*): smeared gauge force through the closure, kick, link update -- against
+    // the oracle's force chain and exp update
+    {
+      Field pm = lo.newGauge(), g2 = lo.newGauge(), p2 = lo.newGauge(), fg = lo.newGauge(), go = gw, po = lo.newGauge();
+      qo_gauge_random_tah(olo, rf2, pm.data());
+      ResidentMD md(ctx, gw, pm);
+      const double p2dev = md.momentumNorm2();
+      double p2host = 0;
+      for (double v : pm) p2host += v * v;
+      CHECK(std::abs(p2dev - p2host) <= 1e-10 * p2host, "momentum norm on the device");   // the host loop above sums naively
+      {
+        HypCoefs::SmearedForce sfr(ctx, hc);             // smears the resident links
+        sfr.gforceResident(1.3);                         // Wilson action of the smeared links, force left on the device
+        md.kick(ResidentMD::Nhyp, -0.2);
+      }
+      md.updateLinks(0.05);
+      md.end(&g2, &p2);
+      // oracle: chain = dS/dV of the Wilson action on the smeared links, smearedForce, TAH(g f^+), p -= 0.2 f, g = exp(0.05 p) g
+      Field ch2 = lo.newGauge(), sg2 = lo.newGauge();
+      qo_nhyp_smear(olo, gw.data(), sg2.data(), 0.4, 0.5, 0.5);
+      qo_gauge_deriv_rect(olo, sg2.data(), ch2.data(), 1.3, 0.0);
+      qo_nhyp_force(olo, gw.data(), sg2.data(), fg.data(), ch2.data(), 0.4, 0.5, 0.5);
+      qo_force_projTAH(olo, fg.data(), gw.data(), 1);
+      po = pm;
+      for (size_t i = 0; i < po.size(); i++) po[i] -= 0.2 * fg[i];
+      qo_gauge_exp_update(olo, go.data(), po.data(), 0.05);
+      printf("resident MD: momenta rel err %g, links rel err %g\n", relerr(p2, po), relerr(g2, go));
+      CHECK(relerr(p2, po) < 1e-11 && relerr(g2, go) < 1e-12, "resident MD step vs oracle");
+    }
     // SciDAC file round trip
     const std::string fn = "/tmp/qexhip_cpp_test.lime";
     saveGauge(lo, gw, fn);
