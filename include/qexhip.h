@@ -63,6 +63,11 @@ int qexhip_device_info(qexhip_handle h, char *buf, int buflen);
 #define QEXHIP_UNIQUE_ID_BYTES 128
 int qexhip_comm_unique_id(char id[QEXHIP_UNIQUE_ID_BYTES]);
 int qexhip_comm_init(qexhip_handle h, const char id[QEXHIP_UNIQUE_ID_BYTES], int nranks, int rank);
+/* What RCCL reports for the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) and the PCI bus id of
+ * the bound GPU -- QEX prints the same facts from QMP at start-up (src/comms/commsQmp.nim:14-33: rank, size).
+ * Without a communicator nranks = 0, rank = -1.  Any output pointer may be NULL.
+ * A context with rankGeom[3] > 1 refuses every exchange / reduction until qexhip_comm_init has run (QEXHIP_ERR_STATE). */
+int qexhip_comm_info(qexhip_handle h, int *nranks, int *rank, int *device, char *busid, int buslen);
 /* test hook: with one rank, route the t-direction hops through the halo path
  * (pack -> RCCL self send/recv -> boundary sweep) instead of the periodic wrap. */
 int qexhip_comm_force_halo(qexhip_handle h, int on);

@@ -317,16 +317,13 @@ static int multi_common(qexhip_ctx *c, double *const *xs, const double *b, const
   HIPCHK(hipSetDevice(c->device));
   DevField *fb;
   CHK(host_in(c, WK_IN, b, &fb));
-  std::vector<DevField> xf(nmass);
+  if (nmass > 32) { qexhip_set_error("multishift: nmass <= 32"); return QEXHIP_ERR_ARG; }
   std::vector<DevField *> xp(nmass);
-  for (int k = 0; k < nmass; k++) { CHK(field_alloc(c, xf[k])); xp[k] = &xf[k]; }
-  int rc;
-  if (full) rc = solve_multi_dev(c, xp, *fb, vals, nmass, r2req, maxits, iters, out);
-  else rc = solve_xx_multi_dev(c, xp, *fb, vals, nmass, r2req, maxits, par_even, iters, hist, histcap);
-  if (rc == 0) for (int k = 0; k < nmass && rc == 0; k++) rc = field_download(c, xf[k], xs[k]);
-  (void)hipStreamSynchronize(c->stream);
-  for (int k = 0; k < nmass; k++) (void)hipFree(xf[k].d);
-  return rc;
+  for (int k = 0; k < nmass; k++) CHK(pool_field(c, POOL_XS + k, &xp[k]));   // persistent: nothing to free on any path
+  if (full) CHK(solve_multi_dev(c, xp, *fb, vals, nmass, r2req, maxits, iters, out));
+  else CHK(solve_xx_multi_dev(c, xp, *fb, vals, nmass, r2req, maxits, par_even, iters, hist, histcap));
+  for (int k = 0; k < nmass; k++) CHK(field_download(c, *xp[k], xs[k]));
+  return 0;
 }
 
 extern "C" int qexhip_stag_solve_xx_multi(qexhip_handle c, double *const *xs, const double *b, const double *shifts,

@@ -53,6 +53,37 @@ void comm_destroy(qexhip_ctx *c) {
   if (c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
 }
 
+// A context created with rankGeom[3] > 1 holds one slab of a larger lattice: without a communicator the only thing
+// the copy fallbacks below could do is wrap that slab onto itself, i.e. silently compute the physics of a different
+// (periodic, smaller) lattice.  Every exchange / reduction entry refuses instead.
+static int need_comm(const qexhip_ctx *c) {
+  if (!c->comm && c->rankGeom[3] > 1) {
+    qexhip_set_error("rankGeom[3] = %d but qexhip_comm_init was not called: refusing to wrap the local slab periodically",
+                     c->rankGeom[3]);
+    return QEXHIP_ERR_STATE;
+  }
+  return 0;
+}
+
+// what RCCL itself says about the communicator (bench.py reports it so that "N ranks" is RCCL's count, not ours)
+extern "C" int qexhip_comm_info(qexhip_handle c, int *nranks, int *rank, int *device, char *busid, int buslen) {
+  if (!c) return QEXHIP_ERR_ARG;
+  int n = 0, r = -1, d = c->device;
+  if (c->comm) {
+    NCCLCHK(ncclCommCount((ncclComm_t)c->comm, &n));
+    NCCLCHK(ncclCommUserRank((ncclComm_t)c->comm, &r));
+    NCCLCHK(ncclCommCuDevice((ncclComm_t)c->comm, &d));
+  }
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+  if (device) *device = d;
+  if (busid && buslen > 0) {
+    busid[0] = 0;
+    HIPCHK(hipDeviceGetPCIBusId(busid, buslen, c->device));
+  }
+  return 0;
+}
+
 static inline int upper(const qexhip_ctx *c) { return (c->rank + 1) % c->nranks; }
 static inline int lower(const qexhip_ctx *c) { return (c->rank - 1 + c->nranks) % c->nranks; }
 
@@ -64,6 +95,7 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
   // overlap == 0: post the exchange on the compute stream itself (no cross-stream events).  Used
   // when the interior sweep is too short to hide the exchange: two cross-stream dependencies
   // cost more than they buy there.
+  CHK(need_comm(c));
   hipStream_t cs = overlap ? c->cstream : c->stream;
   const Geom &g = c->g;
   const size_t face2 = (size_t)g.depth * g.F * 3;  // double2 per face
@@ -93,6 +125,7 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
 
 // send `bytes` to the upper neighbour, receive the same amount from the lower one (stream-ordered)
 int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st) {
+  CHK(need_comm(c));
   if (c->comm) {
     ncclComm_t comm = (ncclComm_t)c->comm;
     NCCLCHK(ncclGroupStart());
@@ -109,6 +142,7 @@ int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, 
 // bottom[k] -> lower neighbour's ghost_hi, top[k] -> upper neighbour's ghost_lo   (same message order as above)
 int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double *const top[], double *const ghost_hi[],
                         double *const ghost_lo[], size_t ndoubles) {
+  CHK(need_comm(c));
   if (c->comm) {
     ncclComm_t comm = (ncclComm_t)c->comm;
     NCCLCHK(ncclGroupStart());
@@ -132,6 +166,7 @@ int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double 
 
 // rank-ordered concatenation of `n` doubles per rank (one rank / no communicator: a copy)
 int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n) {
+  CHK(need_comm(c));
   if (c->comm && c->nranks > 1) {
     NCCLCHK(ncclAllGather(send, recv, n, ncclDouble, (ncclComm_t)c->comm, c->stream));
   } else {
@@ -141,6 +176,7 @@ int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n) {
 }
 
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
+  CHK(need_comm(c));
   if (c->nranks <= 1 || !c->comm) return 0;
   NCCLCHK(ncclAllReduce(dptr, dptr, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
   return 0;

@@ -13,17 +13,25 @@
 #define CGM_MAXM 32
 
 struct CgmScal {
-  int nmass, cont;
+  int nmass, cont, pending, pad;
   double alpha, beta, alphaim1, betaim1;
   double sg[CGM_MAXM], zi[CGM_MAXM], zim1[CGM_MAXM], axz[CGM_MAXM], zip1[CGM_MAXM], bzz[CGM_MAXM];
   double2 *xs[CGM_MAXM], *ps[CGM_MAXM];
 };
 
-// after op.apply and redot: alpha, r -= alpha Ap, x += alpha p   (cgm.nim:226-233)
+// after op.apply and redot: alpha, r -= alpha Ap, x += alpha p   (cgm.nim:226-233).  With ndot > 0 (single rank)
+// every workgroup sums the <p,Ap> workgroup partials of the preceding sweep itself, in the same fixed order, so
+// all agree bit for bit (same device as k_cg_update, blas.hip) and the separate reduction launch disappears.
 __global__ void __launch_bounds__(256) k_cgm_base(double2 *x, double2 *r, const double2 *p, const double2 *Ap,
-                                                 size_t n, const CgScal *s, double *partials) {
+                                                 size_t n, CgScal *s, double *partials, const double *dotp, int ndot) {
   if (s->done) return;
-  const double alpha = (s->pAp != 0.0) ? s->r2 / s->pAp : 0.0;
+  double pAp = s->pAp;
+  if (ndot > 0) {
+    double a = 0;
+    for (int i = threadIdx.x; i < ndot; i += 256) a += dotp[i];
+    pAp = block_sum_256_all(a);
+  }
+  const double alpha = (pAp != 0.0) ? s->r2 / pAp : 0.0;
   double acc = 0;
   for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     double2 pv = p[i], xv = x[i], rv = r[i], av = Ap[i];
@@ -35,40 +43,69 @@ __global__ void __launch_bounds__(256) k_cgm_base(double2 *x, double2 *r, const 
   double t = block_sum_256(acc);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
-__global__ void __launch_bounds__(256) k_cgm_reduce(const double *partials, int n, CgScal *s) {
+// sharded runs: local |r|^2 (and, single launch, the local <p,Ap> when it was deferred) before the all-reduce
+__global__ void __launch_bounds__(256) k_cgm_local_sum(const double *partials, int n, CgScal *s) {
   if (s->done) return;
   double acc = 0;
   for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
   double r = block_sum_256(acc);
   if (threadIdx.x == 0) s->tmp = r;
 }
-// scalar recurrences (cgm.nim:226-266)
-__global__ void k_cgm_scalars(CgScal *s, CgmScal *m, double *hist, int histcap) {
-  if (s->done) return;
-  const double r2i = s->r2, r2ip1 = s->tmp;
-  const double alpha = (s->pAp != 0.0) ? r2i / s->pAp : 0.0;
+// One workgroup closes the iteration: final sum of the |r|^2 partials (n > 0; n == 0: s->tmp already holds the
+// all-reduced value), alpha / beta, the loop condition, and the zeta recurrences of cgm.nim:253-266 -- thread k owns
+// shift k.  `pending` tells the following k_cgm_update that this iteration is live: it has to run once more after
+// the loop condition has turned false (xs[m] += alpha zr ps[m] is outside `if continuing`), so it cannot key on
+// s->done; a later, dead pass through this kernel clears the flag again.
+__global__ void __launch_bounds__(256) k_cgm_close(const double *partials, int n, const double *dotp, int ndot,
+                                                  CgScal *s, CgmScal *m, double *hist, int histcap) {
+  if (s->done) {
+    if (threadIdx.x == 0) m->pending = 0;
+    return;
+  }
+  double r2ip1 = s->tmp;
+  if (n > 0) {
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+    r2ip1 = block_sum_256_all(acc);
+  }
+  double pAp = s->pAp;
+  if (ndot > 0) {
+    double a = 0;
+    for (int i = threadIdx.x; i < ndot; i += 256) a += dotp[i];
+    pAp = block_sum_256_all(a);
+  }
+  const double r2i = s->r2;
+  const double alpha = (pAp != 0.0) ? r2i / pAp : 0.0;
   const double beta = (r2i != 0.0) ? r2ip1 / r2i : 0.0;
-  s->itn += 1;
-  const int cont = (s->itn < s->maxits) && (r2ip1 > s->r2stop);
-  m->cont = cont;
-  m->alpha = alpha; m->beta = beta;
-  for (int k = 1; k < m->nmass; k++) {
-    double zip1d = alpha * m->betaim1 * (m->zim1[k] - m->zi[k]);
-    zip1d += m->zim1[k] * m->alphaim1 * (1.0 + m->sg[k] * alpha);
-    const double zip1 = (zip1d != 0.0) ? m->zi[k] * m->zim1[k] * m->alphaim1 / zip1d : 0.0;
+  const int itn = s->itn + 1;
+  const int cont = (itn < s->maxits) && (r2ip1 > s->r2stop);
+  const double alphaim1 = m->alphaim1, betaim1 = m->betaim1, b2 = s->b2;
+  const int nm = m->nmass;
+  __syncthreads();   // every thread holds the old state before anyone overwrites it
+  const int k = threadIdx.x;
+  if (k >= 1 && k < nm) {
+    double zip1d = alpha * betaim1 * (m->zim1[k] - m->zi[k]);
+    zip1d += m->zim1[k] * alphaim1 * (1.0 + m->sg[k] * alpha);
+    const double zip1 = (zip1d != 0.0) ? m->zi[k] * m->zim1[k] * alphaim1 / zip1d : 0.0;
     const double zr = (m->zi[k] != 0.0) ? zip1 / m->zi[k] : 0.0;
     m->axz[k] = alpha * zr;
     m->zip1[k] = zip1;
     m->bzz[k] = beta * zr * zr;
     if (cont) { m->zim1[k] = m->zi[k]; m->zi[k] = zip1; }
   }
-  m->alphaim1 = alpha; m->betaim1 = beta;
-  s->r2 = r2ip1;
-  if (s->itn < histcap) hist[s->itn] = r2ip1 / s->b2;
+  if (k == 0) {
+    m->cont = cont; m->pending = 1;
+    m->alpha = alpha; m->beta = beta;
+    m->alphaim1 = alpha; m->betaim1 = beta;
+    s->itn = itn;
+    s->r2 = r2ip1;
+    if (itn < histcap) hist[itn] = r2ip1 / b2;
+    if (!cont) s->done = 1;
+  }
 }
 // q := z + beta*q (if continuing); xs[k] += alpha*zr*ps[k]; ps[k] := zip1*r + beta*zr^2*ps[k]
-__global__ void __launch_bounds__(256) k_cgm_update(const double2 *r, size_t n, const CgScal *s, const CgmScal *m) {
-  if (s->done) return;
+__global__ void __launch_bounds__(256) k_cgm_update(const double2 *r, size_t n, const CgmScal *m) {
+  if (!m->pending) return;
   const int cont = m->cont, nm = m->nmass;
   const double beta = m->beta;
   for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -89,10 +126,6 @@ __global__ void __launch_bounds__(256) k_cgm_update(const double2 *r, size_t n, 
     }
   }
 }
-__global__ void k_cgm_end(CgScal *s, const CgmScal *m) {
-  if (s->done) return;
-  if (!m->cont) s->done = 1;
-}
 __global__ void k_cgm_init(CgScal *s, const double *dscal, double r2req, int maxits, double *hist, int histcap) {
   s->b2 = dscal[0];
   s->r2 = dscal[0];  // r := b, r2 = b2 (cgm.nim:169-175)
@@ -102,12 +135,39 @@ __global__ void k_cgm_init(CgScal *s, const double *dscal, double r2req, int max
   s->done = !(s->r2 > s->r2stop);
   if (histcap > 0) hist[0] = (s->b2 != 0.0) ? 1.0 : 0.0;
 }
-
+// r := b; xs[k] := 0; ps[k] := r for every shift in one pass  (cgm.nim:165-207)
+__global__ void __launch_bounds__(256) k_cgm_start(double2 *r, const double2 *b, size_t n, const CgmScal *m) {
+  const int nm = m->nmass;
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const double2 bv = b[i];
+    r[i] = bv;
+    for (int k = 0; k < nm; k++) {
+      m->xs[k][i] = make_double2(0, 0);
+      m->ps[k][i] = bv;
+    }
+  }
+}
 
 static int read_cg(qexhip_ctx *c, CgScal *host) {
   HIPCHK(hipMemcpyAsync(c->pinned, c->cg, sizeof(CgScal), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   memcpy(host, c->pinned, sizeof(CgScal));
+  return 0;
+}
+
+// Persistent workspace of the multi-shift solvers: fields [POOL_PS, POOL_PS+nmass) are the search directions,
+// [POOL_YS, ..) the even/odd solutions of solve_multi_dev, [POOL_XS, ..) the host-pointer entry points' solutions.
+// They live in the context's field table under negative ids, so qexhip_finalize frees them and a change of the
+// ghost geometry re-allocates them like every other field; nothing is allocated or freed per solve after the first.
+int pool_field(qexhip_ctx *c, int idx, DevField **f) {
+  const int id = -(1000 + idx);
+  auto it = c->fields.find(id);
+  if (it == c->fields.end()) {
+    DevField nf;
+    CHK(field_alloc(c, nf));
+    it = c->fields.emplace(id, nf).first;
+  }
+  *f = &it->second;
   return 0;
 }
 
@@ -123,49 +183,63 @@ int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, 
   CHK(get_work(c, WK_AP, &Ap));
   if (c->histcap < std::max(histcap, 1)) {
     if (c->hist) HIPCHK(hipFree(c->hist));
-    c->hist = nullptr;
+    c->hist = nullptr; c->histcap = 0;
     HIPCHK(hipMalloc((void **)&c->hist, sizeof(double) * std::max(histcap, 1)));
     c->histcap = std::max(histcap, 1);
   }
-  // search directions ps[k]: one-parity use of full fields
-  std::vector<DevField> ps(nmass);
-  for (int k = 0; k < nmass; k++) CHK(field_alloc(c, ps[k]));
+  std::vector<DevField *> ps(nmass);
+  for (int k = 0; k < nmass; k++) CHK(pool_field(c, POOL_PS + k, &ps[k]));
   if (!c->cgm_scal) HIPCHK(hipMalloc(&c->cgm_scal, sizeof(CgmScal)));
   CgmScal *g_cgm_dev = (CgmScal *)c->cgm_scal;
-  CgmScal hm;
-  memset(&hm, 0, sizeof(hm));
-  hm.nmass = nmass; hm.cont = 1;
-  hm.alphaim1 = -1.0; hm.betaim1 = 0.0;
+  CgmScal *hm = (CgmScal *)c->pinned;                 // pinned staging: sizeof(CgmScal) <= 4096
+  static_assert(sizeof(CgmScal) <= 4096, "CgmScal must fit the pinned scratch page");
+  memset(hm, 0, sizeof(*hm));
+  hm->nmass = nmass; hm->cont = 1; hm->pending = 0;
+  hm->alphaim1 = -1.0; hm->betaim1 = 0.0;
   for (int k = 0; k < nmass; k++) {
-    hm.sg[k] = (k == 0) ? 0.0 : shifts[k];
-    hm.zi[k] = 1.0; hm.zim1[k] = 1.0;
-    hm.xs[k] = xs[k]->par(par);
-    hm.ps[k] = ps[k].par(par);
+    hm->sg[k] = (k == 0) ? 0.0 : shifts[k];
+    hm->zi[k] = 1.0; hm->zim1[k] = 1.0;
+    hm->xs[k] = xs[k]->par(par);
+    hm->ps[k] = ps[k]->par(par);
   }
-  HIPCHK(hipMemcpyAsync(g_cgm_dev, &hm, sizeof(hm), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));  // hm is a stack object
+  HIPCHK(hipMemcpyAsync(g_cgm_dev, hm, sizeof(*hm), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));            // the pinned page is reused by read_cg below
   const double mass = shifts[0], m2 = mass * mass;
-  CHK(blas_copy(c, *r, b, par));
-  for (int k = 0; k < nmass; k++) {
-    CHK(blas_zero(c, *xs[k], par));
-    CHK(blas_copy(c, ps[k], *r, par));   // q := z ; ps[m] := p (cgm.nim:196-207)
-  }
+  for (int k = 0; k < nmass; k++) CHK(blas_zero(c, *xs[k], 1 - par));   // the other parity of every solution
+  k_cgm_start<<<nb, 256, 0, c->stream>>>(r->par(par), b.par(par), n, g_cgm_dev);   // q := z ; ps[m] := p (cgm.nim:196-207)
+  HIPCHK(hipGetLastError());
   CHK(blas_norm2(c, b, par, &c->dscal[0]));
   k_cgm_init<<<1, 1, 0, c->stream>>>(c->cg, c->dscal, r2req, maxits, c->hist, c->histcap);
   HIPCHK(hipGetLastError());
   CgScal st;
   CHK(read_cg(c, &st));
+  const bool sharded = c->nranks > 1;
+  double *r2p = c->partials + c->part2_off;
   while (!st.done) {
-    int nn = std::min(16, std::max(1, st.maxits - st.itn));
+    int nn = std::min(32, std::max(1, st.maxits - st.itn));
     for (int i = 0; i < nn; i++) {
-      CHK(op_xx(c, *Ap, ps[0], m2, par_even, 1, &c->cg->done));
-      k_cgm_base<<<nb, 256, 0, c->stream>>>(xs[0]->par(par), r->par(par), ps[0].par(par), Ap->par(par), n, c->cg, c->partials);
-      k_cgm_reduce<<<1, 256, 0, c->stream>>>(c->partials, nb, c->cg);
-      HIPCHK(hipGetLastError());
-      if (c->nranks > 1) CHK(comm_allreduce(c, &c->cg->tmp, 1));
-      k_cgm_scalars<<<1, 1, 0, c->stream>>>(c->cg, g_cgm_dev, c->hist, c->histcap);
-      k_cgm_update<<<nb, 256, 0, c->stream>>>(r->par(par), n, c->cg, g_cgm_dev);
-      k_cgm_end<<<1, 1, 0, c->stream>>>(c->cg, g_cgm_dev);
+      int ndot = 0;
+      CHK(op_xx(c, *Ap, *ps[0], m2, par_even, 1, &c->cg->done, sharded ? nullptr : &ndot));
+      {
+        ScopedTimer tm(c, "blas", c->stream);
+        k_cgm_base<<<nb, 256, 0, c->stream>>>(xs[0]->par(par), r->par(par), ps[0]->par(par), Ap->par(par), n, c->cg, r2p,
+                                              c->partials, ndot);
+        HIPCHK(hipGetLastError());
+      }
+      {
+        ScopedTimer tm(c, "reduce", c->stream);
+        if (sharded) {
+          k_cgm_local_sum<<<1, 256, 0, c->stream>>>(r2p, nb, c->cg);
+          HIPCHK(hipGetLastError());
+          CHK(comm_allreduce(c, &c->cg->tmp, 1));
+          k_cgm_close<<<1, 256, 0, c->stream>>>(r2p, 0, c->partials, 0, c->cg, g_cgm_dev, c->hist, c->histcap);
+        } else {
+          k_cgm_close<<<1, 256, 0, c->stream>>>(r2p, nb, c->partials, ndot, c->cg, g_cgm_dev, c->hist, c->histcap);
+        }
+        HIPCHK(hipGetLastError());
+      }
+      ScopedTimer tm(c, "cgm_update", c->stream);
+      k_cgm_update<<<nb, 256, 0, c->stream>>>(r->par(par), n, g_cgm_dev);
       HIPCHK(hipGetLastError());
     }
     CHK(read_cg(c, &st));
@@ -176,7 +250,6 @@ int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, 
     HIPCHK(hipMemcpyAsync(hist, c->hist, sizeof(double) * nh, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
-  for (int k = 0; k < nmass; k++) HIPCHK(hipFree(ps[k].d));
   return 0;
 }
 
@@ -189,12 +262,10 @@ int solve_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, con
   CHK(get_work(c, WK_XT, &xt));
   const double mass = masses[0];
   std::vector<double> shifts(nmass);
-  std::vector<DevField> ysf(nmass);
   std::vector<DevField *> ys(nmass);
   for (int k = 0; k < nmass; k++) {
     shifts[k] = (k == 0) ? masses[0] : 4.0 * (masses[k] * masses[k] - mass * mass);
-    CHK(field_alloc(c, ysf[k]));
-    ys[k] = &ysf[k];
+    CHK(pool_field(c, POOL_YS + k, &ys[k]));
     CHK(blas_zero(c, *xs[k], 2));
   }
   CHK(blas_zero(c, *xt, 2));
@@ -236,7 +307,6 @@ int solve_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, con
     CHK(blas_copy(c, *xs[k], *xt, 2));
   }
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (int k = 0; k < nmass; k++) HIPCHK(hipFree(ysf[k].d));
   if (iters) *iters = its;
   if (r2_final) *r2_final = (b2 != 0.0) ? r2 / b2 : 0.0;
   return 0;

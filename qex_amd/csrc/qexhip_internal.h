@@ -208,6 +208,9 @@ int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, 
                        int nmass, double r2req, int maxits, int par_even, int *iters, double *hist, int histcap);
 int solve_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, const double *masses,
                     int nmass, double r2req, int maxits, int *iters, double *r2_final);
+// persistent multi-shift workspace (multishift.hip): search directions, per-parity solutions, host-entry solutions
+enum { POOL_PS = 0, POOL_YS = 32, POOL_XS = 64 };
+int pool_field(qexhip_ctx *c, int idx, DevField **f);
 
 // ---- force.hip ----
 int stag_outer_host(qexhip_ctx *c, double *f_host, const double *x_host, double se, double so, int accumulate);

@@ -92,8 +92,25 @@ int read_header(FILE *f, LimeHeader &h) {
   h.type = (const char *)b + 16;
   return 1;
 }
-bool skip_data(FILE *f, uint64_t len) { return fseeko(f, (off_t)(len + (8 - len % 8) % 8), SEEK_CUR) == 0; }
+// bytes left between the read position and the end of the file (lengths in LIME headers are untrusted input)
+uint64_t bytes_left(FILE *f) {
+  const off_t here = ftello(f);
+  if (here < 0 || fseeko(f, 0, SEEK_END) != 0) return 0;
+  const off_t end = ftello(f);
+  (void)fseeko(f, here, SEEK_SET);
+  return end > here ? (uint64_t)(end - here) : 0;
+}
+bool skip_data(FILE *f, uint64_t len) {
+  if (len > bytes_left(f)) { qexhip_set_error("lime: record of %llu bytes runs past the end of the file", (unsigned long long)len); return false; }
+  const uint64_t padded = len + (8 - len % 8) % 8;
+  return fseeko(f, (off_t)std::min<uint64_t>(padded, bytes_left(f)), SEEK_CUR) == 0;
+}
 bool read_text(FILE *f, uint64_t len, std::string &s) {
+  // XML / checksum records are a few hundred bytes; refuse anything that could not be one before allocating
+  if (len > (1u << 20) || len > bytes_left(f)) {
+    qexhip_set_error("lime: text record of %llu bytes (limit 1 MiB, and no more than the file holds)", (unsigned long long)len);
+    return false;
+  }
   s.resize(len);
   if (len && fread(&s[0], 1, len, f) != len) return false;
   while (!s.empty() && s.back() == '\0') s.pop_back();

@@ -103,6 +103,13 @@ class Context:
     def comm_init(self, uid, nranks, rank):
         check(lib().qexhip_comm_init(self._h, uid, nranks, rank))
 
+    def comm_info(self):
+        """(nranks, rank, device, pci bus id) as RCCL / HIP report them; nranks = 0 without a communicator"""
+        n, r, d = C.c_int(0), C.c_int(0), C.c_int(0)
+        bus = C.create_string_buffer(64)
+        check(lib().qexhip_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d), bus, 64))
+        return n.value, r.value, d.value, bus.value.decode()
+
     def force_halo(self, on=True):
         check(lib().qexhip_comm_force_halo(self._h, 1 if on else 0))
 
@@ -270,7 +277,7 @@ class Staggered:
         its, fin = C.c_int(0), C.c_double(0)
         if isinstance(x, (list, tuple)):
             ms = np.array([float(v) for v in m], dtype=np.float64)
-            ptrs = (C.c_void_p * len(x))(*[a.ctypes.data for a in x])
+            ptrs = (C.c_void_p * len(x))(*[_p(a).value for a in x])
             check(lib().qexhip_stag_solve_multi(self.ctx._h, ptrs, _p(b), _p(ms), len(x), float(sp.r2req),
                                                 int(sp.maxits), C.byref(its), C.byref(fin)))
         else:
@@ -326,7 +333,7 @@ class Staggered:
         its = C.c_int(0)
         sh = np.array([float(v) for v in shifts], dtype=np.float64)
         hist = np.zeros(max(histcap, 1))
-        ptrs = (C.c_void_p * len(xs))(*[a.ctypes.data for a in xs])
+        ptrs = (C.c_void_p * len(xs))(*[_p(a).value for a in xs])
         check(lib().qexhip_stag_solve_xx_multi(self.ctx._h, ptrs, _p(b), _p(sh), len(xs), float(sp.r2req),
                                                int(sp.maxits), 1 if parEven else 0, C.byref(its), _p(hist), histcap))
         sp.iterations += its.value
@@ -497,7 +504,7 @@ class HisqCoefs:
         def fermionForce(f, psis, scales):
             """fermionForce (hisqhmc.nim:496-541) for the fields psis; the closure must hold the PHASED links"""
             n = len(psis)
-            arr = (C.c_void_p * n)(*[p.ctypes.data for p in psis])
+            arr = (C.c_void_p * n)(*[_p(p).value for p in psis])
             sc = (C.c_double * n)(*[float(v) for v in scales])
             check(lib().qexhip_hisq_fermion_force(ctx._h, _p(f), arr, sc, n))
 
@@ -539,7 +546,7 @@ class HypCoefs:
         def fforce(f, psis, scales, bc="aaaa"):
             """fforce + smeared_one_link_force (staghmc_spv.nim:716-865) for the fields psis"""
             n = len(psis)
-            arr = (C.c_void_p * n)(*[p.ctypes.data for p in psis])
+            arr = (C.c_void_p * n)(*[_p(p).value for p in psis])
             sc = (C.c_double * n)(*[float(v) for v in scales])
             ap = (C.c_int * 4)(*[1 if ch == "a" else 0 for ch in bc])
             check(lib().qexhip_nhyp_fermion_force(ctx._h, _p(f), arr, sc, n, ap, None))
@@ -548,7 +555,7 @@ class HypCoefs:
             """the whole fforce incl. its solves (staghmc_sh.nim:387-427) on the operator's current links
             (build them from this closure: Staggered(ctx, None, smear=...)); returns the iteration counts"""
             n = len(phis)
-            arr = (C.c_void_p * n)(*[p.ctypes.data for p in phis])
+            arr = (C.c_void_p * n)(*[_p(p).value for p in phis])
             ms = (C.c_double * n)(*[float(v) for v in masses])
             sc = (C.c_double * n)(*[float(v) for v in scales])
             rq = (C.c_double * n)(*([float(r2req)] * n if np.isscalar(r2req) else [float(v) for v in r2req]))
