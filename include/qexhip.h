@@ -164,6 +164,10 @@ int qexhip_dev_op_xx(qexhip_handle h, int r_id, int x_id, double m2, int par_eve
 int qexhip_dev_solve_xx(qexhip_handle h, int x_id, int b_id, double mass, double r2req,
                         int maxits, int par_even, int *iters, double *r2_over_b2,
                         double *hist, int histcap);
+/* multi-shift solveXX (Staggered.solveXX(xs, b, ms, sp), src/physics/stagSolve.nim:296-345) on resident fields:
+ * x_ids[k] receives the solution of shift k; shifts as qexhip_stag_solve_xx_multi.  Blocks until finished. */
+int qexhip_dev_solve_xx_multi(qexhip_handle h, const int *x_ids, int b_id, const double *shifts, int nmass,
+                              double r2req, int maxits, int par_even, int *iters, double *hist, int histcap);
 
 /* ---------------- gauge field, plaquette, Wilson flow ----------------
  * qexhip_gauge_set/get: the `g` of src/gauge/wflow.nim:21 (unphased links, periodic). */

@@ -48,6 +48,7 @@ SYMBOLS = [
     ("qexhip_dev_dslash", _ci, [_vp, _ci, _ci, _ci, _cd, _cd]),
     ("qexhip_dev_op_xx", _ci, [_vp, _ci, _ci, _cd, _ci]),
     ("qexhip_dev_solve_xx", _ci, [_vp, _ci, _ci, _cd, _cd, _ci, _ci, _pi, _pd, _vp, _ci]),
+    ("qexhip_dev_solve_xx_multi", _ci, [_vp, _pi, _ci, _pd, _ci, _cd, _ci, _ci, _pi, _vp, _ci]),
     ("qexhip_gauge_set", _ci, [_vp, _vp]),
     ("qexhip_gauge_get", _ci, [_vp, _vp]),
     ("qexhip_plaq", _ci, [_vp, _vp]),

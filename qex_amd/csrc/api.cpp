@@ -446,6 +446,16 @@ extern "C" int qexhip_dev_solve_xx(qexhip_handle c, int x_id, int b_id, double m
   return solve_xx_dev(c, *fx, *fb, mass, r2req, maxits, par_even, iters, r2_over_b2, hist, histcap);
 }
 
+extern "C" int qexhip_dev_solve_xx_multi(qexhip_handle c, const int *x_ids, int b_id, const double *shifts, int nmass,
+                                         double r2req, int maxits, int par_even, int *iters, double *hist, int histcap) {
+  if (!c || !x_ids || !shifts || nmass < 1 || nmass > 32) return QEXHIP_ERR_ARG;
+  DevField *fb;
+  CHK(find_field(c, b_id, &fb));
+  std::vector<DevField *> xp(nmass);
+  for (int k = 0; k < nmass; k++) CHK(find_field(c, x_ids[k], &xp[k]));
+  return solve_xx_multi_dev(c, xp, *fb, shifts, nmass, r2req, maxits, par_even, iters, hist, histcap);
+}
+
 // ---- link smearing ----
 extern "C" int qexhip_fat7(qexhip_handle c, const double *g, const double coef[5], double *fl, double *ll, double naik) {
   if (!c || !g || !coef || !fl) return QEXHIP_ERR_ARG;

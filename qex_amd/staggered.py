@@ -164,6 +164,16 @@ class Context:
                                         C.byref(its), C.byref(fin), _p(hist), histcap))
         return its.value, fin.value, hist[: min(histcap, its.value + 1)]
 
+    def dev_solve_xx_multi(self, x_ids, b_id, shifts, r2req, maxits, par_even=True, histcap=0):
+        """multi-shift solveXX on resident fields (stagSolve.nim:296-345); shifts[0] = base mass"""
+        n = len(x_ids)
+        its = C.c_int(0)
+        hist = np.zeros(max(histcap, 1))
+        check(lib().qexhip_dev_solve_xx_multi(self._h, (C.c_int * n)(*[int(v) for v in x_ids]), b_id,
+                                              (C.c_double * n)(*[float(v) for v in shifts]), n, float(r2req), int(maxits),
+                                              1 if par_even else 0, C.byref(its), _p(hist), histcap))
+        return its.value, hist[: min(histcap, its.value + 1)]
+
     # field algebra hooks (fieldET.nim:605-625,704-724)
     def norm2(self, x, subset="all"):
         out = C.c_double(0)
@@ -474,6 +484,16 @@ def gaugeFlow(ctx, g, steps, eps, measure=None, flow_act="Wilson", plaq=1.0, rec
             check(lib().qexhip_wflow_general(ctx._h, 1, float(eps), float(plaq), float(c2), kind))
             measure(n * eps)
     check(lib().qexhip_gauge_get(ctx._h, _p(g)))
+
+
+def gaugeSet(ctx, g):
+    """upload g as the context's resident gauge field (what plaq / gaugeFlow(..) with g given do first)"""
+    check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+
+
+def gaugeFlowResident(ctx, steps, eps):
+    """`steps` RK3 steps of g.gaugeFlow(steps, eps) (wflow.nim:21-67) on the resident field; nothing crosses PCIe"""
+    check(lib().qexhip_wflow(ctx._h, int(steps), float(eps)))
 
 
 # ---- link construction (src/gauge/fat7l.nim, src/physics/hisqLinks.nim, src/gauge/hypsmear.nim) ----

@@ -148,7 +148,7 @@ def test_eoReconstruct(s8):
     assert relerr(r, ref) < 1e-13
 
 
-def history_tolerance(o, lo, g, g3, b, m, r2req, maxits, par_even, hist_ref):
+def history_tolerance(o, lo, g, g3, b, m, r2req, maxits, par_even, hist_ref, alt_threads=1):
     """CG amplifies rounding differences: two equivalent summation orders drift apart along the
     history (1e-16 at the start, up to percents after hundreds of iterations on badly conditioned
     systems).  The yardstick is the CPU path's own spread when only its reduction order changes
@@ -158,7 +158,7 @@ def history_tolerance(o, lo, g, g3, b, m, r2req, maxits, par_even, hist_ref):
     whole history of BASELINE configs[0] (8^4, m=0.1) to the north star's 1e-6, and the tail of the
     harder systems to max(1e-6, 1000 x CPU self-spread), capped at 10 %."""
     nt = o.num_threads()
-    o.lib().qo_set_num_threads(1)
+    o.lib().qo_set_num_threads(alt_threads)
     _, _, _, h1 = o.solveXX(lo, g, g3, b, m, r2req, maxits, par_even, histcap=len(hist_ref) + 8)
     o.lib().qo_set_num_threads(nt)
     n = min(len(h1), len(hist_ref))
@@ -416,6 +416,31 @@ def test_full_size_solve_true_residual(s32):
     # the same through the oracle's operator (independent arithmetic)
     ro = S.o.D(S.lo, S.g, None, x, 0.1) - S.x
     assert (ro * ro).sum() / (S.x * S.x).sum() <= 1.01e-12
+
+
+def test_full_size_cg_history(s32):
+    """32^4, m = 0.1 (BASELINE configs[1]) on QEX's g.random and g.warm(0.5): the `CG iteration: N  r2/b2:` history
+    (cg.nim:215-217) of the HIP solveEE against the oracle's CG on the same links and source -- iteration count +-1,
+    the first 100 iterations to 1e-10, the whole history held to the CPU path's own spread between two thread counts
+    (two reduction orders of the same algorithm), final residual below the request, same solution to 1e-6."""
+    S = s32
+    sp = S.q.SolverParams(r2req=1e-12, maxits=5000, verbosity=0)
+    x = np.zeros_like(S.x)
+    S.s.solveEE(x, S.x, 0.1, sp, histcap=8192)
+    xr, its, fin, hist = S.o.solveXX(S.lo, S.g, None, S.x, 0.1, 1e-12, 5000, True, histcap=8192)
+    assert abs(sp.iterations - its) <= 1, (sp.iterations, its)
+    n = min(len(hist), len(sp.r2hist))
+    assert n > 100
+    dev = np.abs(sp.r2hist[:n] / hist[:n] - 1)
+    assert dev[:100].max() < 1e-10, dev[:100].max()
+    nt = S.o.num_threads()
+    tol, spread = history_tolerance(S.o, S.lo, S.g, None, S.x, 0.1, 1e-12, 5000, True, hist, alt_threads=max(1, nt // 2))
+    print("32^4 CG history: %d iterations (oracle %d), max deviation %.2e over the whole history, %.2e over the first 100; "
+          "CPU path against itself at %d vs %d threads: %.2e" % (sp.iterations, its, dev.max(), dev[:100].max(), nt, max(1, nt // 2), spread))
+    assert dev.max() < tol, (dev.max(), spread)
+    assert sp.r2 <= 1e-12
+    h = S.lo.vol // 2
+    assert relerr(x[:h], xr[:h]) < 1e-6
 
 
 def test_full_size_plaq_and_flow(s32):

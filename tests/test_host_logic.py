@@ -5,6 +5,7 @@ rehearsal of the t-sharded Dslash: same slab decomposition, same 
 (evaluated by the library's own index functions), same message order as csrc/comm.cpp.
 """
 import ctypes as C
+import json
 import os
 import re
 import socket
@@ -217,3 +218,41 @@ def test_repeated_block_configuration_is_the_periodic_one():
     for i in range(0, los.vol, 5):
         x = [int(v) for v in los.coords[i]]
         assert np.array_equal(slab[i], direct[lo.index(x[:3] + [x[3] + 4])])
+
+
+def _torchrun_bench(nproc, extra, timeout=180):
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "5", "--warmup", "1"] + extra
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT)
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, lines, p.stderr
+
+
+def test_bench_launch_path_two_ranks():
+    """The driver's N > 1 launch (torch.distributed.run, one rank per GPU) rehearsed on CPU with --dry-run: rendezvous on
+    127.0.0.1, barriers, max-over-ranks, one JSON line from rank 0 with the contract's keys.  No GPU work is done or claimed."""
+    rc, lines, err = _torchrun_bench(2, ["--dry-run"])
+    assert rc == 0, err
+    assert len(lines) == 1
+    ln = lines[0]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "ranks"):
+        assert key in ln, key
+    assert ln["n_gpus"] == 2 and ln["dry_run"] is True and ln["value"] is None
+    assert sorted(r["rank"] for r in ln["ranks"]) == [0, 1]
+
+
+def test_bench_watchdog_turns_a_stall_into_a_nonzero_exit():
+    """One rank never reaches the timed barrier: the job must end by itself, with a non-zero status and no line that
+    carries a value (rank 0's line, when it gets out before the launcher tears the group down, carries "error")."""
+    rc, lines, err = _torchrun_bench(2, ["--dry-run", "--dry-run-stall-rank", "1", "--watchdog-s", "3"], timeout=120)
+    assert rc != 0
+    for ln in lines:
+        assert "error" in ln and ln["value"] is None
+    # and a single process stalls out the same way, always with the error line
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--dry-run-stall-rank", "0", "--watchdog-s", "2"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60, cwd=ROOT)
+    assert p.returncode == 3
+    ln = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
+    assert "stalled" in ln["error"] and ln["value"] is None
