@@ -197,3 +197,94 @@ extern "C" int qexhip_tune_stream(qexhip_handle c, int mode, size_t mbytes, int 
   (void)hipFree(a); (void)hipFree(b);
   return 0;
 }
+
+// ---- fp64 vector ceiling actually held by this chip (the number k_force / k_exp_update are priced against) ----
+// `chains` independent v_fma_f64 chains per lane on random-ish data, every SIMD of the chip busy with `wps` wavefronts,
+// long enough (>= 2 ms) for the clock to settle.  kind 1: the 3x3 complex products of su3.h in the same dependency
+// pattern as m3_exp's squaring loop (what the flow's exp actually issues).
+template <int CH>
+__global__ void __launch_bounds__(256) k_fma64(double *out, int iters, double a, double b) {
+  double v[CH];
+#pragma unroll
+  for (int k = 0; k < CH; k++) v[k] = 1e-3 * (threadIdx.x + 1) + k;
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int k = 0; k < CH; k++) v[k] = fma(v[k], a, b);
+  }
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < CH; k++) s += v[k];
+  if (s == 1.2345e300) out[0] = s;
+}
+#include "su3.h"
+__global__ void __launch_bounds__(256) k_expchain(double *out, int iters, double a) {
+  M3 e;
+#pragma unroll
+  for (int k = 0; k < 9; k++) e.e[k] = make_double2(1e-7 * (threadIdx.x + k), -1e-7 * k * a);
+#pragma unroll 1
+  for (int i = 0; i < iters; i++) {
+    M3 t = e;
+    m3_add_diag(t, 2.0);
+    e = m3_mul(e, t);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { e.e[k].x *= 1e-3; e.e[k].y *= 1e-3; }   // keep the values bounded (18 extra multiplies per 216 flop)
+  }
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) s += e.e[k].x + e.e[k].y;
+  if (s == 1.2345e300) out[0] = s;
+}
+// kind 2: m3_exp itself (prologue + 20 squarings + the closing product), `iters` times per wavefront, no memory traffic;
+// kind 3: ONE m3_exp per wavefront and `iters` x as many wavefronts: the launch shape of k_exp_update without its loads
+__global__ void __launch_bounds__(256) k_exponly(double *out, int iters, double a) {
+  M3 v;
+#pragma unroll
+  for (int k = 0; k < 9; k++) v.e[k] = make_double2(1e-3 * (threadIdx.x + k) * a, -1e-3 * k * a);
+  v = m3_tah(v);
+  M3 u = v;
+  m3_add_diag(u, 1.0);
+#pragma unroll 1
+  for (int i = 0; i < iters; i++) {
+    u = m3_mul(m3_exp(v), u);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { v.e[k].x = 0.5 * v.e[k].x + 1e-9 * u.e[k].y; v.e[k].y = 0.5 * v.e[k].y; }
+  }
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) s += u.e[k].x + u.e[k].y;
+  if (s == 1.2345e300) out[0] = s;
+}
+extern "C" int qexhip_tune_fma64(qexhip_handle c, int kind, int chains, int wps, int iters, double *tflops) {
+  if (!c || !tflops || wps < 1 || wps > 8) return -1;
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, c->device));
+  int nblocks = p.multiProcessorCount * wps;            // 256 threads = 4 wavefronts = one per SIMD of a CU
+  if (kind == 3) nblocks *= iters;
+  double *out;
+  HIPCHK(hipMalloc((void **)&out, 64));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  auto run = [&]() {
+    if (kind == 1) k_expchain<<<nblocks, 256, 0, c->stream>>>(out, iters, 0.5);
+    else if (kind == 2) k_exponly<<<nblocks, 256, 0, c->stream>>>(out, iters, 0.5);
+    else if (kind == 3) k_exponly<<<nblocks, 256, 0, c->stream>>>(out, 1, 0.5);
+    else if (chains <= 2) k_fma64<2><<<nblocks, 256, 0, c->stream>>>(out, iters, 0.999, 1e-3);
+    else if (chains <= 4) k_fma64<4><<<nblocks, 256, 0, c->stream>>>(out, iters, 0.999, 1e-3);
+    else if (chains <= 8) k_fma64<8><<<nblocks, 256, 0, c->stream>>>(out, iters, 0.999, 1e-3);
+    else k_fma64<16><<<nblocks, 256, 0, c->stream>>>(out, iters, 0.999, 1e-3);
+  };
+  run();
+  HIPCHK(hipEventRecord(e0, c->stream));
+  run();
+  HIPCHK(hipEventRecord(e1, c->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  const int ch = kind == 1 ? 0 : (chains <= 2 ? 2 : chains <= 4 ? 4 : chains <= 8 ? 8 : 16);
+  const double flop = kind == 1 ? (216.0 + 18.0) * iters : kind == 2 ? 23.0 * 216.0 * iters : kind == 3 ? 23.0 * 216.0 : 2.0 * ch * iters;
+  *tflops = flop * 256.0 * nblocks / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(out);
+  return 0;
+}

@@ -169,6 +169,8 @@ __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict
   int x[4], xpm[4], y[4], z[4];
   coords_of(g, c, p, x);
   shifted(g, x, mu, 1, xpm);
+  // the twelve staples are summed unscaled (accumulating products, no temporary matrix); cp, the same for all of
+  // them, is applied once to the projected force
   M3 acc = m3_zero();
 #pragma unroll 1
   for (int nu = 0; nu < 4; nu++) {
@@ -176,32 +178,33 @@ __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict
     // forward: U_nu(x) U_mu(x+nu) U_nu(x+mu)^+          (stf[mu,nu], staples.nim:181-183)
     shifted(g, x, nu, 1, y);
     M3 t = m3_mul_na(m3_load(G + link_off(g, y, mu), 64), m3_load(G + link_off(g, xpm, nu), 64));
-    M3 s = m3_mul(m3_load(G + link_off(g, x, nu), 64), t);
-    m3_axpy(acc, cp, s);
+    m3_mac(acc, m3_load(G + link_off(g, x, nu), 64), t);
     // backward: U_nu(x-nu)^+ U_mu(x-nu) U_nu(x-nu+mu)   (stu[mu,nu] shifted down, staples.nim:184-186)
     shifted(g, x, nu, -1, y);
     shifted(g, y, mu, 1, z);
     t = m3_mul_an(m3_load(G + link_off(g, y, nu), 64), m3_load(G + link_off(g, y, mu), 64));
-    s = m3_mul(t, m3_load(G + link_off(g, z, nu), 64));
-    m3_axpy(acc, cp, s);
+    m3_mac(acc, t, m3_load(G + link_off(g, z, nu), 64));
   }
   size_t o = link_off(g, x, mu);
   M3 f = m3_tah(m3_mul_na(m3_load(G + o, 64), acc));
   if (Pm) {
     M3 v;
+    const double cfp = cf * cp;
     if (cpm != 0.0) {
       M3 pm = m3_load(Pm + o, 64);
 #pragma unroll
-      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x + cpm * pm.e[k].x, cf * f.e[k].y + cpm * pm.e[k].y);
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x + cpm * pm.e[k].x, cfp * f.e[k].y + cpm * pm.e[k].y);
     } else {
 #pragma unroll
-      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cf * f.e[k].x, cf * f.e[k].y);
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x, cfp * f.e[k].y);
     }
     m3_store(Pm + o, 64, v);
     // fused second half of the RK3 stage (wflow.nim:40-43): U <- exp(v) U into the other buffer, so the
     // compute-bound exp overlaps the L2-bound staple gathers of other waves and v, U are not re-read
     if (Uout) m3_store(Uout + o, 64, m3_mul(m3_exp(v), m3_load(G + o, 64)));
   } else {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { f.e[k].x *= cp; f.e[k].y *= cp; }
     m3_store(F + o, 64, f);
   }
 }

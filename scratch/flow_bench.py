@@ -5,13 +5,14 @@ import qex_amd as q
 from qex_amd._lib import check
 lat=[32,32,32,32]
 lo=q.Layout(lat)
-t=time.time(); g=q.synthetic_random_su3(lo, seed=987654321); print("gen",time.time()-t,flush=True)
+t=time.time(); g=q.RngField(lat,q.RngMilc6,987654321).random(); print("gen",time.time()-t,flush=True)   # QEX g.random
 ctx=q.Context(lat)
 t=time.time(); pl=q.plaq(ctx,g); print("gpu plaq incl upload",time.time()-t, pl, flush=True)
 ctx.timers_enable(1); ctx.timers_reset()
 for i in range(5): q.plaq(ctx)
 L=q.lib()
-t=time.time(); check(L.qexhip_wflow(ctx._h,2,0.01)); ctx.sync(); print("2 flow steps wall",time.time()-t,flush=True)
+check(L.qexhip_wflow(ctx._h,1,0.01)); ctx.sync(); ctx.timers_reset()
+t=time.time(); check(L.qexhip_wflow(ctx._h,4,0.01)); ctx.sync(); print("4 flow steps wall",time.time()-t,flush=True)
 for name in ("plaq","staple","expupdate"):
     n,ms=ctx.timer(name); print(name,n,"calls avg us",1e3*ms/max(n,1))
 pl2=q.plaq(ctx); print("plaq after flow",pl2)
