@@ -391,6 +391,9 @@ int qexhip_debug_geom(const int latLocal[4], int depth, int halo, int out[8]);
 /* position, in the opposite-parity field, of site (c,parity) + hop*mu; ghost positions when halo */
 int qexhip_debug_nbr_pos(const int latLocal[4], int depth, int halo, int c, int parity, int mu, int hop);
 int qexhip_debug_site_coord(const int latLocal[4], int c, int parity, int x[4]);
+/* the (tile, parity) visiting order of the staple kernels for gathers in the (mu, nu) plane: out[k] = 2 tile + parity or
+ * -1 (empty slot); returns the number of entries, or minus the capacity needed.  Must be a permutation. */
+int qexhip_debug_tile_order(const int latLocal[4], int mu, int nu, int *out, int cap);
 
 #ifdef __cplusplus
 }

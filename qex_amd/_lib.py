@@ -115,6 +115,7 @@ SYMBOLS = [
     ("qexhip_debug_geom", _ci, [_pi, _ci, _ci, _pi]),
     ("qexhip_debug_nbr_pos", _ci, [_pi, _ci, _ci, _ci, _ci, _ci, _ci]),
     ("qexhip_debug_site_coord", _ci, [_pi, _ci, _ci, _pi]),
+    ("qexhip_debug_tile_order", _ci, [_pi, _ci, _ci, _pi, _ci]),
 ]
 
 

@@ -139,6 +139,7 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
   if (c->outer_F) (void)hipFree(c->outer_F);
   if (c->obs_table) (void)hipFree(c->obs_table);
   if (c->tile_order) (void)hipFree(c->tile_order);
+  for (int *&t : c->tile_order_pl) if (t) { (void)hipFree(t); t = nullptr; }
   if (c->cgm_scal) (void)hipFree(c->cgm_scal);
   if (c->Wc) (void)hipFree(c->Wc);
   if (c->Ws) (void)hipFree(c->Ws);

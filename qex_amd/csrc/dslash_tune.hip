@@ -81,6 +81,82 @@ __global__ void __launch_bounds__(BS, MINW) k_tune(TuneArgs A) {
   }
 }
 
+// ---- LDS-staged variant (BASELINE north_star: "gauge links staged in LDS") ----
+// Every operand of a hop -- the link (9 x 1 KiB per wavefront) and the neighbour vector (3 x 1 KiB, per-lane gather
+// addresses) -- travels global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR destination), double-buffered per
+// wavefront: the 12 DMAs of direction d+1 are in flight while direction d is read back from LDS (ds_read_b128) and
+// multiplied.  Counted waits: after issuing d+1's 12 DMAs, vmcnt(12) retires exactly direction d's.  24 KiB of LDS
+// per wavefront, 128-thread workgroups: 3 workgroups = 6 wavefronts per CU.
+template <int NDIR>
+__global__ void __launch_bounds__(128, 2) k_tune_lds(TuneArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bid = blockIdx.x;
+  if (A.swz) {
+    int per = A.swz >> 3;
+    bid = (bid & 7) * per + (bid >> 3);
+  }
+  const int c = bid * 128 + threadIdx.x;
+  const Geom &g = A.g;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool live = c < g.Vh;
+  const int cc = live ? c : g.Vh - 1;        // dead lanes of the last workgroup still issue (in-range) DMAs
+  SiteXYZT s = site_coord(g, cc, A.parity);
+  char *wbase = smem + wv * (2 * 12 * 1024);
+  const double2 *w = A.W + (size_t)(cc >> 6) * (NDIR * 576) + (cc & 63);
+  auto stage = [&](int d) {
+    char *buf = wbase + (d & 1) * (12 * 1024);
+    const int mu = (d >> 1) & 3;
+    const int hop = (d >= 8 ? 3 : 1) * ((d & 1) ? -1 : 1);
+    const int pos = nbr_pos<false>(g, cc, s, mu, hop);
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+      __builtin_amdgcn_global_load_lds((const void *)&w[(size_t)d * 576 + k * 64], (__attribute__((address_space(3))) void *)(buf + k * 1024), 16, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      __builtin_amdgcn_global_load_lds((const void *)&A.in[vec_off(pos, k)], (__attribute__((address_space(3))) void *)(buf + (9 + k) * 1024), 16, 0, 0);
+  };
+  double2 acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) acc[k] = make_double2(0.0, 0.0);
+  stage(0);
+#pragma unroll
+  for (int d = 0; d < NDIR; d++) {
+    if (d + 1 < NDIR) {
+      stage(d + 1);
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const double2 *buf = (const double2 *)(wbase + (d & 1) * (12 * 1024));
+    double2 U[9], v[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) U[k] = buf[k * 64 + lane];
+    const double sg = (d & 1) ? -1.0 : 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double2 t = buf[(9 + k) * 64 + lane];
+      v[k] = make_double2(sg * t.x, sg * t.y);
+    }
+    mv3t(acc, U, v);
+    // the buffer read here is overwritten by the DMAs issued at the top of the NEXT iteration: LDS reads complete
+    // in order with respect to this wavefront's later LDS-DMA writes only after lgkmcnt(0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      d2v t; t.x = acc[k].x; t.y = acc[k].y;
+      __builtin_nontemporal_store(t, (d2v *)&A.out[vec_off(c, k)]);
+    }
+  }
+}
+template <int NDIR>
+static void launch_tune_lds(TuneArgs &A, int swz_on, hipStream_t st) {
+  int nb = (A.g.Vh + 127) / 128;
+  A.swz = (swz_on && nb >= 64 && (nb & 7) == 0) ? nb : 0;
+  k_tune_lds<NDIR><<<nb, 128, 2 * 2 * 12 * 1024, st>>>(A);
+}
+
 template <int VAR, int BS, int MINW, int NDIR = 8>
 static void launch_tune(TuneArgs &A, int swz_on, hipStream_t st) {
   int nb = (A.g.Vh + BS - 1) / BS;
@@ -120,6 +196,7 @@ extern "C" int qexhip_tune_dslash(qexhip_handle c, int variant, int swz, int nre
       case 11: launch_tune<0, 256, 4>(A, swz, c->stream); break;
       case 12: launch_tune<2, 256, 3>(A, swz, c->stream); break;
       case 13: launch_tune<7, 256, 1>(A, swz, c->stream); break;
+      case 20: launch_tune_lds<8>(A, swz, c->stream); break;
       case 100: launch_tune<5, 256, 1, 16>(A, swz, c->stream); break;
       case 101: launch_tune<7, 256, 1, 16>(A, swz, c->stream); break;
       case 102: launch_tune<13, 256, 1, 16>(A, swz, c->stream); break;
@@ -141,6 +218,16 @@ extern "C" int qexhip_tune_dslash(qexhip_handle c, int variant, int swz, int nre
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return 0;
+}
+
+// |out|^2 of the field the variants write (parity 0 of the WK_OUT work field): a variant is only compared on time
+// with another when both leave the same result
+extern "C" int qexhip_tune_dslash_norm2(qexhip_handle c, double *n2) {
+  if (!c || !n2) return -1;
+  DevField *fout;
+  CHK(get_work(c, WK_OUT, &fout));
+  CHK(blas_norm2(c, *fout, 0, &c->dscal[8]));
+  return read_scalars(c, &c->dscal[8], 1, n2);
 }
 
 // plain device-to-device streaming copy of n bytes with 16-byte accesses: the measured HBM ceiling

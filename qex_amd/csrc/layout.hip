@@ -360,3 +360,89 @@ int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk_out) {
   return 0;
 }
 
+
+// Visiting order for the kernels whose gathers stay in ONE plane (the generic staple and its derivative: sites
+// x, x+-mu, x+-nu, x-mu+nu, x-nu+mu only).  What is in flight on an XCD at any time is a window of ~256 table entries
+// (32 CUs x 2 workgroups x 4 wavefronts): the window should be compact IN THE PLANE, so that the shifted reads of its
+// wavefronts land on lines their neighbours in the window fetch anyway, and thin in the other directions, where nothing
+// is shared.  The XCDs split the lattice along a direction OUTSIDE the plane (no halo between their regions at all).
+// A tile is 64 consecutive sites of one parity (x fastest): x never needs blocking, y comes in units of 64/Xh rows.
+// Like tile_order_table this is a permutation of the (tile, parity) pairs -- any order gives the same results.
+static void tile_order_plane_host(const Geom &g, int mu, int nu, std::vector<int> &h) {
+  const int n = 2 * g.ntile, chunk = (n + 7) / 8;
+  const bool inpl[4] = {mu == 0 || nu == 0, mu == 1 || nu == 1, mu == 2 || nu == 2, mu == 3 || nu == 3};
+  // direction the XCDs split along: the slowest one outside the plane
+  int dpart = 3;
+  while (dpart > 0 && inpl[dpart]) dpart--;
+  // block extents (sites) in y, z, t: a budget of 128 tile positions, spent on the plane's directions first
+  const int rows_per_tile = std::max(1, 64 / std::max(1, g.Xh));
+  int ext[4] = {0, rows_per_tile, 1, 1};
+  long budget = 128;
+  auto spend = [&](int d, long cap) {
+    long full = d == 1 ? std::max(1, g.X[1] / rows_per_tile) : g.X[d];      // in tile positions
+    long e = std::max(1L, std::min(std::min(full, cap), budget));
+    ext[d] = (int)(d == 1 ? e * rows_per_tile : e);
+    budget = std::max(1L, budget / e);
+  };
+  int pd[2], npd = 0;
+  for (int d = 3; d >= 1; d--) if (inpl[d]) pd[npd++] = d;
+  if (npd == 2) { spend(pd[1], 8); spend(pd[0], budget); }           // two blocked directions: 8 x 16 positions
+  else if (npd == 1) spend(pd[0], budget);
+  for (int d = 1; d <= 3; d++) if (!inpl[d] && d != dpart) spend(d, budget);   // leftover budget: a direction outside the plane
+  struct Ent { long key0, key1; int e; };
+  std::vector<Ent> v(n);
+  for (int p = 0; p < 2; p++)
+    for (int tile = 0; tile < g.ntile; tile++) {
+      unsigned r = (unsigned)tile * 64u / (unsigned)g.Xh;             // first site of the tile
+      int xc[4];
+      xc[0] = 0;
+      xc[1] = r % g.X[1]; r /= g.X[1];
+      xc[2] = r % g.X[2]; xc[3] = r / g.X[2];
+      Ent &a = v[(size_t)p * g.ntile + tile];
+      a.e = 2 * tile + p;
+      // key0: the split direction slowest, then the others (storage order)
+      long k0 = xc[dpart];
+      for (int d = 3; d >= 1; d--) if (d != dpart) k0 = k0 * 4096 + xc[d];
+      a.key0 = k0 * 2 + p;
+      // key1: block index (slow: directions outside the plane, then inside), then position inside the block, parity last
+      long kb = 0, ki = 0;
+      for (int pass = 0; pass < 2; pass++)
+        for (int d = 3; d >= 1; d--) {
+          if ((pass == 0) == inpl[d]) continue;                        // pass 0: outside the plane, pass 1: inside
+          kb = kb * 4096 + xc[d] / ext[d];
+          ki = ki * 4096 + xc[d] % ext[d];
+        }
+      a.key1 = (kb * (1L << 36) + ki) * 2 + p;
+    }
+  std::sort(v.begin(), v.end(), [](const Ent &a, const Ent &b) { return a.key0 < b.key0; });
+  h.assign((size_t)8 * chunk, -1);
+  for (int k = 0; k < 8; k++) {
+    const int lo = std::min(n, k * chunk), hi = std::min(n, (k + 1) * chunk);
+    std::sort(v.begin() + lo, v.begin() + hi, [](const Ent &a, const Ent &b) { return a.key1 < b.key1; });
+    for (int j = lo; j < hi; j++) h[(size_t)k * chunk + (j - lo)] = v[j].e;
+  }
+}
+int tile_order_plane(qexhip_ctx *c, int mu, int nu, const int **tab, int *chunk_out) {
+  const Geom &g = c->g;
+  const int n = 2 * g.ntile, chunk = (n + 7) / 8;
+  static const int use = [] { const char *e = getenv("QEXHIP_ORD_PLANE"); return e ? atoi(e) : 1; }();
+  if (!use || mu == nu || mu < 0 || nu < 0 || mu > 3 || nu > 3) return tile_order_table(c, tab, chunk_out);
+  int *&slot = c->tile_order_pl[mu * 4 + nu];
+  if (slot) { *tab = slot; *chunk_out = chunk; return 0; }
+  std::vector<int> h;
+  tile_order_plane_host(g, mu, nu, h);
+  HIPCHK(hipMalloc(&slot, h.size() * sizeof(int)));
+  HIPCHK(hipMemcpy(slot, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  *tab = slot; *chunk_out = chunk;
+  return 0;
+}
+// host-callable (no GPU): the table tile_order_plane would upload; out holds 8 * ((2 ntile + 7) / 8) entries, -1 = empty slot
+extern "C" int qexhip_debug_tile_order(const int latLocal[4], int mu, int nu, int *out, int cap) {
+  Geom g;
+  if (geom_init(g, latLocal, 1, 0) || mu == nu || mu < 0 || nu < 0 || mu > 3 || nu > 3 || !out) return -1;
+  std::vector<int> h;
+  tile_order_plane_host(g, mu, nu, h);
+  if ((int)h.size() > cap) return -(int)h.size();
+  for (size_t i = 0; i < h.size(); i++) out[i] = h[i];
+  return (int)h.size();
+}

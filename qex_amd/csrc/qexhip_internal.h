@@ -104,6 +104,7 @@ struct qexhip_ctx {
   // small per-context device scratch owned by single kernels' host wrappers
   double2 *outer_F = nullptr; size_t outer_Fn = 0;   // force field of stag_outer_host (force.hip)
   int *tile_order = nullptr; int tile_order_n = 0;   // blocked (tile, parity) visiting order of the gather kernels (gauge.hip)
+  int *tile_order_pl[16]{};                          // the same for kernels that shift in the (mu, nu) plane only (layout.hip)
   void *obs_table = nullptr;                         // ObsTable of gauge_flow_obs (gauge.hip)
   void *batch = nullptr;                             // BatchState of the lock-step multi-system CG (batch.hip)
   void *cgm_scal = nullptr;                          // CgmScal of the multi-shift solver (multishift.hip)
@@ -188,6 +189,7 @@ int blas_axpby(qexhip_ctx *c, double a, const DevField &x, double b, const DevFi
 int blas_norm2(qexhip_ctx *c, const DevField &x, int parity, double *dev_out);   // rank-global
 int blas_redot(qexhip_ctx *c, const DevField &x, const DevField &y, int parity, double *dev_out);
 int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk);   // blocked (tile, parity) visiting order, layout.hip
+int tile_order_plane(qexhip_ctx *c, int mu, int nu, const int **tab, int *chunk);   // order for kernels whose gathers stay in the (mu, nu) plane
 int reduce_partials(qexhip_ctx *c, int n, double *dev_out);  // sum partials[0..n) -> dev_out (+ allreduce)
 int read_scalars(qexhip_ctx *c, const double *dev, int n, double *host);  // sync readback
 int blas_grid(const qexhip_ctx *c, int parity_count);

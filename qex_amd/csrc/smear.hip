@@ -62,11 +62,11 @@ __device__ __forceinline__ void shift_sm(const Geom &g, const int x[4], int mu, 
 }
 
 // blocked visiting order for the gather kernels (tile_order_table, layout.hip); QEXHIP_SMEAR_ORD=0 falls back to the plain order
-static int smear_order(qexhip_ctx *c, const Geom &g, const int **order, int *chunk, int *nblk) {
+static int smear_order(qexhip_ctx *c, const Geom &g, const int **order, int *chunk, int *nblk, int mu = -1, int nu = -1) {
   static const int use = [] { const char *e = getenv("QEXHIP_SMEAR_ORD"); return e ? atoi(e) : 1; }();
   *order = nullptr; *chunk = 0; *nblk = (g.V + 255) / 256;
   if (!use) return 0;
-  CHK(tile_order_table(c, order, chunk));
+  CHK(tile_order_plane(c, mu, nu, order, chunk));     // mu < 0: the generic blocked order
   *nblk = 8 * ((*chunk + 3) / 4);
   return 0;
 }
@@ -232,8 +232,8 @@ __global__ void __launch_bounds__(256) k_projUderiv(Geom g, MViewW dst, MView U,
 // symStapleDeriv (smearutil.nim:22-50) gathered per site:
 //   f1(x) += g2(x) g1(x+mu) c(x+nu)^+ + c(x) g1(x+mu) g2(x+nu)^+ + [g2^+ g1 c(+nu) + c^+ g1 g2(+nu)](x-mu)
 //   f2(x) += g1(x) c(x+nu) g1(x+mu)^+ + [g1^+ c g1(+mu)](x-nu)
-template <bool SCALED, bool HALO, bool SB>   // SCALED: f += coef * (derivative) instead of accumulating in place; SB: scheduling fences
-__global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu, int swz,
+template <bool SCALED, bool HALO, bool SB, int WPE = 2>   // SCALED: f += coef * (derivative) instead of accumulating in place; SB: scheduling fences; WPE: wavefronts per SIMD the registers are capped for
+__global__ void __launch_bounds__(256, WPE) k_staple_deriv(Geom g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu, int swz,
                                                       int z1, int z2,      // z1 / z2: f1 / f2 start from zero (first contribution)
                                                       double coef, const int *order, int chunk) {
   int p, c;
@@ -302,6 +302,106 @@ __global__ void __launch_bounds__(256) k_staple_deriv(Geom g, MViewW f1, MViewW 
     }
     m3_store(f2.p + o0 * f2.tstride + l, 64, a);
   }
+}
+// Two symStapleDerivs in one pass.  Every call of the nHYP back-propagation has a partner with the roles of its fields
+// exchanged: (g1, g2, cA, mu, nu) adds into (f1, f2) and (g2, g1, cB, nu, mu) adds into (f2, f1) -- hypsmear.nim:175-245
+// visits both (mu, nu) and (nu, mu) at every level.  Run one after the other the pair reads five fields and
+// read-modify-writes two, twice; here g1, g2 are fetched once for both (the second use of a line is an L1/L2 hit inside
+// the same wavefront), f1 and f2 are read and written once, and only the two chain fields differ: 6 field reads + 2 writes
+// instead of 10 + 4 per pair.  The kernel is bound by what crosses L2 (PMC: 2.2 GB per single call, 33 % L2 hit rate),
+// so that is where the time goes.
+//   F1(x) += g2(x) g1(x+mu) cA(x+nu)^+ + cA(x) g1(x+mu) g2(x+nu)^+ + [g2^+ g1 cA(+nu) + cA^+ g1 g2(+nu)](x-mu)     (call A, f1)
+//          + g2(x) cB(x+mu) g2(x+nu)^+ + [g2^+ cB g2(+nu)](x-mu)                                                  (call B, f2)
+//   F2(x) += g1(x) cA(x+nu) g1(x+mu)^+ + [g1^+ cA g1(+mu)](x-nu)                                                  (call A, f2)
+//          + g1(x) g2(x+nu) cB(x+mu)^+ + cB(x) g2(x+nu) g1(x+mu)^+ + [g1^+ g2 cB(+mu) + cB^+ g2 g1(+mu)](x-nu)     (call B, f1)
+template <bool HALO>
+__global__ void __launch_bounds__(256) k_staple_deriv_pair(Geom g, MViewW F1, MViewW F2, MView g1, MView g2, MView cA, MView cB, int mu, int nu,
+                                                          int z1, int z2, const int *order, int chunk) {
+  const int slot = 4 * (blockIdx.x >> 3) + (threadIdx.x >> 6);
+  const int e = slot < chunk ? order[(blockIdx.x & 7) * chunk + slot] : -1;
+  if (e < 0) return;
+  const int p = e & 1, c = (e >> 1) * 64 + (threadIdx.x & 63);
+  if (c >= g.Vh) return;
+  int x[4], xpm[4], xpn[4], xmm[4], xmn[4], xmmpn[4], xmnpm[4];
+  coords_sm(g, c, p, x);
+  shift_sm_t<HALO>(g, x, mu, 1, xpm);
+  shift_sm_t<HALO>(g, x, nu, 1, xpn);
+  shift_sm_t<HALO>(g, x, mu, -1, xmm);
+  shift_sm_t<HALO>(g, x, nu, -1, xmn);
+  shift_sm_t<HALO>(g, xmm, nu, 1, xmmpn);
+  shift_sm_t<HALO>(g, xmn, mu, 1, xmnpm);
+  const size_t o0 = ((size_t)p * g.etile + (c >> 6));
+  const int l = c & 63;
+#define LD(F, X) m3_load((F).p + site_off_t<HALO>(g, X, (F).tstride), 64)
+#define LD0(F) m3_load((F).p + o0 * (F).tstride + l, 64)
+#define FENCE() __builtin_amdgcn_sched_barrier(0)   /* keep the loads of the next group from being hoisted above this one */
+  // Both accumulators stay in registers and the twelve terms are grouped by the corner of the plaquette they live on, so
+  // that every operand is loaded once (20 gathers + 2 read-modify-writes instead of 32) and products that are adjoints
+  // of each other or share a factor are formed once (9 products + 8 accumulations instead of 12 + 12):
+  //   corner x:     T = g1(+mu) cA(+nu)^+ + cB(+mu) g2(+nu)^+,  S = g1(+mu) g2(+nu)^+
+  //                 F1 += g2 T + cA S          F2 += g1 T^+ + cB S^+
+  //   corner x-mu:  F1 += g2^+ [g1 cA(+nu) + cB g2(+nu)] + cA^+ [g1 g2(+nu)]        (all fields at x-mu)
+  //   corner x-nu:  F2 += g1^+ [g2 cB(+mu) + cA g1(+mu)] + cB^+ [g2 g1(+mu)]        (all fields at x-nu)
+  M3 a1 = z1 ? m3_zero() : LD0(F1), a2 = z2 ? m3_zero() : LD0(F2);
+  {
+    M3 T, S;
+    {
+      const M3 g1pm = LD(g1, xpm);
+      T = m3_mul_na(g1pm, LD(cA, xpn));
+      FENCE();
+      const M3 g2pn = LD(g2, xpn);
+      S = m3_mul_na(g1pm, g2pn);
+      FENCE();
+      m3_mac_na(T, LD(cB, xpm), g2pn);
+    }
+    FENCE();
+    m3_mac(a1, LD0(g2), T);
+    FENCE();
+    m3_mac_na(a2, LD0(g1), T);
+    FENCE();
+    m3_mac(a1, LD0(cA), S);
+    FENCE();
+    m3_mac_na(a2, LD0(cB), S);
+    FENCE();
+  }
+  {
+    M3 T, S;
+    {
+      const M3 g1mm = LD(g1, xmm);
+      T = m3_mul(g1mm, LD(cA, xmmpn));
+      FENCE();
+      const M3 g2q = LD(g2, xmmpn);
+      S = m3_mul(g1mm, g2q);
+      FENCE();
+      m3_mac(T, LD(cB, xmm), g2q);
+    }
+    FENCE();
+    m3_mac_an(a1, LD(g2, xmm), T);
+    FENCE();
+    m3_mac_an(a1, LD(cA, xmm), S);
+    FENCE();
+  }
+  m3_store(F1.p + o0 * F1.tstride + l, 64, a1);
+  {
+    M3 T, S;
+    {
+      const M3 g2mn = LD(g2, xmn);
+      T = m3_mul(g2mn, LD(cB, xmnpm));
+      FENCE();
+      const M3 g1q = LD(g1, xmnpm);
+      S = m3_mul(g2mn, g1q);
+      FENCE();
+      m3_mac(T, LD(cA, xmn), g1q);
+    }
+    FENCE();
+    m3_mac_an(a2, LD(g1, xmn), T);
+    FENCE();
+    m3_mac_an(a2, LD(cB, xmn), S);
+  }
+  m3_store(F2.p + o0 * F2.tstride + l, 64, a2);
+#undef LD
+#undef LD0
+#undef FENCE
 }
 __global__ void __launch_bounds__(256) k_projectU(Geom g, MViewW dst, MView src) {
   int i = blockIdx.x * 256 + threadIdx.x;
@@ -434,7 +534,7 @@ struct Smear {
     ScopedTimer tm(c, "smear", c->stream);
     static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
     const int *order; int chunk, nblk;
-    CHK(smear_order(c, g, &order, &chunk, &nblk));
+    CHK(smear_order(c, g, &order, &chunk, &nblk, mu, nu));
     if (g.halo) k_gen_staple<true><<<nblk, 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk);
     else k_gen_staple<false><<<nblk, 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk);
     HIPCHK(hipGetLastError());
@@ -484,7 +584,7 @@ struct Smear {
     ScopedTimer tm(c, "smear_deriv", c->stream);
     // (scheduling fences cost 3 % here: 48.5 vs 46.9 ms per HISQ force, A/B on one GPU)
     const int *order; int chunk, nblk;
-    CHK(smear_order(c, g, &order, &chunk, &nblk));
+    CHK(smear_order(c, g, &order, &chunk, &nblk, mu, nu));
     if (g.halo) k_staple_deriv<true, true, false><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, 0, 0, coef, order, chunk);
     else k_staple_deriv<true, false, false><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, 0, 0, coef, order, chunk);
     HIPCHK(hipGetLastError());
@@ -690,11 +790,28 @@ static int staple_deriv(qexhip_ctx *c, const Geom &g, MViewW f1, MViewW f2, MVie
                         int z1 = 0, int z2 = 0) {
   static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
   const int *order; int chunk, nblk;
-  CHK(smear_order(c, g, &order, &chunk, &nblk));
+  CHK(smear_order(c, g, &order, &chunk, &nblk, mu, nu));
   // in-place accumulating form: scheduling fences between the products bring it from 256 VGPRs / 1 wave per SIMD
   // to 216 / 2 (192 in the sharded form) and the nHYP chain from 24.2 to 23.2 ms (sharded, 48^3x12: 31.2 -> 26.1 ms)
+  static const int wpe = [] { const char *e = getenv("QEXHIP_SDERIV_WPE"); return e ? atoi(e) : 2; }();
   if (g.halo) k_staple_deriv<false, true, true><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2, 1.0, order, chunk);
+  else if (wpe == 3) k_staple_deriv<false, false, true, 3><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2, 1.0, order, chunk);
   else k_staple_deriv<false, false, true><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2, 1.0, order, chunk);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// the (mu, nu) and (nu, mu) symStapleDerivs of a level in one pass (k_staple_deriv_pair); QEXHIP_SDERIV_PAIR=0: two single calls
+static int staple_deriv_pair(qexhip_ctx *c, const Geom &g, MViewW F1, MViewW F2, MView g1, MView g2, MView cA, MView cB, int mu, int nu,
+                             int z1, int z2) {
+  static const int pair = [] { const char *e = getenv("QEXHIP_SDERIV_PAIR"); return e ? atoi(e) : 1; }();
+  const int *order; int chunk, nblk;
+  CHK(smear_order(c, g, &order, &chunk, &nblk, mu, nu));
+  if (!pair || !order) {
+    CHK(staple_deriv(c, g, F1, F2, g1, g2, cA, mu, nu, z1, z2));
+    return staple_deriv(c, g, F2, F1, g2, g1, cB, nu, mu, 0, 0);
+  }
+  if (g.halo) k_staple_deriv_pair<true><<<nblk, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk);
+  else k_staple_deriv_pair<false><<<nblk, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -715,10 +832,9 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
   HIPCHK(hipGetLastError());
   CHK(S.ghosts_g(st->fc));          // t-sharded: a chain field is read at shifted sites by the staple derivative
   for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) {
-      if (nu == mu) continue;
-      CHK(staple_deriv(c, g, S.fvw(st->fl2[nu][mu]), S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[nu][mu]), S.fv(st->K.l2[mu][nu]),
-                       S.gv(st->fc, mu), mu, nu, !t2[nu][mu], !t2[mu][nu]));
+    for (int nu = mu + 1; nu < 4; nu++) {       // (mu, nu) and (nu, mu) together
+      CHK(staple_deriv_pair(c, g, S.fvw(st->fl2[nu][mu]), S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[nu][mu]), S.fv(st->K.l2[mu][nu]),
+                            S.gv(st->fc, mu), S.gv(st->fc, nu), mu, nu, !t2[nu][mu], !t2[mu][nu]));
       t2[nu][mu] = t2[mu][nu] = true;
     }
   HIPCHK(hipGetLastError());
@@ -730,17 +846,16 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
       CHK(S.ghosts_f(st->fl2[mu][nu]));
     }
   HIPCHK(hipGetLastError());
+  // the call (mu, nu, a) and its partner (a, nu, mu) share b = 6 - mu - nu - a and exchange the roles of their fields
   for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) {
-      if (nu == mu) continue;
-      for (int a = 0; a < 4; a++) {
-        if (a == mu || a == nu) continue;
+    for (int a = mu + 1; a < 4; a++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu || nu == a) continue;
         const int b = 6 - mu - nu - a;
-        CHK(staple_deriv(c, g, S.fvw(st->fl1[a][b]), S.fvw(st->fl1[mu][b]), S.fv(st->K.l1[a][b]), S.fv(st->K.l1[mu][b]),
-                         S.fv(st->fl2[mu][nu]), mu, a, !t1[a][b], !t1[mu][b]));
+        CHK(staple_deriv_pair(c, g, S.fvw(st->fl1[a][b]), S.fvw(st->fl1[mu][b]), S.fv(st->K.l1[a][b]), S.fv(st->K.l1[mu][b]),
+                              S.fv(st->fl2[mu][nu]), S.fv(st->fl2[a][nu]), mu, a, !t1[a][b], !t1[mu][b]));
         t1[a][b] = t1[mu][b] = true;
       }
-    }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
     for (int nu = 0; nu < 4; nu++) {
@@ -751,11 +866,9 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
     }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) {
-      if (nu == mu) continue;
-      CHK(staple_deriv(c, g, S.gvw(st->F, nu), S.gvw(st->F, mu), S.gv(st->G, nu), S.gv(st->G, mu),
-                                                  S.fv(st->fl1[mu][nu]), mu, nu));
-    }
+    for (int nu = mu + 1; nu < 4; nu++)
+      CHK(staple_deriv_pair(c, g, S.gvw(st->F, nu), S.gvw(st->F, mu), S.gv(st->G, nu), S.gv(st->G, mu),
+                            S.fv(st->fl1[mu][nu]), S.fv(st->fl1[nu][mu]), mu, nu, 0, 0));
   HIPCHK(hipGetLastError());
   return 0;
 }

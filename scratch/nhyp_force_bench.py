@@ -1,7 +1,7 @@
 import sys, time; sys.path.insert(0,'.')
 import numpy as np, qex_amd as q
 lat=[32,32,32,32]; lo=q.Layout(lat)
-g=q.synthetic_random_su3(lo, spread=0.3)
+g=q.RngField(lat,q.RngMilc6,987654321).warm(0.5)   # QEX g.warm(0.5)
 ctx=q.Context(lat)
 fl=np.zeros_like(g); f=np.zeros_like(g)
 hc=q.HypCoefs(0.4,0.5,0.5)

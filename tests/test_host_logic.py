@@ -256,3 +256,24 @@ def test_bench_watchdog_turns_a_stall_into_a_nonzero_exit():
     assert p.returncode == 3
     ln = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
     assert "stalled" in ln["error"] and ln["value"] is None
+
+
+@pytest.mark.parametrize("lat", [[32, 32, 32, 32], [8, 8, 8, 8], [4, 6, 10, 6], [48, 48, 48, 12], [16, 4, 8, 24]])
+def test_plane_tile_order_is_a_permutation(lat):
+    """The per-plane visiting order of the staple kernels (csrc/layout.hip: tile_order_plane) only re-orders the
+    work: every (tile, parity) pair appears exactly once for each of the twelve (mu, nu)."""
+    import qex_amd
+
+    L = qex_amd.lib()
+    vh = int(np.prod(lat)) // 2
+    ntile = (vh + 63) // 64
+    cap = 8 * ((2 * ntile + 7) // 8)
+    out = (C.c_int * cap)()
+    for mu in range(4):
+        for nu in range(4):
+            if mu == nu:
+                continue
+            n = L.qexhip_debug_tile_order((C.c_int * 4)(*lat), mu, nu, out, cap)
+            assert n == cap
+            e = np.array(out[:n])
+            assert sorted(e[e >= 0].tolist()) == list(range(2 * ntile)), (lat, mu, nu)
