@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The oracle is OpenMP code with many short parallel regions.  libgomp's default is to spin at barriers, which turns into
+# minutes of wasted CPU as soon as anything else in the test process (a HIP runtime helper thread, a child process of a
+# launch test) competes for the cores of a small CI box; a bounded spin (then sleep) keeps the short regions fast and the pathological case away.
+os.environ.setdefault("GOMP_SPINCOUNT", "30000")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
