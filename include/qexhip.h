@@ -50,6 +50,9 @@ typedef struct qexhip_ctx *qexhip_handle;
 int qexhip_init(qexhip_handle *h, int device, const int latLocal[4],
                 const int rankGeom[4], const int rankCoord[4]);
 int qexhip_finalize(qexhip_handle h);
+/* number of HIP devices this process can bind (qudaInit takes the device from the caller too,
+ * src/quda/qudaWrapperImpl.nim:70-83): a host picks device = (rank on its node) mod this count */
+int qexhip_device_count(int *n);
 const char *qexhip_last_error(void);
 /* wait for all work queued on the context's streams */
 int qexhip_sync(qexhip_handle h);

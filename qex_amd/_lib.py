@@ -17,6 +17,7 @@ _pi, _pd = C.POINTER(C.c_int), C.POINTER(C.c_double)
 SYMBOLS = [
     ("qexhip_init", _ci, [C.POINTER(_vp), _ci, _pi, _pi, _pi]),
     ("qexhip_finalize", _ci, [_vp]),
+    ("qexhip_device_count", _ci, [_pi]),
     ("qexhip_last_error", C.c_char_p, []),
     ("qexhip_sync", _ci, [_vp]),
     ("qexhip_device_info", _ci, [_vp, C.c_char_p, _ci]),

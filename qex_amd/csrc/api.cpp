@@ -123,6 +123,12 @@ extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], 
   return 0;
 }
 
+extern "C" int qexhip_device_count(int *n) {
+  if (!n) return QEXHIP_ERR_ARG;
+  HIPCHK(hipGetDeviceCount(n));
+  return 0;
+}
+
 extern "C" int qexhip_finalize(qexhip_handle c) {
   if (!c) return QEXHIP_ERR_ARG;
   (void)hipSetDevice(c->device);

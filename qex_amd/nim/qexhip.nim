@@ -11,7 +11,7 @@
 ## (there is no Nim compiler in the build image); the C ABI it binds is exercised by the
 ## Python/ctypes tests instead.
 
-import os
+import os, strutils
 import base, layout, field
 import physics/qcdTypes
 import physics/stagD
@@ -26,6 +26,8 @@ type QexhipHandle* = pointer
 
 proc qexhip_init(h: ptr QexhipHandle; device: cint; latLocal, rankGeom, rankCoord: ptr cint): cint {.qh.}
 proc qexhip_finalize(h: QexhipHandle): cint {.qh.}
+proc qexhip_device_count(n: ptr cint): cint {.qh.}
+proc qexhip_comm_info(h: QexhipHandle; nranks, rank, device: ptr cint; busid: cstring; buslen: cint): cint {.qh.}
 proc qexhip_last_error(): cstring {.qh.}
 proc qexhip_comm_unique_id(id: ptr char): cint {.qh.}
 proc qexhip_comm_init(h: QexhipHandle; id: ptr char; nranks, rank: cint): cint {.qh.}
@@ -98,13 +100,25 @@ proc hipSetup*(l: Layout): Layout[1] =
       lat[i] = l.localGeom[i].cint
       rg[i] = l.rankGeom[i].cint
       rc[i] = rcs[i]
-    let dev = (l.myRank mod 8).cint          # one GPU per rank, as qudaInit assumes
+    # one GPU per rank, as qudaInit assumes: the rank's index on its node (launcher-provided) modulo the visible devices
+    var ndev: cint
+    chk qexhip_device_count(ndev.addr)
+    var localRank = l.myRank
+    for v in ["OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID", "LOCAL_RANK"]:
+      if existsEnv(v):
+        localRank = parseInt(getEnv(v))
+        break
+    let dev = (localRank mod ndev.int).cint
     chk qexhip_init(hipParam.h.addr, dev, lat[0].addr, rg[0].addr, rc[0].addr)
     if l.nRanks > 1:
       var id: array[128, char]
       if l.myRank == 0: chk qexhip_comm_unique_id(id[0].addr)
       QMP_broadcast(id[0].addr, 128)         # comms/qmp.nim
       chk qexhip_comm_init(hipParam.h, id[0].addr, l.nRanks.cint, l.myRank.cint)
+      var nr, rk, dv: cint
+      var bus = newString(64)
+      chk qexhip_comm_info(hipParam.h, nr.addr, rk.addr, dv.addr, bus.cstring, 64)
+      echoAll "libqexhip: rank ", l.myRank, " = RCCL rank ", rk, " of ", nr, " on device ", dv, " (", $bus.cstring, ")"
     hipParam.layout1 = l.physGeom.newLayout 1
     hipParam.initialized = true
   hipParam.layout1
