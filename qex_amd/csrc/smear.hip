@@ -305,100 +305,77 @@ __global__ void __launch_bounds__(256, WPE) k_staple_deriv(Geom g, MViewW f1, MV
 }
 // Two symStapleDerivs in one pass.  Every call of the nHYP back-propagation has a partner with the roles of its fields
 // exchanged: (g1, g2, cA, mu, nu) adds into (f1, f2) and (g2, g1, cB, nu, mu) adds into (f2, f1) -- hypsmear.nim:175-245
-// visits both (mu, nu) and (nu, mu) at every level.  Run one after the other the pair reads five fields and
-// read-modify-writes two, twice; here g1, g2 are fetched once for both (the second use of a line is an L1/L2 hit inside
-// the same wavefront), f1 and f2 are read and written once, and only the two chain fields differ: 6 field reads + 2 writes
-// instead of 10 + 4 per pair.  The kernel is bound by what crosses L2 (PMC: 2.2 GB per single call, 33 % L2 hit rate),
-// so that is where the time goes.
-//   F1(x) += g2(x) g1(x+mu) cA(x+nu)^+ + cA(x) g1(x+mu) g2(x+nu)^+ + [g2^+ g1 cA(+nu) + cA^+ g1 g2(+nu)](x-mu)     (call A, f1)
-//          + g2(x) cB(x+mu) g2(x+nu)^+ + [g2^+ cB g2(+nu)](x-mu)                                                  (call B, f2)
-//   F2(x) += g1(x) cA(x+nu) g1(x+mu)^+ + [g1^+ cA g1(+mu)](x-nu)                                                  (call A, f2)
-//          + g1(x) g2(x+nu) cB(x+mu)^+ + cB(x) g2(x+nu) g1(x+mu)^+ + [g1^+ g2 cB(+mu) + cB^+ g2 g1(+mu)](x-nu)     (call B, f1)
+// visits both (mu, nu) and (nu, mu) at every level.  Summed, the pair is
+//   F1(x) += g2 T + cA S + g2(-mu)^+ [g1(-mu) cA(-mu+nu) + cB(-mu) g2(-mu+nu)] + cA(-mu)^+ [g1(-mu) g2(-mu+nu)]
+//   F2(x) += g1 T^+ + cB S^+ + g1(-nu)^+ [g2(-nu) cB(-nu+mu) + cA(-nu) g1(-nu+mu)] + cB(-nu)^+ [g2(-nu) g1(-nu+mu)]
+//   with T = g1(+mu) cA(+nu)^+ + cB(+mu) g2(+nu)^+,  S = g1(+mu) g2(+nu)^+        (fields without argument: at x)
+// and F2 is F1 with (g1, cA, mu) <-> (g2, cB, nu).  So ONE code path serves both: wavefront 2k of a workgroup forms F1
+// of tile k, wavefront 2k+1 forms F2 of the same tile with the roles exchanged (wavefront-uniform pointer selects).
+// Against two single calls: 6 field reads + 2 writes instead of 10 + 4 (the partner's operands are fetched at the same
+// moment by the same CU: L1 / L2 hits), products that are adjoints of each other or share a factor formed once per
+// wavefront, and only HALF as many tiles in flight per XCD for the same number of resident wavefronts -- the kernel is
+// bound by what misses the 4 MB L2 (PMC: 33 % hit rate, 2.7x its unique bytes fetched, for the one-tile-per-wavefront
+// form), so the smaller working set is worth more than the duplicated corner products cost.
 template <bool HALO>
 __global__ void __launch_bounds__(256) k_staple_deriv_pair(Geom g, MViewW F1, MViewW F2, MView g1, MView g2, MView cA, MView cB, int mu, int nu,
                                                           int z1, int z2, const int *order, int chunk) {
-  const int slot = 4 * (blockIdx.x >> 3) + (threadIdx.x >> 6);
+  const int wv = threadIdx.x >> 6;
+  const int slot = 2 * (blockIdx.x >> 3) + (wv >> 1);
   const int e = slot < chunk ? order[(blockIdx.x & 7) * chunk + slot] : -1;
   if (e < 0) return;
   const int p = e & 1, c = (e >> 1) * 64 + (threadIdx.x & 63);
   if (c >= g.Vh) return;
-  int x[4], xpm[4], xpn[4], xmm[4], xmn[4], xmmpn[4], xmnpm[4];
+  const bool second = __builtin_amdgcn_readfirstlane(wv & 1) != 0;      // wavefront-uniform role
+  const MViewW Fo = second ? F2 : F1;
+  const MView ga = second ? g2 : g1, gb = second ? g1 : g2, ca = second ? cB : cA, cb = second ? cA : cB;
+  const int m = second ? nu : mu, n = second ? mu : nu;
+  const int zo = second ? z2 : z1;
+  int x[4], xpm[4], xpn[4], xmm[4], xmmpn[4];
   coords_sm(g, c, p, x);
-  shift_sm_t<HALO>(g, x, mu, 1, xpm);
-  shift_sm_t<HALO>(g, x, nu, 1, xpn);
-  shift_sm_t<HALO>(g, x, mu, -1, xmm);
-  shift_sm_t<HALO>(g, x, nu, -1, xmn);
-  shift_sm_t<HALO>(g, xmm, nu, 1, xmmpn);
-  shift_sm_t<HALO>(g, xmn, mu, 1, xmnpm);
+  shift_sm_t<HALO>(g, x, m, 1, xpm);
+  shift_sm_t<HALO>(g, x, n, 1, xpn);
+  shift_sm_t<HALO>(g, x, m, -1, xmm);
+  shift_sm_t<HALO>(g, xmm, n, 1, xmmpn);
   const size_t o0 = ((size_t)p * g.etile + (c >> 6));
   const int l = c & 63;
 #define LD(F, X) m3_load((F).p + site_off_t<HALO>(g, X, (F).tstride), 64)
 #define LD0(F) m3_load((F).p + o0 * (F).tstride + l, 64)
 #define FENCE() __builtin_amdgcn_sched_barrier(0)   /* keep the loads of the next group from being hoisted above this one */
-  // Both accumulators stay in registers and the twelve terms are grouped by the corner of the plaquette they live on, so
-  // that every operand is loaded once (20 gathers + 2 read-modify-writes instead of 32) and products that are adjoints
-  // of each other or share a factor are formed once (9 products + 8 accumulations instead of 12 + 12):
-  //   corner x:     T = g1(+mu) cA(+nu)^+ + cB(+mu) g2(+nu)^+,  S = g1(+mu) g2(+nu)^+
-  //                 F1 += g2 T + cA S          F2 += g1 T^+ + cB S^+
-  //   corner x-mu:  F1 += g2^+ [g1 cA(+nu) + cB g2(+nu)] + cA^+ [g1 g2(+nu)]        (all fields at x-mu)
-  //   corner x-nu:  F2 += g1^+ [g2 cB(+mu) + cA g1(+mu)] + cB^+ [g2 g1(+mu)]        (all fields at x-nu)
-  M3 a1 = z1 ? m3_zero() : LD0(F1), a2 = z2 ? m3_zero() : LD0(F2);
+  M3 a = zo ? m3_zero() : LD0(Fo);
   {
     M3 T, S;
     {
-      const M3 g1pm = LD(g1, xpm);
-      T = m3_mul_na(g1pm, LD(cA, xpn));
+      const M3 gap = LD(ga, xpm);
+      T = m3_mul_na(gap, LD(ca, xpn));
       FENCE();
-      const M3 g2pn = LD(g2, xpn);
-      S = m3_mul_na(g1pm, g2pn);
+      const M3 gbn = LD(gb, xpn);
+      S = m3_mul_na(gap, gbn);
       FENCE();
-      m3_mac_na(T, LD(cB, xpm), g2pn);
+      m3_mac_na(T, LD(cb, xpm), gbn);
     }
     FENCE();
-    m3_mac(a1, LD0(g2), T);
+    m3_mac(a, LD0(gb), T);
     FENCE();
-    m3_mac_na(a2, LD0(g1), T);
-    FENCE();
-    m3_mac(a1, LD0(cA), S);
-    FENCE();
-    m3_mac_na(a2, LD0(cB), S);
+    m3_mac(a, LD0(ca), S);
     FENCE();
   }
   {
     M3 T, S;
     {
-      const M3 g1mm = LD(g1, xmm);
-      T = m3_mul(g1mm, LD(cA, xmmpn));
+      const M3 gam = LD(ga, xmm);
+      T = m3_mul(gam, LD(ca, xmmpn));
       FENCE();
-      const M3 g2q = LD(g2, xmmpn);
-      S = m3_mul(g1mm, g2q);
+      const M3 gbq = LD(gb, xmmpn);
+      S = m3_mul(gam, gbq);
       FENCE();
-      m3_mac(T, LD(cB, xmm), g2q);
+      m3_mac(T, LD(cb, xmm), gbq);
     }
     FENCE();
-    m3_mac_an(a1, LD(g2, xmm), T);
+    m3_mac_an(a, LD(gb, xmm), T);
     FENCE();
-    m3_mac_an(a1, LD(cA, xmm), S);
-    FENCE();
+    m3_mac_an(a, LD(ca, xmm), S);
   }
-  m3_store(F1.p + o0 * F1.tstride + l, 64, a1);
-  {
-    M3 T, S;
-    {
-      const M3 g2mn = LD(g2, xmn);
-      T = m3_mul(g2mn, LD(cB, xmnpm));
-      FENCE();
-      const M3 g1q = LD(g1, xmnpm);
-      S = m3_mul(g2mn, g1q);
-      FENCE();
-      m3_mac(T, LD(cA, xmn), g1q);
-    }
-    FENCE();
-    m3_mac_an(a2, LD(g1, xmn), T);
-    FENCE();
-    m3_mac_an(a2, LD(cB, xmn), S);
-  }
-  m3_store(F2.p + o0 * F2.tstride + l, 64, a2);
+  m3_store(Fo.p + o0 * Fo.tstride + l, 64, a);
 #undef LD
 #undef LD0
 #undef FENCE
@@ -535,8 +512,13 @@ struct Smear {
     static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
     const int *order; int chunk, nblk;
     CHK(smear_order(c, g, &order, &chunk, &nblk, mu, nu));
-    if (g.halo) k_gen_staple<true><<<nblk, 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk);
-    else k_gen_staple<false><<<nblk, 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk);
+    // Dynamic LDS the kernel never touches, as an occupancy limiter: 60 KB per workgroup admits two workgroups (8
+    // wavefronts = 8 tiles) per CU instead of the 3-4 its registers allow.  The kernel is bound by what misses the XCD's
+    // 4 MB L2, and fewer tiles in flight keep the lines its wavefronts share alive: nHYP smearing 7.27 -> 6.70 ms at 32^4
+    // (45 KB: 7.14, 100 KB = one workgroup per CU: 7.41).  QEXHIP_STAPLE_LDS=0 switches it off.
+    static const int ldsb = [] { const char *e = getenv("QEXHIP_STAPLE_LDS"); return e ? atoi(e) : 60000; }();
+    if (g.halo) k_gen_staple<true><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk);
+    else k_gen_staple<false><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -810,8 +792,9 @@ static int staple_deriv_pair(qexhip_ctx *c, const Geom &g, MViewW F1, MViewW F2,
     CHK(staple_deriv(c, g, F1, F2, g1, g2, cA, mu, nu, z1, z2));
     return staple_deriv(c, g, F2, F1, g2, g1, cB, nu, mu, 0, 0);
   }
-  if (g.halo) k_staple_deriv_pair<true><<<nblk, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk);
-  else k_staple_deriv_pair<false><<<nblk, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk);
+  const int nb2 = 8 * ((chunk + 1) / 2);         // two wavefronts per tile: 2 table slots per 256-thread workgroup
+  if (g.halo) k_staple_deriv_pair<true><<<nb2, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk);
+  else k_staple_deriv_pair<false><<<nb2, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk);
   HIPCHK(hipGetLastError());
   return 0;
 }
