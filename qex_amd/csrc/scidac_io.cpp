@@ -204,7 +204,7 @@ int scan(FILE *f, FileInfo &I) {
 }
 }  // namespace
 
-extern "C" int qexhip_io_gauge_info(const char *path, int lat[4], char *precision, int *checksums_present) {
+static int io_gauge_info_impl(const char *path, int lat[4], char *precision, int *checksums_present) {
   if (!path) return QEXHIP_ERR_ARG;
   FILE *f = fopen(path, "rb");
   if (!f) { qexhip_set_error("scidac: cannot open file"); return QEXHIP_ERR_ARG; }
@@ -219,13 +219,13 @@ extern "C" int qexhip_io_gauge_info(const char *path, int lat[4], char *precisio
 }
 
 static int read_gauge_impl(const char *path, const int lat[4], int t0, int nt, double *g, unsigned *suma, unsigned *sumb);
-extern "C" int qexhip_io_read_gauge(const char *path, const int lat[4], double *g, unsigned *suma, unsigned *sumb) {
+static int io_read_gauge_impl(const char *path, const int lat[4], double *g, unsigned *suma, unsigned *sumb) {
   if (!path || !lat || !g) return QEXHIP_ERR_ARG;
   return read_gauge_impl(path, lat, 0, lat[3], g, suma, sumb);
 }
 // one rank's slab t0 <= t < t0 + nt of a file holding the GLOBAL lattice `lat`; g is the local field (its own
 // even-odd order).  The whole record is read, so the checksums are still verified.
-extern "C" int qexhip_io_read_gauge_slab(const char *path, const int lat[4], int t0, int nt, double *g) {
+static int io_read_gauge_slab_impl(const char *path, const int lat[4], int t0, int nt, double *g) {
   if (!path || !lat || !g || t0 < 0 || nt < 2 || (nt & 1) || (t0 & 1) || t0 + nt > lat[3]) return QEXHIP_ERR_ARG;
   return read_gauge_impl(path, lat, t0, nt, g, nullptr, nullptr);
 }
@@ -275,7 +275,7 @@ static int read_gauge_impl(const char *path, const int lat[4], int t0, int nt, d
   return 0;
 }
 
-extern "C" int qexhip_io_write_gauge(const char *path, const int lat[4], const double *g, char precision,
+static int io_write_gauge_impl(const char *path, const int lat[4], const double *g, char precision,
                                      const char *file_md, const char *record_md) {
   if (!path || !lat || !g || (precision != 'F' && precision != 'D')) return QEXHIP_ERR_ARG;
   if (!file_md) file_md = "<?xml version=\"1.0\"?>\n<note>generated by QEX</note>\n";            // gaugeUtils.nim:108
@@ -340,7 +340,7 @@ extern "C" int qexhip_io_write_gauge(const char *path, const int lat[4], const d
 // ---- generic site records: what Writer.write / Reader.read do for any field type (writerQiolite.nim:96-166,
 // readerQiolite.nim:120-200): `site_bytes` per site in x-fastest order, every `word_bytes`-wide word big-endian.
 // data: host array in the library's even-odd site order, words in host byte order.
-extern "C" int qexhip_io_write_field(const char *path, const int lat[4], const void *data, int site_bytes, int word_bytes,
+static int io_write_field_impl(const char *path, const int lat[4], const void *data, int site_bytes, int word_bytes,
                                      const char *datatype, char precision, int colors, int datacount, const char *file_md,
                                      const char *record_md) {
   if (!path || !lat || !data || !datatype || site_bytes < 1 || (word_bytes != 4 && word_bytes != 8) || site_bytes % word_bytes ||
@@ -408,7 +408,7 @@ extern "C" int qexhip_io_write_field(const char *path, const int lat[4], const v
   return 0;
 }
 
-extern "C" int qexhip_io_read_field(const char *path, const int lat[4], void *data, int site_bytes, int word_bytes, char datatype[64]) {
+static int io_read_field_impl(const char *path, const int lat[4], void *data, int site_bytes, int word_bytes, char datatype[64]) {
   if (!path || !lat || !data || site_bytes < 1 || (word_bytes != 4 && word_bytes != 8) || site_bytes % word_bytes) return QEXHIP_ERR_ARG;
   FILE *f = fopen(path, "rb");
   if (!f) { qexhip_set_error("scidac: cannot open file"); return QEXHIP_ERR_ARG; }
@@ -449,7 +449,7 @@ extern "C" int qexhip_io_read_field(const char *path, const int lat[4], void *da
 
 // Reader.fileMetadata / Reader.recordMetadata (src/io/readerQiolite.nim:37-68,120-135): the user strings of the first
 // record; returns the lengths needed (incl. the terminating 0) when a buffer is too small or NULL
-extern "C" int qexhip_io_metadata(const char *path, char *file_md, int file_cap, char *record_md, int record_cap, int *file_len,
+static int io_metadata_impl(const char *path, char *file_md, int file_cap, char *record_md, int record_cap, int *file_len,
                                   int *record_len) {
   if (!path) return QEXHIP_ERR_ARG;
   FILE *f = fopen(path, "rb");
@@ -467,3 +467,31 @@ extern "C" int qexhip_io_metadata(const char *path, char *file_md, int file_cap,
   if (record_md && record_cap > 0) { strncpy(record_md, I.record_md.c_str(), record_cap - 1); record_md[record_cap - 1] = 0; }
   return 0;
 }
+
+// ---- the C boundary: no C++ exception may cross it (a truncated or hostile file must come back as QEXHIP_ERR_IO, not as
+// std::terminate inside the caller's process) ----
+#include <exception>
+#include <new>
+template <class F> static int guarded(F f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc &) {
+    qexhip_set_error("scidac: out of memory (a record length in the file?)");
+  } catch (const std::exception &e) {
+    qexhip_set_error("scidac: %s", e.what());
+  } catch (...) {
+    qexhip_set_error("scidac: unknown exception");
+  }
+  return QEXHIP_ERR_IO;
+}
+extern "C" int qexhip_io_gauge_info(const char *path, int lat[4], char *precision, int *checksums_present) { return guarded([&] { return io_gauge_info_impl(path, lat, precision, checksums_present); }); }
+extern "C" int qexhip_io_read_gauge(const char *path, const int lat[4], double *g, unsigned *suma, unsigned *sumb) { return guarded([&] { return io_read_gauge_impl(path, lat, g, suma, sumb); }); }
+extern "C" int qexhip_io_read_gauge_slab(const char *path, const int lat[4], int t0, int nt, double *g) { return guarded([&] { return io_read_gauge_slab_impl(path, lat, t0, nt, g); }); }
+extern "C" int qexhip_io_write_gauge(const char *path, const int lat[4], const double *g, char precision,
+                                     const char *file_md, const char *record_md) { return guarded([&] { return io_write_gauge_impl(path, lat, g, precision, file_md, record_md); }); }
+extern "C" int qexhip_io_write_field(const char *path, const int lat[4], const void *data, int site_bytes, int word_bytes,
+                                     const char *datatype, char precision, int colors, int datacount, const char *file_md,
+                                     const char *record_md) { return guarded([&] { return io_write_field_impl(path, lat, data, site_bytes, word_bytes, datatype, precision, colors, datacount, file_md, record_md); }); }
+extern "C" int qexhip_io_read_field(const char *path, const int lat[4], void *data, int site_bytes, int word_bytes, char datatype[64]) { return guarded([&] { return io_read_field_impl(path, lat, data, site_bytes, word_bytes, datatype); }); }
+extern "C" int qexhip_io_metadata(const char *path, char *file_md, int file_cap, char *record_md, int record_cap, int *file_len,
+                                  int *record_len) { return guarded([&] { return io_metadata_impl(path, file_md, file_cap, record_md, record_cap, file_len, record_len); }); }
