@@ -488,6 +488,7 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "ntstore") c->opt_ntstore = value;
   else if (n == "overlap") c->opt_overlap = value;
   else if (n == "batch_multi") c->opt_batch_multi = value;
+  else if (n == "multi_reduce") c->opt_multi_reduce = value;
   else { qexhip_set_error("unknown option"); return QEXHIP_ERR_ARG; }
   return 0;
 }

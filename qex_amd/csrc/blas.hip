@@ -116,7 +116,7 @@ int reduce_partials(qexhip_ctx *c, int n, double *dev_out) {
     k_reduce_final<<<1, 256, 0, c->stream>>>(c->partials, n, dev_out, nullptr);
     HIPCHK(hipGetLastError());
   }
-  if (c->nranks > 1) CHK(comm_allreduce(c, dev_out, 1));
+  if (multi_rank(c)) CHK(comm_allreduce(c, dev_out, 1));
   return 0;
 }
 
@@ -249,7 +249,7 @@ int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const 
     HIPCHK(hipGetLastError());
   }
   ScopedTimer tm(c, "reduce", c->stream);
-  if (c->nranks > 1) {
+  if (multi_rank(c)) {
     k_reduce_cg<<<1, 256, 0, c->stream>>>(r2p, nb, &c->cg->tmp, c->cg);
     HIPCHK(hipGetLastError());
     CHK(comm_allreduce(c, &c->cg->tmp, 1));

@@ -177,7 +177,7 @@ int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n) {
 
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
   CHK(need_comm(c));
-  if (c->nranks <= 1 || !c->comm) return 0;
+  if (!multi_rank(c) || !c->comm) return 0;    // one rank without the rehearsal hook, or no communicator: nothing to sum
   NCCLCHK(ncclAllReduce(dptr, dptr, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
   return 0;
 }

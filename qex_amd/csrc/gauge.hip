@@ -539,7 +539,7 @@ static int gauge_ghosts(qexhip_ctx *c, int depth) {
 }
 // rank-sum of n device scalars, then read back
 static int read_global(qexhip_ctx *c, double *dev, int n, double *host) {
-  if (c->nranks > 1) CHK(comm_allreduce(c, dev, n));
+  if (multi_rank(c)) CHK(comm_allreduce(c, dev, n));
   return read_scalars(c, dev, n, host);
 }
 static inline int ghost_depth_for(double c2, int kind) { return (kind == 0 && c2 != 0.0) ? 2 : 1; }

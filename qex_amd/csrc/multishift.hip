@@ -213,7 +213,7 @@ int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, 
   HIPCHK(hipGetLastError());
   CgScal st;
   CHK(read_cg(c, &st));
-  const bool sharded = c->nranks > 1;
+  const bool sharded = multi_rank(c);
   double *r2p = c->partials + c->part2_off;
   while (!st.done) {
     int nn = std::min(32, std::max(1, st.maxits - st.itn));

@@ -95,6 +95,8 @@ struct qexhip_ctx {
   // compressed links (recon = 1: rows 0,1 + sign mask; 2: rows 0,1 + det; row 2 rebuilt in the kernel)
   double2 *Wc = nullptr; unsigned long long *Ws = nullptr; size_t Wc_rows = 0; int recon = 0; double recon_dev = 0;
   int opt_batch_multi = 0; // test hook: take the multi-rank reduction branch of the batched CG on one rank
+  int opt_multi_reduce = 0; // test hook: take the multi-rank reduction branches of CG / multi-shift CG / norms on one rank
+                            // (with a one-rank RCCL communicator the all-reduces are real collectives)
   int opt_recon = 2;      // QEXHIP_RECON: 0 keeps the 18-real links always, 1 sign format only, 2 also the U(3) format
   int opt_overlap = -1;  // QEXHIP_OVERLAP: 1 always use the comm stream, 0 never, -1 by interior size
   // natural gauge (flow)
@@ -153,6 +155,9 @@ int nhyp_fforce(qexhip_ctx *c, double *f_host, int n, const double *const *phi, 
                 const double *r2req, int maxits, int bcmask, const int ph[4], int *iters);
 int solve_batch_host(qexhip_ctx *c, int n, double *const *x, const double *const *b, const double *mass,
                      const double *r2req, int maxits, int xx_parity, int *iters, double *r2);
+
+// reductions end in an all-reduce: more than one rank, or the one-rank rehearsal of that code path
+inline bool multi_rank(const qexhip_ctx *c) { return c->nranks > 1 || c->opt_multi_reduce; }
 
 // ---- comm.cpp ----
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready, records ev_halo

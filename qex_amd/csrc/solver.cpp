@@ -114,7 +114,7 @@ int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2
       CHK(cg_xpay(c, *p, *r, par));                                   // cg.nim:186-193
       int ndot = 0;                                                   // single rank: <p,Ap> partials are
       CHK(op_xx(c, *Ap, *p, m2, par_even, 1, &c->cg->done,            // summed inside cg_update
-                c->nranks > 1 ? nullptr : &ndot));                    // cg.nim:200, qLAp :206
+                multi_rank(c) ? nullptr : &ndot));                    // cg.nim:200, qLAp :206
       CHK(cg_update(c, x, *r, *p, *Ap, par, ndot));                   // cg.nim:208-213 + loop bookkeeping
     }
     CHK(read_cg(c, &st));

@@ -592,3 +592,47 @@ def test_largest_single_gpu_lattice_48x96(oracle):
     s2 = q.newStag(ctx2, g)
     s2.D(D0, x, 0.0)
     assert relerr(D0, Dx) < 1e-15
+
+
+@pytest.mark.parametrize("naik", [False, True])
+def test_multi_rank_code_path_on_one_rank(oracle, naik):
+    """Everything a rank of a t-sharded job executes, on one GPU: ghost zones, the exchange through a ONE-RANK RCCL
+    communicator (ncclSend/ncclRecv to self on the second stream), and -- option "multi_reduce" -- the multi-rank
+    reduction branches of the CG, the multi-shift CG and the norms (partial sums -> one-block sum -> ncclAllReduce ->
+    bookkeeping kernel), which a single rank otherwise never takes.  Must reproduce the periodic single-rank results."""
+    import qex_amd as q
+
+    A = Setup(oracle, [8, 8, 8, 8], naik=naik)
+    lat = [8, 8, 8, 8]
+    ctx = q.Context(lat)
+    ctx.comm_init(q.Context.unique_id(), 1, 0)
+    assert ctx.comm_info()[:2] == (1, 0)                       # what RCCL itself reports
+    ctx.force_halo(True)
+    ctx.set_option("overlap", 1)
+    ctx.set_option("multi_reduce", 1)
+    s = q.newStag3(ctx, A.g, A.g3) if naik else q.newStag(ctx, A.g)
+    assert abs(ctx.norm2(A.x) / oracle.norm2(A.lo, A.x, 2) - 1) < 1e-13
+    spa, spb = q.SolverParams(r2req=1e-12, maxits=2000, verbosity=0), q.SolverParams(r2req=1e-12, maxits=2000, verbosity=0)
+    xa, xb = np.zeros_like(A.x), np.zeros_like(A.x)
+    A.s.solveEE(xa, A.x, 0.1, spa, histcap=4096)
+    s.solveEE(xb, A.x, 0.1, spb, histcap=4096)
+    assert abs(spa.iterations - spb.iterations) <= 1
+    n = min(len(spa.r2hist), len(spb.r2hist))
+    assert np.abs(spb.r2hist[:100] / spa.r2hist[:100] - 1).max() < 1e-10 and n > 100
+    assert relerr(xb, xa) < 1e-6
+    masses = [0.1, 0.2, 0.4]
+    shifts = [masses[0]] + [4.0 * (m * m - masses[0] ** 2) for m in masses[1:]]
+    ya, yb = [np.zeros_like(A.x) for _ in masses], [np.zeros_like(A.x) for _ in masses]
+    spa, spb = q.SolverParams(r2req=1e-12, maxits=2000, verbosity=0), q.SolverParams(r2req=1e-12, maxits=2000, verbosity=0)
+    A.s.solveXX_multi(ya, A.x, shifts, spa, histcap=4096)
+    s.solveXX_multi(yb, A.x, shifts, spb, histcap=4096)
+    assert abs(spa.iterations - spb.iterations) <= 1
+    assert np.abs(spb.r2hist[:100] / spa.r2hist[:100] - 1).max() < 1e-10
+    for a, b in zip(ya, yb):
+        assert relerr(b, a) < 1e-6
+    x1, x2 = np.zeros_like(A.x), np.zeros_like(A.x)
+    A.s.solve(x1, A.x, 0.1, q.SolverParams(r2req=1e-12, maxits=10000, verbosity=0))
+    s.solve(x2, A.x, 0.1, q.SolverParams(r2req=1e-12, maxits=10000, verbosity=0))
+    assert relerr(x2, x1) < 1e-7
+    g0 = oracle.gauge_random(A.lo, seed=SEED)
+    assert np.max(np.abs(q.plaq(ctx, g0) - q.plaq(A.ctx, g0))) < 1e-15
