@@ -117,6 +117,7 @@ extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], 
   if (const char *e = getenv("QEXHIP_NTSTORE")) c->opt_ntstore = atoi(e);
   if (const char *e = getenv("QEXHIP_OVERLAP")) c->opt_overlap = atoi(e);
   if (const char *e = getenv("QEXHIP_RECON")) c->opt_recon = atoi(e);
+  if (const char *e = getenv("QEXHIP_FLOW_EXP")) c->opt_flow_exp = atoi(e);
   c->nranks = 1;  // until qexhip_comm_init
   c->rank = 0;
   *h = c;
@@ -489,6 +490,7 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "overlap") c->opt_overlap = value;
   else if (n == "batch_multi") c->opt_batch_multi = value;
   else if (n == "multi_reduce") c->opt_multi_reduce = value;
+  else if (n == "flow_exp") c->opt_flow_exp = value;
   else { qexhip_set_error("unknown option"); return QEXHIP_ERR_ARG; }
   return 0;
 }

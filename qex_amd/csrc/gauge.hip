@@ -142,6 +142,8 @@ __global__ void __launch_bounds__(256) k_plaq_final(const double *partials, int 
 // mappings for A/B runs: 0 = mu-major lanes, 1 = tiles in storage order, 2 = storage order, contiguous per XCD.
 // flow mode (Pm != nullptr): the RK3 combination v = cf*f + cpm*p (wflow.nim:39,48,57) is formed here
 // and written over the momentum field, so the exp kernel reads one field less and F is not needed.
+// CLOSED: exp(v) in closed form (m3_exp_tah, su3.h) instead of the reference's Taylor + 20 squarings: option "flow_exp"
+template <bool CLOSED>
 __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict__ G, double2 *F, double cp, int mode,
                                                double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk) {
   int mu, p, c;
@@ -201,7 +203,73 @@ __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict
     m3_store(Pm + o, 64, v);
     // fused second half of the RK3 stage (wflow.nim:40-43): U <- exp(v) U into the other buffer, so the
     // compute-bound exp overlaps the L2-bound staple gathers of other waves and v, U are not re-read
-    if (Uout) m3_store(Uout + o, 64, m3_mul(m3_exp(v), m3_load(G + o, 64)));
+    if (Uout) m3_store(Uout + o, 64, m3_mul(CLOSED ? m3_exp_tah(v) : m3_exp(v), m3_load(G + o, 64)));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { f.e[k].x *= cp; f.e[k].y *= cp; }
+    m3_store(F + o, 64, f);
+  }
+}
+
+// k_force with the links that the four directions of a tile share passed through LDS (mode 3 only).  The kernel pays for
+// its gathers at the CU's L2->L1 rate (profiles/r02_kforce_experiments.md): of the 19 matrices a lane fetches, U_nu(x) and
+// U_nu(x-nu) (nu != mu) are the same for the three wavefronts with mu != nu -- and they are the workgroup's own links
+// U_mu(x), U_mu(x-mu) of wavefront nu.  Every wavefront therefore loads its own two once, puts them into LDS (8 x 9 KiB),
+// ONE barrier, and reads its six shared operands back from there: 14 global matrix loads per lane instead of 19.
+template <bool CLOSED>
+__global__ void __launch_bounds__(256) k_force_lds(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
+                                                   double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk) {
+  extern __shared__ double2 smU[];                    // [2 nu + (0: U_nu(x) | 1: U_nu(x-nu))][9][64]
+  const int e = order[(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)];
+  if (e < 0) return;                                  // the whole workgroup together
+  const int mu = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p = e & 1;
+  const int c0 = (e >> 1) * 64 + lane;
+  const bool live = c0 < g.Vh;
+  const int c = live ? c0 : g.Vh - 1;                 // padding lanes of the last tile work on a valid site and store nothing
+  int x[4], xpm[4], y[4], z[4];
+  coords_of(g, c, p, x);
+  shifted(g, x, mu, 1, xpm);
+  const size_t o = link_off(g, x, mu);
+  {
+    shifted(g, x, mu, -1, y);
+    const M3 a = m3_load(G + o, 64), b = m3_load(G + link_off(g, y, mu), 64);
+    double2 *s0 = smU + (size_t)(2 * mu) * 576 + lane;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { s0[k * 64] = a.e[k]; s0[576 + k * 64] = b.e[k]; }
+  }
+  __syncthreads();
+  M3 acc = m3_zero();
+#pragma unroll 1
+  for (int nu = 0; nu < 4; nu++) {
+    if (nu == mu) continue;
+    const double2 *sn = smU + (size_t)(2 * nu) * 576 + lane;
+    // forward: U_nu(x) U_mu(x+nu) U_nu(x+mu)^+          (stf[mu,nu], staples.nim:181-183)
+    shifted(g, x, nu, 1, y);
+    M3 t = m3_mul_na(m3_load(G + link_off(g, y, mu), 64), m3_load(G + link_off(g, xpm, nu), 64));
+    m3_mac(acc, m3_load(sn, 64), t);
+    // backward: U_nu(x-nu)^+ U_mu(x-nu) U_nu(x-nu+mu)   (stu[mu,nu] shifted down, staples.nim:184-186)
+    shifted(g, x, nu, -1, y);
+    shifted(g, y, mu, 1, z);
+    t = m3_mul_an(m3_load(sn + 576, 64), m3_load(G + link_off(g, y, mu), 64));
+    m3_mac(acc, t, m3_load(G + link_off(g, z, nu), 64));
+  }
+  const M3 U = m3_load(smU + (size_t)(2 * mu) * 576 + lane, 64);
+  M3 f = m3_tah(m3_mul_na(U, acc));
+  if (!live) return;
+  if (Pm) {
+    M3 v;
+    const double cfp = cf * cp;
+    if (cpm != 0.0) {
+      const M3 pm = m3_load(Pm + o, 64);
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x + cpm * pm.e[k].x, cfp * f.e[k].y + cpm * pm.e[k].y);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x, cfp * f.e[k].y);
+    }
+    m3_store(Pm + o, 64, v);
+    if (Uout) m3_store(Uout + o, 64, m3_mul(CLOSED ? m3_exp_tah(v) : m3_exp(v), U));
   } else {
 #pragma unroll
     for (int k = 0; k < 9; k++) { f.e[k].x *= cp; f.e[k].y *= cp; }
@@ -404,6 +472,7 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
 __device__ const signed char RECT_STEPS[6][5] = {
     {2, 2, 1, -2, -2}, {2, 1, 1, -2, -1}, {-1, 2, 1, 1, -2},          // +nu
     {-2, -2, 1, 2, 2}, {-2, 1, 1, 2, -1}, {-1, -2, 1, 1, 2}};         // -nu
+template <bool CLOSED>
 __global__ void __launch_bounds__(256) k_force_gen(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
                                                    double c2, int kind, double2 *Pm, double cf, double cpm, int raw, double2 *Uout,
                                                    const int *order, int chunk) {
@@ -483,7 +552,7 @@ __global__ void __launch_bounds__(256) k_force_gen(Geom g, const double2 *__rest
     m3_store(Pm + o, 64, v);
     // fused second half of the RK3 stage (wflow.nim:40-43): U <- exp(v) U into the other buffer, so the
     // compute-bound exp overlaps the L2-bound staple gathers of other waves and v, U are not re-read
-    if (Uout) m3_store(Uout + o, 64, m3_mul(m3_exp(v), m3_load(G + o, 64)));
+    if (Uout) m3_store(Uout + o, 64, m3_mul(CLOSED ? m3_exp_tah(v) : m3_exp(v), m3_load(G + o, 64)));
   } else {
     m3_store(F + o, 64, f);
   }
@@ -497,7 +566,7 @@ int gauge_deriv_dev(qexhip_ctx *c, const double2 *G, double2 *F, double cplaq, d
   ScopedTimer tm(c, "staple", c->stream);
   const int *order = nullptr; int chunk = 0;
   CHK(tile_order_table(c, &order, &chunk));
-  k_force_gen<<<8 * chunk, 256, 0, c->stream>>>(c->g, G, F, cplaq / 3.0, k2, kind, nullptr, 0.0, 0.0, 1, nullptr, order, chunk);
+  k_force_gen<false><<<8 * chunk, 256, 0, c->stream>>>(c->g, G, F, cplaq / 3.0, k2, kind, nullptr, 0.0, 0.0, 1, nullptr, order, chunk);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -630,11 +699,29 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
   if (c2 != 0.0) {
     // kind 0: cr = c.rect/nc ; kind 1: ca = 2 c.adjplaq/nc^2
     const double k2 = kind == 0 ? c2 / 3.0 : 2.0 * c2 / 9.0;
-    k_force_gen<<<8 * chunk, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind,
-                                                  flow ? c->gn->P : nullptr, cf, cpm, 0, Uout, order, chunk);
+    if (Uout && c->opt_flow_exp)
+      k_force_gen<true><<<8 * chunk, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind, c->gn->P, cf, cpm, 0, Uout, order, chunk);
+    else
+      k_force_gen<false><<<8 * chunk, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind,
+                                                         flow ? c->gn->P : nullptr, cf, cpm, 0, Uout, order, chunk);
   } else {
     // (capping the registers for 3 or 4 waves/SIMD spills: 1460 / 2370 us against 1310 us fused at 2 waves/SIMD)
-    k_force<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, flow ? c->gn->P : nullptr, cf, cpm, Uout, order, chunk);
+    static const int lds = [] { const char *e = getenv("QEXHIP_FORCE_LDS"); return e ? atoi(e) : 1; }();
+    const bool closed = Uout && c->opt_flow_exp;
+    if (lds && mode == 3) {
+      const size_t shb = (size_t)8 * 576 * sizeof(double2);       // 72 KiB: two workgroups per CU, as the registers allow anyway
+      static bool attr_done = false;
+      if (!attr_done) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+        attr_done = true;
+      }
+      if (closed) k_force_lds<true><<<nb, 256, shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, c->gn->P, cf, cpm, Uout, order, chunk);
+      else k_force_lds<false><<<nb, 256, shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, flow ? c->gn->P : nullptr, cf, cpm, Uout, order, chunk);
+    } else if (closed)
+      k_force<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, c->gn->P, cf, cpm, Uout, order, chunk);
+    else
+      k_force<false><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, flow ? c->gn->P : nullptr, cf, cpm, Uout, order, chunk);
   }
   HIPCHK(hipGetLastError());
   return 0;

@@ -180,6 +180,72 @@ __host__ __device__ __forceinline__ M3 m3_exp(const M3 &m) {
   return e;
 }
 
+// exp of a TRACELESS ANTI-HERMITIAN matrix in closed form (Cayley-Hamilton; Morningstar & Peardon, Phys. Rev. D 69, 054501,
+// eqs. 19-33): v = iQ, exp(iQ) = f0 + f1 Q + f2 Q^2 with f_j from c0 = det Q, c1 = tr Q^2 / 2.  One matrix product,
+// one trace and a handful of scalar functions instead of the 22 products of m3_exp: the same matrix function, NOT the
+// reference's algorithm (matexp.nim: order-4 Taylor at v/2^20, 20 squarings), so it is an opt-in of the flow only
+// (option "flow_exp" = 1); it agrees with m3_exp to the rounding error of m3_exp's squarings (~2e-15 absolute,
+// tests/cpp/test_exp_ch.cpp) and is unitary to 4e-16 where m3_exp is to 2e-15.
+__host__ __device__ __forceinline__ M3 m3_exp_tah(const M3 &v) {
+  // Q = -i v  (Hermitian, traceless);  Q2 = Q Q = -(v v)
+  M3 Q, Q2;
+#pragma unroll
+  for (int k = 0; k < 9; k++) Q.e[k] = make_double2(v.e[k].y, -v.e[k].x);
+  Q2 = m3_mul(Q, Q);
+  const double c1 = 0.5 * (Q2.e[0].x + Q2.e[4].x + Q2.e[8].x);
+  // c0 = det Q = tr(Q^3)/3 = Re tr(Q Q2)/3
+  double t3 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) t3 += Q.e[3 * i + k].x * Q2.e[3 * k + i].x - Q.e[3 * i + k].y * Q2.e[3 * k + i].y;
+  double c0 = t3 * (1.0 / 3.0);
+  M3 r;
+  if (c1 < 1e-8) {
+    // |v| < 1e-4: exp = 1 + v + v^2/2 + v^3/6 + v^4/24 to 1e-21; v^2 = -Q2
+    M3 v3 = m3_mul(v, Q2);                       // = -v^3
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.e[k] = make_double2(v.e[k].x - 0.5 * Q2.e[k].x - (1.0 / 6.0) * v3.e[k].x,
+                                                     v.e[k].y - 0.5 * Q2.e[k].y - (1.0 / 6.0) * v3.e[k].y);
+    M3 q4 = m3_mul(Q2, Q2);                      // = v^4
+    m3_axpy(r, 1.0 / 24.0, q4);
+    m3_add_diag(r, 1.0);
+    return r;
+  }
+  const bool neg = c0 < 0.0;                     // f_j(-c0) = (-1)^j conj f_j(c0): evaluate at |c0| (eq. 34)
+  c0 = fabs(c0);
+  const double c13 = c1 * (1.0 / 3.0);
+  const double c0max = 2.0 * c13 * sqrt(c13);
+  const double th = acos(fmin(1.0, c0 / c0max));
+  const double u = sqrt(c13) * cos(th * (1.0 / 3.0));
+  const double w = sqrt(c1) * sin(th * (1.0 / 3.0));
+  const double w2 = w * w, u2 = u * u;
+  const double xi0 = fabs(w) < 0.05 ? 1.0 - w2 * (1.0 / 6.0) * (1.0 - w2 * (1.0 / 20.0) * (1.0 - w2 * (1.0 / 42.0))) : sin(w) / w;
+  const double cw = cos(w);
+  const double cu = cos(u), su = sin(u);
+  const double c2u = cu * cu - su * su, s2u = 2.0 * su * cu;     // e^{2iu}
+  // h_j = A_j e^{2iu} + e^{-iu} (B_j + i C_j)
+  const double b0 = 8.0 * u2 * cw, d0 = 2.0 * u * (3.0 * u2 + w2) * xi0;
+  const double b1 = -2.0 * u * cw, d1 = (3.0 * u2 - w2) * xi0;
+  const double b2 = -cw, d2 = -3.0 * u * xi0;
+  const double a0 = u2 - w2, a1 = 2.0 * u;
+  // e^{-iu} (b + i d) = (b cu + d su) + i (d cu - b su)
+  const double den = 1.0 / (9.0 * u2 - w2);
+  double f0r = (a0 * c2u + b0 * cu + d0 * su) * den, f0i = (a0 * s2u + d0 * cu - b0 * su) * den;
+  double f1r = (a1 * c2u + b1 * cu + d1 * su) * den, f1i = (a1 * s2u + d1 * cu - b1 * su) * den;
+  double f2r = (c2u + b2 * cu + d2 * su) * den, f2i = (s2u + d2 * cu - b2 * su) * den;
+  if (neg) { f0i = -f0i; f1r = -f1r; f2i = -f2i; }
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    r.e[k].x = f1r * Q.e[k].x - f1i * Q.e[k].y + f2r * Q2.e[k].x - f2i * Q2.e[k].y;
+    r.e[k].y = f1r * Q.e[k].y + f1i * Q.e[k].x + f2r * Q2.e[k].y + f2i * Q2.e[k].x;
+  }
+  r.e[0].x += f0r; r.e[0].y += f0i;
+  r.e[4].x += f0r; r.e[4].y += f0i;
+  r.e[8].x += f0r; r.e[8].y += f0i;
+  return r;
+}
+
 // eigs3 + rsqrtPHM3f + rsqrtPHM3 + projectU (matrixFunctions.nim:79-182,279-313)
 // z = (x^+ x + 1e-20)^(-1/2)   (projectUrsqrt, matrixFunctions.nim:301-306)
 __host__ __device__ __forceinline__ M3 m3_rsqrt_xdx(const M3 &x) {

@@ -9,8 +9,10 @@ from test_oracle_golden import G3_TABLES
 pytestmark = pytest.mark.gpu
 
 
-def test_G3_on_gpu(oracle):
-    """The whole twflow_topo.nim sequence with the flow AND the observables on the GPU."""
+@pytest.mark.parametrize("flow_exp", [1, 0])
+def test_G3_on_gpu(oracle, flow_exp):
+    """The whole twflow_topo.nim sequence with the flow AND the observables on the GPU (flow_exp: the flow's closed-form
+    exp, the default, and the reference's Taylor + squarings algorithm)."""
     import qex_amd as q
 
     o = oracle
@@ -18,6 +20,7 @@ def test_G3_on_gpu(oracle):
     rf = o.RngField(lo, o.RNG_MRG32K3A, 17 ** 13)
     g = o.gauge_warm(lo, 0.4, rf)
     ctx = q.Context([8, 8, 8, 8])
+    ctx.set_option("flow_exp", flow_exp)
 
     def check(tab):
         for loop, want in G3_TABLES[tab].items():

@@ -329,14 +329,19 @@ def test_gauge_force(oracle):
     assert relerr(f, oracle.gauge_force(lo, g)) < 1e-13
 
 
-def test_wflow_golden(oracle):
-    """G2 (src/gauge/wflow.nim:92-99,124-149): plaquettes after gaugeFlow(6, 0.01), rel 2e-14."""
+@pytest.mark.parametrize("flow_exp", [1, 0])
+def test_wflow_golden(oracle, flow_exp):
+    """G2 (src/gauge/wflow.nim:92-99,124-149): plaquettes after gaugeFlow(6, 0.01), rel 2e-14 -- the reference's own
+    tolerance -- with the flow's default closed-form exp(v) (flow_exp = 1: the same matrix function by Cayley-Hamilton,
+    csrc/su3.h m3_exp_tah) and with the reference's algorithm (flow_exp = 0: order-4 Taylor at v/2^20 + 20 squarings,
+    matexp.nim), which is also what the oracle runs; the flowed links agree with the oracle's to 1e-12 either way."""
     import qex_amd as q
 
     lo = oracle.Layout([8, 8, 8, 8])
     g = oracle.gauge_random(lo)
     gref = g.copy()
     ctx = q.Context([8, 8, 8, 8])
+    ctx.set_option("flow_exp", flow_exp)
     q.gaugeFlow(ctx, g, 6, 0.01)
     p0 = np.array([0.01960725848281519, 0.01982378149813489, 0.01938877647467847,
                    0.0185899778070918, 0.0180821938831715, 0.01876842496122964])
@@ -449,6 +454,11 @@ def test_full_size_plaq_and_flow(s32):
     assert np.max(np.abs(pl - S.o.plaq(S.lo, S.g0))) < 1e-15
     g = S.g0.copy()
     S.q.gaugeFlow(S.ctx, g, 1, 0.01)
+    S.ctx.set_option("flow_exp", 0)                   # the reference's exp algorithm: same links to rounding
+    g_ref_alg = S.g0.copy()
+    S.q.gaugeFlow(S.ctx, g_ref_alg, 1, 0.01)
+    S.ctx.set_option("flow_exp", 1)
+    assert relerr(g, g_ref_alg) < 1e-14
     m = (g[..., 0] + 1j * g[..., 1]).reshape(-1, 3, 3)[::257]
     assert np.abs(np.einsum("nij,nkj->nik", m, m.conj()) - np.eye(3)).max() < 1e-10   # stays in SU(3)
     assert np.abs(np.linalg.det(m) - 1).max() < 1e-10
