@@ -41,3 +41,16 @@ def test_cpp_host_parity_program():
     p = subprocess.run([EXE], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300)
     print(p.stdout)
     assert p.returncode == 0 and "Passed" in p.stdout, p.stdout
+
+
+def test_closed_form_exp_against_the_reference_algorithm_and_long_double(tmp_path):
+    """csrc/su3.h is host-callable: the flow's closed-form exp (m3_exp_tah) against the reference-algorithm exp (m3_exp:
+    order-4 Taylor at v/2^20 + 20 squarings, matexp.nim) and a long-double series, over 4400 random, diagonal and
+    nearly degenerate traceless anti-Hermitian matrices of norm 1e-9 ... 20 (tests/cpp/test_exp_ch.cpp states the bounds:
+    never further from the exact result than 1.5 x the reference algorithm or 2e-15)."""
+    exe = str(tmp_path / "test_exp_ch")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "qex_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "test_exp_ch.cpp"), "-o", exe])
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    print(p.stdout)
+    assert p.returncode == 0 and "0 scale(s) out of bounds" in p.stdout, p.stdout
