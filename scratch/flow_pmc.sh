@@ -11,7 +11,7 @@ run() { # name, env..., counters
   for e in $envs; do export $e; done
   timeout -k 5 120 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 profiles/pmc_workload.py flow > $OUT/$name.log 2>&1 || { echo "$name failed"; tail -5 $OUT/$name.log; }
 }
-for cfg in "fused3 QEXHIP_FLOW_FUSED=1 QEXHIP_FORCE_MODE=3" "fused6 QEXHIP_FLOW_FUSED=1 QEXHIP_FORCE_MODE=6" "unfused6 QEXHIP_FLOW_FUSED=0 QEXHIP_FORCE_MODE=6"; do
+for cfg in "ldsch QEXHIP_FORCE_LDS=1 QEXHIP_FLOW_EXP=1" "nolds QEXHIP_FORCE_LDS=0 QEXHIP_FLOW_EXP=1"; do
   set -- $cfg; tag=$1; shift; envs="$*"
   run ${tag}_sq "$envs" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VMEM
   run ${tag}_sq2 "$envs" SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_WAVES SQ_IFETCH GRBM_GUI_ACTIVE
