@@ -224,7 +224,12 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
     // overlap the exchange with the interior sweep on a second stream only when the interior is
     // long enough to hide it (measured on one MI355X with a one-rank communicator: the two
     // cross-stream dependencies cost ~20 us per sweep; an interior of 128k sites runs ~30 us)
-    const int overlap = c->opt_overlap >= 0 ? c->opt_overlap : ((hi_beg - lo_end) >= 131072);
+    // ... and only when a face is big enough for its transfer to cost more than the split does: in the one-rank
+    // rehearsal (no transport time at all) the interior / boundary split with its two cross-stream events costs ~15 us
+    // per sweep (48^3 x 12: 417 vs 388 us per iteration; 32^3 x 16: 253 vs 218); a 48^3 face is 2.65 MB per direction
+    // (tens of microseconds on an xGMI link), a 32^3 face 0.79 MB
+    const size_t face_bytes = (size_t)g.depth * g.F * 48;
+    const int overlap = c->opt_overlap >= 0 ? c->opt_overlap : ((hi_beg - lo_end) >= 131072 && face_bytes >= ((size_t)1 << 20));
     if (overlap) HIPCHK(hipEventRecord(c->ev_ready, c->stream));
     CHK(comm_halo_exchange(c, in, 1 - parity, overlap));
     if (!overlap) {
