@@ -463,7 +463,25 @@ struct Smear {
     gsz = 4 * fsz;
   }
   ~Smear() { (void)hipStreamSynchronize(c->stream); for (auto p : owned) (void)hipFree(p); }
+  // One slab for the fields of a long-lived state (the nHYP closure keeps 92 matrix fields, 14 GB at 32^4): a hipMalloc
+  // costs milliseconds whatever its size, 77 of them made the first smearGetForce of a context take 240 ms.
+  double2 *slab = nullptr;
+  size_t slab_n = 0, slab_used = 0;
+  int reserve(size_t n) {
+    if (slab) return 0;
+    HIPCHK(hipMalloc((void **)&slab, n * sizeof(double2)));
+    HIPCHK(hipMemsetAsync(slab, 0, n * sizeof(double2), c->stream));
+    owned.push_back(slab);
+    slab_n = n; slab_used = 0;
+    return 0;
+  }
   int alloc(double2 **p, size_t n) {
+    const size_t n16 = (n + 15) & ~(size_t)15;            // keep every field 256-byte aligned inside the slab
+    if (slab && slab_used + n16 <= slab_n) {
+      *p = slab + slab_used;                              // already zeroed by reserve()
+      slab_used += n16;
+      return 0;
+    }
     HIPCHK(hipMalloc((void **)p, n * sizeof(double2)));
     HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(double2), c->stream));
     owned.push_back(*p);
@@ -751,6 +769,8 @@ int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, doub
   Smear &S = st->S;
   st->a1 = a1; st->a2 = a2; st->a3 = a3;
   if (fresh) {
+    // G, FL, F, fc, flx: 5 gauge-shaped fields; fl1, fl2: 24 matrix fields; l1, l2, l1x, l2x: 48 (nhyp() below)
+    CHK(S.reserve(5 * S.gsz + 72 * S.fsz + 128 * 16));
     CHK(S.alloc(&st->G, S.gsz)); CHK(S.alloc(&st->FL, S.gsz)); CHK(S.alloc(&st->F, S.gsz)); CHK(S.alloc(&st->fc, S.gsz));
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
