@@ -6,6 +6,7 @@
 set -e -o pipefail
 TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 # 1. per-kernel time of the default bench command (the 32^4 workload alone: no CPU leg, no 48^3x96 leg)
