@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict
 // U_nu(x-nu) (nu != mu) are the same for the three wavefronts with mu != nu -- and they are the workgroup's own links
 // U_mu(x), U_mu(x-mu) of wavefront nu.  Every wavefront therefore loads its own two once, puts them into LDS (8 x 9 KiB),
 // ONE barrier, and reads its six shared operands back from there: 14 global matrix loads per lane instead of 19.
-template <bool CLOSED>
+template <bool CLOSED, bool HALO>
 __global__ void __launch_bounds__(256) k_force_lds(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
                                                    double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk) {
   extern __shared__ double2 smU[];                    // [2 nu + (0: U_nu(x) | 1: U_nu(x-nu))][9][64]
@@ -229,11 +229,11 @@ __global__ void __launch_bounds__(256) k_force_lds(Geom g, const double2 *__rest
   const int c = live ? c0 : g.Vh - 1;                 // padding lanes of the last tile work on a valid site and store nothing
   int x[4], xpm[4], y[4], z[4];
   coords_of(g, c, p, x);
-  shifted(g, x, mu, 1, xpm);
-  const size_t o = link_off(g, x, mu);
+  shifted_t<HALO>(g, x, mu, 1, xpm);
+  const size_t o = link_off_t<HALO>(g, x, mu);
   {
-    shifted(g, x, mu, -1, y);
-    const M3 a = m3_load(G + o, 64), b = m3_load(G + link_off(g, y, mu), 64);
+    shifted_t<HALO>(g, x, mu, -1, y);
+    const M3 a = m3_load(G + o, 64), b = m3_load(G + link_off_t<HALO>(g, y, mu), 64);
     double2 *s0 = smU + (size_t)(2 * mu) * 576 + lane;
 #pragma unroll
     for (int k = 0; k < 9; k++) { s0[k * 64] = a.e[k]; s0[576 + k * 64] = b.e[k]; }
@@ -245,14 +245,14 @@ __global__ void __launch_bounds__(256) k_force_lds(Geom g, const double2 *__rest
     if (nu == mu) continue;
     const double2 *sn = smU + (size_t)(2 * nu) * 576 + lane;
     // forward: U_nu(x) U_mu(x+nu) U_nu(x+mu)^+          (stf[mu,nu], staples.nim:181-183)
-    shifted(g, x, nu, 1, y);
-    M3 t = m3_mul_na(m3_load(G + link_off(g, y, mu), 64), m3_load(G + link_off(g, xpm, nu), 64));
+    shifted_t<HALO>(g, x, nu, 1, y);
+    M3 t = m3_mul_na(m3_load(G + link_off_t<HALO>(g, y, mu), 64), m3_load(G + link_off_t<HALO>(g, xpm, nu), 64));
     m3_mac(acc, m3_load(sn, 64), t);
     // backward: U_nu(x-nu)^+ U_mu(x-nu) U_nu(x-nu+mu)   (stu[mu,nu] shifted down, staples.nim:184-186)
-    shifted(g, x, nu, -1, y);
-    shifted(g, y, mu, 1, z);
-    t = m3_mul_an(m3_load(sn + 576, 64), m3_load(G + link_off(g, y, mu), 64));
-    m3_mac(acc, t, m3_load(G + link_off(g, z, nu), 64));
+    shifted_t<HALO>(g, x, nu, -1, y);
+    shifted_t<HALO>(g, y, mu, 1, z);
+    t = m3_mul_an(m3_load(sn + 576, 64), m3_load(G + link_off_t<HALO>(g, y, mu), 64));
+    m3_mac(acc, t, m3_load(G + link_off_t<HALO>(g, z, nu), 64));
   }
   const M3 U = m3_load(smU + (size_t)(2 * mu) * 576 + lane, 64);
   M3 f = m3_tah(m3_mul_na(U, acc));
@@ -712,12 +712,17 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
       const size_t shb = (size_t)8 * 576 * sizeof(double2);       // 72 KiB: two workgroups per CU, as the registers allow anyway
       static bool attr_done = false;
       if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
-        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
         attr_done = true;
       }
-      if (closed) k_force_lds<true><<<nb, 256, shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, c->gn->P, cf, cpm, Uout, order, chunk);
-      else k_force_lds<false><<<nb, 256, shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, flow ? c->gn->P : nullptr, cf, cpm, Uout, order, chunk);
+      double2 *Pf = (closed || flow) ? c->gn->P : nullptr;
+#define QX_FLDS(CL, HL) k_force_lds<CL, HL><<<nb, 256, shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk)
+      if (closed) { if (c->g.halo) QX_FLDS(true, true); else QX_FLDS(true, false); }
+      else { if (c->g.halo) QX_FLDS(false, true); else QX_FLDS(false, false); }
+#undef QX_FLDS
     } else if (closed)
       k_force<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, c->gn->P, cf, cpm, Uout, order, chunk);
     else
