@@ -646,3 +646,23 @@ def test_multi_rank_code_path_on_one_rank(oracle, naik):
     assert relerr(x2, x1) < 1e-7
     g0 = oracle.gauge_random(A.lo, seed=SEED)
     assert np.max(np.abs(q.plaq(ctx, g0) - q.plaq(A.ctx, g0))) < 1e-15
+
+
+@pytest.mark.parametrize("flow_exp", [1, 0])
+def test_force_and_flow_on_a_lattice_with_a_ragged_last_tile(oracle, flow_exp):
+    """4 x 6 x 10 x 6: 720 sites per parity = 11 tiles of 64 and a quarter.  The force / flow kernels give a whole
+    workgroup (four directions, shared links through LDS, one barrier) to every tile, so the padding lanes of the last
+    tile must go through the barrier and store nothing: force and three flow steps against the oracle."""
+    import qex_amd as q
+
+    lat = [4, 6, 10, 6]
+    lo = oracle.Layout(lat)
+    g = oracle.gauge_random(lo, seed=SEED)
+    ctx = q.Context(lat)
+    ctx.set_option("flow_exp", flow_exp)
+    assert relerr(q.gaugeForce(ctx, g), oracle.gauge_force(lo, g)) < 1e-13
+    gref = g.copy()
+    q.gaugeFlow(ctx, g, 3, 0.02)
+    oracle.wflow(lo, gref, 3, 0.02)
+    assert relerr(g, gref) < 1e-12
+    assert np.max(np.abs(q.plaq(ctx, g) - oracle.plaq(lo, gref))) < 1e-14
