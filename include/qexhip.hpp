@@ -104,6 +104,24 @@ class Context {
   Context(const Context &) = delete;
   Context &operator=(const Context &) = delete;
   std::string info() const { char b[512]; check(qexhip_device_info(h, b, 512)); return b; }
+  // multi-rank set-up as hipSetup of qexhip.nim: rank 0 calls uniqueId(), the host broadcasts it, every rank calls commInit
+  static std::array<char, QEXHIP_UNIQUE_ID_BYTES> uniqueId() {
+    std::array<char, QEXHIP_UNIQUE_ID_BYTES> id{};
+    check(qexhip_comm_unique_id(id.data()));
+    return id;
+  }
+  void commInit(const std::array<char, QEXHIP_UNIQUE_ID_BYTES> &id, int nranks, int rank) { check(qexhip_comm_init(h, id.data(), nranks, rank)); }
+  // what RCCL reports for the communicator + the PCI bus id of the bound GPU
+  struct CommInfo { int nranks, rank, device; std::string busId; };
+  CommInfo commInfo() const {
+    CommInfo ci{0, -1, 0, ""};
+    char bus[64] = "";
+    check(qexhip_comm_info(h, &ci.nranks, &ci.rank, &ci.device, bus, 64));
+    ci.busId = bus;
+    return ci;
+  }
+  void setOption(const char *name, int value) { check(qexhip_set_option(h, name, value)); }   // e.g. "flow_exp", 0
+  static int deviceCount() { int n = 0; check(qexhip_device_count(&n)); return n; }
 };
 
 class Staggered {
