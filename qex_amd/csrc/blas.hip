@@ -146,11 +146,52 @@ int read_scalars(qexhip_ctx *c, const double *dev, int n, double *host) {
 }
 
 // ---------------- CG-specific fused kernels (src/solvers/cg.nim:174-214) ----------------
+// One iteration is three kinds of launch: k_cg_xpay, two Dslash sweeps, k_cg_update.  The end-of-iteration bookkeeping
+// (rzold := rz, r2 := |r|^2, ++itn, history, loop condition; cg.nim:174,194,214-217) is done by the k_cg_xpay that opens
+// the NEXT iteration: every workgroup sums the |r|^2 workgroup partials itself (same fixed order in every workgroup, so
+// all agree bit for bit) and workgroup 0 writes the state of iteration k into slot k&1 of the CgScal while the others
+// still read slot (k-1)&1 -- no launch of its own, no read/write race.  The host passes k; at the end of a chunk of
+// iterations k_cg_close does the same bookkeeping alone so that the host can read the state (`rolled` then tells the
+// next k_cg_xpay that slot k&1 is already written).
+// Sharded, the partial VECTORS are all-reduced (a few KB: the same latency as one double), which keeps the two one-block
+// reduction launches out of the iteration as well.
+__device__ __forceinline__ double cg_sum_parts(const double *parts, int n) {
+  double a = 0;
+  for (int i = threadIdx.x; i < n; i += 256) a += parts[i];
+  return block_sum_256_all(a);
+}
+__device__ __forceinline__ void cg_roll(CgScal *s, int k, double r2k, double *hist, int histcap) {
+  const int cur = k & 1;
+  s->r2s[cur] = r2k;
+  s->itns[cur] = k;
+  s->dones[cur] = !(k < s->maxits && r2k > s->r2stop);
+  if (k < histcap) hist[k] = r2k / s->b2;
+}
+__device__ __forceinline__ void cg_carry(CgScal *s, int k) {   // finished earlier: carry the final state forward
+  const int cur = k & 1, prv = cur ^ 1;
+  s->r2s[cur] = s->r2s[prv];
+  s->itns[cur] = s->itns[prv];
+  s->dones[cur] = 1;
+}
 // q := z (itn 0) | q := z + beta*q, beta = rz/rzo   (cg.nim:186-193; cpNone: z=r, q=p)
-__global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, size_t n, const CgScal *s) {
-  if (s->done) return;
-  const bool first = (s->itn == 0);
-  const double beta = s->r2 / s->rzo;
+__global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, size_t n, CgScal *s, int k, int rolled,
+                                                const double *r2parts, int nparts, double *hist, int histcap) {
+  const int cur = k & 1, prv = cur ^ 1;
+  double r2k;
+  if (rolled) {
+    if (s->dones[cur]) return;
+    r2k = s->r2s[cur];
+  } else {
+    if (s->dones[prv]) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) cg_carry(s, k);
+      return;
+    }
+    r2k = cg_sum_parts(r2parts, nparts);
+    if (blockIdx.x == 0 && threadIdx.x == 0) cg_roll(s, k, r2k, hist, histcap);
+    if (!(k < s->maxits && r2k > s->r2stop)) return;
+  }
+  const bool first = (k == 0);
+  const double beta = r2k / s->r2s[prv];
   for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     double2 rv = r[i];
     if (first) p[i] = rv;
@@ -161,20 +202,13 @@ __global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, s
   }
 }
 // alpha = rz/qLAp; x += alpha*p; r -= alpha*Ap; partial |r|^2   (cg.nim:208-213)
-// With ndot > 0 (single rank) every workgroup first sums the <p,Ap> workgroup partials of the
-// preceding Dslash sweep itself -- same fixed order in every workgroup, so all agree bit for bit --
-// which removes the separate reduction launch from the iteration.
+// With ndot > 0 every workgroup first sums the <p,Ap> workgroup partials of the preceding Dslash sweep itself.
 __global__ void __launch_bounds__(256) k_cg_update(double2 *x, double2 *r, const double2 *p, const double2 *Ap,
-                                                  size_t n, const CgScal *s, double *partials,
+                                                  size_t n, const CgScal *s, int k, double *partials,
                                                   const double *dotp, int ndot) {
-  if (s->done) return;
-  double pAp = s->pAp;
-  if (ndot > 0) {
-    double a = 0;
-    for (int i = threadIdx.x; i < ndot; i += 256) a += dotp[i];
-    pAp = block_sum_256_all(a);
-  }
-  const double alpha = s->r2 / pAp;
+  if (s->dones[k & 1]) return;
+  const double pAp = (ndot > 0) ? cg_sum_parts(dotp, ndot) : s->pAp;
+  const double alpha = s->r2s[k & 1] / pAp;
   double acc = 0;
   for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     double2 pv = p[i], xv = x[i], rv = r[i], av = Ap[i];
@@ -196,67 +230,46 @@ __global__ void k_cg_init(CgScal *s, const double *dscal, double r2req, int maxi
   s->itn = 0;
   s->maxits = maxits;
   s->done = !(0 < maxits && s->r2 > s->r2stop);
+  s->r2s[0] = s->r2; s->itns[0] = 0; s->dones[0] = s->done;
+  s->r2s[1] = 1.0; s->itns[1] = 0; s->dones[1] = s->done;
   if (histcap > 0) hist[0] = (s->b2 != 0.0) ? s->r2 / s->b2 : 0.0;
 }
-// end of iteration: rzo = rz; ++itn; r2 = |r|^2; history; loop condition
-__global__ void k_cg_finish(CgScal *s, double *hist, int histcap) {
-  if (s->done) return;
-  s->rzo = s->r2;
-  s->r2 = s->tmp;
-  s->itn += 1;
-  if (s->itn < histcap) hist[s->itn] = s->r2 / s->b2;
-  if (!(s->itn < s->maxits && s->r2 > s->r2stop)) s->done = 1;
-}
-// single rank: final sum of the |r|^2 partials and the end-of-iteration bookkeeping in one launch
-__global__ void __launch_bounds__(256) k_cg_reduce_finish(const double *partials, int n, CgScal *s, double *hist, int histcap) {
-  if (s->done) return;
-  double acc = 0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
-  double r = block_sum_256(acc);
-  if (threadIdx.x == 0) {
-    s->rzo = s->r2;
-    s->r2 = r;
-    s->itn += 1;
-    if (s->itn < histcap) hist[s->itn] = s->r2 / s->b2;
-    if (!(s->itn < s->maxits && s->r2 > s->r2stop)) s->done = 1;
+// end of a chunk: the bookkeeping of the last iteration, so that the host can read slot k&1
+__global__ void __launch_bounds__(256) k_cg_close(CgScal *s, int k, const double *r2parts, int nparts, double *hist, int histcap) {
+  if (s->dones[(k & 1) ^ 1]) {
+    if (threadIdx.x == 0) cg_carry(s, k);
+    return;
   }
-}
-__global__ void __launch_bounds__(256) k_reduce_cg(const double *partials, int n, double *out, const CgScal *s) {
-  if (s->done) return;
-  double acc = 0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
-  double r = block_sum_256(acc);
-  if (threadIdx.x == 0) *out = r;
+  double r2k = cg_sum_parts(r2parts, nparts);
+  if (threadIdx.x == 0) cg_roll(s, k, r2k, hist, histcap);
 }
 
-int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity) {
+int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity, int k, int rolled) {
   size_t n = body2(c);
   ScopedTimer tm(c, "blas", c->stream);
-  k_cg_xpay<<<grid_for(n), 256, 0, c->stream>>>(p.par(parity), r.par(parity), n, c->cg);
+  k_cg_xpay<<<grid_for(n), 256, 0, c->stream>>>(p.par(parity), r.par(parity), n, c->cg, k, rolled,
+                                               c->partials + c->part2_off, grid_for(n), c->hist, c->histcap);
   HIPCHK(hipGetLastError());
   return 0;
 }
-// ndot > 0: <p,Ap> is still in workgroup partials c->partials[0..ndot) (deferred, single rank);
-// the |r|^2 partials go to the upper part of the buffer.
-int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity, int ndot) {
+// ndot > 0: <p,Ap> is still in workgroup partials c->partials[0..ndot) (deferred); the |r|^2 partials go to the upper
+// part of the buffer and stay there for the next k_cg_xpay / k_cg_close.
+int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity, int k, int ndot) {
   size_t n = body2(c);
   int nb = grid_for(n);
   double *r2p = c->partials + c->part2_off;
+  if (multi_rank(c) && ndot > 0) CHK(comm_allreduce(c, c->partials, ndot));
   {
     ScopedTimer tm(c, "blas", c->stream);
-    k_cg_update<<<nb, 256, 0, c->stream>>>(x.par(parity), r.par(parity), p.par(parity), Ap.par(parity), n, c->cg, r2p,
+    k_cg_update<<<nb, 256, 0, c->stream>>>(x.par(parity), r.par(parity), p.par(parity), Ap.par(parity), n, c->cg, k, r2p,
                                            c->partials, ndot);
     HIPCHK(hipGetLastError());
   }
-  ScopedTimer tm(c, "reduce", c->stream);
-  if (multi_rank(c)) {
-    k_reduce_cg<<<1, 256, 0, c->stream>>>(r2p, nb, &c->cg->tmp, c->cg);
-    HIPCHK(hipGetLastError());
-    CHK(comm_allreduce(c, &c->cg->tmp, 1));
-    k_cg_finish<<<1, 1, 0, c->stream>>>(c->cg, c->hist, c->histcap);
-  } else {
-    k_cg_reduce_finish<<<1, 256, 0, c->stream>>>(r2p, nb, c->cg, c->hist, c->histcap);
-  }
+  if (multi_rank(c)) CHK(comm_allreduce(c, r2p, nb));
+  return 0;
+}
+int cg_close(qexhip_ctx *c, int k) {
+  k_cg_close<<<1, 256, 0, c->stream>>>(c->cg, k, c->partials + c->part2_off, grid_for(body2(c)), c->hist, c->histcap);
   HIPCHK(hipGetLastError());
   return 0;
 }

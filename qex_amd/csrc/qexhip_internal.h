@@ -50,6 +50,10 @@ struct DevField {  // full-volume colour vector: parity halves, each with its gh
 struct CgScal {
   double b2, r2, rzo, pAp, r2stop, tmp;
   int itn, maxits, done, pad;
+  // plain CG (blas.hip): state after k iterations in slot k&1, so that the kernel which closes iteration k-1 can
+  // write slot k&1 while its other workgroups still read slot (k-1)&1
+  double r2s[2];
+  int itns[2], dones[2];
 };
 
 struct TimerSlot {
@@ -202,8 +206,9 @@ int reduce_partials(qexhip_ctx *c, int n, double *dev_out);  // sum partials[0..
 int read_scalars(qexhip_ctx *c, const double *dev, int n, double *host);  // sync readback
 int blas_grid(const qexhip_ctx *c, int parity_count);
 // CG fused kernels
-int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity);
-int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity, int ndot);
+int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity, int k, int rolled);
+int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity, int k, int ndot);
+int cg_close(qexhip_ctx *c, int k);
 int cg_init(qexhip_ctx *c, double r2req, int maxits);  // after b2 (dscal[0]) and r2 (dscal[1]) are known
 
 // ---- solver.cpp ----

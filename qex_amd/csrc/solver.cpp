@@ -106,19 +106,27 @@ int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2
   CHK(cg_init(c, r2req, maxits));
   CgScal st;
   CHK(read_cg(c, &st));
-  int chunk = 32;
-  while (!st.done) {
-    int n = std::min(chunk, st.maxits - st.itn);
+  int chunk = 32, k = 0, rolled = 1;              // k_cg_init wrote slot 0
+  bool done = st.dones[0];
+  double r2 = st.r2s[0];
+  while (!done) {
+    int n = std::min(chunk, st.maxits - k);
     if (n <= 0) break;
-    for (int i = 0; i < n; i++) {
-      CHK(cg_xpay(c, *p, *r, par));                                   // cg.nim:186-193
-      int ndot = 0;                                                   // single rank: <p,Ap> partials are
-      CHK(op_xx(c, *Ap, *p, m2, par_even, 1, &c->cg->done,            // summed inside cg_update
-                multi_rank(c) ? nullptr : &ndot));                    // cg.nim:200, qLAp :206
-      CHK(cg_update(c, x, *r, *p, *Ap, par, ndot));                   // cg.nim:208-213 + loop bookkeeping
+    for (int i = 0; i < n; i++, k++) {
+      CHK(cg_xpay(c, *p, *r, par, k, rolled));                        // cg.nim:186-193 (+ bookkeeping of k-1)
+      rolled = 0;
+      int ndot = 0;                                                   // <p,Ap> partials are summed inside
+      CHK(op_xx(c, *Ap, *p, m2, par_even, 1, &c->cg->dones[k & 1], &ndot));   // cg_update; cg.nim:200, qLAp :206
+      CHK(cg_update(c, x, *r, *p, *Ap, par, k, ndot));                // cg.nim:208-213
     }
+    CHK(cg_close(c, k));
+    rolled = 1;
     CHK(read_cg(c, &st));
+    done = st.dones[k & 1];
+    r2 = st.r2s[k & 1];
+    st.itn = st.itns[k & 1];
   }
+  st.r2 = r2;
   if (iters) *iters = st.itn;
   if (r2_over_b2) *r2_over_b2 = (st.b2 != 0.0) ? st.r2 / st.b2 : 0.0;
   if (hist && histcap > 0) {
