@@ -43,16 +43,8 @@ __global__ void __launch_bounds__(256) k_cgm_base(double2 *x, double2 *r, const 
   double t = block_sum_256(acc);
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
-// sharded runs: local |r|^2 (and, single launch, the local <p,Ap> when it was deferred) before the all-reduce
-__global__ void __launch_bounds__(256) k_cgm_local_sum(const double *partials, int n, CgScal *s) {
-  if (s->done) return;
-  double acc = 0;
-  for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
-  double r = block_sum_256(acc);
-  if (threadIdx.x == 0) s->tmp = r;
-}
-// One workgroup closes the iteration: final sum of the |r|^2 partials (n > 0; n == 0: s->tmp already holds the
-// all-reduced value), alpha / beta, the loop condition, and the zeta recurrences of cgm.nim:253-266 -- thread k owns
+// One workgroup closes the iteration: final sum of the |r|^2 partials (sharded: the all-reduced partial vector; n == 0:
+// s->tmp holds the value), alpha / beta, the loop condition, and the zeta recurrences of cgm.nim:253-266 -- thread k owns
 // shift k.  `pending` tells the following k_cgm_update that this iteration is live: it has to run once more after
 // the loop condition has turned false (xs[m] += alpha zr ps[m] is outside `if continuing`), so it cannot key on
 // s->done; a later, dead pass through this kernel clears the flag again.
@@ -219,23 +211,20 @@ int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, 
     int nn = std::min(32, std::max(1, st.maxits - st.itn));
     for (int i = 0; i < nn; i++) {
       int ndot = 0;
-      CHK(op_xx(c, *Ap, *ps[0], m2, par_even, 1, &c->cg->done, sharded ? nullptr : &ndot));
+      CHK(op_xx(c, *Ap, *ps[0], m2, par_even, 1, &c->cg->done, &ndot));
+      // sharded: the workgroup partials themselves are all-reduced (a few KB, the latency of one double), so the
+      // iteration needs no one-block reduction launches; ndot == 0: big local volume, op_xx has reduced <p,Ap> already
+      if (sharded && ndot > 0) CHK(comm_allreduce(c, c->partials, ndot));
       {
         ScopedTimer tm(c, "blas", c->stream);
         k_cgm_base<<<nb, 256, 0, c->stream>>>(xs[0]->par(par), r->par(par), ps[0]->par(par), Ap->par(par), n, c->cg, r2p,
                                               c->partials, ndot);
         HIPCHK(hipGetLastError());
       }
+      if (sharded) CHK(comm_allreduce(c, r2p, nb));
       {
         ScopedTimer tm(c, "reduce", c->stream);
-        if (sharded) {
-          k_cgm_local_sum<<<1, 256, 0, c->stream>>>(r2p, nb, c->cg);
-          HIPCHK(hipGetLastError());
-          CHK(comm_allreduce(c, &c->cg->tmp, 1));
-          k_cgm_close<<<1, 256, 0, c->stream>>>(r2p, 0, c->partials, 0, c->cg, g_cgm_dev, c->hist, c->histcap);
-        } else {
-          k_cgm_close<<<1, 256, 0, c->stream>>>(r2p, nb, c->partials, ndot, c->cg, g_cgm_dev, c->hist, c->histcap);
-        }
+        k_cgm_close<<<1, 256, 0, c->stream>>>(r2p, nb, c->partials, ndot, c->cg, g_cgm_dev, c->hist, c->histcap);
         HIPCHK(hipGetLastError());
       }
       ScopedTimer tm(c, "cgm_update", c->stream);

@@ -232,6 +232,39 @@ __global__ void __launch_bounds__(256) k_projUderiv(Geom g, MViewW dst, MView U,
   for (int k = 0; k < 9; k++) { r.e[k].x *= alp; r.e[k].y *= alp; }
   m3_store(dst.p + t * dst.tstride + l, 64, r);
 }
+// The projUderiv calls of one level in ONE launch: blockIdx.y = mu, and a lane walks the nn constituents (mu; nu_j) of its
+// link in the order the separate launches had (so f[mu] accumulates bit for bit the same) -- f[mu] is read and written
+// once instead of nn times (1584 instead of 2160 B per site and direction at nn = 3), 3 launches instead of 28 per chain
+struct ProjBatch {
+  MViewW dst[4][3];
+  MView X[4][3], C[4][3];
+  MViewW f[4];
+  int nn, accumulate;
+  double ma, alp;
+};
+__global__ void __launch_bounds__(256) k_projUderiv_batch(Geom g, ProjBatch B) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.V) return;
+  const int mu = blockIdx.y;
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  const size_t t = (size_t)p * g.etile + (c >> 6);
+  const int l = c & 63;
+  const MViewW f = B.f[mu];
+  M3 o = B.accumulate ? m3_load(f.p + t * f.tstride + l, 64) : m3_zero();
+#pragma unroll 1
+  for (int j = 0; j < B.nn; j++) {
+    const MView X = B.X[mu][j], C = B.C[mu][j];
+    const MViewW dst = B.dst[mu][j];
+    const M3 x = m3_load(X.p + t * X.tstride + l, 64);
+    const M3 ch = m3_load(C.p + t * C.tstride + l, 64);
+    M3 r = m3_projectUderiv(x, ch);
+    m3_axpy(o, B.ma, r);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { r.e[k].x *= B.alp; r.e[k].y *= B.alp; }
+    m3_store(dst.p + t * dst.tstride + l, 64, r);
+  }
+  m3_store(f.p + t * f.tstride + l, 64, o);
+}
 // symStapleDeriv (smearutil.nim:22-50) gathered per site:
 //   f1(x) += g2(x) g1(x+mu) c(x+nu)^+ + c(x) g1(x+mu) g2(x+nu)^+ + [g2^+ g1 c(+nu) + c^+ g1 g2(+nu)](x-mu)
 //   f2(x) += g1(x) c(x+nu) g1(x+mu)^+ + [g1^+ c g1(+mu)](x-nu)
@@ -831,9 +864,20 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
   ScopedTimer tm(c, "nhyp_force", c->stream);
   // fl1 / fl2 are sums of several staple derivatives: the first contribution to each writes, the rest accumulate
   bool t1[4][4] = {}, t2[4][4] = {};
-  for (int mu = 0; mu < 4; mu++) {
-    k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->fc, mu), noU, S.gv(st->K.flx, mu), S.gv(st->F, mu),
-                                              S.gvw(st->F, mu), ma3, alp3, 0);
+  static const int batch = getenv("QEXHIP_PROJ_BATCH") ? atoi(getenv("QEXHIP_PROJ_BATCH")) : 1;
+  ProjBatch PB;
+  if (batch) {
+    for (int mu = 0; mu < 4; mu++) {
+      PB.dst[mu][0] = S.gvw(st->fc, mu); PB.X[mu][0] = S.gv(st->K.flx, mu); PB.C[mu][0] = S.gv(st->F, mu);
+      PB.f[mu] = S.gvw(st->F, mu);
+    }
+    PB.nn = 1; PB.accumulate = 0; PB.ma = ma3; PB.alp = alp3;
+    k_projUderiv_batch<<<dim3(nblk, 4), 256, 0, c->stream>>>(g, PB);
+  } else {
+    for (int mu = 0; mu < 4; mu++) {
+      k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->fc, mu), noU, S.gv(st->K.flx, mu), S.gv(st->F, mu),
+                                                S.gvw(st->F, mu), ma3, alp3, 0);
+    }
   }
   HIPCHK(hipGetLastError());
   CHK(S.ghosts_g(st->fc));          // t-sharded: a chain field is read at shifted sites by the staple derivative
@@ -844,13 +888,31 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
       t2[nu][mu] = t2[mu][nu] = true;
     }
   HIPCHK(hipGetLastError());
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) {
-      if (nu == mu) continue;
-      k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[mu][nu]), S.fv(st->K.l2x[mu][nu]),
-                                                S.fv(st->fl2[mu][nu]), S.gvw(st->F, mu), ma2, alp2, 1);
-      CHK(S.ghosts_f(st->fl2[mu][nu]));
+  if (batch) {
+    for (int mu = 0; mu < 4; mu++) {
+      int j = 0;
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        PB.dst[mu][j] = S.fvw(st->fl2[mu][nu]); PB.X[mu][j] = S.fv(st->K.l2x[mu][nu]); PB.C[mu][j] = S.fv(st->fl2[mu][nu]);
+        j++;
+      }
+      PB.f[mu] = S.gvw(st->F, mu);
     }
+    PB.nn = 3; PB.accumulate = 1; PB.ma = ma2; PB.alp = alp2;
+    k_projUderiv_batch<<<dim3(nblk, 4), 256, 0, c->stream>>>(g, PB);
+    HIPCHK(hipGetLastError());
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++)
+        if (nu != mu) CHK(S.ghosts_f(st->fl2[mu][nu]));
+  } else {
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[mu][nu]), S.fv(st->K.l2x[mu][nu]),
+                                                  S.fv(st->fl2[mu][nu]), S.gvw(st->F, mu), ma2, alp2, 1);
+        CHK(S.ghosts_f(st->fl2[mu][nu]));
+      }
+  }
   HIPCHK(hipGetLastError());
   // the call (mu, nu, a) and its partner (a, nu, mu) share b = 6 - mu - nu - a and exchange the roles of their fields
   for (int mu = 0; mu < 4; mu++)
@@ -863,13 +925,31 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
         t1[a][b] = t1[mu][b] = true;
       }
   HIPCHK(hipGetLastError());
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = 0; nu < 4; nu++) {
-      if (nu == mu) continue;
-      k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl1[mu][nu]), S.fv(st->K.l1[mu][nu]), S.fv(st->K.l1x[mu][nu]),
-                                                S.fv(st->fl1[mu][nu]), S.gvw(st->F, mu), ma1, alp1, 1);
-      CHK(S.ghosts_f(st->fl1[mu][nu]));
+  if (batch) {
+    for (int mu = 0; mu < 4; mu++) {
+      int j = 0;
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        PB.dst[mu][j] = S.fvw(st->fl1[mu][nu]); PB.X[mu][j] = S.fv(st->K.l1x[mu][nu]); PB.C[mu][j] = S.fv(st->fl1[mu][nu]);
+        j++;
+      }
+      PB.f[mu] = S.gvw(st->F, mu);
     }
+    PB.nn = 3; PB.accumulate = 1; PB.ma = ma1; PB.alp = alp1;
+    k_projUderiv_batch<<<dim3(nblk, 4), 256, 0, c->stream>>>(g, PB);
+    HIPCHK(hipGetLastError());
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++)
+        if (nu != mu) CHK(S.ghosts_f(st->fl1[mu][nu]));
+  } else {
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = 0; nu < 4; nu++) {
+        if (nu == mu) continue;
+        k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl1[mu][nu]), S.fv(st->K.l1[mu][nu]), S.fv(st->K.l1x[mu][nu]),
+                                                  S.fv(st->fl1[mu][nu]), S.gvw(st->F, mu), ma1, alp1, 1);
+        CHK(S.ghosts_f(st->fl1[mu][nu]));
+      }
+  }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
     for (int nu = mu + 1; nu < 4; nu++)
