@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict
 // ONE barrier, and reads its six shared operands back from there: 14 global matrix loads per lane instead of 19.
 template <bool CLOSED, bool HALO>
 __global__ void __launch_bounds__(256) k_force_lds(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
-                                                   double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk) {
+                                                   double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk, int nt) {
   extern __shared__ double2 smU[];                    // [2 nu + (0: U_nu(x) | 1: U_nu(x-nu))][9][64]
   const int e = order[(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)];
   if (e < 0) return;                                  // the whole workgroup together
@@ -261,19 +261,22 @@ __global__ void __launch_bounds__(256) k_force_lds(Geom g, const double2 *__rest
     M3 v;
     const double cfp = cf * cp;
     if (cpm != 0.0) {
-      const M3 pm = m3_load(Pm + o, 64);
+      const M3 pm = nt ? m3_load_nt(Pm + o, 64) : m3_load(Pm + o, 64);
 #pragma unroll
       for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x + cpm * pm.e[k].x, cfp * f.e[k].y + cpm * pm.e[k].y);
     } else {
 #pragma unroll
       for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x, cfp * f.e[k].y);
     }
-    m3_store(Pm + o, 64, v);
-    if (Uout) m3_store(Uout + o, 64, m3_mul(CLOSED ? m3_exp_tah(v) : m3_exp(v), U));
+    if (nt) m3_store_nt(Pm + o, 64, v); else m3_store(Pm + o, 64, v);
+    if (Uout) {
+      const M3 un = m3_mul(CLOSED ? m3_exp_tah(v) : m3_exp(v), U);
+      if (nt) m3_store_nt(Uout + o, 64, un); else m3_store(Uout + o, 64, un);
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 9; k++) { f.e[k].x *= cp; f.e[k].y *= cp; }
-    m3_store(F + o, 64, f);
+    if (nt) m3_store_nt(F + o, 64, f); else m3_store(F + o, 64, f);
   }
 }
 
@@ -719,7 +722,8 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
         attr_done = true;
       }
       double2 *Pf = (closed || flow) ? c->gn->P : nullptr;
-#define QX_FLDS(CL, HL) k_force_lds<CL, HL><<<nb, 256, shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk)
+      static const int fnt = [] { const char *e = getenv("QEXHIP_FORCE_NT"); return e ? atoi(e) : 1; }();
+#define QX_FLDS(CL, HL) k_force_lds<CL, HL><<<nb, 256, shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk, fnt)
       if (closed) { if (c->g.halo) QX_FLDS(true, true); else QX_FLDS(true, false); }
       else { if (c->g.halo) QX_FLDS(false, true); else QX_FLDS(false, false); }
 #undef QX_FLDS

@@ -77,7 +77,7 @@ static int smear_order(qexhip_ctx *c, const Geom &g, const int **order, int *chu
 // (the `l.proj lx` that follows the last staple of a level).
 template <bool HALO>
 __global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, int swz,
-                                                    MView init, double cinit, MViewW proj, const int *order, int chunk) {
+                                                    MView init, double cinit, MViewW proj, const int *order, int chunk, int nt) {
   int p, c;
   if (order) {   // blocked visiting order (tile_order_table): wavefront w takes slot 4*(b>>3)+w of XCD b&7
     const int slot = 4 * (blockIdx.x >> 3) + (threadIdx.x >> 6);
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, in
   M3 u = m3_mul(t, m3_load(A.p + site_off_t<HALO>(g, xmnpm, A.tstride), 64));
 #pragma unroll
   for (int k = 0; k < 9; k++) { s.e[k].x += u.e[k].x; s.e[k].y += u.e[k].y; }
-  if (st.p) m3_store(st.p + site_off_t<HALO>(g, x, st.tstride), 64, s);
+  if (st.p) { if (nt) m3_store_nt(st.p + site_off_t<HALO>(g, x, st.tstride), 64, s); else m3_store(st.p + site_off_t<HALO>(g, x, st.tstride), 64, s); }
   if (acc.p) {
     double2 *a = acc.p + site_off_t<HALO>(g, x, acc.tstride);
     M3 o;
@@ -113,11 +113,14 @@ __global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, in
 #pragma unroll
       for (int k = 0; k < 9; k++) { o.e[k].x *= cinit; o.e[k].y *= cinit; }
     } else {
-      o = m3_load(a, 64);
+      o = nt ? m3_load_nt(a, 64) : m3_load(a, 64);
     }
     m3_axpy(o, coef, s);
-    m3_store(a, 64, o);
-    if (proj.p) m3_store(proj.p + site_off_t<HALO>(g, x, proj.tstride), 64, m3_projectU(o));
+    if (nt) m3_store_nt(a, 64, o); else m3_store(a, 64, o);
+    if (proj.p) {
+      const M3 pr = m3_projectU(o);
+      if (nt) m3_store_nt(proj.p + site_off_t<HALO>(g, x, proj.tstride), 64, pr); else m3_store(proj.p + site_off_t<HALO>(g, x, proj.tstride), 64, pr);
+    }
   }
 }
 // dst += coef * src
@@ -239,7 +242,7 @@ struct ProjBatch {
   MViewW dst[4][3];
   MView X[4][3], C[4][3];
   MViewW f[4];
-  int nn, accumulate;
+  int nn, accumulate, nt;
   double ma, alp;
 };
 __global__ void __launch_bounds__(256) k_projUderiv_batch(Geom g, ProjBatch B) {
@@ -250,20 +253,21 @@ __global__ void __launch_bounds__(256) k_projUderiv_batch(Geom g, ProjBatch B) {
   const size_t t = (size_t)p * g.etile + (c >> 6);
   const int l = c & 63;
   const MViewW f = B.f[mu];
-  M3 o = B.accumulate ? m3_load(f.p + t * f.tstride + l, 64) : m3_zero();
+  const int nt = B.nt;
+  M3 o = B.accumulate ? (nt ? m3_load_nt(f.p + t * f.tstride + l, 64) : m3_load(f.p + t * f.tstride + l, 64)) : m3_zero();
 #pragma unroll 1
   for (int j = 0; j < B.nn; j++) {
     const MView X = B.X[mu][j], C = B.C[mu][j];
     const MViewW dst = B.dst[mu][j];
-    const M3 x = m3_load(X.p + t * X.tstride + l, 64);
-    const M3 ch = m3_load(C.p + t * C.tstride + l, 64);
+    const M3 x = nt ? m3_load_nt(X.p + t * X.tstride + l, 64) : m3_load(X.p + t * X.tstride + l, 64);
+    const M3 ch = nt ? m3_load_nt(C.p + t * C.tstride + l, 64) : m3_load(C.p + t * C.tstride + l, 64);
     M3 r = m3_projectUderiv(x, ch);
     m3_axpy(o, B.ma, r);
 #pragma unroll
     for (int k = 0; k < 9; k++) { r.e[k].x *= B.alp; r.e[k].y *= B.alp; }
-    m3_store(dst.p + t * dst.tstride + l, 64, r);
+    if (nt) m3_store_nt(dst.p + t * dst.tstride + l, 64, r); else m3_store(dst.p + t * dst.tstride + l, 64, r);
   }
-  m3_store(f.p + t * f.tstride + l, 64, o);
+  if (nt) m3_store_nt(f.p + t * f.tstride + l, 64, o); else m3_store(f.p + t * f.tstride + l, 64, o);
 }
 // symStapleDeriv (smearutil.nim:22-50) gathered per site:
 //   f1(x) += g2(x) g1(x+mu) c(x+nu)^+ + c(x) g1(x+mu) g2(x+nu)^+ + [g2^+ g1 c(+nu) + c^+ g1 g2(+nu)](x-mu)
@@ -354,7 +358,7 @@ __global__ void __launch_bounds__(256, WPE) k_staple_deriv(Geom g, MViewW f1, MV
 // form), so the smaller working set is worth more than the duplicated corner products cost.
 template <bool HALO>
 __global__ void __launch_bounds__(256) k_staple_deriv_pair(Geom g, MViewW F1, MViewW F2, MView g1, MView g2, MView cA, MView cB, int mu, int nu,
-                                                          int z1, int z2, const int *order, int chunk) {
+                                                          int z1, int z2, const int *order, int chunk, int nt) {
   const int wv = threadIdx.x >> 6;
   const int slot = 2 * (blockIdx.x >> 3) + (wv >> 1);
   const int e = slot < chunk ? order[(blockIdx.x & 7) * chunk + slot] : -1;
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(256) k_staple_deriv_pair(Geom g, MViewW F1, MV
 #define LD(F, X) m3_load((F).p + site_off_t<HALO>(g, X, (F).tstride), 64)
 #define LD0(F) m3_load((F).p + o0 * (F).tstride + l, 64)
 #define FENCE() __builtin_amdgcn_sched_barrier(0)   /* keep the loads of the next group from being hoisted above this one */
-  M3 a = zo ? m3_zero() : LD0(Fo);
+  M3 a = zo ? m3_zero() : (nt ? m3_load_nt(Fo.p + o0 * Fo.tstride + l, 64) : LD0(Fo));
   {
     M3 T, S;
     {
@@ -411,7 +415,8 @@ __global__ void __launch_bounds__(256) k_staple_deriv_pair(Geom g, MViewW F1, MV
     FENCE();
     m3_mac_an(a, LD(ca, xmm), S);
   }
-  m3_store(Fo.p + o0 * Fo.tstride + l, 64, a);
+  if (nt) m3_store_nt(Fo.p + o0 * Fo.tstride + l, 64, a);
+  else m3_store(Fo.p + o0 * Fo.tstride + l, 64, a);
 #undef LD
 #undef LD0
 #undef FENCE
@@ -571,8 +576,9 @@ struct Smear {
     // 4 MB L2, and fewer tiles in flight keep the lines its wavefronts share alive: nHYP smearing 7.27 -> 6.70 ms at 32^4
     // (45 KB: 7.14, 100 KB = one workgroup per CU: 7.41).  QEXHIP_STAPLE_LDS=0 switches it off.
     static const int ldsb = [] { const char *e = getenv("QEXHIP_STAPLE_LDS"); return e ? atoi(e) : 60000; }();
-    if (g.halo) k_gen_staple<true><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk);
-    else k_gen_staple<false><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk);
+    static const int gnt = [] { const char *e = getenv("QEXHIP_STAPLE_NT"); return e ? atoi(e) : 1; }();
+    if (g.halo) k_gen_staple<true><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk, gnt);
+    else k_gen_staple<false><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk, gnt);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -849,8 +855,9 @@ static int staple_deriv_pair(qexhip_ctx *c, const Geom &g, MViewW F1, MViewW F2,
     return staple_deriv(c, g, F2, F1, g2, g1, cB, nu, mu, 0, 0);
   }
   const int nb2 = 8 * ((chunk + 1) / 2);         // two wavefronts per tile: 2 table slots per 256-thread workgroup
-  if (g.halo) k_staple_deriv_pair<true><<<nb2, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk);
-  else k_staple_deriv_pair<false><<<nb2, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk);
+  static const int nt = [] { const char *e = getenv("QEXHIP_SDERIV_NT"); return e ? atoi(e) : 1; }();
+  if (g.halo) k_staple_deriv_pair<true><<<nb2, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk, nt);
+  else k_staple_deriv_pair<false><<<nb2, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk, nt);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -866,6 +873,7 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
   bool t1[4][4] = {}, t2[4][4] = {};
   static const int batch = getenv("QEXHIP_PROJ_BATCH") ? atoi(getenv("QEXHIP_PROJ_BATCH")) : 1;
   ProjBatch PB;
+  PB.nt = getenv("QEXHIP_PROJ_NT") ? atoi(getenv("QEXHIP_PROJ_NT")) : 1;
   if (batch) {
     for (int mu = 0; mu < 4; mu++) {
       PB.dst[mu][0] = S.gvw(st->fc, mu); PB.X[mu][0] = S.gv(st->K.flx, mu); PB.C[mu][0] = S.gv(st->F, mu);

@@ -25,6 +25,27 @@ __host__ __device__ __forceinline__ void m3_store(double2 *p, int stride, const 
 #pragma unroll
   for (int k = 0; k < 9; k++) p[(size_t)k * stride] = a.e[k];
 }
+#if defined(__HIPCC__)
+// streaming forms for data nobody reads again soon (an accumulator's read-modify-write): they leave the L2 to the operands
+// that neighbouring sites share
+typedef double m3_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ M3 m3_load_nt(const double2 *p, int stride) {
+  M3 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    m3_d2v t = __builtin_nontemporal_load((const m3_d2v *)&p[(size_t)k * stride]);
+    r.e[k] = make_double2(t.x, t.y);
+  }
+  return r;
+}
+__device__ __forceinline__ void m3_store_nt(double2 *p, int stride, const M3 &a) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    m3_d2v t = {a.e[k].x, a.e[k].y};
+    __builtin_nontemporal_store(t, (m3_d2v *)&p[(size_t)k * stride]);
+  }
+}
+#endif
 // The products are written as chained multiply-adds (s += a*b; s -= c*d; ...) so that hipcc
 // contracts every term into one v_fma_f64: 4 FMAs per complex multiply-accumulate, 108 per 3x3
 // product (a `cmul` temporary followed by an add costs 6 instructions per term).
