@@ -212,7 +212,22 @@ __host__ __device__ __forceinline__ M3 m3_exp_tah(const M3 &v) {
   M3 Q, Q2;
 #pragma unroll
   for (int k = 0; k < 9; k++) Q.e[k] = make_double2(v.e[k].y, -v.e[k].x);
-  Q2 = m3_mul(Q, Q);
+  // Q Hermitian => Q2 Hermitian: three off-diagonal products and the three row norms instead of nine products
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double d = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) d = fma(Q.e[3 * i + k].x, Q.e[3 * i + k].x, fma(Q.e[3 * i + k].y, Q.e[3 * i + k].y, d));
+    Q2.e[4 * i] = make_double2(d, 0.0);
+#pragma unroll
+    for (int j = i + 1; j < 3; j++) {
+      double sx = 0.0, sy = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) M3_MAC(sx, sy, Q.e[3 * i + k].x, Q.e[3 * i + k].y, Q.e[3 * k + j].x, Q.e[3 * k + j].y);
+      Q2.e[3 * i + j] = make_double2(sx, sy);
+      Q2.e[3 * j + i] = make_double2(sx, -sy);
+    }
+  }
   const double c1 = 0.5 * (Q2.e[0].x + Q2.e[4].x + Q2.e[8].x);
   // c0 = det Q = tr(Q^3)/3 = Re tr(Q Q2)/3
   double t3 = 0.0;
@@ -238,12 +253,14 @@ __host__ __device__ __forceinline__ M3 m3_exp_tah(const M3 &v) {
   const double c13 = c1 * (1.0 / 3.0);
   const double c0max = 2.0 * c13 * sqrt(c13);
   const double th = acos(fmin(1.0, c0 / c0max));
-  const double u = sqrt(c13) * cos(th * (1.0 / 3.0));
-  const double w = sqrt(c1) * sin(th * (1.0 / 3.0));
+  double st3, ct3, sw, cw, su, cu;                 // one range reduction per angle
+  sincos(th * (1.0 / 3.0), &st3, &ct3);
+  const double u = sqrt(c13) * ct3;
+  const double w = sqrt(c1) * st3;
   const double w2 = w * w, u2 = u * u;
-  const double xi0 = fabs(w) < 0.05 ? 1.0 - w2 * (1.0 / 6.0) * (1.0 - w2 * (1.0 / 20.0) * (1.0 - w2 * (1.0 / 42.0))) : sin(w) / w;
-  const double cw = cos(w);
-  const double cu = cos(u), su = sin(u);
+  sincos(w, &sw, &cw);
+  const double xi0 = fabs(w) < 0.05 ? 1.0 - w2 * (1.0 / 6.0) * (1.0 - w2 * (1.0 / 20.0) * (1.0 - w2 * (1.0 / 42.0))) : sw / w;
+  sincos(u, &su, &cu);
   const double c2u = cu * cu - su * su, s2u = 2.0 * su * cu;     // e^{2iu}
   // h_j = A_j e^{2iu} + e^{-iu} (B_j + i C_j)
   const double b0 = 8.0 * u2 * cw, d0 = 2.0 * u * (3.0 * u2 + w2) * xi0;
