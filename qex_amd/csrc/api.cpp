@@ -118,6 +118,7 @@ extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], 
   if (const char *e = getenv("QEXHIP_OVERLAP")) c->opt_overlap = atoi(e);
   if (const char *e = getenv("QEXHIP_RECON")) c->opt_recon = atoi(e);
   if (const char *e = getenv("QEXHIP_FLOW_EXP")) c->opt_flow_exp = atoi(e);
+  if (const char *e = getenv("QEXHIP_OBS_CLOVER")) c->opt_obs_clover = atoi(e);
   c->nranks = 1;  // until qexhip_comm_init
   c->rank = 0;
   *h = c;
@@ -491,6 +492,7 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "batch_multi") c->opt_batch_multi = value;
   else if (n == "multi_reduce") c->opt_multi_reduce = value;
   else if (n == "flow_exp") c->opt_flow_exp = value;
+  else if (n == "obs_clover") c->opt_obs_clover = value;
   else { qexhip_set_error("unknown option"); return QEXHIP_ERR_ARG; }
   return 0;
 }

@@ -61,6 +61,17 @@ __device__ __forceinline__ void shifted_t(const Geom &g, const int x[4], int mu,
   if (HALO && mu == 3) { y[3] = v; return; }         // t sharded: no wrap, ghosts
   y[mu] = v >= g.X[mu] ? v - g.X[mu] : (v < 0 ? v + g.X[mu] : v);
 }
+// shifted_t with a direction that is only known at run time (wavefront-uniform): every coordinate is visited with a
+// static index, so x[] and y[] stay in registers (indexing them with mu sends them to scratch)
+template <bool HALO>
+__device__ __forceinline__ void shifted_dyn(const Geom &g, const int x[4], int mu, int d, int y[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int v = x[k] + (mu == k ? d : 0);
+    if (HALO && k == 3) y[k] = v;
+    else y[k] = v >= g.X[k] ? v - g.X[k] : (v < 0 ? v + g.X[k] : v);
+  }
+}
 __device__ __forceinline__ size_t link_off(const Geom &g, const int x[4], int mu) {
   return g.halo ? link_off_t<true>(g, x, mu) : link_off_t<false>(g, x, mu);
 }
@@ -92,7 +103,9 @@ __global__ void __launch_bounds__(256) k_gauge_from_tiles(Geom g, double2 *__res
 // Visiting order from tile_order_table: wavefront w of workgroup b takes table slot 4*(b>>3)+w of XCD b&7.
 // The four local links stay in registers (16 link loads per site).  Walking the six planes one at a time instead
 // (24 loads, 8 of them L1 hits, 132 VGPR = 3 waves/SIMD instead of 1) measured 383 us against 277 us at 32^4: the
-// kernel is bound by the number of L2->L1 requests, not by occupancy.
+// kernel is bound by the number of L2->L1 requests, not by occupancy.  (Round 2: a workgroup per tile with six
+// wavefronts, one per plane, and the four site links through LDS -- the same 16 loads at three wavefronts per SIMD -- measured
+// 285-291 us against 230: rejected as well.)
 template <bool HALO>
 __global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict__ G, double *partials, const int *order, int chunk) {
   double pl[6] = {0, 0, 0, 0, 0, 0};
@@ -383,6 +396,118 @@ __global__ void __launch_bounds__(256) k_flow_obs(Geom g, const double2 *__restr
   r = block_sum_256(et); if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = r;
   r = block_sum_256(q);  if (threadIdx.x == 0) partials[2 * gridDim.x + blockIdx.x] = r;
 }
+// loop == 1 (the plain clover: four plaquette leaves per plane), the observable of every flow step.  The path walker above
+// fetches 96 matrices per site for it; here a workgroup is one tile x SIX wavefronts, wavefront w = plane w.  The eight
+// links every plane of a site touches, U_mu(x) and U_mu(x-mu), go through LDS once (72 KiB, as k_force_lds), each wavefront
+// gathers the eight remaining links of its plane: 56 matrices per site.  The leaves are multiplied and summed in the order
+// of the path table, so F is bit for bit the path walker's.  The F of a dual pair (F10 & F32, F20 & F31, F21 & F30) meet
+// through the same LDS for the Q density.
+template <bool HALO>
+__global__ void __launch_bounds__(384, 3) k_flow_obs_clover(Geom g, const double2 *__restrict__ G, double *partials,
+                                                            const int *order, int chunk) {
+  extern __shared__ double2 smO[];                    // [2 mu + (0: U_mu(x) | 1: U_mu(x-mu))][9][64], later F[plane][9][64]
+  __shared__ double red[3][6];
+  const int e = order[(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double es = 0, et = 0, q = 0;
+  if (e >= 0) {                                       // the whole workgroup together
+    const int p = e & 1;
+    const int c0 = (e >> 1) * 64 + lane;
+    const bool live = c0 < g.Vh;
+    const int c = live ? c0 : g.Vh - 1;               // padding lanes of the last tile work on a valid site and count nothing
+    int x[4], y[4], z[4];
+    coords_of(g, c, p, x);
+    for (int id = w; id < 8; id += 6) {
+      const int mu = id >> 1;
+      shifted_dyn<HALO>(g, x, mu, (id & 1) ? -1 : 0, y);
+      const M3 m = m3_load(G + link_off_t<HALO>(g, y, mu), 64);
+      double2 *d = smO + (size_t)id * 576 + lane;
+#pragma unroll
+      for (int k = 0; k < 9; k++) d[k * 64] = m.e[k];
+    }
+    __syncthreads();
+    const int a = (w & 1) ? 3 : (w == 0 ? 1 : 2);     // planes (1,0) (3,2) (2,0) (3,1) (2,1) (3,0)
+    const int b = (w == 0 || w == 2 || w == 5) ? 0 : (w == 1 ? 2 : 1);
+    const double2 *Ua = smO + (size_t)(2 * a) * 576 + lane, *Ub = smO + (size_t)(2 * b) * 576 + lane;
+    M3 acc = m3_zero();
+    {                                                 // {-a,-b,a,b}: U_a(x-a)^+ U_b(x-a-b)^+ U_a(x-a-b) U_b(x-b)
+      M3 m = m3_adj(m3_load(Ua + 576, 64));
+      shifted_dyn<HALO>(g, x, a, -1, y);
+      shifted_dyn<HALO>(g, y, b, -1, z);
+      m = m3_mul_na(m, m3_load(G + link_off_t<HALO>(g, z, b), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul(m, m3_load(G + link_off_t<HALO>(g, z, a), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul(m, m3_load(Ub + 576, 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m3_axpy(acc, 0.25, m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {                                                 // {-b,a,b,-a}: U_b(x-b)^+ U_a(x-b) U_b(x-b+a) U_a(x)^+
+      M3 m = m3_adj(m3_load(Ub + 576, 64));
+      shifted_dyn<HALO>(g, x, b, -1, y);
+      shifted_dyn<HALO>(g, y, a, 1, z);
+      m = m3_mul(m, m3_load(G + link_off_t<HALO>(g, y, a), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul(m, m3_load(G + link_off_t<HALO>(g, z, b), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul_na(m, m3_load(Ua, 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m3_axpy(acc, 0.25, m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {                                                 // {a,b,-a,-b}: U_a(x) U_b(x+a) U_a(x+b)^+ U_b(x)^+
+      M3 m = m3_load(Ua, 64);
+      shifted_dyn<HALO>(g, x, a, 1, y);
+      m = m3_mul(m, m3_load(G + link_off_t<HALO>(g, y, b), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      shifted_dyn<HALO>(g, x, b, 1, y);
+      m = m3_mul_na(m, m3_load(G + link_off_t<HALO>(g, y, a), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul_na(m, m3_load(Ub, 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m3_axpy(acc, 0.25, m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {                                                 // {b,-a,-b,a}: U_b(x) U_a(x+b-a)^+ U_b(x-a)^+ U_a(x-a)
+      M3 m = m3_load(Ub, 64);
+      shifted_dyn<HALO>(g, x, a, -1, y);
+      shifted_dyn<HALO>(g, y, b, 1, z);
+      m = m3_mul_na(m, m3_load(G + link_off_t<HALO>(g, z, a), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul_na(m, m3_load(G + link_off_t<HALO>(g, y, b), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul(m, m3_load(Ua + 576, 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m3_axpy(acc, 0.25, m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const M3 F = m3_tah(acc);
+    const double ff = m3_retr_mul(F, F);
+    __syncthreads();                                  // every wavefront is done with the links
+    {
+      double2 *d = smO + (size_t)w * 576 + lane;
+#pragma unroll
+      for (int k = 0; k < 9; k++) d[k * 64] = F.e[k];
+    }
+    __syncthreads();
+    if (live) {
+      if (w & 1) et = ff;                             // the partner of a pair always has mu = 3
+      else {
+        es = ff;
+        const M3 fb = m3_load(smO + (size_t)(w + 1) * 576 + lane, 64);
+        q = (w == 2 ? -1.0 : 1.0) * m3_retr_mul(F, fb);   // Q = -(1/4pi^2) (F10 F32 - F20 F31 + F21 F30)
+      }
+    }
+  }
+  es = wave_sum(es); et = wave_sum(et); q = wave_sum(q);
+  if (lane == 0) { red[0][w] = es; red[1][w] = et; red[2][w] = q; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const double *r = red[threadIdx.x];
+    partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = ((r[0] + r[1]) + (r[2] + r[3])) + (r[4] + r[5]);
+  }
+}
 __global__ void __launch_bounds__(256) k_obs_final(const double *partials, int nb, double vol, double *out) {
   for (int k = 0; k < 3; k++) {
     double acc = 0;
@@ -454,7 +579,20 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
   const int *order = nullptr; int chunk = 0, nb = 0;
   double *part = nullptr;
   CHK(ordered_sites(c, &order, &chunk, &nb, &part));
-  {
+  if (loop == 1 && c->opt_obs_clover) {
+    const size_t shb = (size_t)8 * 576 * sizeof(double2);
+    static bool attr_done = false;
+    if (!attr_done) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_flow_obs_clover<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+      HIPCHK(hipFuncSetAttribute((const void *)k_flow_obs_clover<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
+      attr_done = true;
+    }
+    nb = 8 * chunk;                                   // one workgroup per tile
+    ScopedTimer tm(c, "flowobs", c->stream);
+    if (c->g.halo) k_flow_obs_clover<true><<<nb, 384, shb, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+    else k_flow_obs_clover<false><<<nb, 384, shb, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+    HIPCHK(hipGetLastError());
+  } else {
     ScopedTimer tm(c, "flowobs", c->stream);
     k_flow_obs<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, dT, part, order, chunk);
     HIPCHK(hipGetLastError());
@@ -659,11 +797,12 @@ int gauge_get(qexhip_ctx *c, double *g) {
 static int ordered_sites(qexhip_ctx *c, const int **order, int *chunk, int *nb, double **part) {
   CHK(tile_order_table(c, order, chunk));
   *nb = 8 * ((*chunk + 3) / 4);
-  if (c->gn->npp < 6 * *nb) {
+  const int need = 6 * 8 * *chunk;                      // six plaquette sums (or three observables) per tile-workgroup
+  if (c->gn->npp < need) {
     if (c->gn->pp) (void)hipFree(c->gn->pp);
     c->gn->pp = nullptr; c->gn->npp = 0;
-    HIPCHK(hipMalloc((void **)&c->gn->pp, sizeof(double) * 6 * *nb));
-    c->gn->npp = 6 * *nb;
+    HIPCHK(hipMalloc((void **)&c->gn->pp, sizeof(double) * need));
+    c->gn->npp = need;
   }
   *part = c->gn->pp;
   return 0;

@@ -101,6 +101,7 @@ struct qexhip_ctx {
   int opt_batch_multi = 0; // test hook: take the multi-rank reduction branch of the batched CG on one rank
   int opt_multi_reduce = 0; // test hook: take the multi-rank reduction branches of CG / multi-shift CG / norms on one rank
                             // (with a one-rank RCCL communicator the all-reduces are real collectives)
+  int opt_obs_clover = 1; // QEXHIP_OBS_CLOVER / option "obs_clover": 1 = the tile-per-workgroup clover kernel for fmunu(loop = 1); 0 = the path walker
   int opt_flow_exp = 1;   // QEXHIP_FLOW_EXP / option "flow_exp": 1 = closed-form exp(v) in the fused Wilson-flow stage (same function,
                           // another algorithm than the reference's; agrees with it to ~1e-15 per element; the default); 0 = the reference's
                           // Taylor + 20 squarings (matexp.nim), which the MD link updates always use

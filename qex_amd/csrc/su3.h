@@ -25,6 +25,14 @@ __host__ __device__ __forceinline__ void m3_store(double2 *p, int stride, const 
 #pragma unroll
   for (int k = 0; k < 9; k++) p[(size_t)k * stride] = a.e[k];
 }
+__host__ __device__ __forceinline__ M3 m3_adj(const M3 &u) {
+  M3 m;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int q = 0; q < 3; q++) m.e[3 * r + q] = make_double2(u.e[3 * q + r].x, -u.e[3 * q + r].y);
+  return m;
+}
 #if defined(__HIPCC__)
 // streaming forms for data nobody reads again soon (an accumulator's read-modify-write): they leave the L2 to the operands
 // that neighbouring sites share

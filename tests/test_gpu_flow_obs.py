@@ -50,3 +50,27 @@ def test_flow_obs_vs_oracle_other_lattice(oracle):
         assert np.max(np.abs(got - want)) < 1e-12 * max(1.0, np.abs(want).max()), (loop, got, want)
     with pytest.raises(q.QexHipError):
         q.flowEQ(ctx, 2)                 # fmunu uses loop in [1,3,4,5]
+
+
+@pytest.mark.parametrize("lat,halo", [([8, 8, 8, 8], False), ([4, 6, 8, 4], False), ([12, 6, 6, 10], False),
+                                     ([8, 8, 8, 8], True), ([8, 8, 4, 6], True)])
+def test_clover_kernel_against_the_path_walker_and_the_oracle(oracle, lat, halo):
+    """fmunu(loop = 1) has its own kernel (workgroup = tile x six planes, shared links through LDS): it must give what the
+    generic path walker (option obs_clover = 0) gives -- same leaves, same order -- on lattices with a ragged last tile and
+    through the ghost zones of a t-sharded rank, and both must match the oracle."""
+    import qex_amd as q
+
+    o = oracle
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 987654321)
+    g = o.gauge_warm(lo, 0.3, rf)
+    want = o.flow_EQ(lo, g, 1)
+    ctx = q.Context(lat)
+    if halo:
+        ctx.force_halo(True)
+    got = {}
+    for v in (1, 0):
+        ctx.set_option("obs_clover", v)
+        got[v] = q.flowEQ(ctx, 1, g)
+        assert np.max(np.abs(got[v] - want)) < 1e-12 * max(1.0, np.abs(want).max()), (v, got[v], want)
+    assert np.max(np.abs(got[1] - got[0])) < 1e-14 * max(1.0, np.abs(want).max()), got
