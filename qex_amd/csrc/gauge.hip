@@ -138,12 +138,11 @@ __global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict_
 }
 
 __global__ void __launch_bounds__(256) k_plaq_final(const double *partials, int nb, double norm, double *out) {
-  for (int k = 0; k < 6; k++) {
-    double acc = 0;
-    for (int i = threadIdx.x; i < nb; i += 256) acc += partials[(size_t)k * nb + i];
-    double r = block_sum_256(acc);
-    if (threadIdx.x == 0) out[k] = r / norm;
-  }
+  const int k = blockIdx.x;                    // one workgroup per plane
+  double acc = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += partials[(size_t)k * nb + i];
+  double r = block_sum_256(acc);
+  if (threadIdx.x == 0) out[k] = r / norm;
 }
 
 // force: one lane per (mu, site).  F_mu(x) = TAH( U_mu(x) [cp * sum_nu (fwd + bwd staples)]^+ )
@@ -509,12 +508,11 @@ __global__ void __launch_bounds__(384, 3) k_flow_obs_clover(Geom g, const double
   }
 }
 __global__ void __launch_bounds__(256) k_obs_final(const double *partials, int nb, double vol, double *out) {
-  for (int k = 0; k < 3; k++) {
-    double acc = 0;
-    for (int i = threadIdx.x; i < nb; i += 256) acc += partials[(size_t)k * nb + i];
-    double r = block_sum_256(acc);
-    if (threadIdx.x == 0) out[k] = r;          // raw sums: rank-summed and normalised by the caller
-  }
+  const int k = blockIdx.x;                    // one workgroup per observable
+  double acc = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += partials[(size_t)k * nb + i];
+  double r = block_sum_256(acc);
+  if (threadIdx.x == 0) out[k] = r;            // raw sums: rank-summed and normalised by the caller
 }
 
 // host: build the path table for plane (mu,nu) -> (step +-1, step +-2)
@@ -597,7 +595,7 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
     k_flow_obs<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, dT, part, order, chunk);
     HIPCHK(hipGetLastError());
   }
-  k_obs_final<<<1, 256, 0, c->stream>>>(part, nb, (double)c->g.V, &c->dscal[24]);
+  k_obs_final<<<3, 256, 0, c->stream>>>(part, nb, (double)c->g.V, &c->dscal[24]);
   HIPCHK(hipGetLastError());
   CHK(read_global(c, &c->dscal[24], 3, out));
   const double vol = (double)c->g.V * (double)c->nranks;
@@ -820,7 +818,7 @@ int gauge_plaq(qexhip_ctx *c, double out[6]) {
     HIPCHK(hipGetLastError());
   }
   // pl[i]/(physVol*np*nc)  (gaugeUtils.nim:277); rankSum before the normalisation (:275-279)
-  k_plaq_final<<<1, 256, 0, c->stream>>>(part, nb, 1.0, &c->dscal[16]);
+  k_plaq_final<<<6, 256, 0, c->stream>>>(part, nb, 1.0, &c->dscal[16]);
   HIPCHK(hipGetLastError());
   CHK(read_global(c, &c->dscal[16], 6, out));
   const double norm = (double)c->g.V * (double)c->nranks * 18.0;
