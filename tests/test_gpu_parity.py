@@ -196,6 +196,19 @@ def test_solveXX_maxits_and_zero_rhs(s8):
     x = np.zeros_like(S.x)
     S.s.solveEE(x, S.x, 0.1, sp, histcap=64)
     assert sp.iterations == 7 and len(sp.r2hist) == 8      # not converging is not an error
+    # the device loop queues 32 iterations at a time and closes the last one in the next launch: stopping at, just before
+    # and just after a chunk boundary must give the same residuals as the uninterrupted run, entry for entry
+    spl = q.SolverParams(r2req=1e-30, maxits=100, verbosity=0)
+    xl = np.zeros_like(S.x)
+    S.s.solveEE(xl, S.x, 0.1, spl, histcap=128)
+    assert spl.iterations == 100 and len(spl.r2hist) == 101
+    for mi in (1, 31, 32, 33, 64, 65):
+        sp = q.SolverParams(r2req=1e-30, maxits=mi, verbosity=0)
+        x = np.zeros_like(S.x)
+        S.s.solveEE(x, S.x, 0.1, sp, histcap=128)
+        assert sp.iterations == mi and len(sp.r2hist) == mi + 1, (mi, sp.iterations, len(sp.r2hist))
+        assert np.array_equal(np.asarray(sp.r2hist), np.asarray(spl.r2hist)[:mi + 1]), mi
+        assert sp.r2 == spl.r2hist[mi]
     sp = q.SolverParams(r2req=1e-12, maxits=100, verbosity=0)
     z = np.zeros_like(S.x)
     x = np.ones_like(S.x)
