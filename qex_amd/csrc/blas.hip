@@ -166,12 +166,14 @@ __device__ __forceinline__ void cg_roll(CgScal *s, int k, double r2k, double *hi
   s->itns[cur] = k;
   s->dones[cur] = !(k < s->maxits && r2k > s->r2stop);
   if (k < histcap) hist[k] = r2k / s->b2;
+  s->agree[0] = r2k; s->agree[1] = -r2k; s->agree[2] = (double)k; s->agree[3] = -(double)k;
 }
 __device__ __forceinline__ void cg_carry(CgScal *s, int k) {   // finished earlier: carry the final state forward
   const int cur = k & 1, prv = cur ^ 1;
   s->r2s[cur] = s->r2s[prv];
   s->itns[cur] = s->itns[prv];
   s->dones[cur] = 1;
+  s->agree[0] = s->r2s[prv]; s->agree[1] = -s->r2s[prv]; s->agree[2] = (double)s->itns[prv]; s->agree[3] = -(double)s->itns[prv];
 }
 // q := z (itn 0) | q := z + beta*q, beta = rz/rzo   (cg.nim:186-193; cpNone: z=r, q=p)
 __global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, size_t n, CgScal *s, int k, int rolled,
@@ -271,7 +273,7 @@ int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const 
 int cg_close(qexhip_ctx *c, int k) {
   k_cg_close<<<1, 256, 0, c->stream>>>(c->cg, k, c->partials + c->part2_off, grid_for(body2(c)), c->hist, c->histcap);
   HIPCHK(hipGetLastError());
-  return 0;
+  return comm_agree_post(c);
 }
 int cg_init(qexhip_ctx *c, double r2req, int maxits) {
   k_cg_init<<<1, 1, 0, c->stream>>>(c->cg, c->dscal, r2req, maxits, c->hist, c->histcap);

@@ -181,3 +181,23 @@ int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
   NCCLCHK(ncclAllReduce(dptr, dptr, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
   return 0;
 }
+
+// The CG loops run their control flow on every rank separately (loop condition on the rank's own copy of the all-reduced
+// residual, as the reference does after its QMP sum, cg.nim:174): if two ranks ever held different bits they would leave
+// the loop at different iterations and the next collective would never complete.  At the end of every chunk of iterations
+// the state the host is about to read is therefore max-reduced as {r2, -r2, itn, -itn}; max and min must coincide.
+int comm_agree_post(qexhip_ctx *c) {
+  CHK(need_comm(c));
+  if (!multi_rank(c) || !c->comm) return 0;
+  NCCLCHK(ncclAllReduce(c->cg->agree, c->cg->agree, 4, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));
+  return 0;
+}
+int comm_agree_check(qexhip_ctx *c, const CgScal &h) {
+  if (!multi_rank(c) || !c->comm) return 0;
+  if (h.agree[0] != -h.agree[1] || h.agree[2] != -h.agree[3]) {
+    qexhip_set_error("sharded CG: the ranks disagree on the residual (%.17g .. %.17g) or the iteration count (%g .. %g) -- "
+                     "the all-reduce did not return the same bits on every rank", -h.agree[1], h.agree[0], -h.agree[3], h.agree[2]);
+    return QEXHIP_ERR_COMM;
+  }
+  return 0;
+}

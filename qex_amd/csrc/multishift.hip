@@ -91,6 +91,7 @@ __global__ void __launch_bounds__(256) k_cgm_close(const double *partials, int n
     m->alphaim1 = alpha; m->betaim1 = beta;
     s->itn = itn;
     s->r2 = r2ip1;
+    s->agree[0] = r2ip1; s->agree[1] = -r2ip1; s->agree[2] = (double)itn; s->agree[3] = -(double)itn;
     if (itn < histcap) hist[itn] = r2ip1 / b2;
     if (!cont) s->done = 1;
   }
@@ -231,7 +232,9 @@ int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, 
       k_cgm_update<<<nb, 256, 0, c->stream>>>(r->par(par), n, g_cgm_dev);
       HIPCHK(hipGetLastError());
     }
+    CHK(comm_agree_post(c));
     CHK(read_cg(c, &st));
+    CHK(comm_agree_check(c, st));
   }
   if (iters) *iters = st.itn;
   if (hist && histcap > 0) {

@@ -54,6 +54,9 @@ struct CgScal {
   // write slot k&1 while its other workgroups still read slot (k-1)&1
   double r2s[2];
   int itns[2], dones[2];
+  // sharded: {r2, -r2, itn, -itn} of the state the host is about to read, max-reduced over the ranks at the end of a chunk:
+  // the ranks decide on `done` each for itself, so their residuals must agree bit for bit (comm_agree)
+  double agree[4];
 };
 
 struct TimerSlot {
@@ -170,6 +173,8 @@ inline bool multi_rank(const qexhip_ctx *c) { return c->nranks > 1 || c->opt_mul
 // ---- comm.cpp ----
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready, records ev_halo
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
+int comm_agree_post(qexhip_ctx *c);                               // max-reduce c->cg->agree over the ranks (on stream)
+int comm_agree_check(qexhip_ctx *c, const CgScal &host);          // after the state was read back: all ranks hold the same residual and count
 int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n);
 int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double *const top[], double *const ghost_hi[],
                         double *const ghost_lo[], size_t ndoubles);

@@ -122,6 +122,7 @@ int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2
     CHK(cg_close(c, k));
     rolled = 1;
     CHK(read_cg(c, &st));
+    CHK(comm_agree_check(c, st));
     done = st.dones[k & 1];
     r2 = st.r2s[k & 1];
     st.itn = st.itns[k & 1];
