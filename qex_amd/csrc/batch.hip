@@ -145,7 +145,7 @@ struct BatchBlas {
   double *glob;      // multi-rank: [0..4) rank-summed <p,Ap>, [4..8) rank-summed |r|^2 (contiguous for one all-reduce)
   int ndot;          // > 0: deferred <p,Ap> partial sum inside k_cgb_update; 0: pAp from the state; -1: from glob
 };
-// the three CG kernels of blas.hip (k_cg_xpay, k_cg_update, k_cg_reduce_finish), system = blockIdx.y
+// the CG kernels of blas.hip in their round-1 form (xpay, update, one-block reduce + bookkeeping), system = blockIdx.y
 __global__ void __launch_bounds__(256) k_cgb_xpay(BatchBlas B, size_t n) {
   const int j = blockIdx.y;
   const CgScal *s = &B.st[j];
