@@ -254,13 +254,18 @@ int qexhip_stag_solve_batch(qexhip_handle h, int n, double *const *x, const doub
  * by rows 0,1 and its determinant (row2 = det * conj(row0 x row1)), and the sweep is HBM-bound, so:
  *   1: every link is SU(3) up to a sign (thin links with BC + staggered phases): rows 0,1 + a sign bit, 96 B/link
  *   2: every link is U(3) (nHYP-smeared links): rows 0,1 + det, 112 B/link
- *   0: otherwise (HISQ fat links, QEX's `random` start, which is unitary only to 1e-11): all 18 reals, 144 B/link
+ *   0: otherwise (HISQ fat links; QEX's `random` start, 1.3 % of whose links are further than 5e-14 from unitary, the
+ *      worst 2.5e-9): all 18 reals, 144 B/link
  * chosen only if ALL links reproduce their stored row 2 to 5e-14 (a few hundred ulp: exactly unitary links of a 48^3x96 lattice peak at ~2e-14); max_dev = the largest deviation found for the
  * chosen format.  Row 2 is rebuilt in registers.  QEXHIP_RECON=0|1|2 caps the format.  No counterpart in QEX (its
  * CPU Dslash always reads full links, stagD.nim:349-395); QUDA's reconstruct-12/13 is the precedent. */
 int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double *max_dev);
 /* Tuning switches, same names as the QEXHIP_<NAME> environment variables read at init: "recon" (link
- * compression on/off, effective at the next set_links), "swz", "ntstore", "overlap". */
+ * compression on/off, effective at the next set_links), "swz", "ntstore", "overlap" (face exchange on the second stream
+ * beside the interior sweep: -1 auto, 0, 1), "batch_multi", "multi_reduce" (take the sharded reduction branches on one
+ * rank: test hook), "flow_exp" (1: closed-form exp in the Wilson-flow stage, the default; 0: the reference's Taylor +
+ * 20 squarings, matexp.nim), "obs_clover" (1: the dedicated kernel for fmunu(loop = 1), the default; 0: the generic path
+ * walker).  Unknown names are an error (QEXHIP_ERR_ARG). */
 int qexhip_set_option(qexhip_handle h, const char *name, int value);
 
 /* Smear on the device and hand the result straight to the operator (replaces smear -> rephase ->
