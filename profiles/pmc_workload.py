@@ -44,10 +44,11 @@ if "naik" in what:                     # HISQ links, 10-shift multi-shift CG
     shifts = [masses[0]] + [4.0 * (m * m - masses[0] ** 2) for m in masses[1:]]
     xids = [ctx.field_new() for _ in masses]
     ctx.dev_solve_xx_multi(xids, bid, shifts, 0.0, 20, True)
-if "flow" in what:                     # Wilson flow: 2 RK3 steps + plaquette
+if "flow" in what:                     # Wilson flow: 2 RK3 steps + plaquette + clover observables
     q.gaugeSet(ctx, g0)
     q.gaugeFlowResident(ctx, 2, 0.01)
     q.plaq(ctx)
+    q.flowEQ(ctx, 1)                   # the clover E, Q a flow loop measures after every step
 if "nhyp" in what:                     # nHYP smearing closure + the force chain (twice)
     hc = q.HypCoefs(0.4, 0.5, 0.5)
     sf = hc.smearGetForce(ctx, g0)

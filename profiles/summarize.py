@@ -57,7 +57,7 @@ if rd and cp_w:
     for kpat, key in (("k_dslash<8, false, false, false, 0>", "dslash8_sweep1_18real"), ("k_dslash<8, false, true, true, 0>", "dslash8_sweep2_18real"),
                       ("k_dslash<8, false, false, false, 1>", "dslash8_sweep1_recon12"), ("k_dslash<8, false, true, true, 1>", "dslash8_sweep2_recon12"),
                       ("k_dslash<16, false, false, false, 0>", "dslash16_sweep1_18real"), ("k_dslash<16, false, true, true, 0>", "dslash16_sweep2_18real"),
-                      ("k_force", "k_force"), ("k_plaq", "k_plaq"), ("k_staple_deriv<", "k_staple_deriv"), ("k_staple_deriv_pair", "k_staple_deriv_pair"), ("k_gen_staple", "k_gen_staple"), ("k_cgm_update", "k_cgm_update")):
+                      ("k_force", "k_force"), ("k_plaq", "k_plaq"), ("k_flow_obs_clover", "k_flow_obs_clover"), ("k_projUderiv_batch", "k_projUderiv_batch"), ("k_staple_deriv<", "k_staple_deriv"), ("k_staple_deriv_pair", "k_staple_deriv_pair"), ("k_gen_staple", "k_gen_staple"), ("k_cgm_update", "k_cgm_update")):
         fe, wr = mean(kpat, "FETCH_SIZE"), mean(kpat, "WRITE_SIZE")
         if fe is not None and wr is not None:
             tj[key + "_bytes"] = fe * 1024.0 * fcorr + wr * 1024.0 * wcorr
