@@ -11,6 +11,7 @@
 #include "../../include/qexhip.h"
 #include <rccl/rccl.h>
 #include <cstring>
+#include <cmath>
 
 #define NCCLCHK(expr)                                                                      \
   do {                                                                                     \
@@ -194,7 +195,8 @@ int comm_agree_post(qexhip_ctx *c) {
 }
 int comm_agree_check(qexhip_ctx *c, const CgScal &h) {
   if (!multi_rank(c) || !c->comm) return 0;
-  if (h.agree[0] != -h.agree[1] || h.agree[2] != -h.agree[3]) {
+  const bool both_nan = std::isnan(h.agree[0]) && std::isnan(h.agree[1]);     // a NaN residual ends the loop on every rank alike
+  if ((!both_nan && h.agree[0] != -h.agree[1]) || h.agree[2] != -h.agree[3]) {
     qexhip_set_error("sharded CG: the ranks disagree on the residual (%.17g .. %.17g) or the iteration count (%g .. %g) -- "
                      "the all-reduce did not return the same bits on every rank", -h.agree[1], h.agree[0], -h.agree[3], h.agree[2]);
     return QEXHIP_ERR_COMM;
