@@ -213,7 +213,15 @@ __global__ void __launch_bounds__(256) k_links_compress(size_t nrows, const doub
   } else {
     o[6 * 64] = ph;
   }
-  atomicMax(maxdev, __float_as_uint((float)dev));        // dev >= 0: the uint order is the float order
+  // one value per wavefront, and an atomic only from a wavefront that raises the maximum seen so far (a plain read first:
+  // 131072 read-modify-writes on one address cost 1.1 of the kernel's 1.5 ms at 32^4)
+  unsigned int bits = __float_as_uint((float)dev);       // dev >= 0: the uint order is the float order
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned int o2 = __shfl_xor(bits, off, 64);
+    bits = o2 > bits ? o2 : bits;
+  }
+  if (l == 0 && bits > __hip_atomic_load(maxdev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxdev, bits);
 }
 int links_compress(qexhip_ctx *c) {
   const Geom &g = c->g;
