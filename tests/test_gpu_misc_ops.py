@@ -170,3 +170,28 @@ def test_gpu_action_and_plaquette_repeat_exactly():
         assert q.gaugeAction(ctx, None, plaq=6.0) == a0
     # gaugeAction1 = -(beta / 3) sum_P Re tr U_P (gaugeAction.nim:61-84) and plaq_i = sum Re tr / (18 V)
     assert abs(a0 + 6.0 * 6.0 * lo.vol * p0.sum()) <= 1e-12 * abs(a0)
+
+
+def test_bench_two_ranks_share_one_gpu_rehearsal():
+    """The driver's N = 2 launch line with the GPU work really done: two ranks under torch.distributed.run, both on GPU 0
+    (RCCL refuses duplicate devices, so --rehearse-no-rccl lets every rank wrap its own slab instead of talking to its
+    neighbour: the numbers mean nothing, the launch / shard / barrier / reduction / reporting path is the real one).
+    Must end with status 0 and one parsable line that carries both ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--rehearse-no-rccl", "--no-48x96"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(x) for x in p.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    ln = lines[0]
+    assert "error" not in ln and ln["n_gpus"] == 2 and ln["value"] > 0 and ln["scaling"] == "strong"
+    assert sorted(r["rank"] for r in ln["ranks"]) == [0, 1]
+    assert 0 < ln["roofline"]["frac"] <= 1
