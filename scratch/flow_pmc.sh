@@ -13,6 +13,7 @@ run() { # name, env..., counters
 }
 for cfg in "ldsch QEXHIP_FORCE_LDS=1 QEXHIP_FLOW_EXP=1" "nolds QEXHIP_FORCE_LDS=0 QEXHIP_FLOW_EXP=1"; do
   set -- $cfg; tag=$1; shift; envs="$*"
+  if [ -n "$FLOW_PMC_ONLY" ] && [ "$FLOW_PMC_ONLY" != "$tag" ]; then continue; fi
   run ${tag}_sq "$envs" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_VMEM
   run ${tag}_sq2 "$envs" SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_WAVES SQ_IFETCH GRBM_GUI_ACTIVE
   run ${tag}_tcp "$envs" TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum
@@ -29,7 +30,7 @@ for d in sorted(glob.glob(out + "/*/")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
-            if not any(s in k for s in ("k_force", "k_exp_update", "k_plaq<")): continue
+            if not any(s in k for s in ("k_force", "k_exp_update", "k_plaq<", "k_flow_obs")): continue
             a = acc[(k, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
     for (k, c), (s, n) in acc.items():
         rows[(tag, k)][c] = s / n
