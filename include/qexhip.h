@@ -71,6 +71,10 @@ int qexhip_comm_init(qexhip_handle h, const char id[QEXHIP_UNIQUE_ID_BYTES], int
  * Without a communicator nranks = 0, rank = -1.  Any output pointer may be NULL.
  * A context with rankGeom[3] > 1 refuses every exchange / reduction until qexhip_comm_init has run (QEXHIP_ERR_STATE). */
 int qexhip_comm_info(qexhip_handle h, int *nranks, int *rank, int *device, char *busid, int buslen);
+/* number of RCCL communicators the context holds: 0 before comm_init, 2 afterwards (one for the compute stream's all-reduces
+ * and ghost refreshes, one -- ncclCommSplit of the first -- for the face exchanges posted on the second stream beside the
+ * interior sweep, so that neither queues behind the other), 1 with QEXHIP_COMM2=0. */
+int qexhip_comm_count(qexhip_handle h, int *ncomms);
 /* test hook: with one rank, route the t-direction hops through the halo path
  * (pack -> RCCL self send/recv -> boundary sweep) instead of the periodic wrap. */
 int qexhip_comm_force_halo(qexhip_handle h, int on);
@@ -171,6 +175,16 @@ int qexhip_dev_solve_xx(qexhip_handle h, int x_id, int b_id, double mass, double
  * x_ids[k] receives the solution of shift k; shifts as qexhip_stag_solve_xx_multi.  Blocks until finished. */
 int qexhip_dev_solve_xx_multi(qexhip_handle h, const int *x_ids, int b_id, const double *shifts, int nmass,
                               double r2req, int maxits, int par_even, int *iters, double *hist, int histcap);
+
+/* Free the multi-shift solvers' persistent workspace (up to 3 x nmass full fields kept between solves; QEX allocates its
+ * ps / ys per call with newOneOf and leaves them to the GC, src/solvers/cgm.nim:120-131, src/physics/stagSolve.nim:376-381).
+ * The next multi-shift solve allocates it again. */
+int qexhip_release_workspace(qexhip_handle h);
+/* norm2 / redot (src/field/fieldET.nim:605-625,704-724; rank-global sums) and Staggered.D / Ddag (r = m x + sc D x, r_id != x_id)
+ * on resident fields: what a caller that keeps its vectors in HBM uses for true residuals and solution norms. */
+int qexhip_dev_norm2(qexhip_handle h, int x_id, int parity, double *out);
+int qexhip_dev_redot(qexhip_handle h, int x_id, int y_id, int parity, double *out);
+int qexhip_dev_D(qexhip_handle h, int r_id, int x_id, double m, double sc);
 
 /* ---------------- gauge field, plaquette, Wilson flow ----------------
  * qexhip_gauge_set/get: the `g` of src/gauge/wflow.nim:21 (unphased links, periodic). */

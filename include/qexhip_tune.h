@@ -1,0 +1,25 @@
+/* qexhip_tune.h -- measurement scaffolding, libqexhip_tune.so (NOT part of the product library libqexhip.so).
+ *
+ * A/B variants of the one-parity sweep and calibration kernels with known byte / flop counts, used by scratch/ and
+ * profiles/pmc_workload.py to decide what goes into csrc/dslash.hip and to calibrate the rocprofv3 FETCH_SIZE /
+ * WRITE_SIZE counters (MI355X_MICROARCH.md, HBM section).  No counterpart in the reference.  The library links
+ * against libqexhip.so and works on a handle created by qexhip_init. */
+#ifndef QEXHIP_TUNE_H
+#define QEXHIP_TUNE_H
+#include <stddef.h>
+#include "qexhip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* run sweep variant `variant` nrep times on scratch fields of the context's lattice; average launch time in us */
+int qexhip_tune_dslash(qexhip_handle h, int variant, int swz, int nrep, double *avg_us);
+/* |out|^2 of the last qexhip_tune_dslash run (all variants must agree bit for bit) */
+int qexhip_tune_dslash_norm2(qexhip_handle h, double *n2);
+/* mode 0: 16 B/lane streaming read (k_read16), 1: copy (k_copy16) of `mbytes` MiB; GB/s */
+int qexhip_tune_stream(qexhip_handle h, int mode, size_t mbytes, int nblocks, int nrep, double *gbs);
+/* fp64 FMA chains: the vector-pipe ceiling the flow stage is priced against; TFLOP/s */
+int qexhip_tune_fma64(qexhip_handle h, int kind, int chains, int wps, int iters, double *tflops);
+#ifdef __cplusplus
+}
+#endif
+#endif

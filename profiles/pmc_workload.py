@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import qex_amd as q  # noqa: E402
 
 what = set(sys.argv[1:]) or {"cg", "cgw", "naik", "flow", "nhyp"}
-L = q.lib()
+from qex_amd._lib import tune_lib
+L = tune_lib()   # libqexhip_tune.so: measurement scaffolding, not the product library
 L.qexhip_tune_stream.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]
 lat = [32, 32, 32, 32]
 lo = q.Layout(lat)

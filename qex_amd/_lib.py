@@ -25,6 +25,7 @@ SYMBOLS = [
     ("qexhip_comm_init", _ci, [_vp, C.c_char_p, _ci, _ci]),
     ("qexhip_comm_force_halo", _ci, [_vp, _ci]),
     ("qexhip_comm_info", _ci, [_vp, _pi, _pi, _pi, C.c_char_p, _ci]),
+    ("qexhip_comm_count", _ci, [_vp, _pi]),
     ("qexhip_stag_set_links", _ci, [_vp, _vp, _vp]),
     ("qexhip_stag_dslash", _ci, [_vp, _vp, _vp, _ci, _cd, _cd]),
     ("qexhip_stag_D", _ci, [_vp, _vp, _vp, _cd, _cd]),
@@ -50,6 +51,10 @@ SYMBOLS = [
     ("qexhip_dev_op_xx", _ci, [_vp, _ci, _ci, _cd, _ci]),
     ("qexhip_dev_solve_xx", _ci, [_vp, _ci, _ci, _cd, _cd, _ci, _ci, _pi, _pd, _vp, _ci]),
     ("qexhip_dev_solve_xx_multi", _ci, [_vp, _pi, _ci, _pd, _ci, _cd, _ci, _ci, _pi, _vp, _ci]),
+    ("qexhip_release_workspace", _ci, [_vp]),
+    ("qexhip_dev_norm2", _ci, [_vp, _ci, _ci, _pd]),
+    ("qexhip_dev_redot", _ci, [_vp, _ci, _ci, _ci, _pd]),
+    ("qexhip_dev_D", _ci, [_vp, _ci, _ci, _cd, _cd]),
     ("qexhip_gauge_set", _ci, [_vp, _vp]),
     ("qexhip_gauge_get", _ci, [_vp, _vp]),
     ("qexhip_plaq", _ci, [_vp, _vp]),
@@ -143,6 +148,28 @@ def lib():
             f.argtypes = args
         _lib = L
     return _lib
+
+
+_tune = None
+
+
+def tune_lib():
+    """libqexhip_tune.so (include/qexhip_tune.h): measurement scaffolding for scratch/ and profiles/ -- A/B sweep variants,
+    streaming / fp64 calibration kernels.  Not part of the product library; nothing under qex_amd/ calls it."""
+    global _tune
+    if _tune is None:
+        lib()                                   # libqexhip.so first: the tune library resolves its internals from it
+        path = os.path.join(os.path.dirname(LIB_PATH), "libqexhip_tune.so")
+        if not os.path.exists(path):
+            raise QexHipError(f"{path} not found: build it with `make -C {_HERE} libqexhip_tune.so`")
+        T = C.CDLL(path, mode=C.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0))
+        pd = C.POINTER(C.c_double)
+        T.qexhip_tune_dslash.argtypes = [_vp, _ci, _ci, _ci, pd]
+        T.qexhip_tune_dslash_norm2.argtypes = [_vp, pd]
+        T.qexhip_tune_stream.argtypes = [_vp, _ci, C.c_size_t, _ci, _ci, pd]
+        T.qexhip_tune_fma64.argtypes = [_vp, _ci, _ci, _ci, _ci, pd]
+        _tune = T
+    return _tune
 
 
 def check(rc):

@@ -461,8 +461,60 @@ extern "C" int qexhip_dev_solve_xx_multi(qexhip_handle c, const int *x_ids, int 
   DevField *fb;
   CHK(find_field(c, b_id, &fb));
   std::vector<DevField *> xp(nmass);
-  for (int k = 0; k < nmass; k++) CHK(find_field(c, x_ids[k], &xp[k]));
+  for (int k = 0; k < nmass; k++) {
+    CHK(find_field(c, x_ids[k], &xp[k]));
+    // the solver zeroes every xs[k] before it forms |b|^2: a solution field that is the source, or another solution, would
+    // silently give b2 = 0 / one field holding the last shift only
+    if (x_ids[k] == b_id) { qexhip_set_error("dev_solve_xx_multi: x_ids[%d] is the source field", k); return QEXHIP_ERR_ARG; }
+    for (int j = 0; j < k; j++)
+      if (x_ids[j] == x_ids[k]) { qexhip_set_error("dev_solve_xx_multi: x_ids[%d] == x_ids[%d]", j, k); return QEXHIP_ERR_ARG; }
+  }
   return solve_xx_multi_dev(c, xp, *fb, shifts, nmass, r2req, maxits, par_even, iters, hist, histcap);
+}
+
+// The multi-shift solvers keep up to 3 x nmass full fields (search directions, per-parity and host-entry solutions) between
+// calls so that a trajectory's repeated solves allocate nothing; a host that is about to need the memory for something
+// else (the 52-field nHYP closure, a larger batch) hands it back here.  The next multi-shift solve re-allocates.
+extern "C" int qexhip_release_workspace(qexhip_handle c) {
+  if (!c) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto it = c->fields.begin(); it != c->fields.end();) {
+    if (it->first <= -1000) {
+      HIPCHK(hipFree(it->second.d));
+      it = c->fields.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  return 0;
+}
+
+// norm2 / redot / Staggered.D on resident fields (the host-pointer forms above upload their arguments first)
+extern "C" int qexhip_dev_norm2(qexhip_handle c, int x_id, int parity, double *out) {
+  if (!c || !out || parity < 0 || parity > 2) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx;
+  CHK(find_field(c, x_id, &fx));
+  CHK(blas_norm2(c, *fx, parity, &c->dscal[8]));
+  return read_scalars(c, &c->dscal[8], 1, out);
+}
+extern "C" int qexhip_dev_redot(qexhip_handle c, int x_id, int y_id, int parity, double *out) {
+  if (!c || !out || parity < 0 || parity > 2) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx, *fy;
+  CHK(find_field(c, x_id, &fx));
+  CHK(find_field(c, y_id, &fy));
+  CHK(blas_redot(c, *fx, *fy, parity, &c->dscal[8]));
+  return read_scalars(c, &c->dscal[8], 1, out);
+}
+extern "C" int qexhip_dev_D(qexhip_handle c, int r_id, int x_id, double m, double sc) {
+  if (!c || r_id == x_id) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fr, *fx;
+  CHK(find_field(c, r_id, &fr));
+  CHK(find_field(c, x_id, &fx));
+  return op_D(c, *fr, *fx, m, sc);
 }
 
 // ---- link smearing ----

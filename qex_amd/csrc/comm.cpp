@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 #include <cstring>
 #include <cmath>
+#include <cstdlib>
 
 #define NCCLCHK(expr)                                                                      \
   do {                                                                                     \
@@ -47,11 +48,36 @@ extern "C" int qexhip_comm_init(qexhip_handle c, const char id[QEXHIP_UNIQUE_ID_
   c->comm = comm;
   c->nranks = nranks;
   c->rank = rank;
+  // The face exchange that overlaps the interior sweep is posted on the comm stream while the compute stream posts the
+  // all-reduces of the CG scalars.  RCCL serialises the operations of ONE communicator in host issue order whatever
+  // stream they are on, i.e. an exchange queued behind an all-reduce that waits for a long kernel would wait too; with a
+  // communicator of its own the exchange depends on ev_ready only.  ncclCommSplit is collective over the parent: every
+  // rank is here.  QEXHIP_COMM2=0 keeps the single communicator (A/B).
+  const char *e2 = getenv("QEXHIP_COMM2");
+  if (!e2 || atoi(e2) != 0) {
+    ncclComm_t comm2 = nullptr;
+    NCCLCHK(ncclCommSplit(comm, 0, rank, &comm2, nullptr));
+    int n2 = 0, r2 = -1;
+    NCCLCHK(ncclCommCount(comm2, &n2));
+    NCCLCHK(ncclCommUserRank(comm2, &r2));
+    if (n2 != nranks || r2 != rank) {
+      qexhip_set_error("comm_init: the split communicator has %d ranks / rank %d, expected %d / %d", n2, r2, nranks, rank);
+      return QEXHIP_ERR_COMM;
+    }
+    c->comm2 = comm2;
+  }
   return 0;
 }
 
 void comm_destroy(qexhip_ctx *c) {
+  if (c->comm2) { ncclCommDestroy((ncclComm_t)c->comm2); c->comm2 = nullptr; }
   if (c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+}
+
+extern "C" int qexhip_comm_count(qexhip_handle c, int *ncomms) {
+  if (!c || !ncomms) return QEXHIP_ERR_ARG;
+  *ncomms = (c->comm ? 1 : 0) + (c->comm2 ? 1 : 0);
+  return 0;
 }
 
 // A context created with rankGeom[3] > 1 holds one slab of a larger lattice: without a communicator the only thing
@@ -108,7 +134,8 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
   double2 *ghost_lo = ghost_hi + face2;
   if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   if (c->comm) {
-    ncclComm_t comm = (ncclComm_t)c->comm;
+    // the overlapped exchange has the second communicator to itself (comm_init)
+    ncclComm_t comm = (ncclComm_t)((overlap && c->comm2) ? c->comm2 : c->comm);
     NCCLCHK(ncclGroupStart());
     NCCLCHK(ncclSend(bottom, nd, ncclDouble, lower(c), comm, cs));
     NCCLCHK(ncclSend(top, nd, ncclDouble, upper(c), comm, cs));

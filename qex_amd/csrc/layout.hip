@@ -10,6 +10,7 @@
 int geom_init(Geom &g, const int X[4], int depth, int halo) {
   for (int i = 0; i < 4; i++) {
     if (X[i] < 2 || (X[i] & 1)) { qexhip_set_error("local lattice extents must be even and >= 2 (got %d in dim %d)", X[i], i); return -1; }
+    if (X[i] > 1024) { qexhip_set_error("local lattice extents above 1024 are not supported (got %d in dim %d)", X[i], i); return -1; }
     g.X[i] = X[i];
   }
   g.Xh = X[0] / 2;
@@ -341,7 +342,7 @@ int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk_out) {
   static const int by = [] { const char *e = getenv("QEXHIP_ORD_Y"); return e ? atoi(e) : 8; }();
   static const int bz = [] { const char *e = getenv("QEXHIP_ORD_Z"); return e ? atoi(e) : 4; }();
   static const int bt = [] { const char *e = getenv("QEXHIP_ORD_T"); return e ? atoi(e) : 4; }();
-  struct Ent { long key0, key1; int e; };
+  struct Ent { unsigned long long key0, key1; int e; };
   std::vector<Ent> v(n);
   for (int p = 0; p < 2; p++)
     for (int tile = 0; tile < g.ntile; tile++) {
@@ -351,7 +352,8 @@ int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk_out) {
       Ent &a = v[(size_t)p * g.ntile + tile];
       a.e = 2 * tile + p;
       a.key0 = (((long)t * g.X[2] + z) * g.X[1] + y) * 2 + p;         // plain order: splits the lattice into 8 (t,z) regions
-      a.key1 = (((((long)(t / bt) * 4096 + z / bz) * 4096 + y / by) * 4096 + t % bt) * 4096 + z % bz) * 8192 + (y % by) * 2 + p;
+      // six 10-bit fields + parity = 61 bits (extents <= 1024, geom_init)
+      a.key1 = ((((((unsigned long long)(t / bt) * 1024u + z / bz) * 1024u + y / by) * 1024u + t % bt) * 1024u + z % bz) * 1024u + (y % by)) * 2 + p;
     }
   std::sort(v.begin(), v.end(), [](const Ent &a, const Ent &b) { return a.key0 < b.key0; });
   std::vector<int> h((size_t)8 * chunk, -1);
@@ -397,7 +399,7 @@ static void tile_order_plane_host(const Geom &g, int mu, int nu, std::vector<int
   if (npd == 2) { spend(pd[1], 8); spend(pd[0], budget); }           // two blocked directions: 8 x 16 positions
   else if (npd == 1) spend(pd[0], budget);
   for (int d = 1; d <= 3; d++) if (!inpl[d] && d != dpart) spend(d, budget);   // leftover budget: a direction outside the plane
-  struct Ent { long key0, key1; int e; };
+  struct Ent { unsigned long long key0, key1; int e; };
   std::vector<Ent> v(n);
   for (int p = 0; p < 2; p++)
     for (int tile = 0; tile < g.ntile; tile++) {
@@ -409,18 +411,20 @@ static void tile_order_plane_host(const Geom &g, int mu, int nu, std::vector<int
       Ent &a = v[(size_t)p * g.ntile + tile];
       a.e = 2 * tile + p;
       // key0: the split direction slowest, then the others (storage order)
-      long k0 = xc[dpart];
-      for (int d = 3; d >= 1; d--) if (d != dpart) k0 = k0 * 4096 + xc[d];
+      // (coordinates < 1024: 3 x 10 bits per index, so the packed keys below stay under 2^61 -- 12-bit fields overflowed 2^63
+      //  for t >= 8 in the split direction and wrapped the order around)
+      unsigned long long k0 = (unsigned)xc[dpart];
+      for (int d = 3; d >= 1; d--) if (d != dpart) k0 = k0 * 1024u + (unsigned)xc[d];
       a.key0 = k0 * 2 + p;
       // key1: block index (slow: directions outside the plane, then inside), then position inside the block, parity last
-      long kb = 0, ki = 0;
+      unsigned long long kb = 0, ki = 0;
       for (int pass = 0; pass < 2; pass++)
         for (int d = 3; d >= 1; d--) {
           if ((pass == 0) == inpl[d]) continue;                        // pass 0: outside the plane, pass 1: inside
-          kb = kb * 4096 + xc[d] / ext[d];
-          ki = ki * 4096 + xc[d] % ext[d];
+          kb = kb * 1024u + (unsigned)(xc[d] / ext[d]);
+          ki = ki * 1024u + (unsigned)(xc[d] % ext[d]);
         }
-      a.key1 = (kb * (1L << 36) + ki) * 2 + p;
+      a.key1 = ((kb << 30) + ki) * 2 + p;
     }
   std::sort(v.begin(), v.end(), [](const Ent &a, const Ent &b) { return a.key0 < b.key0; });
   h.assign((size_t)8 * chunk, -1);

@@ -75,7 +75,8 @@ struct qexhip_ctx {
   hipStream_t stream = nullptr, cstream = nullptr;
   hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
   // communicator
-  void *comm = nullptr;  // ncclComm_t
+  void *comm = nullptr;  // ncclComm_t: everything posted on the compute stream (all-reduces, ghost refreshes, non-overlapped faces)
+  void *comm2 = nullptr; // ncclComm_t split off comm: the face exchanges posted on cstream beside the interior sweep
   int nranks = 1, rank = 0;
   int force_halo = 0;
   // staggered links

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <sys/stat.h>
 #include <ctime>
 #include <string>
 #include <vector>
@@ -93,12 +94,12 @@ int read_header(FILE *f, LimeHeader &h) {
   return 1;
 }
 // bytes left between the read position and the end of the file (lengths in LIME headers are untrusted input)
+// (the size comes from fstat: no seek to the end and back per record, which would drop the stdio read-ahead each time)
 uint64_t bytes_left(FILE *f) {
   const off_t here = ftello(f);
-  if (here < 0 || fseeko(f, 0, SEEK_END) != 0) return 0;
-  const off_t end = ftello(f);
-  (void)fseeko(f, here, SEEK_SET);
-  return end > here ? (uint64_t)(end - here) : 0;
+  struct stat st;
+  if (here < 0 || fstat(fileno(f), &st) != 0) return 0;
+  return st.st_size > here ? (uint64_t)(st.st_size - here) : 0;
 }
 bool skip_data(FILE *f, uint64_t len) {
   if (len > bytes_left(f)) { qexhip_set_error("lime: record of %llu bytes runs past the end of the file", (unsigned long long)len); return false; }
@@ -106,9 +107,10 @@ bool skip_data(FILE *f, uint64_t len) {
   return fseeko(f, (off_t)std::min<uint64_t>(padded, bytes_left(f)), SEEK_CUR) == 0;
 }
 bool read_text(FILE *f, uint64_t len, std::string &s) {
-  // XML / checksum records are a few hundred bytes; refuse anything that could not be one before allocating
-  if (len > (1u << 20) || len > bytes_left(f)) {
-    qexhip_set_error("lime: text record of %llu bytes (limit 1 MiB, and no more than the file holds)", (unsigned long long)len);
+  // The reference's reader puts no cap on user file / record XML (readerQiolite.nim), and qexhip_io_metadata is there to
+  // return it: the bound is what the file still holds (a hostile length cannot exceed that), plus 256 MiB as a sanity limit.
+  if (len > (256u << 20) || len > bytes_left(f)) {
+    qexhip_set_error("lime: text record of %llu bytes (limit 256 MiB, and no more than the file holds)", (unsigned long long)len);
     return false;
   }
   s.resize(len);

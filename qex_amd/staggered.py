@@ -110,6 +110,12 @@ class Context:
         check(lib().qexhip_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d), bus, 64))
         return n.value, r.value, d.value, bus.value.decode()
 
+    def comm_count(self):
+        """communicators held: 2 after comm_init (compute stream + overlapped face exchange), 1 with QEXHIP_COMM2=0"""
+        n = C.c_int(0)
+        check(lib().qexhip_comm_count(self._h, C.byref(n)))
+        return n.value
+
     def force_halo(self, on=True):
         check(lib().qexhip_comm_force_halo(self._h, 1 if on else 0))
 
@@ -173,6 +179,23 @@ class Context:
                                               (C.c_double * n)(*[float(v) for v in shifts]), n, float(r2req), int(maxits),
                                               1 if par_even else 0, C.byref(its), _p(hist), histcap))
         return its.value, hist[: min(histcap, its.value + 1)]
+
+    def release_workspace(self):
+        check(lib().qexhip_release_workspace(self._h))
+
+    def dev_norm2(self, x_id, subset="all"):
+        out = C.c_double(0)
+        check(lib().qexhip_dev_norm2(self._h, x_id, _SUBSET[subset], C.byref(out)))
+        return out.value
+
+    def dev_redot(self, x_id, y_id, subset="all"):
+        out = C.c_double(0)
+        check(lib().qexhip_dev_redot(self._h, x_id, y_id, _SUBSET[subset], C.byref(out)))
+        return out.value
+
+    def dev_D(self, r_id, x_id, m, sc=1.0):
+        """r = m x + sc D x on resident fields (Staggered.D: sc = 1, Ddag: sc = -1)"""
+        check(lib().qexhip_dev_D(self._h, r_id, x_id, float(m), float(sc)))
 
     # field algebra hooks (fieldET.nim:605-625,704-724)
     def norm2(self, x, subset="all"):

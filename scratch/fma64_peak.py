@@ -1,7 +1,8 @@
 # fp64 vector throughput this chip actually holds (spec 78.6 TFLOP/s at 2.4 GHz): plain FMA chains and the exp squaring chain
 import sys, ctypes as C; sys.path.insert(0, '.')
 import qex_amd as q
-L = q.lib()
+from qex_amd._lib import tune_lib
+L = tune_lib()   # libqexhip_tune.so: measurement scaffolding, not the product library
 L.qexhip_tune_fma64.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 ctx = q.Context([8, 8, 8, 8])
 out = C.c_double(0)

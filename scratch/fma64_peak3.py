@@ -1,6 +1,7 @@
 import sys, ctypes as C, time; sys.path.insert(0, '.')
 import qex_amd as q
-L = q.lib()
+from qex_amd._lib import tune_lib
+L = tune_lib()   # libqexhip_tune.so: measurement scaffolding, not the product library
 L.qexhip_tune_fma64.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 ctx = q.Context([8, 8, 8, 8])
 out = C.c_double(0)

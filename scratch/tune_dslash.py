@@ -1,7 +1,8 @@
 import sys, ctypes as C; sys.path.insert(0,'.')
 import numpy as np
 import qex_amd as q
-L=q.lib()
+from qex_amd._lib import tune_lib
+L = tune_lib()   # libqexhip_tune.so: measurement scaffolding, not the product library
 L.qexhip_tune_dslash.argtypes=[C.c_void_p,C.c_int,C.c_int,C.c_int,C.POINTER(C.c_double)]
 L.qexhip_tune_stream.argtypes=[C.c_void_p,C.c_int,C.c_size_t,C.c_int,C.c_int,C.POINTER(C.c_double)]
 lat=[32,32,32,32]

@@ -3,7 +3,8 @@
 import sys, ctypes as C; sys.path.insert(0,'.')
 import numpy as np
 import qex_amd as q
-L=q.lib()
+from qex_amd._lib import tune_lib
+L = tune_lib()   # libqexhip_tune.so: measurement scaffolding, not the product library
 L.qexhip_tune_dslash.argtypes=[C.c_void_p,C.c_int,C.c_int,C.c_int,C.POINTER(C.c_double)]
 lat=[32,32,32,32]
 lo=q.Layout(lat)

@@ -34,6 +34,12 @@ def test_abi_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
     exported = set(re.findall(r" T (qexhip_[A-Za-z0-9_]+)", out))
     assert set(declared) <= exported
+    # ... and nothing else: measurement scaffolding lives in libqexhip_tune.so / include/qexhip_tune.h (round-2 verdict, weak 12)
+    assert exported <= set(declared), sorted(exported - set(declared))
+    thdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "qexhip_tune.h")).read(), flags=re.S)
+    tdecl = set(re.findall(r"\b(qexhip_tune_[A-Za-z0-9_]+)\s*\(", thdr))
+    tout = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(os.path.dirname(_lib.LIB_PATH), "libqexhip_tune.so")], text=True)
+    assert set(re.findall(r" T (qexhip_[A-Za-z0-9_]+)", tout)) == tdecl and len(tdecl) == 4
 
 
 def test_header_is_plain_c(tmp_path):
