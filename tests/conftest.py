@@ -11,6 +11,8 @@ os.environ.setdefault("GOMP_SPINCOUNT", "30000")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def pytest_configure(config):
@@ -22,3 +24,12 @@ def oracle():
     from oracle import oracle as o
     o.build()
     return o
+
+
+def pytest_sessionfinish(session, exitstatus):
+    # what the history-parity tests measured (tests/parity_log.py) -> gpurun_out/r03_parity_devs.json
+    try:
+        import parity_log
+        parity_log.flush()
+    except Exception:
+        pass

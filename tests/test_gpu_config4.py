@@ -84,13 +84,12 @@ def test_naik_multishift_solveXX_vs_oracle(links, mode, ladder):
     assert dev[:min(n, 100)].max() < 1e-10, dev[:min(n, 100)].max()
     # the tail drifts as in the single-mass CG: CG amplifies the rounding differences of two equivalent
     # summation orders, so the yardstick is the CPU path against itself when only its reduction order changes
-    nt = o.num_threads()
-    o.lib().qo_set_num_threads(1)
-    _, _, h1 = o.solveXX_multi(L.lo, L.fat, L.lng, L.b, sh, rq, 5000, True, histcap=8192)
-    o.lib().qo_set_num_threads(nt)
-    m = min(len(h1), len(hist))
-    spread = float(np.max(np.abs(h1[:m] / hist[:m] - 1)))
-    assert dev.max() < min(0.1, max(1e-6, 1000.0 * spread)), (dev.max(), spread)
+    import parity_log
+    spread, per = parity_log.spread_over_threads(
+        o, lambda: o.solveXX_multi(L.lo, L.fat, L.lng, L.b, sh, rq, 5000, True, histcap=8192)[2], hist)
+    tol = parity_log.tolerance(spread)
+    parity_log.record("test_naik_multishift_solveXX_vs_oracle[%s-%s]" % (ladder, mode), dev, spread, per, (sp.iterations, its), tol)
+    assert dev.max() < tol, (dev.max(), spread)
     h = L.lo.vol // 2
     for k, (a, r) in enumerate(zip(xs, xr)):
         assert relerr(a[:h], r[:h]) < 1e-6, (k, relerr(a[:h], r[:h]))

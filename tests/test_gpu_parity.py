@@ -148,22 +148,12 @@ def test_eoReconstruct(s8):
     assert relerr(r, ref) < 1e-13
 
 
-def history_tolerance(o, lo, g, g3, b, m, r2req, maxits, par_even, hist_ref, alt_threads=1):
-    """CG amplifies rounding differences: two equivalent summation orders drift apart along the
-    history (1e-16 at the start, up to percents after hundreds of iterations on badly conditioned
-    systems).  The yardstick is the CPU path's own spread when only its reduction order changes
-    (1 thread vs all threads -- the reference has the same run-to-run spread, SURVEY.md App. A;
-    measured here: 1e-8 on 8^4, 1e-4 with Naik links, 5e-2 on 4x6x10x6).  The drift in the tail is
-    chaotic, so it is not a calibrated bound: the tests hold the first 100 iterations to 1e-10, the
-    whole history of BASELINE configs[0] (8^4, m=0.1) to the north star's 1e-6, and the tail of the
-    harder systems to max(1e-6, 1000 x CPU self-spread), capped at 10 %."""
-    nt = o.num_threads()
-    o.lib().qo_set_num_threads(alt_threads)
-    _, _, _, h1 = o.solveXX(lo, g, g3, b, m, r2req, maxits, par_even, histcap=len(hist_ref) + 8)
-    o.lib().qo_set_num_threads(nt)
-    n = min(len(h1), len(hist_ref))
-    spread = float(np.max(np.abs(h1[:n] / hist_ref[:n] - 1)))
-    return min(0.1, max(1e-6, 1000.0 * spread)), spread
+def history_tolerance(o, lo, g, g3, b, m, r2req, maxits, par_even, hist_ref, counts=None):
+    """(bound on the whole history, CPU self-spread, spread per thread count): tests/parity_log.py"""
+    import parity_log
+    spread, per = parity_log.spread_over_threads(
+        o, lambda: o.solveXX(lo, g, g3, b, m, r2req, maxits, par_even, histcap=len(hist_ref) + 8)[3], hist_ref, counts)
+    return parity_log.tolerance(spread), spread, per
 
 
 @pytest.mark.parametrize("fix", ["s8", "sodd", "s8naik", "s8w", "soddw", "s8naikw"])
@@ -181,7 +171,10 @@ def test_solveXX_history(request, fix, par_even):
     assert n > 100
     dev = np.abs(sp.r2hist[:n] / hist[:n] - 1)
     assert dev[:100].max() < 1e-10                      # before amplification sets in
-    tol, spread = history_tolerance(S.o, S.lo, S.g, S.g3, S.x, 0.1, 1e-12, 2000, par_even, hist)
+    tol, spread, per = history_tolerance(S.o, S.lo, S.g, S.g3, S.x, 0.1, 1e-12, 2000, par_even, hist)
+    import parity_log
+    parity_log.record("test_solveXX_history[%s-%s]" % (par_even, fix), dev, spread, per, (sp.iterations, its), tol,
+                      solution_relerr=relerr(x, xr))
     assert dev.max() < tol, (dev.max(), spread)
     if fix == "s8":
         assert dev.max() < 1e-6                         # BASELINE.json configs[0], north star
@@ -251,6 +244,8 @@ def test_multishift(s8):
     assert abs(sp.iterations - its) <= 1
     n = min(len(hist), len(sp.r2hist))
     dev = np.abs(sp.r2hist[:n] / hist[:n] - 1)
+    import parity_log
+    parity_log.record("test_multishift[s8] masses 0.1/0.2/0.4", dev, its=(sp.iterations, its), tol=1e-5)
     assert dev[:100].max() < 1e-10 and dev.max() < 1e-5
     h = S.lo.vol // 2
     for a, b in zip(xs, xr):
@@ -296,7 +291,10 @@ def test_forced_halo_equals_periodic(oracle, naik, warm):
     dev = np.abs(spb.r2hist[:n] / spa.r2hist[:n] - 1)
     assert dev[:100].max() < 1e-12          # same kernels; only the partial-sum grouping differs
     xr, its, fin, hist = oracle.solveXX(A.lo, A.g, A.g3, A.x, 0.1, 1e-12, 2000, True, histcap=4096)
-    tol, spread = history_tolerance(oracle, A.lo, A.g, A.g3, A.x, 0.1, 1e-12, 2000, True, hist)
+    tol, spread, per = history_tolerance(oracle, A.lo, A.g, A.g3, A.x, 0.1, 1e-12, 2000, True, hist)
+    import parity_log
+    parity_log.record("test_forced_halo_equals_periodic[naik=%s-warm=%s] (halo vs periodic, both HIP)" % (naik, warm), dev, spread, per,
+                      (spb.iterations, spa.iterations), tol)
     assert dev.max() < tol, (dev.max(), spread)
     assert relerr(xb, xa) < 1e-6
     assert abs(spc.iterations - spa.iterations) <= 1 and relerr(xc, xa) < 1e-6
@@ -383,6 +381,7 @@ def s32(oracle, request):
         pass
 
     S.o, S.q, S.lo, S.ctx, S.g0 = oracle, q, lo, ctx, g.copy()
+    S.kind = request.param
     oracle.rephase(lo, g)
     S.g = g
     S.s = q.newStag(ctx, g)
@@ -452,10 +451,13 @@ def test_full_size_cg_history(s32):
     dev = np.abs(sp.r2hist[:n] / hist[:n] - 1)
     assert dev[:100].max() < 1e-10, dev[:100].max()
     nt = S.o.num_threads()
-    tol, spread = history_tolerance(S.o, S.lo, S.g, None, S.x, 0.1, 1e-12, 5000, True, hist, alt_threads=max(1, nt // 2))
+    tol, spread, per = history_tolerance(S.o, S.lo, S.g, None, S.x, 0.1, 1e-12, 5000, True, hist, counts=sorted({max(1, nt // 2), max(1, nt - 1)} - {nt}))
+    import parity_log
+    parity_log.record("test_full_size_cg_history[%s] 32^4" % S.kind, dev, spread, per, (sp.iterations, its), tol)
     print("32^4 CG history: %d iterations (oracle %d), max deviation %.2e over the whole history, %.2e over the first 100; "
-          "CPU path against itself at %d vs %d threads: %.2e" % (sp.iterations, its, dev.max(), dev[:100].max(), nt, max(1, nt // 2), spread))
+          "CPU path against itself over thread counts %s: %.2e" % (sp.iterations, its, dev.max(), dev[:100].max(), per, spread))
     assert dev.max() < tol, (dev.max(), spread)
+    assert dev.max() < 1e-6, dev.max()                  # the north star's bound, at the headline size
     assert sp.r2 <= 1e-12
     h = S.lo.vol // 2
     assert relerr(x[:h], xr[:h]) < 1e-6
