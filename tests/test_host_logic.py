@@ -283,3 +283,48 @@ def test_plane_tile_order_is_a_permutation(lat):
             assert n == cap
             e = np.array(out[:n])
             assert sorted(e[e >= 0].tolist()) == list(range(2 * ntile)), (lat, mu, nu)
+
+
+def test_shard_check_compare_logic():
+    """qex_amd/selfcheck.compare: what bench.py --gpus N uses to hold its sharded run to the committed single-GPU numbers"""
+    import copy
+    from qex_amd import selfcheck as sc
+
+    want = sc.load_fixture([32, 32, 32, 32], 0.1)
+    assert want is not None and sc.load_fixture([32, 32, 32, 32], 0.2) is None and sc.load_fixture([4, 4, 4, 4], 0.1) is None
+    v = want["values"]
+    assert len(v["cg_hist"]) == sc.NHIST + 1 and len(v["naik_x2"]) == 10 and len(v["plaq"]) == 6
+    assert sc.compare(copy.deepcopy(v), want)["ok"]
+    for key, fac, cls in (("Db2", 1 + 1e-9, "operator"), ("b2", 1 - 1e-9, "operator"), ("cg_x2", 1 + 1e-5, "history"), ("naik_its", 2, None)):
+        g = copy.deepcopy(v)
+        g[key] = g[key] * fac
+        r = sc.compare(g, want)
+        assert not r["ok"] and any(key in f for f in r["failed"]), (key, r)
+    g = copy.deepcopy(v)
+    g["cg_hist"][7] *= 1 + 1e-5
+    assert not sc.compare(g, want)["ok"]
+    g = copy.deepcopy(v)
+    g["cg_hist"][7] *= 1 + 1e-8                  # inside the north star's 1e-6
+    g["plaq"][3] += 1e-12                        # inside 1e-10 of 1/6
+    assert sc.compare(g, want)["ok"]
+    g["plaq"][3] += 1e-9
+    assert not sc.compare(g, want)["ok"]
+    g = copy.deepcopy(v)
+    g["naik_x2"][9] *= 1 + 1e-7
+    assert not sc.compare(g, want)["ok"]
+
+
+@pytest.mark.parametrize("lat", [[8, 8, 8, 8], [32, 32, 32, 32]])
+def test_shard_check_fixture_against_the_oracle(lat):
+    """tests/golden/shard_checks.json holds the PRODUCT's single-GPU numbers; the oracle (pinned to the reference's golden
+    vectors, tests/test_oracle_golden.py) must reproduce them from the same seeds: plaquettes, |b|^2, |D b|^2, the first 20 CG
+    residuals, and the converged Naik 10-shift norms and iteration count (tests/golden/make_shard_checks.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_shard_checks as gen
+    from qex_amd import selfcheck as sc
+
+    want = sc.load_fixture(lat, 0.1)
+    assert want is not None and want["vs_oracle"]["ok"]
+    r = sc.compare(gen.oracle_values(lat), want)
+    assert r["ok"], r
+    assert r["max_rel"]["operator"] < 1e-13 and r["max_rel"]["history"] < 1e-11 and r["max_rel"]["solution"] < 1e-12, r
