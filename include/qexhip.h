@@ -279,7 +279,8 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  * beside the interior sweep: -1 auto, 0, 1), "batch_multi", "multi_reduce" (take the sharded reduction branches on one
  * rank: test hook), "flow_exp" (1: closed-form exp in the Wilson-flow stage, the default; 0: the reference's Taylor +
  * 20 squarings, matexp.nim), "obs_clover" (1: the dedicated kernel for fmunu(loop = 1), the default; 0: the generic path
- * walker).  Unknown names are an error (QEXHIP_ERR_ARG). */
+ * walker), "flow_ring" (1: the Wilson-flow stage as a loader / consumer kernel, csrc/flow_stage.hip -- a measured alternative,
+ * slower than the default 0 on MI355X).  Unknown names are an error (QEXHIP_ERR_ARG). */
 int qexhip_set_option(qexhip_handle h, const char *name, int value);
 
 /* Smear on the device and hand the result straight to the operator (replaces smear -> rephase ->

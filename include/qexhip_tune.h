@@ -19,6 +19,9 @@ int qexhip_tune_dslash_norm2(qexhip_handle h, double *n2);
 int qexhip_tune_stream(qexhip_handle h, int mode, size_t mbytes, int nblocks, int nrep, double *gbs);
 /* fp64 FMA chains: the vector-pipe ceiling the flow stage is priced against; TFLOP/s */
 int qexhip_tune_fma64(qexhip_handle h, int kind, int chains, int wps, int iters, double *tflops);
+/* the Wilson-flow stage's operand gathers alone (48 matrices per 64-site tile of the resident links, into registers):
+ * nw wavefronts per workgroup (divides 48), wgpc workgroups per CU, depth matrices in flight per wavefront (1, 2, 4, 6); us */
+int qexhip_tune_gather(qexhip_handle h, int nw, int wgpc, int depth, int nrep, double *avg_us);
 #ifdef __cplusplus
 }
 #endif

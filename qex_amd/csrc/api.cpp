@@ -119,6 +119,16 @@ extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], 
   if (const char *e = getenv("QEXHIP_RECON")) c->opt_recon = atoi(e);
   if (const char *e = getenv("QEXHIP_FLOW_EXP")) c->opt_flow_exp = atoi(e);
   if (const char *e = getenv("QEXHIP_OBS_CLOVER")) c->opt_obs_clover = atoi(e);
+  if (const char *e = getenv("QEXHIP_FLOW_RING")) c->opt_flow_ring = atoi(e);
+  {
+    // LDS a workgroup may ask for (160 KiB on gfx950): the large-LDS kernels (k_flow_stage 144 KiB, k_force_lds and
+    // k_flow_obs_clover 72 KiB) fall back to their plain forms when the device offers less
+    int a = 0, b = 0;
+    (void)hipDeviceGetAttribute(&a, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
+    (void)hipDeviceGetAttribute(&b, hipDeviceAttributeSharedMemPerBlockOptin, device);
+    (void)hipGetLastError();
+    c->max_lds_optin = a > b ? a : b;
+  }
   c->nranks = 1;  // until qexhip_comm_init
   c->rank = 0;
   *h = c;
@@ -545,6 +555,7 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "multi_reduce") c->opt_multi_reduce = value;
   else if (n == "flow_exp") c->opt_flow_exp = value;
   else if (n == "obs_clover") c->opt_obs_clover = value;
+  else if (n == "flow_ring") c->opt_flow_ring = value;
   else { qexhip_set_error("unknown option"); return QEXHIP_ERR_ARG; }
   return 0;
 }

@@ -375,3 +375,94 @@ extern "C" int qexhip_tune_fma64(qexhip_handle c, int kind, int chains, int wps,
   (void)hipFree(out);
   return 0;
 }
+
+
+// ---- what the CU's L2 -> L1 path delivers for the Wilson-flow stage's operand stream (round 3) ----
+// The 48 operand matrices of a 64-site tile (flow_stage.hip: 8 own/back links, 36 plane operands, 4 momenta ~ here all taken
+// from U), gathered by NW wavefronts per workgroup into REGISTERS, D matrices in flight per wavefront, nothing else: no LDS,
+// no barrier, 18 integer ops per matrix to keep the loads alive.  Persistent workgroups walk tile_order_table.
+#include "gauge_index.h"
+template <int D>
+__global__ void __launch_bounds__(512) k_gather_test(Geom g, const double2 *__restrict__ U, const int *__restrict__ order, int chunk,
+                                                       unsigned long long *out) {
+  const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, jstride = gridDim.x >> 3;
+  const int *ord = order + (size_t)xcd * chunk;
+  M3 st[D];
+  unsigned long long acc = 0;
+  // unit u of this wavefront: tile u / npw of the workgroup's list, kind wave + nw * (u % npw); npw kinds per wavefront and tile
+  const int npw = 48 / nw;
+  int ntile = 0;
+  for (int j = j0; j < chunk; j += jstride) { if (ord[j] < 0) break; ntile++; }
+  const int nunit = ntile * npw;
+  FsSite s;
+  int cur = -1;
+  auto src = [&](int u) -> const double2 * {
+    const int uc = u < nunit ? u : nunit - 1;
+    const int ti = uc / npw, k = wave + nw * (uc - ti * npw);
+    if (ti != cur) {
+      const int e = ord[j0 + ti * jstride];
+      int c = (e >> 1) * 64 + lane;
+      if (c >= g.Vh) c = g.Vh - 1;
+      fs_site(g, c, e & 1, s);
+      cur = ti;
+    }
+    // kind k of 48: group k / 4 (0 own, 1 back, 2..10 the rounds, 11 momenta ~ own), slot w = k % 4
+    const int gi = k >> 2, w = k & 3;
+    int lex = s.lex, par = s.par, mu = w;
+    if (gi == 1) fs_hop<false>(g, s, w, -1, lex, par);
+    else if (gi >= 2 && gi <= 10) {
+      const int r = (gi - 2) / 3 + 1, kk = (gi - 2) % 3, q = w ^ r;
+      if (kk == 0) fs_hop<false>(g, s, q, 1, lex, par);
+      else if (kk == 1) { fs_hop<false>(g, s, w, -1, lex, par); mu = q; }
+      else { fs_hop<false>(g, s, w, -1, lex, par); fs_hop<false>(g, s, q, 1, lex, par); }
+    }
+    return U + fs_link_off(g, lex, par, mu);
+  };
+  if (nunit == 0) return;
+#pragma unroll
+  for (int d = 0; d < D; d++) { st[d] = m3_load(src(d), 64); __builtin_amdgcn_sched_barrier(0); }
+  for (int u0 = 0; u0 < nunit; u0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) acc ^= (unsigned long long)__double_as_longlong(st[d].e[k].x) + (unsigned long long)__double_as_longlong(st[d].e[k].y);
+      st[d] = m3_load(src(u0 + d + D), 64);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (acc == 0x123456789abcdefull) out[0] = acc;
+}
+// nw wavefronts per workgroup (divides 48), wgpc workgroups per CU, depth matrices in flight per wavefront (2, 4, 6, 8);
+// returns the average launch time; the lattice's resident links (qexhip_gauge_set) are the table
+extern "C" int qexhip_tune_gather(qexhip_handle c, int nw, int wgpc, int depth, int nrep, double *avg_us) {
+  if (!c || !avg_us || nw < 1 || nw > 8 || 48 % nw || wgpc < 1) return -1;
+  const double2 *U = gauge_links_dev(c);
+  if (!U) { qexhip_set_error("tune_gather: qexhip_gauge_set first"); return -3; }
+  const int *order = nullptr; int chunk = 0;
+  CHK(tile_order_table(c, &order, &chunk));
+  unsigned long long *out;
+  HIPCHK(hipMalloc((void **)&out, 8));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  const int nb = 256 * wgpc;
+  auto run = [&]() {
+    if (depth == 2) k_gather_test<2><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
+    else if (depth == 4) k_gather_test<4><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
+    else if (depth == 6) k_gather_test<6><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
+    else k_gather_test<1><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
+  };
+  run();
+  HIPCHK(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < nrep; i++) run();
+  HIPCHK(hipEventRecord(e1, c->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *avg_us = 1e3 * ms / nrep;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

@@ -15,6 +15,7 @@
 #include "qexhip_internal.h"
 #include "reduce.h"
 #include "su3.h"
+#include "gauge_index.h"
 #include <utility>
 #include <algorithm>
 #include <cstdlib>
@@ -35,43 +36,6 @@ static int gauge_ghosts(qexhip_ctx *c, int depth);
 static int read_global(qexhip_ctx *c, double *dev, int n, double *host);
 static int ordered_sites(qexhip_ctx *c, const int **order, int *chunk, int *nb, double **part);
 
-__device__ __forceinline__ void coords_of(const Geom &g, int c, int p, int x[4]) {
-  unsigned r = (unsigned)c;
-  int xh = r % (unsigned)g.Xh; r /= (unsigned)g.Xh;
-  x[1] = r % (unsigned)g.X[1]; r /= (unsigned)g.X[1];
-  x[2] = r % (unsigned)g.X[2];
-  x[3] = r / (unsigned)g.X[2];
-  x[0] = 2 * xh + ((x[1] + x[2] + x[3] + p) & 1);
-}
-// HALO as a template parameter for the kernels whose register allocation is tight (k_plaq spills with a runtime
-// flag); the runtime-flag forms below serve everything else
-template <bool HALO>
-__device__ __forceinline__ size_t link_off_t(const Geom &g, const int x[4], int mu) {
-  int t = x[3];
-  if (HALO) t = t < 0 ? t + g.X[3] + 6 : t;          // virtual slices: Xt..Xt+2 -> ghost_hi (in place), -3..-1 -> ghost_lo
-  int lex = x[0] + g.X[0] * (x[1] + g.X[1] * (x[2] + g.X[2] * t));
-  int p = (x[0] + x[1] + x[2] + x[3]) & 1;
-  int c = lex >> 1;
-  return (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
-}
-template <bool HALO>
-__device__ __forceinline__ void shifted_t(const Geom &g, const int x[4], int mu, int d, int y[4]) {
-  y[0] = x[0]; y[1] = x[1]; y[2] = x[2]; y[3] = x[3];
-  int v = y[mu] + d;
-  if (HALO && mu == 3) { y[3] = v; return; }         // t sharded: no wrap, ghosts
-  y[mu] = v >= g.X[mu] ? v - g.X[mu] : (v < 0 ? v + g.X[mu] : v);
-}
-// shifted_t with a direction that is only known at run time (wavefront-uniform): every coordinate is visited with a
-// static index, so x[] and y[] stay in registers (indexing them with mu sends them to scratch)
-template <bool HALO>
-__device__ __forceinline__ void shifted_dyn(const Geom &g, const int x[4], int mu, int d, int y[4]) {
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int v = x[k] + (mu == k ? d : 0);
-    if (HALO && k == 3) y[k] = v;
-    else y[k] = v >= g.X[k] ? v - g.X[k] : (v < 0 ? v + g.X[k] : v);
-  }
-}
 __device__ __forceinline__ size_t link_off(const Geom &g, const int x[4], int mu) {
   return g.halo ? link_off_t<true>(g, x, mu) : link_off_t<false>(g, x, mu);
 }
@@ -577,13 +541,12 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
   const int *order = nullptr; int chunk = 0, nb = 0;
   double *part = nullptr;
   CHK(ordered_sites(c, &order, &chunk, &nb, &part));
-  if (loop == 1 && c->opt_obs_clover) {
-    const size_t shb = (size_t)8 * 576 * sizeof(double2);
-    static bool attr_done = false;
-    if (!attr_done) {
+  const size_t shb = (size_t)8 * 576 * sizeof(double2);
+  if (loop == 1 && c->opt_obs_clover && c->max_lds_optin >= (int)shb) {
+    if (!(c->lds_attr_done & 2)) {
       HIPCHK(hipFuncSetAttribute((const void *)k_flow_obs_clover<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
       HIPCHK(hipFuncSetAttribute((const void *)k_flow_obs_clover<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
-      attr_done = true;
+      c->lds_attr_done |= 2;
     }
     nb = 8 * chunk;                                   // one workgroup per tile
     ScopedTimer tm(c, "flowobs", c->stream);
@@ -752,6 +715,8 @@ static int read_global(qexhip_ctx *c, double *dev, int n, double *host) {
 }
 static inline int ghost_depth_for(double c2, int kind) { return (kind == 0 && c2 != 0.0) ? 2 : 1; }
 
+const double2 *gauge_links_dev(qexhip_ctx *c) { return c->gn ? c->gn->U : nullptr; }
+
 void gauge_free(qexhip_ctx *c) {
   if (!c->gn) return;
   if (c->gn->U) (void)hipFree(c->gn->U);
@@ -848,15 +813,17 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
     // (capping the registers for 3 or 4 waves/SIMD spills: 1460 / 2370 us against 1310 us fused at 2 waves/SIMD)
     static const int lds = [] { const char *e = getenv("QEXHIP_FORCE_LDS"); return e ? atoi(e) : 1; }();
     const bool closed = Uout && c->opt_flow_exp;
-    if (lds && mode == 3) {
-      const size_t shb = (size_t)8 * 576 * sizeof(double2);       // 72 KiB: two workgroups per CU, as the registers allow anyway
-      static bool attr_done = false;
-      if (!attr_done) {
+    const size_t shb = (size_t)8 * 576 * sizeof(double2);         // 72 KiB: two workgroups per CU, as the registers allow anyway
+    // the Wilson-flow stage proper (staples -> v -> exp(v) U): loader / consumer kernel, flow_stage.hip (144 KiB of LDS)
+    if (flow && Uout && mode == 3 && c->opt_flow_ring && c->max_lds_optin >= (int)(16 * 576 * sizeof(double2))) {
+      CHK(flow_stage_launch(c, c->gn->U, c->gn->P, Uout, cplaq / 3.0, cf, cpm, order, chunk, closed));
+    } else if (lds && mode == 3 && c->max_lds_optin >= (int)shb) {
+      if (!(c->lds_attr_done & 1)) {
         HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
         HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
         HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
         HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
-        attr_done = true;
+        c->lds_attr_done |= 1;
       }
       double2 *Pf = (closed || flow) ? c->gn->P : nullptr;
       static const int fnt = [] { const char *e = getenv("QEXHIP_FORCE_NT"); return e ? atoi(e) : 1; }();

@@ -105,6 +105,8 @@ struct qexhip_ctx {
   int opt_batch_multi = 0; // test hook: take the multi-rank reduction branch of the batched CG on one rank
   int opt_multi_reduce = 0; // test hook: take the multi-rank reduction branches of CG / multi-shift CG / norms on one rank
                             // (with a one-rank RCCL communicator the all-reduces are real collectives)
+  int opt_flow_ring = 0;  // QEXHIP_FLOW_RING / option "flow_ring": 1 = the loader / consumer flow stage (flow_stage.hip: measured alternative,
+                          // 850-900 us against 720-780, profiles/r03_flow_stage_experiments.md); 0 = k_force_lds, the default
   int opt_obs_clover = 1; // QEXHIP_OBS_CLOVER / option "obs_clover": 1 = the tile-per-workgroup clover kernel for fmunu(loop = 1); 0 = the path walker
   int opt_flow_exp = 1;   // QEXHIP_FLOW_EXP / option "flow_exp": 1 = closed-form exp(v) in the fused Wilson-flow stage (same function,
                           // another algorithm than the reference's; agrees with it to ~1e-15 per element; the default); 0 = the reference's
@@ -121,6 +123,8 @@ struct qexhip_ctx {
   int *tile_order_pl[16]{};                          // the same for kernels that shift in the (mu, nu) plane only (layout.hip)
   void *obs_table = nullptr;                         // ObsTable of gauge_flow_obs (gauge.hip)
   void *batch = nullptr;                             // BatchState of the lock-step multi-system CG (batch.hip)
+  int lds_attr_done = 0;                             // per context (= per device): which kernels had MaxDynamicSharedMemorySize raised (bit 0 k_force_lds, 1 k_flow_obs_clover, 2 k_flow_stage)
+  int max_lds_optin = 0;                             // hipDeviceAttributeMaxSharedMemoryPerBlock(Optin): the large-LDS kernels fall back when it is too small
   void *cgm_scal = nullptr;                          // CgmScal of the multi-shift solver (multishift.hip)
 };
 
@@ -279,3 +283,7 @@ int md_save_links(qexhip_ctx *c);
 int md_restore_links(qexhip_ctx *c);
 int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]);
 void gauge_free(qexhip_ctx *c);
+const double2 *gauge_links_dev(qexhip_ctx *c);   // resident natural-layout links (nullptr before qexhip_gauge_set)
+// ---- flow_stage.hip ----
+int flow_stage_launch(qexhip_ctx *c, const double2 *U, double2 *P, double2 *Uout, double cp, double cf, double cpm,
+                      const int *order, int chunk, bool closed);

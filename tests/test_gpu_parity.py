@@ -340,12 +340,14 @@ def test_gauge_force(oracle):
     assert relerr(f, oracle.gauge_force(lo, g)) < 1e-13
 
 
+@pytest.mark.parametrize("flow_ring", [0, 1])
 @pytest.mark.parametrize("flow_exp", [1, 0])
-def test_wflow_golden(oracle, flow_exp):
+def test_wflow_golden(oracle, flow_exp, flow_ring):
     """G2 (src/gauge/wflow.nim:92-99,124-149): plaquettes after gaugeFlow(6, 0.01), rel 2e-14 -- the reference's own
     tolerance -- with the flow's default closed-form exp(v) (flow_exp = 1: the same matrix function by Cayley-Hamilton,
     csrc/su3.h m3_exp_tah) and with the reference's algorithm (flow_exp = 0: order-4 Taylor at v/2^20 + 20 squarings,
-    matexp.nim), which is also what the oracle runs; the flowed links agree with the oracle's to 1e-12 either way."""
+    matexp.nim), which is also what the oracle runs; the flowed links agree with the oracle's to 1e-12 either way.
+    flow_ring = 1: the stage as the loader / consumer kernel (csrc/flow_stage.hip, the measured alternative to k_force_lds)."""
     import qex_amd as q
 
     lo = oracle.Layout([8, 8, 8, 8])
@@ -353,6 +355,7 @@ def test_wflow_golden(oracle, flow_exp):
     gref = g.copy()
     ctx = q.Context([8, 8, 8, 8])
     ctx.set_option("flow_exp", flow_exp)
+    ctx.set_option("flow_ring", flow_ring)
     q.gaugeFlow(ctx, g, 6, 0.01)
     p0 = np.array([0.01960725848281519, 0.01982378149813489, 0.01938877647467847,
                    0.0185899778070918, 0.0180821938831715, 0.01876842496122964])
@@ -674,8 +677,9 @@ def test_multi_rank_code_path_on_one_rank(oracle, naik):
     assert np.max(np.abs(q.plaq(ctx, g0) - q.plaq(A.ctx, g0))) < 1e-15
 
 
+@pytest.mark.parametrize("flow_ring", [0, 1])
 @pytest.mark.parametrize("flow_exp", [1, 0])
-def test_force_and_flow_on_a_lattice_with_a_ragged_last_tile(oracle, flow_exp):
+def test_force_and_flow_on_a_lattice_with_a_ragged_last_tile(oracle, flow_exp, flow_ring):
     """4 x 6 x 10 x 6: 720 sites per parity = 11 tiles of 64 and a quarter.  The force / flow kernels give a whole
     workgroup (four directions, shared links through LDS, one barrier) to every tile, so the padding lanes of the last
     tile must go through the barrier and store nothing: force and three flow steps against the oracle."""
@@ -686,6 +690,7 @@ def test_force_and_flow_on_a_lattice_with_a_ragged_last_tile(oracle, flow_exp):
     g = oracle.gauge_random(lo, seed=SEED)
     ctx = q.Context(lat)
     ctx.set_option("flow_exp", flow_exp)
+    ctx.set_option("flow_ring", flow_ring)
     assert relerr(q.gaugeForce(ctx, g), oracle.gauge_force(lo, g)) < 1e-13
     gref = g.copy()
     q.gaugeFlow(ctx, g, 3, 0.02)
