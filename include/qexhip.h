@@ -208,6 +208,11 @@ int qexhip_wflow_general(qexhip_handle h, int nsteps, double eps, double cplaq, 
  * (src/gauge/gaugeUtils.nim:1162-1271); loop in {1,3,4,5} selects the clover improvement
  * (1x1 | +2x2+3x3 | +2x2+1x2+1x3 | all five loop shapes, coefficients of :1128-1146). */
 int qexhip_flow_EQ(qexhip_handle h, int loop, double out[3]);
+/* What a flow loop measures after every step (src/flow/gauge_flow.nim:139-156,360-379; tests/base/twflow_topo.nim:4-10:
+ * `g.plaq` and `EQ` = fmunu(1) -> densityE, topoQ) in ONE pass over the resident links: the plaquette of a plane is the
+ * trace of one of the four clover leaves of that plane, so plaq[6] (as qexhip_plaq) and EQ[3] (as qexhip_flow_EQ with
+ * loop = 1) come out of the same kernel. */
+int qexhip_flow_measure(qexhip_handle h, double plaq[6], double EQ[3]);
 /* The remaining gauge-sector pieces an HMC trajectory needs, on the resident field (set with qexhip_gauge_set):
  *   action: gc.gaugeAction1(g) (crect) / gc.actionA(g) (cadjplaq) (src/gauge/gaugeAction.nim:61-142,614-681),
  *           coefficients as GaugeActionCoeffs(plaq, rect | adjplaq); at most one of crect, cadjplaq non-zero

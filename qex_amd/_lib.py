@@ -61,6 +61,7 @@ SYMBOLS = [
     ("qexhip_gauge_force", _ci, [_vp, _vp, _cd]),
     ("qexhip_wflow", _ci, [_vp, _ci, _cd]),
     ("qexhip_flow_EQ", _ci, [_vp, _ci, _vp]),
+    ("qexhip_flow_measure", _ci, [_vp, _vp, _vp]),
     ("qexhip_gauge_force_general", _ci, [_vp, _vp, _cd, _cd, _ci]),
     ("qexhip_wflow_general", _ci, [_vp, _ci, _cd, _cd, _cd, _ci]),
     ("qexhip_fat7", _ci, [_vp, _vp, _pd, _vp, _vp, _cd]),

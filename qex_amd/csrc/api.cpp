@@ -681,6 +681,15 @@ extern "C" int qexhip_wflow_general(qexhip_handle c, int nsteps, double eps, dou
   return gauge_wflow(c, nsteps, eps, cplaq, c2, kind);
 }
 extern "C" int qexhip_flow_EQ(qexhip_handle c, int loop, double out[3]) { if (!c || !out) return QEXHIP_ERR_ARG; return gauge_flow_obs(c, loop, out); }
+extern "C" int qexhip_flow_measure(qexhip_handle c, double plaq[6], double EQ[3]) {
+  if (!c || !plaq || !EQ) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  // the dedicated kernel when it is available (one pass over the links for all nine numbers), two passes otherwise
+  const int rc = gauge_flow_obs(c, 1, EQ, plaq);
+  if (rc != -3) return rc;
+  CHK(gauge_plaq(c, plaq));
+  return gauge_flow_obs(c, 1, EQ);
+}
 extern "C" int qexhip_gauge_action(qexhip_handle c, double cplaq, double crect, double cadj, double *out) {
   if (!c || !out) return QEXHIP_ERR_ARG;
   if (crect != 0.0 && cadj != 0.0) { qexhip_set_error("rect and adjplaq together are not a QEX action"); return QEXHIP_ERR_ARG; }

@@ -369,10 +369,10 @@ template <bool HALO>
 __global__ void __launch_bounds__(384, 3) k_flow_obs_clover(Geom g, const double2 *__restrict__ G, double *partials,
                                                             const int *order, int chunk) {
   extern __shared__ double2 smO[];                    // [2 mu + (0: U_mu(x) | 1: U_mu(x-mu))][9][64], later F[plane][9][64]
-  __shared__ double red[3][6];
+  __shared__ double red[4][6];
   const int e = order[(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double es = 0, et = 0, q = 0;
+  double es = 0, et = 0, q = 0, pl = 0;               // pl: Re tr of the plaquette of this wavefront's plane at x
   if (e >= 0) {                                       // the whole workgroup together
     const int p = e & 1;
     const int c0 = (e >> 1) * 64 + lane;
@@ -429,6 +429,9 @@ __global__ void __launch_bounds__(384, 3) k_flow_obs_clover(Geom g, const double
       __builtin_amdgcn_sched_barrier(0);
       m = m3_mul_na(m, m3_load(Ub, 64));
       __builtin_amdgcn_sched_barrier(0);
+      // this leaf IS the plaquette U_a(x) U_b(x+a) U_a(x+b)^+ U_b(x)^+ of plaq (gaugeUtils.nim:213-282): its trace is the
+      // plaquette observable of the plane, for free
+      if (live) pl = m.e[0].x + m.e[4].x + m.e[8].x;
       m3_axpy(acc, 0.25, m);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -463,12 +466,17 @@ __global__ void __launch_bounds__(384, 3) k_flow_obs_clover(Geom g, const double
       }
     }
   }
-  es = wave_sum(es); et = wave_sum(et); q = wave_sum(q);
-  if (lane == 0) { red[0][w] = es; red[1][w] = et; red[2][w] = q; }
+  es = wave_sum(es); et = wave_sum(et); q = wave_sum(q); pl = wave_sum(pl);
+  if (lane == 0) { red[0][w] = es; red[1][w] = et; red[2][w] = q; red[3][w] = pl; }
   __syncthreads();
   if (threadIdx.x < 3) {
     const double *r = red[threadIdx.x];
     partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = ((r[0] + r[1]) + (r[2] + r[3])) + (r[4] + r[5]);
+  } else if (threadIdx.x < 9) {
+    // planes of wavefronts 0..5: (1,0) (3,2) (2,0) (3,1) (2,1) (3,0) -> plaq's index mu (mu - 1) / 2 + nu: 0 5 1 4 2 3
+    const int wv = threadIdx.x - 3;
+    const int ip = wv == 0 ? 0 : (wv == 1 ? 5 : (wv == 2 ? 1 : (wv == 3 ? 4 : (wv == 4 ? 2 : 3))));
+    partials[(size_t)(3 + ip) * gridDim.x + blockIdx.x] = red[3][wv];
   }
 }
 __global__ void __launch_bounds__(256) k_obs_final(const double *partials, int nb, double vol, double *out) {
@@ -527,7 +535,8 @@ static int obs_build_table(int loop, ObsTable &T) {
   return 0;
 }
 
-int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
+// plaq6 != nullptr (loop 1, clover kernel only): the six plaquettes of plaq come out of the same pass (qexhip_flow_measure)
+int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3], double *plaq6) {
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
   for (int d = 0; d < 4; d++)
     if (loop > 1 && c->g.X[d] < 4) { qexhip_set_error("improved fmunu needs extents >= 4"); return -1; }
@@ -542,7 +551,9 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
   double *part = nullptr;
   CHK(ordered_sites(c, &order, &chunk, &nb, &part));
   const size_t shb = (size_t)8 * 576 * sizeof(double2);
-  if (loop == 1 && c->opt_obs_clover && c->max_lds_optin >= (int)shb) {
+  const bool clover = loop == 1 && c->opt_obs_clover && c->max_lds_optin >= (int)shb;
+  if (plaq6 && !clover) { qexhip_set_error("flow_measure: the fused pass is the clover kernel's (loop 1, option obs_clover)"); return -3; }
+  if (clover) {
     if (!(c->lds_attr_done & 2)) {
       HIPCHK(hipFuncSetAttribute((const void *)k_flow_obs_clover<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
       HIPCHK(hipFuncSetAttribute((const void *)k_flow_obs_clover<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
@@ -558,10 +569,14 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]) {
     k_flow_obs<<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, dT, part, order, chunk);
     HIPCHK(hipGetLastError());
   }
-  k_obs_final<<<3, 256, 0, c->stream>>>(part, nb, (double)c->g.V, &c->dscal[24]);
+  const int nobs = plaq6 ? 9 : 3;
+  k_obs_final<<<nobs, 256, 0, c->stream>>>(part, nb, (double)c->g.V, &c->dscal[24]);
   HIPCHK(hipGetLastError());
-  CHK(read_global(c, &c->dscal[24], 3, out));
+  double res[9];
+  CHK(read_global(c, &c->dscal[24], nobs, res));
+  for (int k = 0; k < 3; k++) out[k] = res[k];
   const double vol = (double)c->g.V * (double)c->nranks;
+  if (plaq6) for (int k = 0; k < 6; k++) plaq6[k] = res[3 + k] / (vol * 18.0);    // pl[i]/(physVol*np*nc), gaugeUtils.nim:277
   out[0] = -out[0] / vol; out[1] = -out[1] / vol;
   out[2] = -out[2] / (4.0 * 3.14159265358979323846 * 3.14159265358979323846);
   return 0;
@@ -760,7 +775,7 @@ int gauge_get(qexhip_ctx *c, double *g) {
 static int ordered_sites(qexhip_ctx *c, const int **order, int *chunk, int *nb, double **part) {
   CHK(tile_order_table(c, order, chunk));
   *nb = 8 * ((*chunk + 3) / 4);
-  const int need = 6 * 8 * *chunk;                      // six plaquette sums (or three observables) per tile-workgroup
+  const int need = 9 * 8 * *chunk;                      // six plaquette sums and / or three observables per tile-workgroup
   if (c->gn->npp < need) {
     if (c->gn->pp) (void)hipFree(c->gn->pp);
     c->gn->pp = nullptr; c->gn->npp = 0;

@@ -268,7 +268,7 @@ int gauge_get(qexhip_ctx *c, double *g);
 int gauge_plaq(qexhip_ctx *c, double out[6]);
 int gauge_force(qexhip_ctx *c, double *f_host, double cplaq, double c2 = 0.0, int kind = 0);
 int gauge_wflow(qexhip_ctx *c, int nsteps, double eps, double cplaq = 1.0, double c2 = 0.0, int kind = 0);
-int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3]);
+int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3], double *plaq6 = nullptr);
 int gauge_action(qexhip_ctx *c, double cplaq, double c2, int kind, double *out);
 int gauge_md_update(qexhip_ctx *c, const double *p_host, double t);
 int gauge_reunit(qexhip_ctx *c);

@@ -415,6 +415,16 @@ def flowEQ(ctx, loop=1, g=None):
     return out
 
 
+def flowMeasure(ctx, g=None):
+    """(plaq[6], [E_s, E_t, Q]) of the resident (or given) field in one pass: what the measure block of a flow loop prints
+    after every step (src/flow/gauge_flow.nim:139-156,360-379)"""
+    if g is not None:
+        check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+    pl, eq = np.zeros(6), np.zeros(3)
+    check(lib().qexhip_flow_measure(ctx._h, _p(pl), _p(eq)))
+    return pl, eq
+
+
 def gaugeAction(ctx, g=None, plaq=1.0, rect=0.0, adjplaq=0.0):
     """gc.gaugeAction1(g) / gc.actionA(g) (gaugeAction.nim:61-142,614-681) of g (or of the resident field)"""
     if g is not None:

@@ -74,3 +74,42 @@ def test_clover_kernel_against_the_path_walker_and_the_oracle(oracle, lat, halo)
         got[v] = q.flowEQ(ctx, 1, g)
         assert np.max(np.abs(got[v] - want)) < 1e-12 * max(1.0, np.abs(want).max()), (v, got[v], want)
     assert np.max(np.abs(got[1] - got[0])) < 1e-14 * max(1.0, np.abs(want).max()), got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("halo", [False, True])
+def test_flow_measure_is_plaq_and_EQ_in_one_pass(oracle, halo):
+    """qexhip_flow_measure: the plaquettes (gaugeUtils.nim:213-282) and the clover E_s, E_t, Q (gauge_flow.nim:360-379) a flow
+    loop prints after every step, from ONE kernel -- the plaquette of a plane is the trace of one clover leaf.  Against the
+    separate entry points, the oracle, and the reference's own plaquette vector G1 (tests/reprod/trandgauge.nim:17, its bound
+    1e-30 on the summed squared differences)."""
+    import qex_amd as q
+
+    lat = [8, 8, 8, 8]
+    lo = oracle.Layout(lat)
+    g = oracle.gauge_random(lo)                    # G1: RngMilc6, seed 17^7
+    ctx = q.Context(lat)
+    if halo:
+        ctx.force_halo(True)
+    pl, eq = q.flowMeasure(ctx, g)
+    g1 = np.array([0.0006005738094166639, 0.0007744149733359666, 0.000491692592364555,
+                   -0.0002244585371871249, -0.000700363878755635, -4.121898341926528e-05])
+    assert ((pl - g1) ** 2).sum() <= 1e-30
+    assert np.abs(pl - q.plaq(ctx)).max() < 1e-17 and np.abs(pl - oracle.plaq(lo, g)).max() < 1e-17
+    assert np.array_equal(eq, q.flowEQ(ctx, 1))    # the same kernel, the same sums
+    assert np.allclose(eq, oracle.flow_EQ(lo, g, 1), rtol=1e-12, atol=1e-12)
+    # after a few flow steps (smooth field: plaquettes of order 0.02) and on a lattice with a ragged last tile
+    q.gaugeFlowResident(ctx, 3, 0.01)
+    pl, eq = q.flowMeasure(ctx)
+    assert np.abs(pl - q.plaq(ctx)).max() < 1e-16 and np.array_equal(eq, q.flowEQ(ctx, 1))
+    if not halo:
+        lat2 = [4, 6, 10, 6]
+        lo2 = oracle.Layout(lat2)
+        g2 = oracle.gauge_random(lo2, seed=5)
+        c2 = q.Context(lat2)
+        pl, eq = q.flowMeasure(c2, g2)
+        assert np.abs(pl - oracle.plaq(lo2, g2)).max() < 1e-16
+        assert np.allclose(eq, oracle.flow_EQ(lo2, g2, 1), rtol=1e-12, atol=1e-12)
+        c2.set_option("obs_clover", 0)             # without the dedicated kernel: two passes, same numbers
+        pl2, eq2 = q.flowMeasure(c2)
+        assert np.abs(pl2 - pl).max() < 1e-16 and np.allclose(eq2, eq, rtol=1e-12, atol=1e-13)
