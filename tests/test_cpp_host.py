@@ -11,17 +11,19 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "test_stag_prop")
+SHIM = os.path.join(ROOT, "tests", "cpp", "test_shim_sequence")
 
 
-def build():
+def build(exe=EXE):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libqexoracle.so"])
-    src = os.path.join(ROOT, "tests", "cpp", "test_stag_prop.cpp")
-    if os.path.exists(EXE) and os.path.getmtime(EXE) > max(
+    src = exe + ".cpp"
+    if os.path.exists(exe) and os.path.getmtime(exe) > max(
             os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "include", "qexhip.hpp")),
+            os.path.getmtime(os.path.join(ROOT, "include", "qexhip.h")),
             os.path.getmtime(os.path.join(ROOT, "qex_amd", "libqexhip.so"))):
         return
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle"),
-           src, "-o", EXE,
+           src, "-o", exe,
            "-L" + os.path.join(ROOT, "qex_amd"), "-lqexhip", "-L" + os.path.join(ROOT, "oracle"), "-lqexoracle",
            "-Wl,-rpath," + os.path.join(ROOT, "qex_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
            "-Wl,-rpath,/opt/rocm/lib", "-fopenmp"]
@@ -41,6 +43,35 @@ def test_cpp_host_parity_program():
     p = subprocess.run([EXE], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=300)
     print(p.stdout)
     assert p.returncode == 0 and "Passed" in p.stdout, p.stdout
+
+
+def test_nim_shim_call_sequence_compiles_and_binds_what_the_shim_declares():
+    """tests/cpp/test_shim_sequence.cpp performs the C calls of every proc of qex_amd/nim/qexhip.nim (no Nim compiler in the
+    image); here: it builds, and every `importc` line of the shim names an entry point include/qexhip.h declares."""
+    import re
+
+    build(SHIM)
+    out = subprocess.check_output(["ldd", SHIM], text=True)
+    assert "libqexhip.so" in out and "not found" not in out
+    nim = open(os.path.join(ROOT, "qex_amd", "nim", "qexhip.nim")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "qexhip.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(qexhip_[A-Za-z0-9_]+)\s*\(", hdr))
+    imported = set(re.findall(r"^proc (qexhip_[A-Za-z0-9_]+)\(", nim, flags=re.M))
+    assert len(imported) >= 45 and imported <= declared, sorted(imported - declared)
+    # every entry point a wrapper proc calls is one the C++ replay calls too
+    called = set(re.findall(r"chk (qexhip_[A-Za-z0-9_]+)\(", nim)) | set(re.findall(r"chk (qexhip_[A-Za-z0-9_]+) *\(", nim))
+    cpp = open(SHIM + ".cpp").read()
+    missing = sorted(n for n in called if n + "(" not in cpp and n not in ("qexhip_comm_unique_id", "qexhip_comm_init", "qexhip_comm_info"))
+    assert not missing, missing
+
+
+@pytest.mark.gpu
+def test_nim_shim_call_sequence_against_the_oracle():
+    build(SHIM)
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    p = subprocess.run([SHIM], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+    print(p.stdout)
+    assert p.returncode == 0 and "shim sequence: Passed" in p.stdout, p.stdout
 
 
 def test_closed_form_exp_against_the_reference_algorithm_and_long_double(tmp_path):
