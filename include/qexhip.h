@@ -185,6 +185,12 @@ int qexhip_release_workspace(qexhip_handle h);
 int qexhip_dev_norm2(qexhip_handle h, int x_id, int parity, double *out);
 int qexhip_dev_redot(qexhip_handle h, int x_id, int y_id, int parity, double *out);
 int qexhip_dev_D(qexhip_handle h, int r_id, int x_id, double m, double sc);
+/* r[parity] := 0 (the `phi.odd := 0` of the pseudofermion refresh, staghmc_sh.nim:748-755) */
+int qexhip_dev_zero(qexhip_handle h, int id, int parity);
+/* n x Staggered.solve (qexhip_stag_solve semantics per system) on resident fields, lock-step batches of four on the
+ * operator's current links: faction / pbp of the HMC drivers without moving a vector (staghmc_sh.nim:260-272,339-364) */
+int qexhip_dev_solve_batch(qexhip_handle h, int n, const int *x_ids, const int *b_ids, const double *mass,
+                           const double *r2req, int maxits, int *iters, double *r2);
 
 /* ---------------- gauge field, plaquette, Wilson flow ----------------
  * qexhip_gauge_set/get: the `g` of src/gauge/wflow.nim:21 (unphased links, periodic). */
@@ -331,6 +337,9 @@ int qexhip_nhyp_fforce(qexhip_handle h, double *f, int n, const double *const *p
                        const double *r2req, int maxits, const int antiperiodic[4], const int phases[4], int *iters);
 int qexhip_nhyp_fermion_force(qexhip_handle h, double *f, const double *const *psi, const double *scale, int n,
                               const int antiperiodic[4], const int phases[4]);
+/*   the same with the pseudofermion fields already resident (field ids): nothing but scalars crosses PCIe when f == NULL */
+int qexhip_nhyp_fforce_dev(qexhip_handle h, double *f, int n, const int *phi_ids, const double *mass, const double *scale,
+                           const double *r2req, int maxits, const int antiperiodic[4], const int phases[4], int *iters);
 
 /* ---------------- random number fields and configuration generation (host only, no handle) ----------------
  * newRNGField (src/rng/distributionUtils.nim:306-331): one generator per site of the LOCAL lattice, seeded with
@@ -358,6 +367,21 @@ int qexhip_rng_state_words(qexhip_rng *rng);
 int qexhip_rng_get_state(qexhip_rng *rng, unsigned *out);
 int qexhip_rng_set_state(qexhip_rng *rng, const unsigned *in);
 
+/* The same generators writing into HBM, for the two ends of an HMC trajectory (refresh / measure of the drivers:
+ * src/examples/staghmc_sh.nim:716-757,774-789, src/stagg_pv_hmc/staghmc_spv.nim:1180-1250) -- RngMilc6 fields only.  The
+ * generator states go to the device (36 B per site), one lane per site advances its stream, the states come back: the field's
+ * state afterwards is bit for bit the one the host call of the same name leaves (qexhip_rng_get_state), and host and device
+ * calls can be mixed freely.  Deviates: formed with the device's fp64 log / cos / sqrt; after RngMilc6.gaussian's float32
+ * rounding they equal the host's except where the double falls within ~1e-16 of a float32 rounding boundary (about one
+ * deviate in 1e8, by one float32 ulp); u1 phases agree to 1e-16.
+ *   dev_gaussian_vector: v.gaussian r into the resident colour vector `field_id`      (distributionUtils.nim:64-97)
+ *   dev_u1_vector:       v.u1 r                                                       (:182-211)
+ *   md_refresh_momenta:  p.randomTAH r into the resident MD momenta (gaugeUtils.nim:1356-1383); qexhip_md_begin(h, g, NULL)
+ *                        keeps them, qexhip_md_momentum_norm2 gives 2 T + const. */
+int qexhip_rng_dev_gaussian_vector(qexhip_handle h, qexhip_rng *rng, int field_id);
+int qexhip_rng_dev_u1_vector(qexhip_handle h, qexhip_rng *rng, int field_id);
+int qexhip_md_refresh_momenta(qexhip_handle h, qexhip_rng *rng);
+
 /* ---------------- resident molecular dynamics ----------------
  * The MD loop of QEX's HMC drivers -- mdt (U <- exp(t p) U), mdv (p -= t f), mdvAllfga with its force-gradient shifts
  * (src/examples/staghmc_sh.nim:429-640, src/stagg_pv_hmc/staghmc_spv.nim:873-1061) -- with links and momenta left on the
@@ -365,7 +389,7 @@ int qexhip_rng_set_state(qexhip_rng *rng, const unsigned *in);
  *   source 0: qexhip_md_gauge_force (gc.forceA / gaugeForce of the resident thin links)
  *   source 1: the last force of the nHYP closure: qexhip_nhyp_gauge_force / _fermion_force / _fforce called with f = NULL
  * and qexhip_nhyp_prepare(g = NULL) smears the resident links.  begin uploads (g NULL: keep the resident links of
- * qexhip_gauge_set), end downloads (either pointer may be NULL).  kick: p += t * f.  shift_links: U <- exp(t f) U
+ * qexhip_gauge_set; p NULL: keep the resident momenta, e.g. of qexhip_md_refresh_momenta), end downloads (either pointer may be NULL).  kick: p += t * f.  shift_links: U <- exp(t f) U
  * (fgv / fgvf of the force-gradient update); save / restore bracket it (fgsave / fgload). */
 int qexhip_md_begin(qexhip_handle h, const double *g, const double *p);
 int qexhip_md_end(qexhip_handle h, double *g, double *p);

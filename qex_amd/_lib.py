@@ -97,6 +97,12 @@ SYMBOLS = [
     ("qexhip_rng_random_tah", _ci, [_vp, _vp]),
     ("qexhip_rng_gauge_random", _ci, [_vp, _vp]),
     ("qexhip_rng_gauge_warm", _ci, [_vp, _cd, _vp]),
+    ("qexhip_rng_dev_gaussian_vector", _ci, [_vp, _vp, _ci]),
+    ("qexhip_rng_dev_u1_vector", _ci, [_vp, _vp, _ci]),
+    ("qexhip_md_refresh_momenta", _ci, [_vp, _vp]),
+    ("qexhip_dev_zero", _ci, [_vp, _ci, _ci]),
+    ("qexhip_dev_solve_batch", _ci, [_vp, _ci, _pi, _pi, _pd, _pd, _ci, _pi, _pd]),
+    ("qexhip_nhyp_fforce_dev", _ci, [_vp, _vp, _ci, _pi, _pd, _pd, _pd, _ci, _pi, _pi, _pi]),
     ("qexhip_rng_state_words", _ci, [_vp]),
     ("qexhip_rng_get_state", _ci, [_vp, _vp]),
     ("qexhip_rng_set_state", _ci, [_vp, _vp]),

@@ -660,6 +660,61 @@ extern "C" int qexhip_nhyp_fforce(qexhip_handle c, double *f, int n, const doubl
   for (int mu = 0; mu < 4; mu++) if (antiperiodic ? antiperiodic[mu] : (mu == 3)) mask |= 1 << mu;
   return nhyp_fforce(c, f, n, phi, mass, scale, r2req, maxits, mask, phases ? phases : defph, iters);
 }
+extern "C" int qexhip_nhyp_fforce_dev(qexhip_handle c, double *f, int n, const int *phi_ids, const double *mass,
+                                      const double *scale, const double *r2req, int maxits, const int antiperiodic[4],
+                                      const int phases[4], int *iters) {
+  if (!c || !phi_ids || !mass || !scale || !r2req || n < 1 || n > 64) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  static const int defph[4] = {8, 9, 11, 0};
+  int mask = 0;
+  for (int mu = 0; mu < 4; mu++) if (antiperiodic ? antiperiodic[mu] : (mu == 3)) mask |= 1 << mu;
+  std::vector<DevField *> pf(n);
+  for (int k = 0; k < n; k++) CHK(find_field(c, phi_ids[k], &pf[k]));
+  return nhyp_fforce(c, f, n, nullptr, mass, scale, r2req, maxits, mask, phases ? phases : defph, iters, pf.data());
+}
+// ---- the two ends of a trajectory on resident fields (round 3) ----
+struct qexhip_rng;
+extern "C" int qexhip_rng_dev_gaussian_vector(qexhip_handle c, qexhip_rng *rng, int field_id) {
+  if (!c || !rng) return QEXHIP_ERR_ARG;
+  DevField *f;
+  CHK(find_field(c, field_id, &f));
+  return rng_dev_generate(c, rng, 0, f, nullptr);
+}
+extern "C" int qexhip_rng_dev_u1_vector(qexhip_handle c, qexhip_rng *rng, int field_id) {
+  if (!c || !rng) return QEXHIP_ERR_ARG;
+  DevField *f;
+  CHK(find_field(c, field_id, &f));
+  return rng_dev_generate(c, rng, 1, f, nullptr);
+}
+extern "C" int qexhip_md_refresh_momenta(qexhip_handle c, qexhip_rng *rng) {
+  if (!c || !rng) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  double2 *M = nullptr;
+  CHK(md_momenta_dev(c, &M));
+  return rng_dev_generate(c, rng, 2, nullptr, M);
+}
+extern "C" int qexhip_dev_zero(qexhip_handle c, int id, int parity) {
+  if (!c || parity < 0 || parity > 2) return QEXHIP_ERR_ARG;
+  DevField *f;
+  CHK(find_field(c, id, &f));
+  return blas_zero(c, *f, parity);
+}
+extern "C" int qexhip_dev_solve_batch(qexhip_handle c, int n, const int *x_ids, const int *b_ids, const double *mass,
+                                      const double *r2req, int maxits, int *iters, double *r2) {
+  if (!c || !x_ids || !b_ids || !mass || !r2req || n < 1 || n > 64) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  for (int k0 = 0; k0 < n; k0 += 4) {          // lock-step batches of four, as qexhip_stag_solve_batch
+    const int k = std::min(4, n - k0);
+    DevField *xs[4], *bs[4];
+    for (int j = 0; j < k; j++) {
+      if (x_ids[k0 + j] == b_ids[k0 + j]) { qexhip_set_error("dev_solve_batch: solution and source are the same field"); return QEXHIP_ERR_ARG; }
+      CHK(find_field(c, x_ids[k0 + j], &xs[j]));
+      CHK(find_field(c, b_ids[k0 + j], &bs[j]));
+    }
+    CHK(solve_full_batch_dev(c, k, xs, bs, mass + k0, r2req + k0, maxits, iters ? iters + k0 : nullptr, r2 ? r2 + k0 : nullptr));
+  }
+  return 0;
+}
 extern "C" int qexhip_nhyp_release(qexhip_handle c) {
   if (!c) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
@@ -715,7 +770,7 @@ extern "C" int qexhip_wflow(qexhip_handle c, int nsteps, double eps) { if (!c ||
 
 // ---- resident molecular dynamics (gauge.hip) ----
 extern "C" int qexhip_md_begin(qexhip_handle c, const double *g, const double *p) {
-  if (!c || !p) return QEXHIP_ERR_ARG;
+  if (!c) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
   return md_begin(c, g, p);
 }

@@ -1019,12 +1019,21 @@ int md_begin(qexhip_ctx *c, const double *g, const double *p) {
   CHK(gn_alloc_fp(c));
   const size_t nbytes = c->gn->n2 * sizeof(double2);
   if (!c->gn->M) { HIPCHK(hipMalloc((void **)&c->gn->M, nbytes)); HIPCHK(hipMemsetAsync(c->gn->M, 0, nbytes, c->stream)); }
-  const size_t bytes = (size_t)c->g.V * 72 * sizeof(double);
-  CHK(ensure_stage(c, bytes));
-  HIPCHK(hipMemcpyAsync(c->stage, p, bytes, hipMemcpyHostToDevice, c->stream));
-  k_gauge_to_tiles<<<(c->g.V + 255) / 256, 256, 0, c->stream>>>(c->g, (const double2 *)c->stage, c->gn->M);
-  HIPCHK(hipGetLastError());
+  if (p) {          // p == NULL: keep the resident momenta (qexhip_md_refresh_momenta draws them on the device)
+    const size_t bytes = (size_t)c->g.V * 72 * sizeof(double);
+    CHK(ensure_stage(c, bytes));
+    HIPCHK(hipMemcpyAsync(c->stage, p, bytes, hipMemcpyHostToDevice, c->stream));
+    k_gauge_to_tiles<<<(c->g.V + 255) / 256, 256, 0, c->stream>>>(c->g, (const double2 *)c->stage, c->gn->M);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int md_momenta_dev(qexhip_ctx *c, double2 **M) {
+  if (!c->gn) { qexhip_set_error("no resident gauge field (qexhip_gauge_set / qexhip_md_begin)"); return -3; }
+  const size_t nbytes = c->gn->n2 * sizeof(double2);
+  if (!c->gn->M) { HIPCHK(hipMalloc((void **)&c->gn->M, nbytes)); HIPCHK(hipMemsetAsync(c->gn->M, 0, nbytes, c->stream)); }
+  *M = c->gn->M;
   return 0;
 }
 int md_end(qexhip_ctx *c, double *g, double *p) {

@@ -168,7 +168,7 @@ int batch_io_fields(qexhip_ctx *c, int n, DevField **xs, DevField **bs);
 int solve_full_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const double *mass, const double *r2req,
                          int maxits, int *iters, double *r2_final);
 int nhyp_fforce(qexhip_ctx *c, double *f_host, int n, const double *const *phi, const double *mass, const double *scale,
-                const double *r2req, int maxits, int bcmask, const int ph[4], int *iters);
+                const double *r2req, int maxits, int bcmask, const int ph[4], int *iters, DevField *const *phi_dev = nullptr);
 int solve_batch_host(qexhip_ctx *c, int n, double *const *x, const double *const *b, const double *mass,
                      const double *r2req, int maxits, int xx_parity, int *iters, double *r2);
 
@@ -284,6 +284,10 @@ int md_restore_links(qexhip_ctx *c);
 int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]);
 void gauge_free(qexhip_ctx *c);
 const double2 *gauge_links_dev(qexhip_ctx *c);   // resident natural-layout links (nullptr before qexhip_gauge_set)
+// ---- rng.hip (device-side generation) ----
+struct qexhip_rng;
+int rng_dev_generate(qexhip_ctx *c, qexhip_rng *R, int what, DevField *f, double2 *P);   // what: 0 gaussian vector, 1 u1 vector, 2 randomTAH -> P
+int md_momenta_dev(qexhip_ctx *c, double2 **M);                                          // resident MD momenta (allocated on demand)
 // ---- flow_stage.hip ----
 int flow_stage_launch(qexhip_ctx *c, const double2 *U, double2 *P, double2 *Uout, double cp, double cf, double cpm,
                       const int *order, int chunk, bool closed);

@@ -1,6 +1,9 @@
 // rng.hip -- per-site random number fields and the configuration generators built on them.
-// Host code (no GPU): the deviates must be bit-identical to QEX's, whose gaussians go through libm's log / cos
-// and are then rounded to float32, so they are produced with the host's libm, one generator per site.
+// Host code (no GPU) for everything that defines "the same configuration": the deviates must be bit-identical to QEX's,
+// whose gaussians go through libm's log / cos and are then rounded to float32, so they are produced with the host's libm,
+// one generator per site.  Round 3 adds, at the end of the file, the device form of the RngMilc6 field for the two ENDS of
+// an HMC trajectory (momenta, pseudofermion and pbp sources born in HBM): the integer streams advance bit-identically on
+// the GPU (one lane per site, each stream sequential), the deviates go through the device's libm.
 //
 // Restates (file:line in ctpeterson/qex):
 //   RngMilc6: seedX / nextI / uniform / gaussian     src/rng/milcrng.nim:92-110,120-133,150-154,158-193
@@ -241,4 +244,91 @@ extern "C" int qexhip_rng_set_state(qexhip_rng *R, const unsigned *in) {
     else { memcpy(R->mrg[j].s1, in + 6 * j, 12); memcpy(R->mrg[j].s2, in + 6 * j + 3, 12); }
   }
   return 0;
+}
+
+
+// ================= device-side generation from an RngMilc6 field (the two ends of a trajectory, round 3) =================
+// refresh / measure of the HMC drivers (src/examples/staghmc_sh.nim:716-757,774-789; stagg_pv_hmc/staghmc_spv.nim:1180-1250):
+//   p.randomTAH r;  psi[k][i].gaussian r;  eta.u1 r      (gaugeUtils.nim:1356-1383, distributionUtils.nim:64-97,182-211)
+// with the fields written straight into HBM: the generator states go up (36 B per site), one lane per site advances ITS
+// stream sequentially -- integer arithmetic, so the states that come back are bit for bit the host generator's after the
+// same draws (tests assert it through qexhip_rng_get_state) -- and the deviates are formed with the device's fp64 log / cos /
+// sqrt.  Those agree with glibc's to the last bit or two; after the float32 rounding of RngMilc6.gaussian a deviate therefore
+// differs from the host's (by one float32 ulp) only when the double lands within ~1e-16 of a float32 rounding boundary:
+// about once per 1e8 deviates (tests/test_rng_product.py counts them).  u1 phases carry no float32 rounding: 1e-16 agreement.
+#include "qexhip_internal.h"
+
+__device__ __forceinline__ uint32_t milc6_next(uint32_t *w) {     // w: r0..r6, ic, mult (milcrng.nim:120-133)
+  const uint32_t t = (((w[5] >> 7) | (w[6] << 17)) ^ ((w[4] >> 1) | (w[5] << 23))) & 0x00FFFFFFu;
+  w[6] = w[5]; w[5] = w[4]; w[4] = w[3]; w[3] = w[2]; w[2] = w[1]; w[1] = w[0]; w[0] = t;
+  const uint32_t s = w[7] * w[8] + 12345u;
+  w[7] = s;
+  return t ^ ((s >> 8) & 0x00FFFFFFu);
+}
+__device__ __forceinline__ float milc6_uniform(uint32_t *w) { return (1.0f / (float)0x01000000) * (float)milc6_next(w); }
+__device__ __forceinline__ double milc6_gaussian(uint32_t *w) {
+  const double v = (double)milc6_uniform(w);
+  const double p = (double)milc6_uniform(w) * 2.0 * 3.14159265358979323846;
+  const double r = sqrt(-2.0 * log(v + 9.999999999999999e-308));
+  return (double)(float)(r * cos(p));
+}
+// what: 0 gaussian colour vector, 1 u1 colour vector (-> field v, one parity half after the other);
+//       2 randomTAH (-> natural-layout matrix field P: [parity][tile][mu][9][64])
+__global__ void __launch_bounds__(256) k_rng_milc6(Geom g, uint32_t *__restrict__ state, int what, double2 *v, size_t vhalf, double2 *P) {
+  const int i = blockIdx.x * 256 + threadIdx.x;          // host site index j = c + parity * Vh
+  if (i >= g.V) return;
+  uint32_t w[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) w[k] = state[(size_t)9 * i + k];
+  const int p = i >= g.Vh, c = i - p * g.Vh;
+  if (what == 2) {
+    const double s2 = 0.70710678118654752440, s3 = 0.57735026918962576450;
+#pragma unroll 1
+    for (int mu = 0; mu < 4; mu++) {                      // randTah3, draws in the order r3 r8 r01 r02 r12 i01 i02 i12
+      const double r3 = s2 * milc6_gaussian(w);
+      const double r8 = s2 * s3 * milc6_gaussian(w);
+      const double r01 = s2 * milc6_gaussian(w), r02 = s2 * milc6_gaussian(w), r12 = s2 * milc6_gaussian(w);
+      const double i01 = s2 * milc6_gaussian(w), i02 = s2 * milc6_gaussian(w), i12 = s2 * milc6_gaussian(w);
+      double2 *d = P + (((size_t)p * g.etile + (c >> 6)) * 4 + mu) * 576 + (c & 63);
+      d[0 * 64] = make_double2(0.0, r8 + r3); d[1 * 64] = make_double2(r01, i01); d[2 * 64] = make_double2(r02, i02);
+      d[3 * 64] = make_double2(-r01, i01);    d[4 * 64] = make_double2(0.0, r8 - r3); d[5 * 64] = make_double2(r12, i12);
+      d[6 * 64] = make_double2(-r02, i02);    d[7 * 64] = make_double2(-r12, i12);    d[8 * 64] = make_double2(0.0, -2 * r8);
+    }
+  } else {
+    double2 *d = v + (size_t)p * vhalf + vec_off(c, 0);
+#pragma unroll 1
+    for (int k = 0; k < 3; k++) {
+      if (what == 0) {
+        const double re = milc6_gaussian(w);
+        const double im = milc6_gaussian(w);
+        d[k * 64] = make_double2(re, im);
+      } else {
+        const double n = 2.0 * 3.14159265358979323846 * (double)milc6_uniform(w);
+        d[k * 64] = make_double2(cos(n), sin(n));
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) state[(size_t)9 * i + k] = w[k];
+}
+// states up, one kernel, states down (stream-ordered; the host copy of the field stays the single source of truth)
+int rng_dev_generate(qexhip_ctx *c, qexhip_rng *R, int what, DevField *f, double2 *P) {
+  if (!c || !R) return QEXHIP_ERR_ARG;
+  if (R->kind != 0) { qexhip_set_error("device-side generation is implemented for RngMilc6 fields (MRG32k3a: use the host generators)"); return QEXHIP_ERR_ARG; }
+  if (R->vol != (size_t)c->g.V || R->lat[0] != c->g.X[0] || R->lat[1] != c->g.X[1] || R->lat[2] != c->g.X[2] || R->lat[3] != c->g.X[3]) {
+    qexhip_set_error("the RNG field's lattice is not the context's local lattice");
+    return QEXHIP_ERR_ARG;
+  }
+  HIPCHK(hipSetDevice(c->device));
+  const size_t bytes = R->vol * 9 * sizeof(uint32_t);
+  std::vector<uint32_t> h(R->vol * 9);
+  CHK(qexhip_rng_get_state(R, h.data()));
+  CHK(ensure_stage(c, bytes));
+  uint32_t *ds = (uint32_t *)c->stage;
+  HIPCHK(hipMemcpyAsync(ds, h.data(), bytes, hipMemcpyHostToDevice, c->stream));
+  k_rng_milc6<<<(c->g.V + 255) / 256, 256, 0, c->stream>>>(c->g, ds, what, f ? f->d : nullptr, f ? f->half : 0, P);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h.data(), ds, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return qexhip_rng_set_state(R, h.data());
 }

@@ -1218,8 +1218,9 @@ int nhyp_fermion_force(qexhip_ctx *c, double *f_host, const double *const *psi, 
 // solve D(m_k) psi_k = phi_k for the n fields (lock-step batches of four on the operator's current links, which
 // the caller has set from this closure: qexhip_stag_set_links_nhyp(g = NULL)), outer products straight from the
 // device solutions, rephase, chain, TAH.  Only phi goes in and f comes out over PCIe.
+// phi: host sources, or nullptr with phi_dev: sources already resident (pseudofermions born on the device)
 int nhyp_fforce(qexhip_ctx *c, double *f_host, int n, const double *const *phi, const double *mass, const double *scale,
-                const double *r2req, int maxits, int bcmask, const int ph[4], int *iters) {
+                const double *r2req, int maxits, int bcmask, const int ph[4], int *iters, DevField *const *phi_dev) {
   NhypState *st = (NhypState *)c->nhyp;
   if (!st) { qexhip_set_error("nhyp_fforce: call qexhip_nhyp_prepare first (smearGetForce)"); return -1; }
   if (n < 1) { qexhip_set_error("nhyp_fforce: n < 1"); return -1; }
@@ -1227,7 +1228,10 @@ int nhyp_fforce(qexhip_ctx *c, double *f_host, int n, const double *const *phi, 
     const int k = std::min(4, n - k0);
     DevField *xs[4], *bs[4];
     CHK(batch_io_fields(c, k, xs, bs));
-    for (int j = 0; j < k; j++) CHK(field_upload(c, *bs[j], phi[k0 + j]));
+    for (int j = 0; j < k; j++) {
+      if (phi_dev) bs[j] = phi_dev[k0 + j];                 // read only (the solver copies its source first)
+      else CHK(field_upload(c, *bs[j], phi[k0 + j]));
+    }
     CHK(solve_full_batch_dev(c, k, xs, bs, mass + k0, r2req + k0, maxits, iters ? iters + k0 : nullptr, nullptr));
     for (int j = 0; j < k; j++) CHK(stag_outer_dev(c, *xs[j], st->F, scale[k0 + j], -scale[k0 + j], (k0 + j) > 0));
   }

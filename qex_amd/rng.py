@@ -61,6 +61,18 @@ class RngField:
         check(lib().qexhip_rng_gauge_warm(self._h, float(s), g.ctypes.data_as(C.c_void_p)))
         return g
 
+    # ---- the same draws written straight into HBM (RngMilc6 only; the field's state advances exactly as on the host) ----
+    def dev_gaussian_vector(self, ctx, field_id):
+        """v.gaussian r into the resident colour vector `field_id` of ctx"""
+        check(lib().qexhip_rng_dev_gaussian_vector(ctx._h, self._h, int(field_id)))
+
+    def dev_u1_vector(self, ctx, field_id):
+        check(lib().qexhip_rng_dev_u1_vector(ctx._h, self._h, int(field_id)))
+
+    def dev_momenta(self, ctx):
+        """p.randomTAH r into the resident MD momenta of ctx (qexhip_md_refresh_momenta)"""
+        check(lib().qexhip_md_refresh_momenta(ctx._h, self._h))
+
     # ---- checkpoints: write_rng / read_rng of the fork (src/stagg_pv_hmc/staghmc_spv_rng.nim:135-182) ----
     def state(self):
         n = lib().qexhip_rng_state_words(self._h)

@@ -183,6 +183,18 @@ class Context:
     def release_workspace(self):
         check(lib().qexhip_release_workspace(self._h))
 
+    def dev_zero(self, fid, subset="all"):
+        check(lib().qexhip_dev_zero(self._h, int(fid), _SUBSET[subset]))
+
+    def dev_solve_batch(self, x_ids, b_ids, masses, r2req, maxits=1000000):
+        """n x Staggered.solve on resident fields (lock-step batches of four); returns (iterations, r2) per system"""
+        n = len(x_ids)
+        rq = [float(r2req)] * n if np.isscalar(r2req) else [float(v) for v in r2req]
+        its, fin = (C.c_int * n)(), (C.c_double * n)()
+        check(lib().qexhip_dev_solve_batch(self._h, n, (C.c_int * n)(*[int(v) for v in x_ids]), (C.c_int * n)(*[int(v) for v in b_ids]),
+                                           (C.c_double * n)(*[float(v) for v in masses]), (C.c_double * n)(*rq), int(maxits), its, fin))
+        return list(its), list(fin)
+
     def dev_norm2(self, x_id, subset="all"):
         out = C.c_double(0)
         check(lib().qexhip_dev_norm2(self._h, x_id, _SUBSET[subset], C.byref(out)))
@@ -453,7 +465,7 @@ class ResidentMD:
         self.ctx = ctx
 
     def begin(self, g, p):
-        """upload links (None: keep the resident ones) and momenta"""
+        """upload links (None: keep the resident ones) and momenta (None: keep the resident ones, e.g. RngField.dev_momenta)"""
         check(lib().qexhip_md_begin(self.ctx._h, _p(g), _p(p)))
 
     def end(self, g=None, p=None):
@@ -617,7 +629,20 @@ class HypCoefs:
             check(lib().qexhip_nhyp_fforce(ctx._h, _p(f), n, arr, ms, sc, rq, int(maxits), ap, None, its))
             return list(its)
 
+        def fforce_solve_dev(f, phi_ids, masses, scales, r2req, maxits=1000000, bc="aaaa"):
+            """fforce_solve with the pseudofermion fields resident (field ids of ctx)"""
+            n = len(phi_ids)
+            ids = (C.c_int * n)(*[int(v) for v in phi_ids])
+            ms = (C.c_double * n)(*[float(v) for v in masses])
+            sc = (C.c_double * n)(*[float(v) for v in scales])
+            rq = (C.c_double * n)(*([float(r2req)] * n if np.isscalar(r2req) else [float(v) for v in r2req]))
+            ap = (C.c_int * 4)(*[1 if ch == "a" else 0 for ch in bc])
+            its = (C.c_int * n)()
+            check(lib().qexhip_nhyp_fforce_dev(ctx._h, _p(f), n, ids, ms, sc, rq, int(maxits), ap, None, its))
+            return list(its)
+
         smearedForce.gforce, smearedForce.fforce, smearedForce.fforce_solve = gforce, fforce, fforce_solve
+        smearedForce.fforce_solve_dev = fforce_solve_dev
         smearedForce.release = lambda: check(lib().qexhip_nhyp_release(ctx._h))
         return smearedForce
 

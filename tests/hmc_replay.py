@@ -546,3 +546,109 @@ class HipBackend:
 
     def plaq(self, g):
         return self.q.plaq(self.ctx, g)
+
+
+class DeviceEndsReplay(Replay):
+    """The first trajectory of a run with BOTH ENDS on the device as well (round 3): momenta, pseudofermion and pbp sources are
+    drawn by the RngMilc6 field INTO HBM (RngField.dev_*), D / solve / norms run on resident fields, the energies come from the
+    resident links and momenta, and so do reunit, pbp, plaquettes and Polyakov loops.  Between `refresh` and `measure` nothing
+    but scalars and the 36-byte generator states crosses PCIe.  Needs HipBackend(resident=True)."""
+
+    def __init__(self, o, be, cfg, rng):
+        super().__init__(o, be, cfg, rng=rng)
+        self.ctx = be.ctx
+        self.q = be.q
+        self.q.gaugeSet(self.ctx, self.g)             # the unit start goes up once
+        self.phi_ids = None
+        self._tmp = [self.ctx.field_new() for _ in range(2 * len(self.cfg.fields) + 4)]
+
+    def _faction_dev(self):
+        be, cfg, ctx = self.be, self.cfg, self.ctx
+        nf = len(cfg.fields)
+        srcs, ms = [], []
+        for j, (k, i) in enumerate(cfg.fields):
+            if self._last(j):
+                srcs.append(self.phi_ids[j])
+            else:
+                t = self._tmp[j]
+                ctx.dev_D(t, self.phi_ids[j], cfg.hmasses[k][i])
+                srcs.append(t)
+            ms.append(cfg.hmasses[k][-1] if self._last(j) and cfg.hmasses[k] else self._m(j))
+        xs = self._tmp[nf:2 * nf]
+        its, _ = ctx.dev_solve_batch(xs, srcs, ms, RSQ)
+        fa = []
+        for j in range(nf):
+            self.stats["action_iters"][j].append(its[j])
+            fa.append(ctx.dev_norm2(xs[j]))
+        return fa
+
+    def energies_dev(self):
+        fa = self._faction_dev()
+        Sg = self.q.gaugeAction(self.ctx, None, plaq=BETA, adjplaq=BETA * ADJFAC)
+        Sf = [0.5 * v for v in fa]
+        T = 0.5 * self.be.md.momentum_norm2() - 16.0 * self.lo.vol
+        return dict(H=Sg + sum(Sf) + T, Sg=Sg, Sf=Sf, T=T)
+
+    def refresh(self):
+        be, cfg, ctx, rng = self.be, self.cfg, self.ctx, self.rng
+        rng.dev_momenta(ctx)                          # p.randomTAH r, born in HBM
+        be.md.begin(None, None)                       # links and momenta are the resident ones
+        be.md_smear()                                 # closure + operator from the resident links
+        psi = {}
+        for lvl in range(max(len(hm) for hm in cfg.hmasses) + 1):
+            for k in range(len(cfg.masses)):
+                if lvl <= len(cfg.hmasses[k]):
+                    psi[(k, lvl)] = ctx.field_new()
+                    rng.dev_gaussian_vector(ctx, psi[(k, lvl)])
+        self.phi_ids = []
+        a, b = self._tmp[-1], self._tmp[-2]
+        for j, (k, i) in enumerate(cfg.fields):
+            mi = -self._m(j)
+            ph = ctx.field_new()
+            if self._last(j):
+                ctx.dev_D(ph, psi[(k, i)], mi)
+            else:
+                ctx.dev_D(a, psi[(k, i)], mi)
+                ctx.dev_solve_batch([ph], [a], [-cfg.hmasses[k][i]], RSQ)
+            ctx.dev_zero(ph, "odd")
+            self.phi_ids.append(ph)
+        for f in psi.values():
+            ctx.field_free(f)
+        return self.energies_dev()
+
+    def _fforce_resident(self, ix, ts):
+        its = self.be._sf.fforce_solve_dev(None, [self.phi_ids[j] for j in ix], [self._m(j) for j in ix],
+                                           [self.fscale(j, ts[j]) for j in ix], RSQ, bc="pppa")
+        for j, n in zip(ix, its):
+            self.stats["force_iters"][j].append(n)
+
+    def evolve(self):
+        now = 0.0
+        for t, group in schedule(self.cfg):
+            self.be.md_T(t - now)
+            now = t
+            self._mdv_all_resident(group)
+        self.be.md_T(TAU - now)
+
+    def finish_energies(self):
+        self.be.md_smear()
+        return self.energies_dev()
+
+    def measure(self, accepted=True, g0=None):
+        assert accepted, "the device-ends replay covers the ACCEPT branch"
+        from qex_amd._lib import check, lib
+        ctx, q = self.ctx, self.q
+        check(lib().qexhip_gauge_reunit(ctx._h))      # g.reunit on the resident links
+        self.be.md_smear()
+        srcs = [ctx.field_new() for _ in range(2)]
+        for s in srcs:
+            self.rng.dev_u1_vector(ctx, s)
+        xs = self._tmp[:2]
+        its, _ = ctx.dev_solve_batch(xs, srcs, [PBPMASS, PBPMASS], RSQ)
+        pbp = [PBPMASS * ctx.dev_norm2(x) / self.lo.vol for x in xs]
+        pl = q.plaq(ctx)
+        ps, pt = 2.0 * sum(pl[:3]), 2.0 * sum(pl[3:])
+        loops = [q.wline(ctx, [mu + 1] * LAT[mu]) for mu in range(4)]
+        pls = sum(loops[:3]) / 3.0
+        return dict(pbp=pbp, pbp_iters=list(its), plaq=(ps, pt, 0.5 * (ps + pt)),
+                    ploop=(pls.real, pls.imag, loops[3].real, loops[3].imag))

@@ -157,6 +157,48 @@ def test_gpu_replays_reference_trajectory(oracle, run, halo, resident):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("run", [0, 1])
+def test_gpu_replays_reference_trajectory_with_both_ends_on_the_device(oracle, run):
+    """G7 with nothing but scalars (and the 36-byte generator states) crossing PCIe between the unit start and the last
+    printed number: momenta, pseudofermions and pbp sources drawn into HBM by the RngMilc6 field's device form, `Begin H` /
+    `End H` from resident links, momenta and vectors, reunit / pbp / plaquettes / Polyakov loops on the resident field --
+    against the reference's log at its 2e-11, CG iteration statistics included; and the generator states afterwards are bit for
+    bit those of the host generators after the same draws."""
+    import qex_amd as q
+    import hmc_replay as R
+
+    rng = q.RngField(R.LAT, q.RngMilc6, R.SEED)
+    be = R.HipBackend(q, R.LAT, resident=True)
+    r = R.DeviceEndsReplay(oracle, be, R.CONFIGS[run], rng)
+    G = r.cfg.gold
+    _cmp(r.refresh(), G["begin"])
+    r.evolve()
+    _cmp(r.finish_energies(), G["end"])
+    assert G["accept"]
+    m = r.measure(accepted=True)
+    for a, g_ in zip(m["pbp"], G["pbp"]):
+        assert abs(a - g_) < RTOL * g_
+    for a, g_ in zip(m["plaq"], G["plaq"]):
+        assert abs(a - g_) < RTOL * g_
+    for a, g_ in zip(m["ploop"], G["ploop"]):
+        assert abs(a - g_) < RTOL * max(abs(g_), 0.1)
+    if "pbp_iters" in G:
+        assert m["pbp_iters"] == [G["pbp_iters"]] * 2
+    if "force_stats" in G:
+        for v, (cnt, avg, mx) in zip(r.stats["force_iters"], G["force_stats"]):
+            assert (len(v), sum(v) // len(v), max(v)) == (cnt, avg, mx)
+        assert [max(v) for v in r.stats["action_iters"]] == G["action_max"]
+    # the same draws on the host generators: identical states word for word
+    ref = q.RngField(R.LAT, q.RngMilc6, R.SEED)
+    ref.randomTAH()
+    for _ in r.cfg.fields:
+        ref.gaussian_vector()
+    ref.u1_vector()
+    ref.u1_vector()
+    assert np.array_equal(ref.state(), rng.state())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["-resident"]])
 def test_example_log_against_reference_log(extra):
     """The reference's own regression procedure (tests/extra/staghmc_sh/run:43-46): run the example, keep the

@@ -2,6 +2,7 @@
 held to the same golden sets as the oracle (G1, G4, G5) and, deviate for deviate, to the oracle itself.
 Host code only: runs without a GPU."""
 import numpy as np
+import pytest
 
 
 def test_streams_equal_the_oracles_bit_for_bit(oracle):
@@ -58,3 +59,47 @@ def test_sharded_fields_are_slices_of_the_global_one():
             x = ll.coord(i)
             xg = x[:3] + [x[3] + 4 * rank]
             assert np.array_equal(part[i], full[lo.index(xg)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lat", [[8, 8, 8, 8], [16, 16, 16, 16], [4, 6, 10, 6]])
+def test_device_side_generation_against_the_host_generators(lat):
+    """qexhip_rng_dev_* / qexhip_md_refresh_momenta: one lane per site advances ITS RngMilc6 stream on the GPU.  The generator
+    states afterwards are bit for bit the host's (integer arithmetic); the deviates go through the device's log / cos / sqrt, so
+    after RngMilc6.gaussian's float32 rounding they equal the host's except where a double lands on a float32 rounding
+    boundary (expected ~1e-8 of the deviates, each off by one float32 ulp: counted and bounded here); u1 phases agree to 1e-15."""
+    import qex_amd as q
+
+    ctx = q.Context(lat)
+    dev, host = q.RngField(lat, q.RngMilc6, 1234567), q.RngField(lat, q.RngMilc6, 1234567)
+    vol = int(np.prod(lat))
+    q.gaugeSet(ctx, q.unit(q.Layout(lat)))
+    md = q.ResidentMD(ctx)
+    mism, total = 0, 0
+    for rep in range(2):
+        dev.dev_momenta(ctx)
+        md.begin(None, None)
+        p = np.zeros((vol, 4, 3, 3, 2))
+        md.end(None, p)
+        ph = host.randomTAH()
+        bad = p != ph
+        mism += int(bad.sum()); total += p.size
+        assert np.abs(p - ph).max() <= 1.3e-7 * max(1.0, np.abs(ph).max())        # one float32 ulp at most
+        assert abs(md.momentum_norm2() - (ph * ph).sum()) < 1e-9 * (ph * ph).sum()
+        fid = ctx.field_new()
+        dev.dev_gaussian_vector(ctx, fid)
+        v, vh = ctx.field_download(fid), host.gaussian_vector()
+        mism += int((v != vh).sum()); total += v.size
+        assert np.abs(v - vh).max() <= 1.3e-7 * max(1.0, np.abs(vh).max())
+        dev.dev_u1_vector(ctx, fid)
+        u, uh = ctx.field_download(fid), host.u1_vector()
+        assert np.abs(u - uh).max() < 1e-15
+        ctx.field_free(fid)
+        assert np.array_equal(dev.state(), host.state())
+    # host and device draws can be mixed: the stream just continues
+    assert np.array_equal(dev.gaussian_vector(), host.gaussian_vector())
+    print("lattice %s: %d of %d float32-rounded deviates differ from the host's" % (lat, mism, total))
+    assert mism <= max(2, int(2e-6 * total))
+    mr = q.RngField(lat, q.MRG32k3a, 7)
+    with pytest.raises(q.QexHipError, match="RngMilc6"):
+        mr.dev_gaussian_vector(ctx, ctx.field_new())
