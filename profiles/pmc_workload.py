@@ -50,6 +50,7 @@ if "flow" in what:                     # Wilson flow: 2 RK3 steps + plaquette + 
     q.gaugeFlowResident(ctx, 2, 0.01)
     q.plaq(ctx)
     q.flowEQ(ctx, 1)                   # the clover E, Q a flow loop measures after every step
+    q.flowMeasure(ctx)                 # round 3: plaquettes + E, Q from ONE pass (the clover kernel, second dispatch)
 if "nhyp" in what:                     # nHYP smearing closure + the force chain (twice)
     hc = q.HypCoefs(0.4, 0.5, 0.5)
     sf = hc.smearGetForce(ctx, g0)
