@@ -195,3 +195,51 @@ def test_bench_two_ranks_share_one_gpu_rehearsal():
     assert "error" not in ln and ln["n_gpus"] == 2 and ln["value"] > 0 and ln["scaling"] == "strong"
     assert sorted(r["rank"] for r in ln["ranks"]) == [0, 1]
     assert 0 < ln["roofline"]["frac"] <= 1
+    # the self-verification ran through its sharded control flow and says that its numbers mean nothing here
+    assert ln["shard_check"]["ok"] is None and "rehearsal" in ln["shard_check"] and ln["repeats"]["n"] >= 1
+
+
+@pytest.mark.parametrize("comm2", ["1", "0"])
+def test_bench_self_verification_on_the_sharded_code_path(comm2):
+    """bench.py --halo on one GPU: ghost zones, faces through a one-rank RCCL communicator on the second stream (its own
+    communicator, split off the first: QEXHIP_COMM2 = 1, the default; 0 = the single communicator), the multi-rank reduction
+    branches with real all-reduces -- and the run holds ITSELF to tests/golden/shard_checks.json before it times anything:
+    plaquettes, |D b|^2, the first 20 CG residuals, the HISQ Naik 10-shift norms.  A wrong face, a wrong ghost link or a wrong
+    reduction makes the line carry "error" and the exit status non-zero."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", QEXHIP_COMM2=comm2)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--halo", "--steps", "20", "--warmup", "3", "--repeats", "2", "--no-cpu", "--no-48x96"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    ln = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
+    sc = ln["shard_check"]
+    assert sc["ok"] is True and not sc["failed"], sc
+    assert sc["max_rel"]["operator"] <= 1e-10 and sc["max_rel"]["history"] <= 1e-6 and sc["max_rel"]["solution"] <= 1e-8
+    assert ln["rccl_nranks"] == 1 and "error" not in ln
+
+
+def test_bench_self_verification_fails_loudly(tmp_path):
+    """The other half: against a fixture whose |D b|^2 is off by 1e-8 the same run must say which quantity failed, carry
+    "error" in its line and exit non-zero (4), without giving up the measurement it already holds."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = json.load(open(os.path.join(root, "tests", "golden", "shard_checks.json")))
+    fx["lattices"]["32x32x32x32"]["values"]["Db2"] *= 1 + 1e-8
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps(fx))
+    env = dict(os.environ, QEX_SHARD_FIXTURE=str(bad))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "2", "--repeats", "1", "--no-cpu", "--no-48x96", "--no-extra"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=root, env=env)
+    assert p.returncode == 4, (p.returncode, p.stderr[-1000:])
+    ln = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
+    assert ln["shard_check"]["ok"] is False and any("Db2" in f for f in ln["shard_check"]["failed"])
+    assert "self-verification failed" in ln["error"] and ln["value"] > 0
