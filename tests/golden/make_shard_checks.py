@@ -57,10 +57,29 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--oracle-only", action="store_true")
     ap.add_argument("--no-oracle-48x96", action="store_true", help="skip the oracle cross-check of the largest lattice")
+    ap.add_argument("--crosscheck", default=None, metavar="LAT",
+                    help="no GPU: recompute EVERY quantity of the committed entry LAT (e.g. 48x48x48x96, Naik multi-shift included: "
+                         "~40 GB, several minutes) with the oracle, compare, and record the agreement in the entry's vs_oracle")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "shard_checks.json"))
     args = ap.parse_args()
     from qex_amd import selfcheck as sc
 
+    if args.crosscheck:
+        fx = json.load(open(args.out))
+        e = fx["lattices"][args.crosscheck]
+        lat = [int(v) for v in args.crosscheck.split("x")]
+        t0 = time.time()
+        ov = oracle_values(lat, mass=e["mass"], naik=True)
+        c = sc.compare(ov, e)                           # the oracle's numbers held to the committed (product) ones
+        e["vs_oracle"] = {"max_rel": c["max_rel"], "ok": c["ok"], "failed": c["failed"], "covers": sorted(ov.keys()),
+                          "how": "tests/golden/make_shard_checks.py --crosscheck %s (CPU oracle, %d threads, %.0f s)" % (
+                              args.crosscheck, __import__("oracle.oracle", fromlist=["x"]).num_threads(), time.time() - t0)}
+        assert c["ok"], c
+        with open(args.out, "w") as f:
+            json.dump(fx, f, indent=1)
+            f.write("\n")
+        print(args.crosscheck, json.dumps(e["vs_oracle"]))
+        return
     if args.oracle_only:
         for lat in LATS[:2]:
             print(sc.lat_key(lat), json.dumps(oracle_values(lat)))

@@ -243,3 +243,28 @@ def test_bench_self_verification_fails_loudly(tmp_path):
     ln = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
     assert ln["shard_check"]["ok"] is False and any("Db2" in f for f in ln["shard_check"]["failed"])
     assert "self-verification failed" in ln["error"] and ln["value"] > 0
+
+
+@pytest.mark.parametrize("lt", [4, 8])
+def test_self_verification_quantities_on_thin_slabs(lt):
+    """What one rank of an 8- (4-) way split of 32^4 holds is a 32^3 x 4 (x 8) slab: ghost depth 3 of the Naik operator and of
+    the HISQ link construction against only four local slices.  The checked quantities of qex_amd.selfcheck on such a slab
+    with every kernel in its sharded form (ghost zones, one-rank RCCL exchange, multi-rank reduction branches) must equal the
+    periodic kernels' on the same (periodic) lattice."""
+    import qex_amd as q
+    from qex_amd import selfcheck as sc
+
+    lat = [32, 32, 32, lt]
+    g0, g, b = sc.bench_inputs(lat)
+    A = q.Context(lat)
+    ref = sc.compute(A, g0, g, b)
+    A.close()
+    B = q.Context(lat)
+    B.comm_init(q.Context.unique_id(), 1, 0)
+    B.force_halo(True)
+    B.set_option("multi_reduce", 1)
+    got = sc.compute(B, g0, g, b)
+    B.close()
+    r = sc.compare(got, {"values": ref})
+    assert r["ok"] and r["max_rel"]["operator"] < 1e-12 and r["max_rel"]["history"] < 1e-9, r
+    assert got["naik_its"] == ref["naik_its"] and len(got["cg_hist"]) == sc.NHIST + 1
