@@ -62,15 +62,22 @@ ap.add_argument("-trajs", type=int, default=2)
 ap.add_argument("-halo", action="store_true")
 ap.add_argument("-lat", type=int, nargs=4, default=None, help="another lattice than the reference run's 8^4 (no golden log then)")
 ap.add_argument("-resident", action="store_true", help="MD evolution with links and momenta resident on the device (qexhip_md_*)")
+ap.add_argument("-device", action="store_true",
+                help="both ends of the trajectory on the device too (implies -resident): momenta, pseudofermions and pbp sources "
+                     "drawn into HBM by the RngMilc6 field, energies and measurements from resident fields; ACCEPT branch, no "
+                     "reversibility check (tests/hmc_replay.py: DeviceEndsReplay)")
 ap.add_argument("-time", action="store_true", help="print wall time and the kernel-time breakdown of every trajectory")
 a = ap.parse_args()
 
 if a.lat:
     R.LAT = list(a.lat)
 cfg = R.CONFIGS[a.run]
-be = R.HipBackend(q, R.LAT, halo=a.halo, resident=a.resident)
+be = R.HipBackend(q, R.LAT, halo=a.halo, resident=a.resident or a.device)
 print(be.ctx.info())
-r = R.Replay(Host, be, cfg, rng=q.RngField(R.LAT, q.RngMilc6, R.SEED))
+if a.device:
+    r = R.DeviceEndsReplay(Host, be, cfg, q.RngField(R.LAT, q.RngMilc6, R.SEED))
+else:
+    r = R.Replay(Host, be, cfg, rng=q.RngField(R.LAT, q.RngMilc6, R.SEED))
 G = GlobalRng(R.SEED)
 pl = be.plaq(r.g)
 print("MEASplaq ss: %r  st: %r  tot: %r" % (float(2 * sum(pl[:3])), float(2 * sum(pl[3:])), float(0.5 * (2 * sum(pl[:3]) + 2 * sum(pl[3:])))))
@@ -82,13 +89,13 @@ for n in range(1, a.trajs + 1):
         be.ctx.timers_enable(1)
         be.ctx.timers_reset()
         t_traj = time.time()
-    g0 = r.g.copy()
+    g0 = None if a.device else r.g.copy()
     b = r.refresh()
     print("Begin " + fmt(b))
     r.evolve()
     e = r.finish_energies()
     print("End " + fmt(e))
-    if n % 2 == 0:                                             # revCheckFreq = 2
+    if n % 2 == 0 and not a.device:                            # revCheckFreq = 2
         print("Reversed " + fmt(r.reverse_check()))
     dH = e["H"] - b["H"]
     acc, u = math.exp(-dH), G.uniform()
@@ -97,8 +104,12 @@ for n in range(1, a.trajs + 1):
     if a.time:
         parts = {k: be.ctx.timer(k) for k in TIMERS}
         be.ctx.timers_enable(0)
+        be.ctx.sync()
         print("TIME trajectory %d: wall %.2f s; kernel ms: %s" % (n, time.time() - t_traj, "  ".join(
             "%s %.1f (%d)" % (k, ms, cnt) for k, (cnt, ms) in parts.items() if cnt)))
+    if a.device and not ok:
+        print("REJECT with -device: the resident replay covers the ACCEPT branch only; stopping")
+        break
     m = r.measure(accepted=ok, g0=g0)
     for v, its in zip(m["pbp"], m["pbp_iters"]):
         print("stagSolve: %d" % its)
