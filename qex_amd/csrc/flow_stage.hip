@@ -288,41 +288,42 @@ __global__ void __launch_bounds__(512) k_flow_stage(FlowStageArgs a, const int *
 }
 
 // ---- host ----
+// The measurement variants of profiles/r03_flow_stage_experiments.md (DBG = 1: consumers skip the arithmetic, 2: loaders skip the
+// loads, 3: 1 without the result stores, 4: 3 without the LDS hand-off; wrong results by design) are compiled only with
+// -DQEXHIP_FLOW_STAGE_DEBUG (make CXXFLAGS+=-DQEXHIP_FLOW_STAGE_DEBUG) and then selected by QEXHIP_FLOW_STAGE_DBG.
 int flow_stage_launch(qexhip_ctx *c, const double2 *U, double2 *P, double2 *Uout, double cp, double cf, double cpm,
                       const int *order, int chunk, bool closed) {
-  static const int dbg = [] { const char *e = getenv("QEXHIP_FLOW_STAGE_DBG"); return e ? atoi(e) : 0; }();
   static const int wgs = [] { const char *e = getenv("QEXHIP_FLOW_STAGE_WGS"); return e ? atoi(e) : 256; }();   // one per CU
+  static const int rs = [] { const char *e = getenv("QEXHIP_FLOW_STAGE_RS"); return e ? atoi(e) : 1; }();
+#define QX_ATTR(K) HIPCHK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES))
   if (!(c->lds_attr_done & 4)) {
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<true, false, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<false, false, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<true, true, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<false, true, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<true, false, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<true, false, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<true, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<false, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<true, true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<false, true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<true, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<true, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<true, false, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_flow_stage<true, false, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FS_LDS_BYTES));
+    QX_ATTR((k_flow_stage<true, false, 0, 0>)); QX_ATTR((k_flow_stage<false, false, 0, 0>));
+    QX_ATTR((k_flow_stage<true, true, 0, 0>));  QX_ATTR((k_flow_stage<false, true, 0, 0>));
+    QX_ATTR((k_flow_stage<true, false, 0, 1>)); QX_ATTR((k_flow_stage<false, false, 0, 1>));
+    QX_ATTR((k_flow_stage<true, true, 0, 1>));  QX_ATTR((k_flow_stage<false, true, 0, 1>));
+#ifdef QEXHIP_FLOW_STAGE_DEBUG
+    QX_ATTR((k_flow_stage<true, false, 1, 0>)); QX_ATTR((k_flow_stage<true, false, 2, 0>));
+    QX_ATTR((k_flow_stage<true, false, 1, 1>)); QX_ATTR((k_flow_stage<true, false, 3, 1>)); QX_ATTR((k_flow_stage<true, false, 4, 1>));
+#endif
     c->lds_attr_done |= 4;
   }
+#undef QX_ATTR
   FlowStageArgs a;
   a.g = c->g; a.U = U; a.P = P; a.Uout = Uout; a.cp = cp; a.cf = cf; a.cpm = cpm; a.chunk = chunk;
   int nb = wgs & ~7;
   if (nb < 8) nb = 8;
   if (nb > 8 * chunk) nb = 8 * chunk;
-  static const int rs = [] { const char *e = getenv("QEXHIP_FLOW_STAGE_RS"); return e ? atoi(e) : 1; }();
 #define QX_FS(CL, HL) do { if (rs) k_flow_stage<CL, HL, 0, 1><<<nb, 512, FS_LDS_BYTES, c->stream>>>(a, order); \
                            else k_flow_stage<CL, HL, 0, 0><<<nb, 512, FS_LDS_BYTES, c->stream>>>(a, order); } while (0)
-  // measurement only (QEXHIP_FLOW_STAGE_DBG): 1 = consumers skip the arithmetic, 2 = loaders skip the loads; wrong results
+#ifdef QEXHIP_FLOW_STAGE_DEBUG
+  static const int dbg = [] { const char *e = getenv("QEXHIP_FLOW_STAGE_DBG"); return e ? atoi(e) : 0; }();
   if (dbg == 1) { if (rs) k_flow_stage<true, false, 1, 1><<<nb, 512, FS_LDS_BYTES, c->stream>>>(a, order); else k_flow_stage<true, false, 1, 0><<<nb, 512, FS_LDS_BYTES, c->stream>>>(a, order); }
-  else if (dbg == 2) { if (rs) k_flow_stage<true, false, 2, 1><<<nb, 512, FS_LDS_BYTES, c->stream>>>(a, order); else k_flow_stage<true, false, 2, 0><<<nb, 512, FS_LDS_BYTES, c->stream>>>(a, order); }
+  else if (dbg == 2) k_flow_stage<true, false, 2, 0><<<nb, 512, FS_LDS_BYTES, c->stream>>>(a, order);
   else if (dbg == 3) k_flow_stage<true, false, 3, 1><<<nb, 512, FS_LDS_BYTES, c->stream>>>(a, order);
   else if (dbg == 4) k_flow_stage<true, false, 4, 1><<<nb, 512, FS_LDS_BYTES, c->stream>>>(a, order);
-  else if (closed) { if (c->g.halo) QX_FS(true, true); else QX_FS(true, false); }
+  else
+#endif
+  if (closed) { if (c->g.halo) QX_FS(true, true); else QX_FS(true, false); }
   else { if (c->g.halo) QX_FS(false, true); else QX_FS(false, false); }
 #undef QX_FS
   HIPCHK(hipGetLastError());
