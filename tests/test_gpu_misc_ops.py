@@ -268,3 +268,57 @@ def test_self_verification_quantities_on_thin_slabs(lt):
     r = sc.compare(got, {"values": ref})
     assert r["ok"] and r["max_rel"]["operator"] < 1e-12 and r["max_rel"]["history"] < 1e-9, r
     assert got["naik_its"] == ref["naik_its"] and len(got["cg_hist"]) == sc.NHIST + 1
+
+
+def test_resident_field_entry_points_against_the_oracle(oracle):
+    """Round-3 entry points on resident fields, each against the oracle: dev_D (Staggered.D / Ddag), dev_norm2 / dev_redot
+    (fieldET.nim:605-625,704-724), dev_zero, dev_solve_batch (n x Staggered.solve), the alias checks of the multi-shift solver,
+    release_workspace, comm_count."""
+    import qex_amd as q
+
+    o = oracle
+    lat = [4, 6, 8, 4]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 77)
+    g = o.gauge_warm(lo, 0.5, rf)
+    o.rephase(lo, g)
+    x, y = o.vector_gaussian(lo, rf), o.vector_gaussian(lo, rf)
+    ctx = q.Context(lat)
+    assert ctx.comm_count() == 0
+    q.newStag(ctx, g)
+    xi, yi, ri = ctx.field_new(x), ctx.field_new(y), ctx.field_new()
+    for sub, par in (("all", 2), ("even", 0), ("odd", 1)):
+        assert abs(ctx.dev_norm2(xi, sub) - o.norm2(lo, x, par)) < 1e-12 * o.norm2(lo, x, par)
+        assert abs(ctx.dev_redot(xi, yi, sub) - o.redot(lo, x, y, par)) < 1e-12 * o.norm2(lo, x, par)
+    for sc, ref in ((1.0, o.D(lo, g, None, x, 0.13)), (-1.0, o.Ddag(lo, g, None, x, 0.13))):
+        ctx.dev_D(ri, xi, 0.13, sc)
+        r = ctx.field_download(ri)
+        assert np.linalg.norm(r - ref) / np.linalg.norm(ref) < 1e-13
+    ctx.dev_zero(ri, "odd")
+    r = ctx.field_download(ri)
+    assert not r[lo.vol // 2:].any() and r[:lo.vol // 2].any()
+    # n x Staggered.solve on resident fields (six systems: two lock-step batches), iteration counts as the single solves
+    srcs = [x, y, x + y, x - y, 2 * x, y]
+    ms = [0.1, 0.2, 0.15, 0.3, 0.1, 0.25]
+    bids = [ctx.field_new(b) for b in srcs]
+    xids = [ctx.field_new() for _ in srcs]
+    its, r2 = ctx.dev_solve_batch(xids, bids, ms, 1e-14)
+    for k, (b, m) in enumerate(zip(srcs, ms)):
+        xr, oits, fin = o.solve(lo, g, None, b, m, 1e-14, 100000)
+        got = ctx.field_download(xids[k])
+        assert abs(its[k] - oits) <= 2 and r2[k] <= 1e-14 and np.linalg.norm(got - xr) / np.linalg.norm(xr) < 1e-7, (k, its[k], oits)
+    with pytest.raises(q.QexHipError, match="same field"):
+        ctx.dev_solve_batch([bids[0]], [bids[0]], [0.1], 1e-10)
+    # multi-shift on resident fields: aliased solution / source fields are refused, the workspace can be handed back
+    sh = [0.2, 4 * (0.4 ** 2 - 0.2 ** 2)]
+    with pytest.raises(q.QexHipError, match="source field"):
+        ctx.dev_solve_xx_multi([xids[0], bids[0]], bids[0], sh, 1e-10, 100)
+    with pytest.raises(q.QexHipError, match="x_ids"):
+        ctx.dev_solve_xx_multi([xids[0], xids[0]], bids[0], sh, 1e-10, 100)
+    n1, _ = ctx.dev_solve_xx_multi(xids[:2], bids[0], sh, 1e-12, 1000)
+    a = [ctx.field_download(i) for i in xids[:2]]
+    ctx.release_workspace()
+    n2, _ = ctx.dev_solve_xx_multi(xids[:2], bids[0], sh, 1e-12, 1000)
+    assert n1 == n2 and all(np.array_equal(u, ctx.field_download(i)) for u, i in zip(a, xids[:2]))
+    ctx.comm_init(q.Context.unique_id(), 1, 0)
+    assert ctx.comm_count() in (1, 2)
