@@ -420,6 +420,9 @@ __global__ void __launch_bounds__(256, WPE) k_staple_deriv(Geom g, MViewW f1, MV
 // wavefront, and only HALF as many tiles in flight per XCD for the same number of resident wavefronts -- the kernel is
 // bound by what misses the 4 MB L2 (PMC: 33 % hit rate, 2.7x its unique bytes fetched, for the one-tile-per-wavefront
 // form), so the smaller working set is worth more than the duplicated corner products cost.
+// (Round 3: FOUR wavefronts per tile -- role x {forward, backward} half, the backward half handing its partial sum over through
+// LDS, 64 instead of 128 tiles in flight per XCD -- measured 12.5 against 11.75 ms for the chain and was not kept: the halves wait
+// for each other at the hand-off, which costs more than the smaller working set saves.)
 template <bool HALO>
 __global__ void __launch_bounds__(256) k_staple_deriv_pair(Geom g, MViewW F1, MViewW F2, MView g1, MView g2, MView cA, MView cB, int mu, int nu,
                                                           int z1, int z2, const int *order, int chunk, int nt) {
