@@ -415,3 +415,45 @@ def test_gpu_smearing_and_forces_on_the_sharded_path(oracle):
         else:
             tol = 1e-9 if k == "fsolve" else 1e-15                     # solves: summation order of the slab reductions
             assert np.linalg.norm(a[k] - b[k]) <= tol * np.linalg.norm(a[k]), k
+
+
+FAT7_SELFTEST = [("oneLink", (1, 0, 0, 0, 0)), ("threeStaple", (0, 1, 0, 0, 0)), ("fiveStaple", (0, 0, 1, 0, 0)),
+                 ("sevenStaple", (0, 0, 0, 1, 0)), ("lepage", (0, 0, 0, 0, 1)), ("all", (1, 1, 1, 1, 1))]
+
+
+def _checkfat1(plaq_of_fat, coef):
+    """checkfat1 of the reference's own fat7l self-test (src/gauge/fat7l.nim:184-214): on the unit gauge field every fat link
+    is c * 1 with c = oneLink + 6 threeStaple + 24 fiveStaple + 48 sevenStaple + 6 lepage (the number of staples of each
+    kind), so each of the six plaquettes is c^4 / 6; the reference prints `relerr: sqrt(sum (p - s)^2) / s`."""
+    c = coef[0] + 6 * coef[1] + 24 * coef[2] + 48 * coef[3] + 6 * coef[4]
+    s = c ** 4 / 6.0
+    return float(np.sqrt(((np.asarray(plaq_of_fat) - s) ** 2).sum()) / s)
+
+
+def test_oracle_replays_the_fat7l_selftest(oracle):
+    o = oracle
+    lo = o.Layout([8, 8, 8, 8])                       # defaultLat of the self-test, unit gauge (defaultSetup)
+    g = o.gauge_unit(lo)
+    for name, coef in FAT7_SELFTEST:
+        fl, _ = o.fat7(lo, g, coef)
+        assert _checkfat1(o.plaq(lo, fl), coef) < 1e-14, name
+    # the closing lines of the self-test: makeImpLinks with the long links, naik = 1: ll = U U U = 1 -> plaquettes 1/6
+    fl, ll = o.fat7(lo, g, (1, 1, 1, 1, 1), naik=1.0)
+    assert np.abs(o.plaq(lo, ll) - 1.0 / 6.0).max() < 1e-15 and _checkfat1(o.plaq(lo, fl), (1, 1, 1, 1, 1)) < 1e-14
+
+
+@pytest.mark.gpu
+def test_gpu_replays_the_fat7l_selftest(oracle):
+    """the same procedure through qexhip_fat7 and the HIP plaquette kernel (ctx.plaq of the fat links)"""
+    import qex_amd as q
+
+    lat = [8, 8, 8, 8]
+    g = q.unit(q.Layout(lat))
+    ctx = q.Context(lat)
+    for name, coef in FAT7_SELFTEST:
+        fl = np.zeros_like(g)
+        q.makeImpLinks(ctx, fl, g, coef)
+        assert _checkfat1(q.plaq(ctx, fl), coef) < 1e-14, name
+    fl, ll = np.zeros_like(g), np.zeros_like(g)
+    q.makeImpLinks(ctx, fl, g, (1, 1, 1, 1, 1), ll=ll, naik=1.0)
+    assert np.abs(q.plaq(ctx, ll) - 1.0 / 6.0).max() < 1e-15
