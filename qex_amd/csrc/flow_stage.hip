@@ -6,17 +6,24 @@
 //   contractProjectTAH                    src/gauge/gaugeUtils.nim:389-398
 //   one stage of gaugeFlow's RK3          src/gauge/wflow.nim:36-62   (v = cf f + cpm p;  p = v;  U <- exp(v) U)
 //
-// Why another form of k_force_lds (gauge.hip).  That kernel gives a wavefront one direction mu of a 64-site tile; every
-// lane gathers its 14 operand matrices itself, multiplies, then waits for the next gathers.  Its time is the SUM of its
-// gather phase (the CU's L2->L1 path, ~64 GB/s per CU) and its fp64 phase (profiles/r02_kforce_experiments.md): with 256
-// registers per lane only two wavefronts fit a SIMD and both tend to sit in the same phase.  Here the two resources get
-// their own wavefronts (cdna_hip_programming.md 5, "glds": LDS-DMA loader + consumers):
+// STATUS: a measured ALTERNATIVE to k_force_lds (gauge.hip), selected by option "flow_ring" / QEXHIP_FLOW_RING=1, NOT the
+// default: 835-911 us per stage against 707-790 on the same MI355X (profiles/r03_flow_stage_experiments.md has the numbers,
+// the counters and the reasons).  It is kept because it is the form the round-2 review asked for, is tested to the oracle
+// like the default (tests/test_gpu_parity.py, tests/test_gauge_actions.py), and documents what the idea costs on this chip.
+//
+// The idea.  k_force_lds gives a wavefront one direction mu of a 64-site tile; every lane gathers its 14 operand matrices
+// itself, multiplies, then waits for the next gathers.  Its time is roughly the SUM of its gather phase (the CU's L2->L1
+// path, ~64 GB/s per CU) and its fp64 phase (profiles/r02_kforce_experiments.md): with 256 registers per lane only two
+// wavefronts fit a SIMD and both tend to sit in the same phase.  Here the two resources get their own wavefronts
+// (cdna_hip_programming.md 5, "glds": LDS-DMA loader + consumers):
 //
 //   * a persistent workgroup per CU = 4 LOADER wavefronts + 4 CONSUMER wavefronts, walking its XCD's tiles in the
 //     blocked order of tile_order_table;
-//   * loaders never compute: they issue `global_load_lds_dwordx4` (a 1 KiB wave-instruction, no VGPR destination) for
-//     groups of four operand matrices (one 9 KiB slot per loader wavefront) into a ring of three group buffers, two
-//     groups ahead of the consumers, and retire them with COUNTED `s_waitcnt vmcnt(9)`;
+//   * loaders never compute.  Form RS = 0: they issue `global_load_lds_dwordx4` (a 1 KiB wave-instruction, no VGPR
+//     destination) for groups of four operand matrices (one 9 KiB slot per loader wavefront) into a ring of three group
+//     buffers, two groups ahead of the consumers, and retire them with COUNTED `s_waitcnt vmcnt(9)`.  Form RS = 1 (the
+//     default of this kernel): each loader keeps six matrices in flight in its REGISTERS and hands them to a
+//     double-buffered ring with ds_write_b128 (the register file is the larger staging buffer: 216 KiB in flight per CU);
 //   * consumers never touch global memory for operands: they read slots with ds_read_b128 and multiply.  Consumer w owns
 //     the staple DIRECTION w: it keeps U_w(x) and U_w(x-w) in registers for the whole tile and forms, in three rounds
 //     over the perfect matchings {w, w^r} (r = 1, 2, 3) of the four directions, the staples of link b = w^r in the plane
@@ -27,7 +34,7 @@
 //   * consumer w then finishes link w: f = TAH(U acc^+), v = cf cp f + cpm p, p <- v, U' = exp(v) U (non-temporal stores).
 //
 // One phase = one group: 12 per tile (own links, back links, 3 x {forward corners, U_b(x-w), U_w(x-w+b)}, momenta).
-// LDS: ring 3 x 36 KiB + accumulator 36 KiB = 144 KiB of the CU's 160.
+// LDS: ring 3 x 36 KiB (RS = 1 uses two of the three buffers) + accumulator 36 KiB = 144 KiB of the CU's 160.
 #include "qexhip_internal.h"
 #include "su3.h"
 #include "gauge_index.h"
