@@ -342,6 +342,9 @@ int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk_out) {
   static const int by = [] { const char *e = getenv("QEXHIP_ORD_Y"); return e ? atoi(e) : 8; }();
   static const int bz = [] { const char *e = getenv("QEXHIP_ORD_Z"); return e ? atoi(e) : 4; }();
   static const int bt = [] { const char *e = getenv("QEXHIP_ORD_T"); return e ? atoi(e) : 4; }();
+  // QEXHIP_ORD_RZ (1, 2, 4, 8): the XCD regions are split in z as well as t (measurement knob; 1 = t-ranges only)
+  static const int rz_env = [] { const char *e = getenv("QEXHIP_ORD_RZ"); return e ? atoi(e) : 1; }();
+  const int rz = ((rz_env == 2 || rz_env == 4 || rz_env == 8) && g.X[3] % (8 / rz_env) == 0 && g.X[2] % rz_env == 0) ? rz_env : 1;
   struct Ent { unsigned long long key0, key1; int e; };
   std::vector<Ent> v(n);
   for (int p = 0; p < 2; p++)
@@ -352,6 +355,10 @@ int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk_out) {
       Ent &a = v[(size_t)p * g.ntile + tile];
       a.e = 2 * tile + p;
       a.key0 = (((long)t * g.X[2] + z) * g.X[1] + y) * 2 + p;         // plain order: splits the lattice into 8 (t,z) regions
+      if (rz > 1) {                                                    // regions = (8/rz t-ranges) x (rz z-ranges)
+        const int tr = t / (g.X[3] / (8 / rz)), zr = z / (g.X[2] / rz);
+        a.key0 += (unsigned long long)(tr * rz + zr) << 44;
+      }
       // six 10-bit fields + parity = 61 bits (extents <= 1024, geom_init)
       a.key1 = ((((((unsigned long long)(t / bt) * 1024u + z / bz) * 1024u + y / by) * 1024u + t % bt) * 1024u + z % bz) * 1024u + (y % by)) * 2 + p;
     }
