@@ -146,7 +146,7 @@ if rd and cp_w:
         ("k_flow_obs_clover", None, 4 * M * VOL, "4 links per site read once (576 B)"),
         ("k_flow_obs_all", None, 4 * M * VOL, "4 links per site read once (576 B): plaquette + clover E, Q in one pass"),
         ("k_gen_staple", None, 4 * M * VOL, "two input matrices read once, accumulator read + written: 576 B/site unique"),
-        ("k_staple_deriv_pair", None, 8 * M * VOL, "unique bytes of a (mu,nu)/(nu,mu) pair: 6 matrices read, 2 read-modify-written = 1152 B/site"),
+        ("k_staple_deriv_pair", None, 10 * M * VOL, "a (mu,nu)/(nu,mu) pair: 6 matrices read, 2 read and written back = 1440 B/site (rounds 2-3 quoted the 8 reads alone, 1152 B, against read + write traffic)"),
         ("k_projUderiv_batch", None, None, "864 B per link of the batch (sizes differ per level: see dispatches)"),
     ]
     kt = {"source": "profiles/collect.sh " + tag + " (profiles/pmc_workload.py, 32^4)", "fetch_correction": fcorr, "write_correction": wcorr,
