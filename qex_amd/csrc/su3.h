@@ -209,8 +209,9 @@ __host__ __device__ __forceinline__ M3 m3_exp(const M3 &m) {
   return e;
 }
 
-// exp of a TRACELESS ANTI-HERMITIAN matrix in closed form (Cayley-Hamilton; Morningstar & Peardon, Phys. Rev. D 69, 054501,
-// eqs. 19-33): v = iQ, exp(iQ) = f0 + f1 Q + f2 Q^2 with f_j from c0 = det Q, c1 = tr Q^2 / 2.  One matrix product,
+// exp of a TRACELESS ANTI-HERMITIAN matrix through Cayley-Hamilton: v = iQ, exp(iQ) = f0 + f1 Q + f2 Q^2 with f_j from
+// c0 = det Q, c1 = tr Q^2 / 2 -- by the Taylor series reduced with the characteristic polynomial while c1 <= 0.75 (round 3),
+// in closed form beyond (Morningstar & Peardon, Phys. Rev. D 69, 054501, eqs. 19-33).  One matrix product,
 // one trace and a handful of scalar functions instead of the 22 products of m3_exp: the same matrix function, NOT the
 // reference's algorithm (matexp.nim: order-4 Taylor at v/2^20, 20 squarings), so it is an opt-in of the flow only
 // (option "flow_exp" = 1); it agrees with m3_exp to the rounding error of m3_exp's squarings (~2e-15 absolute,
@@ -245,42 +246,52 @@ __host__ __device__ __forceinline__ M3 m3_exp_tah(const M3 &v) {
     for (int k = 0; k < 3; k++) t3 += Q.e[3 * i + k].x * Q2.e[3 * k + i].x - Q.e[3 * i + k].y * Q2.e[3 * k + i].y;
   double c0 = t3 * (1.0 / 3.0);
   M3 r;
-  if (c1 < 1e-8) {
-    // |v| < 1e-4: exp = 1 + v + v^2/2 + v^3/6 + v^4/24 to 1e-21; v^2 = -Q2
-    M3 v3 = m3_mul(v, Q2);                       // = -v^3
+  double f0r, f0i, f1r, f1i, f2r, f2i;
+  if (c1 <= 0.75) {
+    // Every eigenvalue of Q is below sqrt(4 c1 / 3) <= 1 in magnitude (the flow: |v| ~ 0.1): the Taylor series of exp(v) to
+    // order 20, summed by Horner's rule in the quotient ring of the characteristic polynomial v^3 = -c1 v - i c0 --
+    // with P = a0 + a1 v + a2 v^2,  1/n! + v P = (1/n! - i c0 a2) + (a0 - c1 a2) v + a1 v^2: four FMAs per order and no
+    // acos / sincos / sqrt / division (those were ~500 of the ~2750 instructions a lane of the flow stage executes).
+    // exp(v) = a0 + a1 (iQ) - a2 Q^2.
+    constexpr double ifact[21] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                                  1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
+                                  1.0 / 1307674368000.0, 1.0 / 20922789888000.0, 1.0 / 355687428096000.0,
+                                  1.0 / 6402373705728000.0, 1.0 / 121645100408832000.0, 1.0 / 2432902008176640000.0};
+    double a0x = ifact[20], a0y = 0.0, a1x = 0.0, a1y = 0.0, a2x = 0.0, a2y = 0.0;
 #pragma unroll
-    for (int k = 0; k < 9; k++) r.e[k] = make_double2(v.e[k].x - 0.5 * Q2.e[k].x - (1.0 / 6.0) * v3.e[k].x,
-                                                     v.e[k].y - 0.5 * Q2.e[k].y - (1.0 / 6.0) * v3.e[k].y);
-    M3 q4 = m3_mul(Q2, Q2);                      // = v^4
-    m3_axpy(r, 1.0 / 24.0, q4);
-    m3_add_diag(r, 1.0);
-    return r;
+    for (int n = 19; n >= 0; n--) {
+      const double n0x = fma(c0, a2y, ifact[n]), n0y = -c0 * a2x;
+      const double n1x = fma(-c1, a2x, a0x), n1y = fma(-c1, a2y, a0y);
+      a2x = a1x; a2y = a1y; a1x = n1x; a1y = n1y; a0x = n0x; a0y = n0y;
+    }
+    f0r = a0x; f0i = a0y; f1r = -a1y; f1i = a1x; f2r = -a2x; f2i = -a2y;
+  } else {
+    const bool neg = c0 < 0.0;                     // f_j(-c0) = (-1)^j conj f_j(c0): evaluate at |c0| (eq. 34)
+    c0 = fabs(c0);
+    const double c13 = c1 * (1.0 / 3.0);
+    const double c0max = 2.0 * c13 * sqrt(c13);
+    const double th = acos(fmin(1.0, c0 / c0max));
+    double st3, ct3, sw, cw, su, cu;                 // one range reduction per angle
+    sincos(th * (1.0 / 3.0), &st3, &ct3);
+    const double u = sqrt(c13) * ct3;
+    const double w = sqrt(c1) * st3;
+    const double w2 = w * w, u2 = u * u;
+    sincos(w, &sw, &cw);
+    const double xi0 = fabs(w) < 0.05 ? 1.0 - w2 * (1.0 / 6.0) * (1.0 - w2 * (1.0 / 20.0) * (1.0 - w2 * (1.0 / 42.0))) : sw / w;
+    sincos(u, &su, &cu);
+    const double c2u = cu * cu - su * su, s2u = 2.0 * su * cu;     // e^{2iu}
+    // h_j = A_j e^{2iu} + e^{-iu} (B_j + i C_j)
+    const double b0 = 8.0 * u2 * cw, d0 = 2.0 * u * (3.0 * u2 + w2) * xi0;
+    const double b1 = -2.0 * u * cw, d1 = (3.0 * u2 - w2) * xi0;
+    const double b2 = -cw, d2 = -3.0 * u * xi0;
+    const double a0 = u2 - w2, a1 = 2.0 * u;
+    // e^{-iu} (b + i d) = (b cu + d su) + i (d cu - b su)
+    const double den = 1.0 / (9.0 * u2 - w2);
+    f0r = (a0 * c2u + b0 * cu + d0 * su) * den; f0i = (a0 * s2u + d0 * cu - b0 * su) * den;
+    f1r = (a1 * c2u + b1 * cu + d1 * su) * den; f1i = (a1 * s2u + d1 * cu - b1 * su) * den;
+    f2r = (c2u + b2 * cu + d2 * su) * den; f2i = (s2u + d2 * cu - b2 * su) * den;
+    if (neg) { f0i = -f0i; f1r = -f1r; f2i = -f2i; }
   }
-  const bool neg = c0 < 0.0;                     // f_j(-c0) = (-1)^j conj f_j(c0): evaluate at |c0| (eq. 34)
-  c0 = fabs(c0);
-  const double c13 = c1 * (1.0 / 3.0);
-  const double c0max = 2.0 * c13 * sqrt(c13);
-  const double th = acos(fmin(1.0, c0 / c0max));
-  double st3, ct3, sw, cw, su, cu;                 // one range reduction per angle
-  sincos(th * (1.0 / 3.0), &st3, &ct3);
-  const double u = sqrt(c13) * ct3;
-  const double w = sqrt(c1) * st3;
-  const double w2 = w * w, u2 = u * u;
-  sincos(w, &sw, &cw);
-  const double xi0 = fabs(w) < 0.05 ? 1.0 - w2 * (1.0 / 6.0) * (1.0 - w2 * (1.0 / 20.0) * (1.0 - w2 * (1.0 / 42.0))) : sw / w;
-  sincos(u, &su, &cu);
-  const double c2u = cu * cu - su * su, s2u = 2.0 * su * cu;     // e^{2iu}
-  // h_j = A_j e^{2iu} + e^{-iu} (B_j + i C_j)
-  const double b0 = 8.0 * u2 * cw, d0 = 2.0 * u * (3.0 * u2 + w2) * xi0;
-  const double b1 = -2.0 * u * cw, d1 = (3.0 * u2 - w2) * xi0;
-  const double b2 = -cw, d2 = -3.0 * u * xi0;
-  const double a0 = u2 - w2, a1 = 2.0 * u;
-  // e^{-iu} (b + i d) = (b cu + d su) + i (d cu - b su)
-  const double den = 1.0 / (9.0 * u2 - w2);
-  double f0r = (a0 * c2u + b0 * cu + d0 * su) * den, f0i = (a0 * s2u + d0 * cu - b0 * su) * den;
-  double f1r = (a1 * c2u + b1 * cu + d1 * su) * den, f1i = (a1 * s2u + d1 * cu - b1 * su) * den;
-  double f2r = (c2u + b2 * cu + d2 * su) * den, f2i = (s2u + d2 * cu - b2 * su) * den;
-  if (neg) { f0i = -f0i; f1r = -f1r; f2i = -f2i; }
 #pragma unroll
   for (int k = 0; k < 9; k++) {
     r.e[k].x = f1r * Q.e[k].x - f1i * Q.e[k].y + f2r * Q2.e[k].x - f2i * Q2.e[k].y;
