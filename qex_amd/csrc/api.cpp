@@ -120,6 +120,7 @@ extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], 
   if (const char *e = getenv("QEXHIP_FLOW_EXP")) c->opt_flow_exp = atoi(e);
   if (const char *e = getenv("QEXHIP_OBS_CLOVER")) c->opt_obs_clover = atoi(e);
   if (const char *e = getenv("QEXHIP_FLOW_RING")) c->opt_flow_ring = atoi(e);
+  if (const char *e = getenv("QEXHIP_FORCE_PAIR")) c->opt_force_pair = atoi(e);
   {
     // LDS a workgroup may ask for (160 KiB on gfx950): the large-LDS kernels (k_flow_stage 144 KiB, k_force_lds and
     // k_flow_obs_clover 72 KiB) fall back to their plain forms when the device offers less
@@ -186,9 +187,11 @@ extern "C" int qexhip_device_info(qexhip_handle c, char *buf, int buflen) {
   if (!c || !buf) return QEXHIP_ERR_ARG;
   hipDeviceProp_t p;
   HIPCHK(hipGetDeviceProperties(&p, c->device));
-  snprintf(buf, buflen, "%s (%s) CUs=%d mem=%.0fGiB local=%dx%dx%dx%d ranks=%d halo=%d", p.name, p.gcnArchName,
+  // tile_pairs: -1 until a gather kernel has built the visiting order, then whether its slots pair the two parities of a
+  // tile position (k_force_lds2 needs that; otherwise the one-tile kernels run)
+  snprintf(buf, buflen, "%s (%s) CUs=%d mem=%.0fGiB local=%dx%dx%dx%d ranks=%d halo=%d tile_pairs=%d", p.name, p.gcnArchName,
            p.multiProcessorCount, p.totalGlobalMem / 1073741824.0, c->g.X[0], c->g.X[1], c->g.X[2], c->g.X[3],
-           c->rankGeom[3], c->g.halo);
+           c->rankGeom[3], c->g.halo, c->tile_order ? c->tile_pairs_ok : -1);
   return 0;
 }
 
@@ -556,6 +559,7 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "flow_exp") c->opt_flow_exp = value;
   else if (n == "obs_clover") c->opt_obs_clover = value;
   else if (n == "flow_ring") c->opt_flow_ring = value;
+  else if (n == "force_pair") c->opt_force_pair = value;
   else { qexhip_set_error("unknown option"); return QEXHIP_ERR_ARG; }
   return 0;
 }

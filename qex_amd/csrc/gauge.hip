@@ -256,6 +256,96 @@ __global__ void __launch_bounds__(256) k_force_lds(Geom g, const double2 *__rest
   }
 }
 
+// k_force_lds over BOTH parities of a tile position in one workgroup (8 wavefronts: parity x direction).  The two tiles
+// (tile, 0) and (tile, 1) are the same 128 consecutive lattice sites (whole x rows), so a one-hop neighbour in x -- and in
+// y for three rows of four -- is a site of the OTHER wavefront group whose own links are already in LDS.  After the one
+// barrier a lane therefore takes U_a(s) (slot 0) or U_a(s - a) (slot 1) of any site s inside the tile position from LDS
+// and goes to global memory only for the rest: of the 48 neighbour matrices of a site 21 come from LDS on a 32-wide
+// lattice (every operand with a hop in x, 3/4 of those with a hop in y), 35 + 4 global matrix loads per site instead of
+// 56 + 4.  The stage is bound by the CUs' L2->L1 gather rate (profiles/r03_flow_stage_experiments.md), which is what
+// this cuts.  Same products in the same order as k_force_lds: bit-identical results.
+template <bool HALO>
+__device__ __forceinline__ int site_cidx(const Geom &g, const int x[4]) {
+  int t = x[3];
+  if (HALO) t = t < 0 ? t + g.X[3] + 6 : t;
+  return (x[0] + g.X[0] * (x[1] + g.X[1] * (x[2] + g.X[2] * t))) >> 1;
+}
+// U_a(gs) from global memory, unless the site s (parity q = the other one) lies in this tile position: then from the
+// workgroup's LDS copy, slot 0 = U_a(s), slot 1 = U_a(s - a)
+template <bool HALO>
+__device__ __forceinline__ M3 link_lds_or_global(const Geom &g, const double2 *__restrict__ G, const double2 *smq, int tile,
+                                                 const int s[4], int a, int slot, const int gs[4]) {
+  const int cs = site_cidx<HALO>(g, s);
+  if ((cs >> 6) == tile) return m3_load(smq + (size_t)(2 * a + slot) * 576 + (cs & 63), 64);
+  return m3_load(G + link_off_t<HALO>(g, gs, a), 64);
+}
+template <bool CLOSED, bool HALO>
+__global__ void __launch_bounds__(512) k_force_lds2(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
+                                                    double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk, int nt) {
+  extern __shared__ double2 smU[];                    // [parity][2 nu + (0: U_nu(x) | 1: U_nu(x-nu))][9][64]
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e = order[(blockIdx.x & 7) * chunk + 2 * (blockIdx.x >> 3) + (w >> 2)];   // the table holds (tile,0),(tile,1) adjacent
+  if (order[(blockIdx.x & 7) * chunk + 2 * (blockIdx.x >> 3)] < 0) return;            // padding pair: the whole workgroup together
+  const int mu = w & 3;
+  const int p = e & 1, tile = e >> 1;
+  const int c0 = tile * 64 + lane;
+  const bool live = c0 < g.Vh;
+  const int c = live ? c0 : g.Vh - 1;                 // padding lanes of the last tile work on a valid site and store nothing
+  int x[4], xpm[4], y[4], z[4];
+  coords_of(g, c, p, x);
+  shifted_t<HALO>(g, x, mu, 1, xpm);
+  const size_t o = link_off_t<HALO>(g, x, mu);
+  double2 *smp = smU + (size_t)p * 8 * 576;           // this parity's own links
+  const double2 *smq = smU + (size_t)(1 - p) * 8 * 576;   // the other parity's: every one-hop neighbour
+  {
+    shifted_t<HALO>(g, x, mu, -1, y);
+    const M3 a = m3_load(G + o, 64), b = m3_load(G + link_off_t<HALO>(g, y, mu), 64);
+    double2 *s0 = smp + (size_t)(2 * mu) * 576 + lane;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { s0[k * 64] = a.e[k]; s0[576 + k * 64] = b.e[k]; }
+  }
+  __syncthreads();
+  M3 acc = m3_zero();
+#pragma unroll 1
+  for (int nu = 0; nu < 4; nu++) {
+    if (nu == mu) continue;
+    const double2 *sn = smp + (size_t)(2 * nu) * 576 + lane;
+    // forward: U_nu(x) U_mu(x+nu) U_nu(x+mu)^+          (stf[mu,nu], staples.nim:181-183)
+    shifted_t<HALO>(g, x, nu, 1, y);
+    M3 t = m3_mul_na(link_lds_or_global<HALO>(g, G, smq, tile, y, mu, 0, y), link_lds_or_global<HALO>(g, G, smq, tile, xpm, nu, 0, xpm));
+    m3_mac(acc, m3_load(sn, 64), t);
+    // backward: U_nu(x-nu)^+ U_mu(x-nu) U_nu(x-nu+mu)   (stu[mu,nu] shifted down, staples.nim:184-186)
+    shifted_t<HALO>(g, x, nu, -1, y);
+    shifted_t<HALO>(g, y, mu, 1, z);
+    t = m3_mul_an(m3_load(sn + 576, 64), link_lds_or_global<HALO>(g, G, smq, tile, y, mu, 0, y));
+    m3_mac(acc, t, link_lds_or_global<HALO>(g, G, smq, tile, xpm, nu, 1, z));     // U_nu(x+mu-nu) = slot 1 of site x+mu
+  }
+  const M3 U = m3_load(smp + (size_t)(2 * mu) * 576 + lane, 64);
+  M3 f = m3_tah(m3_mul_na(U, acc));
+  if (!live) return;
+  if (Pm) {
+    M3 v;
+    const double cfp = cf * cp;
+    if (cpm != 0.0) {
+      const M3 pm = nt ? m3_load_nt(Pm + o, 64) : m3_load(Pm + o, 64);
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x + cpm * pm.e[k].x, cfp * f.e[k].y + cpm * pm.e[k].y);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x, cfp * f.e[k].y);
+    }
+    if (nt) m3_store_nt(Pm + o, 64, v); else m3_store(Pm + o, 64, v);
+    if (Uout) {
+      const M3 un = m3_mul(CLOSED ? m3_exp_tah(v) : m3_exp(v), U);
+      if (nt) m3_store_nt(Uout + o, 64, un); else m3_store(Uout + o, 64, un);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { f.e[k].x *= cp; f.e[k].y *= cp; }
+    if (nt) m3_store_nt(F + o, 64, f); else m3_store(F + o, 64, f);
+  }
+}
+
 // RK3 stage, second half: U <- exp(v) U with v already in the momentum field (wflow.nim:40-43)
 // body link-tiles of both parity halves: linear index -> offset (skips the ghost tiles of a sharded field)
 __device__ __forceinline__ size_t body_tile_off(size_t tile, size_t ntile4, size_t etile4) {
@@ -832,6 +922,21 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
     // the Wilson-flow stage proper (staples -> v -> exp(v) U): loader / consumer kernel, flow_stage.hip (144 KiB of LDS)
     if (flow && Uout && mode == 3 && c->opt_flow_ring && c->max_lds_optin >= (int)(16 * 576 * sizeof(double2))) {
       CHK(flow_stage_launch(c, c->gn->U, c->gn->P, Uout, cplaq / 3.0, cf, cpm, order, chunk, closed));
+    } else if (lds && mode == 3 && c->opt_force_pair && c->tile_pairs_ok && c->max_lds_optin >= (int)(2 * shb)) {
+      // both parities of a tile position per workgroup (k_force_lds2): 144 KiB of LDS, one workgroup of 8 wavefronts per CU
+      if (!(c->lds_attr_done & 8)) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * shb)));
+        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * shb)));
+        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * shb)));
+        HIPCHK(hipFuncSetAttribute((const void *)k_force_lds2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * shb)));
+        c->lds_attr_done |= 8;
+      }
+      double2 *Pf = (closed || flow) ? c->gn->P : nullptr;
+      static const int fnt = [] { const char *e = getenv("QEXHIP_FORCE_NT"); return e ? atoi(e) : 1; }();
+#define QX_FLDS2(CL, HL) k_force_lds2<CL, HL><<<nb / 2, 512, 2 * shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk, fnt)
+      if (closed) { if (c->g.halo) QX_FLDS2(true, true); else QX_FLDS2(true, false); }
+      else { if (c->g.halo) QX_FLDS2(false, true); else QX_FLDS2(false, false); }
+#undef QX_FLDS2
     } else if (lds && mode == 3 && c->max_lds_optin >= (int)shb) {
       if (!(c->lds_attr_done & 1)) {
         HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));

@@ -369,6 +369,11 @@ int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk_out) {
     std::sort(v.begin() + lo, v.begin() + hi, [](const Ent &a, const Ent &b) { return a.key1 < b.key1; });
     for (int j = lo; j < hi; j++) h[(size_t)k * chunk + (j - lo)] = v[j].e;
   }
+  // k_force_lds2 takes the two parities of a tile position from adjacent slots (2j, 2j+1) of one XCD's list
+  int pairs = (chunk % 2 == 0);
+  for (size_t j = 0; pairs && j + 1 < h.size(); j += 2)
+    if (!((h[j] < 0 && h[j + 1] < 0) || (h[j] >= 0 && h[j + 1] == h[j] + 1 && (h[j] & 1) == 0))) pairs = 0;
+  c->tile_pairs_ok = pairs;
   if (c->tile_order) { (void)hipFree(c->tile_order); c->tile_order = nullptr; }
   HIPCHK(hipMalloc(&c->tile_order, h.size() * sizeof(int)));
   HIPCHK(hipMemcpy(c->tile_order, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));

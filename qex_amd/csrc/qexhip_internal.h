@@ -105,6 +105,7 @@ struct qexhip_ctx {
   int opt_batch_multi = 0; // test hook: take the multi-rank reduction branch of the batched CG on one rank
   int opt_multi_reduce = 0; // test hook: take the multi-rank reduction branches of CG / multi-shift CG / norms on one rank
                             // (with a one-rank RCCL communicator the all-reduces are real collectives)
+  int opt_force_pair = 1; // QEXHIP_FORCE_PAIR / option "force_pair": both parities of a tile position per workgroup in the plaquette force / flow stage (k_force_lds2)
   int opt_flow_ring = 0;  // QEXHIP_FLOW_RING / option "flow_ring": 1 = the loader / consumer flow stage (flow_stage.hip: measured alternative,
                           // 850-900 us against 720-780, profiles/r03_flow_stage_experiments.md); 0 = k_force_lds, the default
   int opt_obs_clover = 1; // QEXHIP_OBS_CLOVER / option "obs_clover": 1 = the tile-per-workgroup clover kernel for fmunu(loop = 1); 0 = the path walker
@@ -119,11 +120,12 @@ struct qexhip_ctx {
   void *hisq = nullptr;   // HisqState (smear.hip): HisqCoefs.smearGetForce's closure
   // small per-context device scratch owned by single kernels' host wrappers
   double2 *outer_F = nullptr; size_t outer_Fn = 0;   // force field of stag_outer_host (force.hip)
+  int tile_pairs_ok = 0;   // tile_order_table: every even slot holds (tile, 0) and the next one (tile, 1) (or both are padding): k_force_lds2
   int *tile_order = nullptr; int tile_order_n = 0;   // blocked (tile, parity) visiting order of the gather kernels (gauge.hip)
   int *tile_order_pl[16]{};                          // the same for kernels that shift in the (mu, nu) plane only (layout.hip)
   void *obs_table = nullptr;                         // ObsTable of gauge_flow_obs (gauge.hip)
   void *batch = nullptr;                             // BatchState of the lock-step multi-system CG (batch.hip)
-  int lds_attr_done = 0;                             // per context (= per device): which kernels had MaxDynamicSharedMemorySize raised (bit 0 k_force_lds, 1 k_flow_obs_clover, 2 k_flow_stage)
+  int lds_attr_done = 0;                             // per context (= per device): which kernels had MaxDynamicSharedMemorySize raised (bit 0 k_force_lds, 1 k_flow_obs_clover, 2 k_flow_stage, 3 k_force_lds2)
   int max_lds_optin = 0;                             // hipDeviceAttributeMaxSharedMemoryPerBlock(Optin): the large-LDS kernels fall back when it is too small
   void *cgm_scal = nullptr;                          // CgmScal of the multi-shift solver (multishift.hip)
 };

@@ -151,6 +151,19 @@ def test_gpu_gauge_sector_on_the_sharded_path(oracle):
     for X in (A, B):
         X.set_option("flow_ring", 0)
     assert np.array_equal(gb, gc) and np.abs(ga - gb).max() < 1e-14
+    # both parities of a tile position per workgroup (option force_pair, k_force_lds2: neighbours inside the tile position
+    # come from LDS) against one tile per workgroup (k_force_lds): the same products in the same order, so bit for bit
+    ga, gb, gc = g.copy(), g.copy(), g.copy()
+    fa = q.gaugeForce(A, g, cplaq=1.0)
+    q.gaugeFlow(A, ga, 2, 0.01)
+    for X in (A, B):
+        X.set_option("force_pair", 0)
+    assert np.array_equal(fa, q.gaugeForce(A, g, cplaq=1.0)) and np.array_equal(fa, q.gaugeForce(B, g, cplaq=1.0))
+    q.gaugeFlow(A, gb, 2, 0.01)
+    q.gaugeFlow(B, gc, 2, 0.01)
+    for X in (A, B):
+        X.set_option("force_pair", 1)
+    assert np.array_equal(ga, gb) and np.array_equal(ga, gc)
     ga, gb = g.copy(), g.copy()
     q.gaugeUpdate(A, ga, p, 0.3)
     q.gaugeUpdate(B, gb, p, 0.3)

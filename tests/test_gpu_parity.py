@@ -679,19 +679,23 @@ def test_multi_rank_code_path_on_one_rank(oracle, naik):
 
 @pytest.mark.parametrize("flow_ring", [0, 1])
 @pytest.mark.parametrize("flow_exp", [1, 0])
-def test_force_and_flow_on_a_lattice_with_a_ragged_last_tile(oracle, flow_exp, flow_ring):
+@pytest.mark.parametrize("lat", [[4, 6, 10, 6], [6, 6, 6, 8]])
+def test_force_and_flow_on_a_lattice_with_a_ragged_last_tile(oracle, flow_exp, flow_ring, lat):
     """4 x 6 x 10 x 6: 720 sites per parity = 11 tiles of 64 and a quarter.  The force / flow kernels give a whole
     workgroup (four directions, shared links through LDS, one barrier) to every tile, so the padding lanes of the last
-    tile must go through the barrier and store nothing: force and three flow steps against the oracle."""
+    tile must go through the barrier and store nothing: force and three flow steps against the oracle.
+    6 x 6 x 6 x 8: 13 tiles and a half, and a visiting order whose slots pair the two parities of a tile position, so the
+    default kernel is the one with both parities per workgroup (k_force_lds2; the first lattice has an odd number of
+    slots per XCD and runs the one-tile kernel); x rows of 3 sites per parity straddle tile borders there."""
     import qex_amd as q
 
-    lat = [4, 6, 10, 6]
     lo = oracle.Layout(lat)
     g = oracle.gauge_random(lo, seed=SEED)
     ctx = q.Context(lat)
     ctx.set_option("flow_exp", flow_exp)
     ctx.set_option("flow_ring", flow_ring)
     assert relerr(q.gaugeForce(ctx, g), oracle.gauge_force(lo, g)) < 1e-13
+    assert ("tile_pairs=%d" % (1 if lat[0] == 6 else 0)) in ctx.info()
     gref = g.copy()
     q.gaugeFlow(ctx, g, 3, 0.02)
     oracle.wflow(lo, gref, 3, 0.02)
