@@ -142,6 +142,7 @@ if rd and cp_w:
         ("k_cgm_update", None, (48 + 96 + 9 * 192) * Vh, "r in, ps[0] in/out, 9 x (xs, ps in/out), 10 shifts"),
         ("k_flow_stage", None, (4 * M * 3 + 4 * M * 2.0 / 3.0) * VOL, "U in, U' out, momentum out, momentum in for stages 2-3 (2112 B/site average)"),
         ("k_force_lds", None, (4 * M * 3 + 4 * M * 2.0 / 3.0) * VOL, "U in, U' out, momentum out, momentum in for stages 2-3 (2112 B/site average)"),
+        ("k_force_lds2", None, (4 * M * 3 + 4 * M * 2.0 / 3.0) * VOL, "U in, U' out, momentum out, momentum in for stages 2-3 (2112 B/site average); both parities of a tile position per workgroup"),
         ("k_plaq", None, 4 * M * VOL, "4 links per site read once (576 B)"),
         ("k_flow_obs_clover", None, 4 * M * VOL, "4 links per site read once (576 B)"),
         ("k_flow_obs_all", None, 4 * M * VOL, "4 links per site read once (576 B): plaquette + clover E, Q in one pass"),
