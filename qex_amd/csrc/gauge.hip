@@ -187,6 +187,36 @@ __global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict
   }
 }
 
+// what k_force_lds and k_force_lds2 do with a link's staple sum: f = TAH(U acc^+) (gaugeUtils.nim:389-398), then either the
+// force itself (F = cp f) or the RK3 stage v = cf cp f + cpm p -> p, U' = exp(v) U (wflow.nim:36-62)
+template <bool CLOSED>
+__device__ __forceinline__ void force_finish(const M3 &U, const M3 &acc, bool live, size_t o, double2 *F, double cp, double2 *Pm,
+                                             double cf, double cpm, double2 *Uout, int nt) {
+  M3 f = m3_tah(m3_mul_na(U, acc));
+  if (!live) return;
+  if (Pm) {
+    M3 v;
+    const double cfp = cf * cp;
+    if (cpm != 0.0) {
+      const M3 pm = nt ? m3_load_nt(Pm + o, 64) : m3_load(Pm + o, 64);
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x + cpm * pm.e[k].x, cfp * f.e[k].y + cpm * pm.e[k].y);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x, cfp * f.e[k].y);
+    }
+    if (nt) m3_store_nt(Pm + o, 64, v); else m3_store(Pm + o, 64, v);
+    if (Uout) {
+      const M3 un = m3_mul(CLOSED ? m3_exp_tah(v) : m3_exp(v), U);
+      if (nt) m3_store_nt(Uout + o, 64, un); else m3_store(Uout + o, 64, un);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; k++) { f.e[k].x *= cp; f.e[k].y *= cp; }
+    if (nt) m3_store_nt(F + o, 64, f); else m3_store(F + o, 64, f);
+  }
+}
+
 // k_force with the links that the four directions of a tile share passed through LDS (mode 3 only).  The kernel pays for
 // its gathers at the CU's L2->L1 rate (profiles/r02_kforce_experiments.md): of the 19 matrices a lane fetches, U_nu(x) and
 // U_nu(x-nu) (nu != mu) are the same for the three wavefronts with mu != nu -- and they are the workgroup's own links
@@ -231,29 +261,7 @@ __global__ void __launch_bounds__(256) k_force_lds(Geom g, const double2 *__rest
     m3_mac(acc, t, m3_load(G + link_off_t<HALO>(g, z, nu), 64));
   }
   const M3 U = m3_load(smU + (size_t)(2 * mu) * 576 + lane, 64);
-  M3 f = m3_tah(m3_mul_na(U, acc));
-  if (!live) return;
-  if (Pm) {
-    M3 v;
-    const double cfp = cf * cp;
-    if (cpm != 0.0) {
-      const M3 pm = nt ? m3_load_nt(Pm + o, 64) : m3_load(Pm + o, 64);
-#pragma unroll
-      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x + cpm * pm.e[k].x, cfp * f.e[k].y + cpm * pm.e[k].y);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x, cfp * f.e[k].y);
-    }
-    if (nt) m3_store_nt(Pm + o, 64, v); else m3_store(Pm + o, 64, v);
-    if (Uout) {
-      const M3 un = m3_mul(CLOSED ? m3_exp_tah(v) : m3_exp(v), U);
-      if (nt) m3_store_nt(Uout + o, 64, un); else m3_store(Uout + o, 64, un);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 9; k++) { f.e[k].x *= cp; f.e[k].y *= cp; }
-    if (nt) m3_store_nt(F + o, 64, f); else m3_store(F + o, 64, f);
-  }
+  force_finish<CLOSED>(U, acc, live, o, F, cp, Pm, cf, cpm, Uout, nt);
 }
 
 // k_force_lds over BOTH parities of a tile position in one workgroup (8 wavefronts: parity x direction).  The two tiles
@@ -321,29 +329,7 @@ __global__ void __launch_bounds__(512) k_force_lds2(Geom g, const double2 *__res
     m3_mac(acc, t, link_lds_or_global<HALO>(g, G, smq, tile, xpm, nu, 1, z));     // U_nu(x+mu-nu) = slot 1 of site x+mu
   }
   const M3 U = m3_load(smp + (size_t)(2 * mu) * 576 + lane, 64);
-  M3 f = m3_tah(m3_mul_na(U, acc));
-  if (!live) return;
-  if (Pm) {
-    M3 v;
-    const double cfp = cf * cp;
-    if (cpm != 0.0) {
-      const M3 pm = nt ? m3_load_nt(Pm + o, 64) : m3_load(Pm + o, 64);
-#pragma unroll
-      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x + cpm * pm.e[k].x, cfp * f.e[k].y + cpm * pm.e[k].y);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x, cfp * f.e[k].y);
-    }
-    if (nt) m3_store_nt(Pm + o, 64, v); else m3_store(Pm + o, 64, v);
-    if (Uout) {
-      const M3 un = m3_mul(CLOSED ? m3_exp_tah(v) : m3_exp(v), U);
-      if (nt) m3_store_nt(Uout + o, 64, un); else m3_store(Uout + o, 64, un);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 9; k++) { f.e[k].x *= cp; f.e[k].y *= cp; }
-    if (nt) m3_store_nt(F + o, 64, f); else m3_store(F + o, 64, f);
-  }
+  force_finish<CLOSED>(U, acc, live, o, F, cp, Pm, cf, cpm, Uout, nt);
 }
 
 // RK3 stage, second half: U <- exp(v) U with v already in the momentum field (wflow.nim:40-43)
