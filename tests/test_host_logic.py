@@ -328,3 +328,23 @@ def test_shard_check_fixture_against_the_oracle(lat):
     r = sc.compare(gen.oracle_values(lat), want)
     assert r["ok"], r
     assert r["max_rel"]["operator"] < 1e-13 and r["max_rel"]["history"] < 1e-11 and r["max_rel"]["solution"] < 1e-12, r
+
+
+def test_every_entry_point_refuses_a_null_handle():
+    """Error behaviour of the boundary (SURVEY 8b "Errors": int return codes, 0 = ok, < 0 = error): every exported function
+    that takes the context handle must answer a NULL handle with a negative code before it touches the device -- this
+    runs without a GPU.  (The RNG-field objects have their own handle type: qexhip_rng_free(NULL) is a no-op by design.)"""
+    import ctypes as C
+
+    from qex_amd import _lib
+
+    L = _lib.lib()
+    swept = 0
+    for name, res, argtypes in _lib.SYMBOLS:
+        if not argtypes or argtypes[0] is not C.c_void_p or res is not C.c_int or name.startswith("qexhip_rng_"):
+            continue
+        args = [0 if t is C.c_int else (0.0 if t is C.c_double else None) for t in argtypes]
+        rc = getattr(L, name)(*args)
+        assert rc < 0, "%s(NULL handle, ...) returned %d" % (name, rc)
+        swept += 1
+    assert swept >= 80
