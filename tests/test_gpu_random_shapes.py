@@ -3,7 +3,8 @@ backward neighbour coincide), rows shorter and longer than a 64-site tile, ragge
 and do not pair the parities (k_force_lds2 / k_force_lds), shapes that can and cannot be sharded in t.  Every shape: the
 one-parity Dslash, D, the first CG residuals, plaquettes, plaquette force and two Wilson-flow steps against the oracle
 (src/physics/stagD.nim:349-395, src/solvers/cg.nim:132-214, src/gauge/gaugeUtils.nim:213-282, src/gauge/wflow.nim:21-67);
-with forced ghost zones where the shape allows it; with Naik links where every extent is >= 4."""
+with forced ghost zones where the shape allows it; with Naik links where every extent is >= 4; nHYP smearing and its force chain
+(hypsmear.nim:49-247) on every shape, the HISQ links (hisqLinks.nim:32-43) where the 3-hop terms fit."""
 import numpy as np
 import pytest
 
@@ -82,4 +83,20 @@ def test_shape(oracle, lat):
             assert relerr(gf, gr) < 1e-12, (lat, halo, fe)
         pl, eq = q.flowMeasure(ctx)
         assert np.max(np.abs(pl - o.plaq(lo, gr))) < 1e-13
+        # smearing and its chain rule (hypsmear.nim:49-247; hisqLinks.nim:32-43 where the 3-hop terms fit)
+        gw = o.gauge_warm(lo, 0.5, o.RngField(lo, o.RNG_MILC6, 21))
+        chain = o.gauge_random_tah(lo, rf) + 0.3 * o.gauge_random(lo, rf)
+        fl = np.zeros_like(gw)
+        sf = q.HypCoefs(0.4, 0.5, 0.5).smearGetForce(ctx, gw, fl)
+        rfl, rfo = o.nhyp_force(lo, gw, chain, 0.4, 0.5, 0.5)
+        assert relerr(fl, rfl) < 1e-12, (lat, halo)
+        f = np.zeros_like(gw)
+        sf(f, chain)
+        assert relerr(f, rfo) < 1e-11, (lat, halo)
+        sf.release()
+        if naik:
+            hf, hl = np.zeros_like(gw), np.zeros_like(gw)
+            q.HisqCoefs().smear(ctx, gw, hf, hl)
+            rhf, rhl = o.hisq_smear(lo, gw)
+            assert relerr(hf, rhf) < 1e-12 and relerr(hl, rhl) < 1e-12, (lat, halo)
         ctx.close()
