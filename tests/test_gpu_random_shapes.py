@@ -72,6 +72,18 @@ def test_shape(oracle, lat):
                 assert n >= 2 and sp.iterations == its
                 assert np.abs(sp.r2hist[:n] / hist[:n] - 1).max() < 1e-9, (lat, halo, use_naik, par_even)
                 assert relerr(xs, xr) < 1e-9
+            # shifted systems (cgm.nim:84-315, stagSolve.nim:296-345)
+            masses = [0.2, 0.5, 1.1]
+            shifts = [masses[0]] + [4.0 * (m * m - masses[0] ** 2) for m in masses[1:]]
+            xm = [np.zeros_like(x) for _ in masses]
+            sp = q.SolverParams(r2req=1e-30, maxits=10, verbosity=0)
+            s.solveXX_multi(xm, x, shifts, sp, parEven=True, histcap=64)
+            xr, its, hist = o.solveXX_multi(lo, g, l3, x, shifts, 1e-30, 10, True, histcap=64)
+            n = min(len(hist), len(sp.r2hist))
+            assert sp.iterations == its and np.abs(sp.r2hist[:n] / hist[:n] - 1).max() < 1e-9
+            h = lo.vol // 2
+            for a, b in zip(xm, xr):
+                assert relerr(a[:h], b[:h]) < 1e-9, (lat, halo, use_naik)
         # gauge sector
         assert np.max(np.abs(q.plaq(ctx, g0) - o.plaq(lo, g0))) < 1e-14
         assert relerr(q.gaugeForce(ctx, g0), o.gauge_force(lo, g0)) < 1e-13
