@@ -231,6 +231,10 @@ int qexhip_gauge_action(qexhip_handle h, double cplaq, double crect, double cadj
 int qexhip_gauge_update(qexhip_handle h, const double *p, double t);
 int qexhip_gauge_reunit(qexhip_handle h);
 int qexhip_wline(qexhip_handle h, const int *path, int n, double out[2]);
+/* the four Polyakov loops wline([mu+1] * L_mu), mu = 0..3, of the resident field in one call: what `meas_ploop`
+ * (src/flow/gauge_flow.nim:137-156) and `ploop` (src/examples/staghmc_sh.nim:281-291) compute with four g.wline calls;
+ * out[2 mu], out[2 mu + 1] = Re, Im (normalised like qexhip_wline: trace / 3, lattice average) */
+int qexhip_polyakov_loops(qexhip_handle h, double out[8]);
 
 /* ---------------- link construction upstream of the solver ----------------
  * g, fl, ll: double[vol][4][3][3][2].

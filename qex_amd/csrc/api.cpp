@@ -770,6 +770,11 @@ extern "C" int qexhip_wline(qexhip_handle c, const int *path, int n, double out[
   HIPCHK(hipSetDevice(c->device));
   return gauge_wline(c, path, n, out);
 }
+extern "C" int qexhip_polyakov_loops(qexhip_handle c, double out[8]) {
+  if (!c || !out) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return gauge_polyakov(c, out);
+}
 extern "C" int qexhip_wflow(qexhip_handle c, int nsteps, double eps) { if (!c || nsteps < 0) return QEXHIP_ERR_ARG; return gauge_wflow(c, nsteps, eps); }
 
 // ---- resident molecular dynamics (gauge.hip) ----

@@ -1275,6 +1275,51 @@ __global__ void __launch_bounds__(256) k_tline_trace(int nsites, int nranks, con
   if (threadIdx.x == 0) partials[2 * gridDim.x + blockIdx.x] = 0.0;
 }
 
+// Straight line that closes on itself through the (local) lattice, direction d < 3 or an unsharded t: the Polyakov loop
+// (src/flow/gauge_flow.nim:137-156, staghmc_sh.nim:281-291).  The trace is cyclic, so every site of a line carries the same
+// value: ONE lane per line multiplies the X[d] links of its line (the field is read once, V / X[d] products of X[d] links
+// instead of V) and the mean over the lines is the mean over the sites the reference takes (gaugeUtils.nim:1079-1112).
+// d >= 0: that direction, partials at `partials`; d < 0: direction blockIdx.y, partials at partials + 1536 * blockIdx.y
+// (gauge_polyakov: the four directions side by side in one launch -- a line is a chain of X[d] dependent products and
+// V / X[d] lanes do not fill the chip, so the directions overlap instead of queueing)
+__global__ void __launch_bounds__(256) k_line_trace(Geom g, const double2 *__restrict__ G, int dsel, double *partials) {
+  const int d = dsel >= 0 ? dsel : (int)blockIdx.y;
+  if (dsel < 0) partials += (size_t)1536 * blockIdx.y;
+  double sr = 0, si = 0;
+  const int Xd = d == 0 ? g.X[0] : (d == 1 ? g.X[1] : (d == 2 ? g.X[2] : g.X[3]));
+  const int nl = g.V / Xd;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < nl; j += gridDim.x * 256) {
+    // the line's site in the hyperplane x[d] = 0: j runs over the other three coordinates, x fastest
+    int x[4], r = j;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (k == d) { x[k] = 0; continue; }
+      x[k] = r % g.X[k]; r /= g.X[k];
+    }
+    M3 m = m3_load(G + link_off(g, x, d), 64);
+    for (int t = 1; t < Xd; t++) {
+      x[0] = d == 0 ? t : x[0]; x[1] = d == 1 ? t : x[1]; x[2] = d == 2 ? t : x[2]; x[3] = d == 3 ? t : x[3];
+      m = m3_mul(m, m3_load(G + link_off(g, x, d), 64));
+    }
+    sr += m.e[0].x + m.e[4].x + m.e[8].x;
+    si += m.e[0].y + m.e[4].y + m.e[8].y;
+  }
+  double r;
+  r = block_sum_256(sr); if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  r = block_sum_256(si); if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = r;
+  if (threadIdx.x == 0) partials[2 * gridDim.x + blockIdx.x] = 0.0;
+}
+// group b (blockIdx.x): out[3 b + k] = sum of partials[1536 b + k nb + (0..nb)]
+__global__ void __launch_bounds__(256) k_sum3_groups(const double *partials, int nb, double *out) {
+  const double *pp = partials + (size_t)1536 * blockIdx.x;
+  for (int k = 0; k < 3; k++) {
+    double acc = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += pp[(size_t)k * nb + i];
+    double r = block_sum_256(acc);
+    if (threadIdx.x == 0) out[3 * blockIdx.x + k] = r;
+  }
+}
+
 int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]) {
   if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
   if (n < 1 || n > 4096) { qexhip_set_error("wline: path length out of range"); return -1; }
@@ -1318,6 +1363,25 @@ int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]) {
     }
     CHK(gauge_ghosts(c, std::max(reach, 1)));
   }
+  {
+    // a straight line once around the lattice in a direction this rank holds whole: one lane per line
+    bool straight = true;
+    for (int k = 1; k < n; k++) if (path[k] != path[0]) straight = false;
+    const int d = std::abs(path[0]) - 1;
+    static const int fast = [] { const char *e = getenv("QEXHIP_WLINE_LINES"); return e ? atoi(e) : 1; }();
+    if (fast && straight && n == g.X[d] && !(g.halo && d == 3)) {
+      const int nl = g.V / g.X[d];
+      const int nbl = std::min((nl + 255) / 256, 1024);
+      k_line_trace<<<nbl, 256, 0, c->stream>>>(g, c->gn->U, d, c->partials);
+      k_sum3<<<1, 256, 0, c->stream>>>(c->partials, nbl, &c->dscal[24]);
+      HIPCHK(hipGetLastError());
+      CHK(read_global(c, &c->dscal[24], 3, s));
+      const double fl = 1.0 / ((double)nl * (double)c->nranks * 3.0);
+      out[0] = s[0] * fl;
+      out[1] = (path[0] > 0 ? 1.0 : -1.0) * s[1] * fl;          // the reversed line is the adjoint
+      return 0;
+    }
+  }
   CHK(ensure_stage(c, 4096 * sizeof(int)));
   HIPCHK(hipMemcpyAsync(c->stage, path, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
   k_wline<<<nb, 256, 0, c->stream>>>(g, c->gn->U, (const int *)c->stage, n, c->partials);
@@ -1326,5 +1390,33 @@ int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]) {
   CHK(read_global(c, &c->dscal[24], 3, s));
   const double fac = 1.0 / ((double)g.V * (double)c->nranks * 3.0);
   out[0] = s[0] * fac; out[1] = s[1] * fac;
+  return 0;
+}
+
+// The four Polyakov loops of a flow-loop / HMC measurement (src/flow/gauge_flow.nim:137-156 `meas_ploop`,
+// src/examples/staghmc_sh.nim:281-291 `ploop`): wline([mu+1] * L_mu) for mu = 0..3 in four launches and ONE read-back.
+// out[2 mu], out[2 mu + 1] = Re, Im.  On a t-sharded field the t line takes gauge_wline's segment path.
+int gauge_polyakov(qexhip_ctx *c, double out[8]) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  const Geom &g = c->g;
+  const int nd = g.halo ? 3 : 4;
+  int nlmax = 0;
+  for (int d = 0; d < nd; d++) nlmax = std::max(nlmax, g.V / g.X[d]);
+  const int nbl = std::min((nlmax + 255) / 256, 512);         // 3 x 512 partials per direction, inside the first 6144 of the buffer
+  k_line_trace<<<dim3(nbl, nd), 256, 0, c->stream>>>(g, c->gn->U, -1, c->partials);
+  k_sum3_groups<<<nd, 256, 0, c->stream>>>(c->partials, nbl, &c->dscal[40]);
+  HIPCHK(hipGetLastError());
+  double s[12];
+  CHK(read_global(c, &c->dscal[40], 3 * nd, s));
+  for (int d = 0; d < nd; d++) {
+    const double fl = 1.0 / ((double)(g.V / g.X[d]) * (double)c->nranks * 3.0);
+    out[2 * d] = s[3 * d] * fl;
+    out[2 * d + 1] = s[3 * d + 1] * fl;
+  }
+  if (nd == 3) {
+    const int Lt = g.X[3] * c->nranks;
+    std::vector<int> path((size_t)Lt, 4);
+    CHK(gauge_wline(c, path.data(), Lt, out + 6));
+  }
   return 0;
 }

@@ -284,6 +284,7 @@ int md_shift_links(qexhip_ctx *c, int source, double t);
 int md_save_links(qexhip_ctx *c);
 int md_restore_links(qexhip_ctx *c);
 int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]);
+int gauge_polyakov(qexhip_ctx *c, double out[8]);
 void gauge_free(qexhip_ctx *c);
 const double2 *gauge_links_dev(qexhip_ctx *c);   // resident natural-layout links (nullptr before qexhip_gauge_set)
 // ---- rng.hip (device-side generation) ----

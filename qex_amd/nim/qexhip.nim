@@ -18,6 +18,7 @@
 ##   src/gauge/wflow.nim:21-67, src/flow/flow.nim:22-90  gaugeFlow       hipGaugeFlow (both forms)
 ##   src/gauge/gaugeUtils.nim:213-282  g.plaq                            hipPlaq
 ##   src/flow/gauge_flow.nim:360-379   EQ                                hipFlowMeasure
+##   src/flow/gauge_flow.nim:137-156   meas_ploop (4 x g.wline)          hipPloops
 ##   src/gauge/hypsmear.nim:49-247     coef.smearGetForce(g, sg, info)   hipSmearGetForce (returns the closure)
 ##     (stagg_pv_hmc/staghmc_spv.nim:989-993)
 ##   stagg_pv_hmc/staghmc_spv.nim:217-228  gforce(act, g, sg, f, sf)     closure.gforce
@@ -85,6 +86,7 @@ proc qexhip_gauge_action(h: QexhipHandle; cplaq, crect, cadjplaq: cdouble; o: pt
 proc qexhip_gauge_update(h: QexhipHandle; p: ptr cdouble; t: cdouble): cint {.qh.}
 proc qexhip_gauge_reunit(h: QexhipHandle): cint {.qh.}
 proc qexhip_wline(h: QexhipHandle; path: ptr cint; n: cint; o: ptr cdouble): cint {.qh.}
+proc qexhip_polyakov_loops(h: QexhipHandle; o: ptr cdouble): cint {.qh.}
 proc qexhip_io_read_gauge(path: cstring; lat: ptr cint; g: ptr cdouble; suma, sumb: ptr cuint): cint {.qh.}
 proc qexhip_rng_get_state(r: pointer; o: ptr cuint): cint {.qh.}
 proc qexhip_rng_set_state(r: pointer; i: ptr cuint): cint {.qh.}
@@ -361,6 +363,14 @@ proc hipFlowMeasure*(): tuple[plaq: seq[float]; es, et, q: float] =
   result.plaq = newSeq[float](6)
   for i in 0..5: result.plaq[i] = pl[i]
   result.es = eq[0]; result.et = eq[1]; result.q = eq[2]
+
+proc hipPloops*(): tuple[pls, plt: tuple[re, im: float]] =
+  ## meas_ploop (flow/gauge_flow.nim:137-156): the four Polyakov loops g.wline(repeat(i+1, L_i)) of the resident field in one
+  ## call; the spatial ones averaged, the temporal one alone, as there
+  var o: array[8, cdouble]
+  chk qexhip_polyakov_loops(hipParam.h, o[0].addr)
+  result.pls = (re: (o[0] + o[2] + o[4]) / 3.0, im: (o[1] + o[3] + o[5]) / 3.0)
+  result.plt = (re: o[6].float, im: o[7].float)
 
 template hipGaugeFlow*(g: array|seq; steps: int; eps: float; measure: untyped) =
   ## g.gaugeFlow(steps, eps): measure (gauge/wflow.nim:21-67).  `wflowT` is injected for `measure`, as there; the flowed

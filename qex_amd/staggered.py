@@ -515,6 +515,16 @@ def wline(ctx, path, g=None):
     return complex(out[0], out[1])
 
 
+def ploops(ctx, g=None):
+    """the four Polyakov loops [g.wline([mu+1] * L_mu) for mu in 0..3] (gauge_flow.nim:137-156 `meas_ploop`,
+    staghmc_sh.nim:281-291 `ploop`) of g, or of the resident field, in one call"""
+    if g is not None:
+        check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+    out = np.zeros(8)
+    check(lib().qexhip_polyakov_loops(ctx._h, _p(out)))
+    return [complex(out[2 * d], out[2 * d + 1]) for d in range(4)]
+
+
 def gaugeFlow(ctx, g, steps, eps, measure=None, flow_act="Wilson", plaq=1.0, rect=0.0, adjplaq=0.0):
     """g.gaugeFlow(steps, eps): measure (wflow.nim:21-67), or the fork's
     gc.gaugeFlow(flow_act, g, steps, eps): measure (src/flow/flow.nim:22-90) with

@@ -89,6 +89,13 @@ static void hipGaugeSet(const Buf &g) { CHK(qexhip_gauge_set(h, g.data())); }
 static void hipGaugeGet(Buf &g) { CHK(qexhip_gauge_get(h, g.data())); }
 static void hipPlaq(double o[6]) { CHK(qexhip_plaq(h, o)); }
 static void hipFlowMeasure(double pl[6], double eq[3]) { CHK(qexhip_flow_measure(h, pl, eq)); }
+// hipPloops: (pls, plt) = (mean of the three spatial loops, the temporal one), as meas_ploop (gauge_flow.nim:137-156)
+static void hipPloops(double pls[2], double plt[2]) {
+  double o[8];
+  CHK(qexhip_polyakov_loops(h, o));
+  pls[0] = (o[0] + o[2] + o[4]) / 3.0; pls[1] = (o[1] + o[3] + o[5]) / 3.0;
+  plt[0] = o[6]; plt[1] = o[7];
+}
 template <class M> static void hipGaugeFlow(Buf &g, int steps, double eps, M measure) {
   hipGaugeSet(g);
   for (int n = 1;; n++) {
@@ -210,6 +217,17 @@ int main() {
       qo_flow_EQ(lo, gr.data(), 1, oeq);
       for (int i = 0; i < 6; i++) CHECK(std::fabs(pl[i] - opl[i]) < 1e-14 && std::fabs(pl2[i] - opl[i]) < 1e-14, "flow t=%g plaq[%d] %g %g %g", t, i, pl[i], pl2[i], opl[i]);
       for (int i = 0; i < 3; i++) CHECK(std::fabs(eq[i] - oeq[i]) < 1e-11 * (1 + std::fabs(oeq[i])), "flow t=%g EQ[%d] %g %g", t, i, eq[i], oeq[i]);
+      // meas_ploop: g.wline(repeat(i+1, pg[i])) for the four directions
+      double pls[2], plt[2], ops[2] = {0, 0}, opt[2] = {0, 0};
+      hipPloops(pls, plt);
+      for (int d = 0; d < 4; d++) {
+        std::vector<int> path((size_t)lat[d], d + 1);
+        double w[2];
+        qo_wline(lo, gr.data(), path.data(), lat[d], w);
+        if (d < 3) { ops[0] += w[0] / 3.0; ops[1] += w[1] / 3.0; } else { opt[0] = w[0]; opt[1] = w[1]; }
+      }
+      CHECK(std::fabs(pls[0] - ops[0]) < 1e-14 && std::fabs(pls[1] - ops[1]) < 1e-14 && std::fabs(plt[0] - opt[0]) < 1e-14 && std::fabs(plt[1] - opt[1]) < 1e-14,
+            "flow t=%g Polyakov loops (%g,%g) (%g,%g) vs (%g,%g) (%g,%g)", t, pls[0], pls[1], plt[0], plt[1], ops[0], ops[1], opt[0], opt[1]);
       nmeas++;
     });
     CHECK(nmeas == 3 && relerr(gf, gr) < 1e-12, "hipGaugeFlow: %d measurements, links %g", nmeas, relerr(gf, gr));

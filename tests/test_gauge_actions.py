@@ -107,6 +107,11 @@ def test_gpu_md_building_blocks(oracle):
     for path in ([4] * lat[3], [1] * lat[0], [1, 2, -1, -2], [-3, 4, 4, 3, -4, -4], [2]):
         w = q.wline(ctx, path, g1)
         assert abs(w - o.wline(lo, g1, path)) < 1e-14
+    # the four Polyakov loops in one call (meas_ploop, gauge_flow.nim:137-156): one lane per LINE instead of per site
+    pl = q.ploops(ctx, g1)
+    for d in range(4):
+        assert abs(pl[d] - o.wline(lo, g1, [d + 1] * lat[d])) < 1e-14
+        assert abs(pl[d] - q.wline(ctx, [d + 1] * lat[d])) < 1e-15 and abs(pl[d].conjugate() - q.wline(ctx, [-(d + 1)] * lat[d])) < 1e-15
 
 
 @pytest.mark.gpu
@@ -177,6 +182,9 @@ def test_gpu_gauge_sector_on_the_sharded_path(oracle):
     # Polyakov line in t is assembled from per-rank segments (all-gather); anything else is refused
     for path in ([4] * 8, [-4] * 8, [1] * 8, [1, 4, -1, -4], [4, 4, 4, 1, -4, -4, -4, -1], [-4, -4, 2, 4, 4, -2]):
         assert abs(q.wline(A, path, ga) - q.wline(B, path, gb)) < 1e-15
+    pa, pb = q.ploops(A), q.ploops(B)
+    for d in range(4):
+        assert abs(pa[d] - pb[d]) < 1e-15 and abs(pa[d] - o.wline(lo, ga, [d + 1] * 8)) < 1e-14
     with pytest.raises(q.QexHipError, match="wline"):
         q.wline(B, [4] * 5 + [1] + [-4] * 5 + [-1], gb)
 
