@@ -871,7 +871,20 @@ int gauge_deriv_dev(qexhip_ctx *c, const double2 *G, double2 *F, double cplaq, d
   ScopedTimer tm(c, "staple", c->stream);
   const int *order = nullptr; int chunk = 0;
   CHK(tile_order_table(c, &order, &chunk));
-  k_force_gen<false><<<8 * chunk, 256, 0, c->stream>>>(c->g, G, F, cplaq / 3.0, k2, kind, nullptr, 0.0, 0.0, 1, nullptr, order, chunk);
+  static const int rectfast = [] { const char *e = getenv("QEXHIP_RECT_FAST"); return e ? atoi(e) : 1; }();
+  if (kind == 0 && c2 != 0.0 && rectfast && c->gn) {
+    // rectangle action: the shared-factor kernel on the double links of G (the context's D2 buffer has the layout of any natural field)
+    if (!c->gn->D2) HIPCHK(hipMalloc((void **)&c->gn->D2, c->gn->n2 * sizeof(double2)));
+    if (c->g.halo) {
+      k_double_links<true><<<2 * c->g.etile, 256, 0, c->stream>>>(c->g, G, c->gn->D2);
+      k_force_rect<false, true><<<8 * chunk, 256, 0, c->stream>>>(c->g, G, c->gn->D2, F, cplaq / 3.0, k2, nullptr, 0.0, 0.0, 1, nullptr, order, chunk);
+    } else {
+      k_double_links<false><<<2 * c->g.ntile, 256, 0, c->stream>>>(c->g, G, c->gn->D2);
+      k_force_rect<false, false><<<8 * chunk, 256, 0, c->stream>>>(c->g, G, c->gn->D2, F, cplaq / 3.0, k2, nullptr, 0.0, 0.0, 1, nullptr, order, chunk);
+    }
+  } else {
+    k_force_gen<false><<<8 * chunk, 256, 0, c->stream>>>(c->g, G, F, cplaq / 3.0, k2, kind, nullptr, 0.0, 0.0, 1, nullptr, order, chunk);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -95,6 +95,17 @@ def test_shape(oracle, lat):
             assert relerr(gf, gr) < 1e-12, (lat, halo, fe)
         pl, eq = q.flowMeasure(ctx)
         assert np.max(np.abs(pl - o.plaq(lo, gr))) < 1e-13
+        # the fork's action-selectable force and flow (flow/flow.nim:22-90): rectangle (2-hop: extents >= 4) and adjoint
+        for cp, c2, kind, act in ((5.0 / 3.0, -1.0 / 12.0, 0, "rect"), (0.9, 0.35, 1, "adj")):
+            if kind == 0 and not naik:
+                continue
+            kw = dict(rect=c2 if kind == 0 else 0.0, adjplaq=c2 if kind == 1 else 0.0)
+            assert relerr(q.gaugeForce(ctx, g0, cplaq=cp, **kw), o.gauge_force_general(lo, g0, cp, c2, kind)) < 1e-13, (lat, halo, act)
+            gf, gr2 = g0.copy(), g0.copy()
+            q.gaugeFlow(ctx, gf, 2, 0.01, flow_act=act, plaq=cp, **kw)
+            o.wflow_general(lo, gr2, 2, 0.01, cp, c2, kind)
+            assert relerr(gf, gr2) < 1e-12, (lat, halo, act)
+        q.gaugeSet(ctx, gr)
         # smearing and its chain rule (hypsmear.nim:49-247; hisqLinks.nim:32-43 where the 3-hop terms fit)
         gw = o.gauge_warm(lo, 0.5, o.RngField(lo, o.RNG_MILC6, 21))
         chain = o.gauge_random_tah(lo, rf) + 0.3 * o.gauge_random(lo, rf)
