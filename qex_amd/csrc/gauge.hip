@@ -1417,35 +1417,120 @@ __global__ void __launch_bounds__(256) k_tline_trace(int nsites, int nranks, con
 // (src/flow/gauge_flow.nim:137-156, staghmc_sh.nim:281-291).  The trace is cyclic, so every site of a line carries the same
 // value: ONE lane per line multiplies the X[d] links of its line (the field is read once, V / X[d] products of X[d] links
 // instead of V) and the mean over the lines is the mean over the sites the reference takes (gaugeUtils.nim:1079-1112).
-// d >= 0: that direction, partials at `partials`; d < 0: direction blockIdx.y, partials at partials + 1536 * blockIdx.y
+// dsel >= 0: that direction, partials at `partials`; dsel = -1 - d0: direction d = d0 + blockIdx.y, partials at partials + 1536 d
 // (gauge_polyakov: the four directions side by side in one launch -- a line is a chain of X[d] dependent products and
 // V / X[d] lanes do not fill the chip, so the directions overlap instead of queueing)
 __global__ void __launch_bounds__(256) k_line_trace(Geom g, const double2 *__restrict__ G, int dsel, double *partials) {
-  const int d = dsel >= 0 ? dsel : (int)blockIdx.y;
-  if (dsel < 0) partials += (size_t)1536 * blockIdx.y;
+  // workgroup = 64 lines x 4 segments: wavefront k multiplies the k-th quarter of its 64 lines (a chain of X[d] / 4
+  // dependent products instead of X[d]), wavefronts 1-3 hand their segment products to wavefront 0 through LDS
+  __shared__ double2 seg[3][9][64];
+  const int d = dsel >= 0 ? dsel : (int)blockIdx.y - dsel - 1;     // dsel = -1 - d0: directions d0 + blockIdx.y
+  if (dsel < 0) partials += (size_t)1536 * d;
   double sr = 0, si = 0;
   const int Xd = d == 0 ? g.X[0] : (d == 1 ? g.X[1] : (d == 2 ? g.X[2] : g.X[3]));
   const int nl = g.V / Xd;
-  for (int j = blockIdx.x * 256 + threadIdx.x; j < nl; j += gridDim.x * 256) {
-    // the line's site in the hyperplane x[d] = 0: j runs over the other three coordinates, x fastest
-    int x[4], r = j;
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int L = (Xd + 3) / 4, t0 = k * L, t1 = min(Xd, t0 + L);
+  for (int j0 = blockIdx.x * 64; j0 < nl; j0 += gridDim.x * 64) {
+    const int j = j0 + lane;
+    M3 m = m3_zero();
+    m3_add_diag(m, 1.0);
+    if (j < nl && t0 < t1) {
+      // the line's site in the hyperplane x[d] = 0: j runs over the other three coordinates, x fastest
+      int x[4], r = j;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (k == d) { x[k] = 0; continue; }
-      x[k] = r % g.X[k]; r /= g.X[k];
+      for (int q = 0; q < 4; q++) {
+        if (q == d) { x[q] = t0; continue; }
+        x[q] = r % g.X[q]; r /= g.X[q];
+      }
+      m = m3_load(G + link_off(g, x, d), 64);
+      for (int t = t0 + 1; t < t1; t++) {
+        x[0] = d == 0 ? t : x[0]; x[1] = d == 1 ? t : x[1]; x[2] = d == 2 ? t : x[2]; x[3] = d == 3 ? t : x[3];
+        m = m3_mul(m, m3_load(G + link_off(g, x, d), 64));
+      }
     }
-    M3 m = m3_load(G + link_off(g, x, d), 64);
-    for (int t = 1; t < Xd; t++) {
-      x[0] = d == 0 ? t : x[0]; x[1] = d == 1 ? t : x[1]; x[2] = d == 2 ? t : x[2]; x[3] = d == 3 ? t : x[3];
-      m = m3_mul(m, m3_load(G + link_off(g, x, d), 64));
+    if (k > 0) {
+#pragma unroll
+      for (int q = 0; q < 9; q++) seg[k - 1][q][lane] = m.e[q];
     }
-    sr += m.e[0].x + m.e[4].x + m.e[8].x;
-    si += m.e[0].y + m.e[4].y + m.e[8].y;
+    __syncthreads();
+    if (k == 0) {
+#pragma unroll 1
+      for (int q3 = 0; q3 < 3; q3++) {
+        M3 o;
+#pragma unroll
+        for (int q = 0; q < 9; q++) o.e[q] = seg[q3][q][lane];
+        m = m3_mul(m, o);
+      }
+      if (j < nl) {
+        sr += m.e[0].x + m.e[4].x + m.e[8].x;
+        si += m.e[0].y + m.e[4].y + m.e[8].y;
+      }
+    }
+    __syncthreads();
   }
   double r;
   r = block_sum_256(sr); if (threadIdx.x == 0) partials[blockIdx.x] = r;
   r = block_sum_256(si); if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = r;
   if (threadIdx.x == 0) partials[2 * gridDim.x + blockIdx.x] = 0.0;
+}
+// Lines along x: a lane per line would gather 16 B from 64 different rows per load (the other directions read whole rows).
+// Here a line occupies W = 2^k consecutive lanes of a wavefront, every lane multiplies S = 4 (or 2) consecutive links of the
+// line and the ordered product of the lanes is formed by a shuffle tree: lane i <- M_i M_{i+s}, s = 1, 2, 4 ... W/2 (lanes
+// beyond the line hold the unit matrix): S - 1 + log2(W) products per lane instead of X[0] dependent ones per line.
+__device__ __forceinline__ M3 m3_shfl_down(const M3 &a, int off) {
+  M3 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.e[k] = make_double2(__shfl_down(a.e[k].x, off, 64), __shfl_down(a.e[k].y, off, 64));
+  return r;
+}
+template <int S>   // S consecutive links per lane (sequential), then the shuffle tree over the W = 2^k >= X[0] / S lanes of a line
+__global__ void __launch_bounds__(256) k_xline_trace(Geom g, const double2 *__restrict__ G, int W, double *partials) {
+  double sr = 0, si = 0;
+  const int nl = g.V / g.X[0];                       // lines
+  const int per = 256 / W;                           // lines per workgroup
+  for (int l0 = blockIdx.x * per; l0 < nl; l0 += gridDim.x * per) {
+    const int j = l0 + (int)threadIdx.x / W, xs = ((int)threadIdx.x % W) * S;
+    M3 m = m3_zero();
+    m3_add_diag(m, 1.0);
+    if (j < nl && xs < g.X[0]) {
+      int x[4], r = j;
+      x[0] = xs;
+      x[1] = r % g.X[1]; r /= g.X[1];
+      x[2] = r % g.X[2]; x[3] = r / g.X[2];
+      m = m3_load(G + link_off(g, x, 0), 64);
+#pragma unroll
+      for (int k = 1; k < S; k++) {
+        x[0] = xs + k;
+        m = m3_mul(m, m3_load(G + link_off(g, x, 0), 64));
+      }
+    }
+    for (int sft = 1; sft < W; sft <<= 1) {
+      const M3 o = m3_shfl_down(m, sft);             // lanes whose partner is out of the line keep garbage nobody reads
+      m = m3_mul(m, o);
+    }
+    if (j < nl && xs == 0) {
+      sr += m.e[0].x + m.e[4].x + m.e[8].x;
+      si += m.e[0].y + m.e[4].y + m.e[8].y;
+    }
+  }
+  double r;
+  r = block_sum_256(sr); if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  r = block_sum_256(si); if (threadIdx.x == 0) partials[gridDim.x + blockIdx.x] = r;
+  if (threadIdx.x == 0) partials[2 * gridDim.x + blockIdx.x] = 0.0;
+}
+// the x lines into `partials` (3 x nb entries): cooperative form while a line fits a wavefront
+static void launch_xlines(qexhip_ctx *c, int nb, double *partials) {
+  const Geom &g = c->g;
+  const int S = (g.X[0] % 4 == 0) ? 4 : 2;
+  if (g.X[0] / S <= 64) {
+    int W = 1;
+    while (W < g.X[0] / S) W <<= 1;
+    if (S == 4) k_xline_trace<4><<<nb, 256, 0, c->stream>>>(g, c->gn->U, W, partials);
+    else k_xline_trace<2><<<nb, 256, 0, c->stream>>>(g, c->gn->U, W, partials);
+  } else {
+    k_line_trace<<<nb, 256, 0, c->stream>>>(g, c->gn->U, 0, partials);
+  }
 }
 // group b (blockIdx.x): out[3 b + k] = sum of partials[1536 b + k nb + (0..nb)]
 __global__ void __launch_bounds__(256) k_sum3_groups(const double *partials, int nb, double *out) {
@@ -1509,8 +1594,9 @@ int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]) {
     static const int fast = [] { const char *e = getenv("QEXHIP_WLINE_LINES"); return e ? atoi(e) : 1; }();
     if (fast && straight && n == g.X[d] && !(g.halo && d == 3)) {
       const int nl = g.V / g.X[d];
-      const int nbl = std::min((nl + 255) / 256, 1024);
-      k_line_trace<<<nbl, 256, 0, c->stream>>>(g, c->gn->U, d, c->partials);
+      const int nbl = std::min((nl + 63) / 64, 1024);
+      if (d == 0) launch_xlines(c, nbl, c->partials);
+      else k_line_trace<<<nbl, 256, 0, c->stream>>>(g, c->gn->U, d, c->partials);
       k_sum3<<<1, 256, 0, c->stream>>>(c->partials, nbl, &c->dscal[24]);
       HIPCHK(hipGetLastError());
       CHK(read_global(c, &c->dscal[24], 3, s));
@@ -1540,8 +1626,9 @@ int gauge_polyakov(qexhip_ctx *c, double out[8]) {
   const int nd = g.halo ? 3 : 4;
   int nlmax = 0;
   for (int d = 0; d < nd; d++) nlmax = std::max(nlmax, g.V / g.X[d]);
-  const int nbl = std::min((nlmax + 255) / 256, 512);         // 3 x 512 partials per direction, inside the first 6144 of the buffer
-  k_line_trace<<<dim3(nbl, nd), 256, 0, c->stream>>>(g, c->gn->U, -1, c->partials);
+  const int nbl = std::min((nlmax + 63) / 64, 512);           // 3 x 512 partials per direction, inside the first 6144 of the buffer
+  launch_xlines(c, nbl, c->partials);                                                   // direction 0 -> group 0
+  k_line_trace<<<dim3(nbl, nd - 1), 256, 0, c->stream>>>(g, c->gn->U, -2, c->partials);  // directions 1 .. nd-1 -> groups 1 ..
   k_sum3_groups<<<nd, 256, 0, c->stream>>>(c->partials, nbl, &c->dscal[40]);
   HIPCHK(hipGetLastError());
   double s[12];

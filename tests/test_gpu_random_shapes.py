@@ -95,6 +95,11 @@ def test_shape(oracle, lat):
             assert relerr(gf, gr) < 1e-12, (lat, halo, fe)
         pl, eq = q.flowMeasure(ctx)
         assert np.max(np.abs(pl - o.plaq(lo, gr))) < 1e-13
+        # Polyakov loops (gauge_flow.nim:137-156): x lines by a shuffle tree over padded power-of-two groups, the others a lane per line
+        pls = q.ploops(ctx)
+        for d in range(4):
+            assert abs(pls[d] - o.wline(lo, gr, [d + 1] * lat[d])) < 1e-14, (lat, halo, d)
+            assert abs(q.wline(ctx, [-(d + 1)] * lat[d]) - pls[d].conjugate()) < 1e-15
         # the fork's action-selectable force and flow (flow/flow.nim:22-90): rectangle (2-hop: extents >= 4) and adjoint
         for cp, c2, kind, act in ((5.0 / 3.0, -1.0 / 12.0, 0, "rect"), (0.9, 0.35, 1, "adj")):
             if kind == 0 and not naik:
