@@ -178,7 +178,8 @@ int qexhip_dev_solve_xx_multi(qexhip_handle h, const int *x_ids, int b_id, const
 
 /* Free the multi-shift solvers' persistent workspace (up to 3 x nmass full fields kept between solves; QEX allocates its
  * ps / ys per call with newOneOf and leaves them to the GC, src/solvers/cgm.nim:120-131, src/physics/stagSolve.nim:376-381).
- * The next multi-shift solve allocates it again. */
+ * The next multi-shift solve allocates it again.  Also frees the double-link field of the rectangle force / Symanzik flow
+ * (one more field the size of the links, rebuilt at the next such call). */
 int qexhip_release_workspace(qexhip_handle h);
 /* norm2 / redot (src/field/fieldET.nim:605-625,704-724; rank-global sums) and Staggered.D / Ddag (r = m x + sc D x, r_id != x_id)
  * on resident fields: what a caller that keeps its vectors in HBM uses for true residuals and solution norms. */

@@ -500,6 +500,7 @@ extern "C" int qexhip_release_workspace(qexhip_handle c) {
       ++it;
     }
   }
+  gauge_release_scratch(c);
   return 0;
 }
 

@@ -933,6 +933,11 @@ static inline int ghost_depth_for(double c2, int kind) { return (kind == 0 && c2
 
 const double2 *gauge_links_dev(qexhip_ctx *c) { return c->gn ? c->gn->U : nullptr; }
 
+// scratch of the gauge sector that can be rebuilt on demand: the double links of the rectangle force (one more field the size
+// of the links; qexhip_release_workspace)
+void gauge_release_scratch(qexhip_ctx *c) {
+  if (c->gn && c->gn->D2) { (void)hipFree(c->gn->D2); c->gn->D2 = nullptr; }
+}
 void gauge_free(qexhip_ctx *c) {
   if (!c->gn) return;
   if (c->gn->U) (void)hipFree(c->gn->U);
