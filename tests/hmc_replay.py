@@ -648,7 +648,7 @@ class DeviceEndsReplay(Replay):
         pbp = [PBPMASS * ctx.dev_norm2(x) / self.lo.vol for x in xs]
         pl = q.plaq(ctx)
         ps, pt = 2.0 * sum(pl[:3]), 2.0 * sum(pl[3:])
-        loops = [q.wline(ctx, [mu + 1] * LAT[mu]) for mu in range(4)]
+        loops = q.ploops(ctx)                                  # the four g.wline([mu+1] * L_mu) of `ploop` in one call
         pls = sum(loops[:3]) / 3.0
         return dict(pbp=pbp, pbp_iters=list(its), plaq=(ps, pt, 0.5 * (ps + pt)),
                     ploop=(pls.real, pls.imag, loops[3].real, loops[3].imag))
