@@ -236,6 +236,10 @@ int qexhip_wline(qexhip_handle h, const int *path, int n, double out[2]);
  * (src/flow/gauge_flow.nim:137-156) and `ploop` (src/examples/staghmc_sh.nim:281-291) compute with four g.wline calls;
  * out[2 mu], out[2 mu + 1] = Re, Im (normalised like qexhip_wline: trace / 3, lattice average) */
 int qexhip_polyakov_loops(qexhip_handle h, double out[8]);
+/* `s4_gauge` of the fork's measurements (src/stagg_pv_hmc/staghmc_spv_meas.nim:25-65; the pure-gauge S4 order parameter of
+ * arXiv:1111.2317, printed as "MEASplaq <dir>-dir even/odd"): the plaquette of plane (mu, nu) at x is added to peo[mu][x_mu mod 2]
+ * and peo[nu][x_nu mod 2]; out[2 d + eo] = peo[d][eo] / (physVol * 0.5 * (nd - 1) * nc), of the resident field */
+int qexhip_plaq_s4(qexhip_handle h, double out[8]);
 
 /* ---------------- link construction upstream of the solver ----------------
  * g, fl, ll: double[vol][4][3][3][2].

@@ -50,6 +50,7 @@ def lib():
         L.qo_setBC.argtypes = [vp, vp]
         L.qo_stagPhase.argtypes = [vp, vp, C.POINTER(ci)]
         L.qo_plaq.argtypes = [vp, vp, vp]
+        L.qo_s4_gauge.argtypes = [vp, vp, vp]
         L.qo_gauge_force.argtypes = [vp, vp, vp]
         L.qo_gauge_deriv.argtypes = [vp, vp, vp, cd]
         L.qo_wflow.argtypes = [vp, vp, ci, cd]
@@ -224,6 +225,13 @@ def plaq(lo, g):
     out = np.zeros(6)
     lib().qo_plaq(lo._h, _p(g), _p(out))
     return out
+
+
+def s4_gauge(lo, g):
+    """g.s4_gauge() (stagg_pv_hmc/staghmc_spv_meas.nim:25-65): peo[dir][even/odd] as a (4, 2) array"""
+    out = np.zeros(8)
+    lib().qo_s4_gauge(lo._h, _p(g), _p(out))
+    return out.reshape(4, 2)
 
 
 def gauge_force(lo, g):

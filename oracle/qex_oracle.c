@@ -564,6 +564,28 @@ void qo_plaq(const qo_layout *lo, const double *g, double out[6]) {
   free(part);
 }
 
+/* s4_gauge (src/stagg_pv_hmc/staghmc_spv_meas.nim:25-65): for mu > nu the site plaquette
+ * ps = redot(U_mu(x) U_nu(x+mu), U_nu(x) U_mu(x+nu)) is added to peo[mu][x_mu mod 2] and peo[nu][x_nu mod 2] (:46-52);
+ * out[2 d + eo] = peo[d][eo] / (physVol * 0.5 * (nd - 1) * nc) (:58-61).  Serial sum (test sizes only). */
+void qo_s4_gauge(const qo_layout *lo, const double *g, double out[8]) {
+  double peo[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int ir = 0; ir < lo->vol; ir++) {
+    int x[4];
+    qo_coord(lo, ir, x);
+    for (int mu = 1; mu < 4; mu++)
+      for (int nu = 0; nu < mu; nu++) {
+        double unumu[18], umunu[18];
+        m_mul(unumu, GLINK(g, ir, nu), GLINK(g, lo->nb[nu][0][ir], mu));
+        m_mul(umunu, GLINK(g, ir, mu), GLINK(g, lo->nb[mu][0][ir], nu));
+        const double ps = m_retr_adj_mul(umunu, unumu);
+        peo[2 * mu + (x[mu] & 1)] += ps;
+        peo[2 * nu + (x[nu] & 1)] += ps;
+      }
+  }
+  const double n = 1.0 / ((double)lo->vol * 0.5 * 3.0 * 3.0);
+  for (int k = 0; k < 8; k++) out[k] = peo[k] * n;
+}
+
 /* ------------------------------------------------------------------ */
 /* gauge force + Wilson flow                                           */
 /* ------------------------------------------------------------------ */

@@ -103,6 +103,7 @@ void qo_force_projTAH(const qo_layout *lo, double *f, const double *g, int adj);
 
 /* ---- flow observables (gaugeUtils.nim:1079-1270): out = {E_s, E_t, Q} ---- */
 void qo_flow_EQ(const qo_layout *lo, const double *g, int loop, double out[3]);
+void qo_s4_gauge(const qo_layout *lo, const double *g, double out[8]);   /* staghmc_spv_meas.nim:25-65 */
 void qo_wline(const qo_layout *lo, const double *g, const int *path, int n, double out[2]);
 
 /* ---- field algebra (fieldET.nim:605-625,704-724) ; parity: 0 even, 1 odd, 2 all ---- */

@@ -90,6 +90,7 @@ SYMBOLS = [
     ("qexhip_gauge_reunit", _ci, [_vp]),
     ("qexhip_wline", _ci, [_vp, _pi, _ci, _vp]),
     ("qexhip_polyakov_loops", _ci, [_vp, _vp]),
+    ("qexhip_plaq_s4", _ci, [_vp, _vp]),
     ("qexhip_rng_new", _ci, [_vp, _ci, C.c_ulonglong, _pi, _pi, _ci]),
     ("qexhip_rng_free", _ci, [_vp]),
     ("qexhip_rng_uniform", _ci, [_vp, _ci, _vp]),

@@ -771,6 +771,11 @@ extern "C" int qexhip_wline(qexhip_handle c, const int *path, int n, double out[
   HIPCHK(hipSetDevice(c->device));
   return gauge_wline(c, path, n, out);
 }
+extern "C" int qexhip_plaq_s4(qexhip_handle c, double out[8]) {
+  if (!c || !out) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  return gauge_plaq_s4(c, out);
+}
 extern "C" int qexhip_polyakov_loops(qexhip_handle c, double out[8]) {
   if (!c || !out) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));

@@ -71,9 +71,12 @@ __global__ void __launch_bounds__(256) k_gauge_from_tiles(Geom g, double2 *__res
 // kernel is bound by the number of L2->L1 requests, not by occupancy.  (Round 2: a workgroup per tile with six
 // wavefronts, one per plane, and the four site links through LDS -- the same 16 loads at three wavefronts per SIMD -- measured
 // 285-291 us against 230: rejected as well.)
-template <bool HALO>
+// S4: instead of the six plane sums, the eight sums of `s4_gauge` (stagg_pv_hmc/staghmc_spv_meas.nim:25-65, the S4 order
+// parameter of arXiv:1111.2317): the plaquette of plane (mu, nu) at x is added to peo[mu][x_mu mod 2] and to peo[nu][x_nu mod 2];
+// partial k = 2 d + (x_d mod 2).
+template <bool HALO, bool S4 = false>
 __global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict__ G, double *partials, const int *order, int chunk) {
-  double pl[6] = {0, 0, 0, 0, 0, 0};
+  double pl[S4 ? 8 : 6] = {0, 0, 0, 0, 0, 0};
   const int slot = 4 * (blockIdx.x >> 3) + (threadIdx.x >> 6);
   const int e = slot < chunk ? order[(blockIdx.x & 7) * chunk + slot] : -1;
   const int p = e & 1, c = (e >> 1) * 64 + (threadIdx.x & 63);
@@ -91,12 +94,19 @@ __global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict_
         M3 unumu = m3_mul(U[nu], m3_load(G + link_off_t<HALO>(g, y, mu), 64));
         shifted_t<HALO>(g, x, mu, 1, y);
         M3 umunu = m3_mul(U[mu], m3_load(G + link_off_t<HALO>(g, y, nu), 64));
-        pl[(mu * (mu - 1)) / 2 + nu] += m3_redot(umunu, unumu);
+        const double ps = m3_redot(umunu, unumu);
+        if (S4) {
+          const bool om = x[mu] & 1, on = x[nu] & 1;     // (a t-sharded slab starts at an even global t: local parity = global)
+          pl[2 * mu] += om ? 0.0 : ps; pl[2 * mu + 1] += om ? ps : 0.0;
+          pl[2 * nu] += on ? 0.0 : ps; pl[2 * nu + 1] += on ? ps : 0.0;
+        } else {
+          pl[(mu * (mu - 1)) / 2 + nu] += ps;
+        }
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
+  for (int k = 0; k < (S4 ? 8 : 6); k++) {
     double r = block_sum_256(pl[k]);
     if (threadIdx.x == 0) partials[(size_t)k * gridDim.x + blockIdx.x] = r;
   }
@@ -1010,6 +1020,27 @@ int gauge_plaq(qexhip_ctx *c, double out[6]) {
   CHK(read_global(c, &c->dscal[16], 6, out));
   const double norm = (double)c->g.V * (double)c->nranks * 18.0;
   for (int k = 0; k < 6; k++) out[k] = out[k] / norm;
+  return 0;
+}
+
+// s4_gauge (stagg_pv_hmc/staghmc_spv_meas.nim:25-65): out[2 d + eo], normalised by physVol * 0.5 * (nd - 1) * nc
+int gauge_plaq_s4(qexhip_ctx *c, double out[8]) {
+  if (!c->gn) { qexhip_set_error("gauge field not set (qexhip_gauge_set)"); return -3; }
+  CHK(gauge_ghosts(c, 1));
+  const int *order = nullptr; int chunk = 0, nb = 0;
+  double *part = nullptr;
+  CHK(ordered_sites(c, &order, &chunk, &nb, &part));
+  {
+    ScopedTimer tm(c, "plaq", c->stream);
+    if (c->g.halo) k_plaq<true, true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+    else k_plaq<false, true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+    HIPCHK(hipGetLastError());
+  }
+  k_plaq_final<<<8, 256, 0, c->stream>>>(part, nb, 1.0, &c->dscal[40]);
+  HIPCHK(hipGetLastError());
+  CHK(read_global(c, &c->dscal[40], 8, out));
+  const double norm = (double)c->g.V * (double)c->nranks * 0.5 * 3.0 * 3.0;
+  for (int k = 0; k < 8; k++) out[k] = out[k] / norm;
   return 0;
 }
 

@@ -285,6 +285,7 @@ int md_save_links(qexhip_ctx *c);
 int md_restore_links(qexhip_ctx *c);
 int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]);
 int gauge_polyakov(qexhip_ctx *c, double out[8]);
+int gauge_plaq_s4(qexhip_ctx *c, double out[8]);
 void gauge_free(qexhip_ctx *c);
 void gauge_release_scratch(qexhip_ctx *c);
 const double2 *gauge_links_dev(qexhip_ctx *c);   // resident natural-layout links (nullptr before qexhip_gauge_set)

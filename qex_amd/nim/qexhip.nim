@@ -19,6 +19,7 @@
 ##   src/gauge/gaugeUtils.nim:213-282  g.plaq                            hipPlaq
 ##   src/flow/gauge_flow.nim:360-379   EQ                                hipFlowMeasure
 ##   src/flow/gauge_flow.nim:137-156   meas_ploop (4 x g.wline)          hipPloops
+##   stagg_pv_hmc/staghmc_spv_meas.nim:25-65  g.s4_gauge               hipS4Gauge
 ##   src/gauge/hypsmear.nim:49-247     coef.smearGetForce(g, sg, info)   hipSmearGetForce (returns the closure)
 ##     (stagg_pv_hmc/staghmc_spv.nim:989-993)
 ##   stagg_pv_hmc/staghmc_spv.nim:217-228  gforce(act, g, sg, f, sf)     closure.gforce
@@ -87,6 +88,7 @@ proc qexhip_gauge_update(h: QexhipHandle; p: ptr cdouble; t: cdouble): cint {.qh
 proc qexhip_gauge_reunit(h: QexhipHandle): cint {.qh.}
 proc qexhip_wline(h: QexhipHandle; path: ptr cint; n: cint; o: ptr cdouble): cint {.qh.}
 proc qexhip_polyakov_loops(h: QexhipHandle; o: ptr cdouble): cint {.qh.}
+proc qexhip_plaq_s4(h: QexhipHandle; o: ptr cdouble): cint {.qh.}
 proc qexhip_io_read_gauge(path: cstring; lat: ptr cint; g: ptr cdouble; suma, sumb: ptr cuint): cint {.qh.}
 proc qexhip_rng_get_state(r: pointer; o: ptr cuint): cint {.qh.}
 proc qexhip_rng_set_state(r: pointer; i: ptr cuint): cint {.qh.}
@@ -363,6 +365,13 @@ proc hipFlowMeasure*(): tuple[plaq: seq[float]; es, et, q: float] =
   result.plaq = newSeq[float](6)
   for i in 0..5: result.plaq[i] = pl[i]
   result.es = eq[0]; result.et = eq[1]; result.q = eq[2]
+
+proc hipS4Gauge*(): seq[array[2, float]] =
+  ## s4_gauge (stagg_pv_hmc/staghmc_spv_meas.nim:25-65) of the resident field: peo[dir][even/odd], already normalised
+  var o: array[8, cdouble]
+  chk qexhip_plaq_s4(hipParam.h, o[0].addr)
+  result = newSeq[array[2, float]](4)
+  for d in 0..3: result[d] = [o[2*d].float, o[2*d+1].float]
 
 proc hipPloops*(): tuple[pls, plt: tuple[re, im: float]] =
   ## meas_ploop (flow/gauge_flow.nim:137-156): the four Polyakov loops g.wline(repeat(i+1, L_i)) of the resident field in one

@@ -515,6 +515,15 @@ def wline(ctx, path, g=None):
     return complex(out[0], out[1])
 
 
+def s4_gauge(ctx, g=None):
+    """g.s4_gauge() (stagg_pv_hmc/staghmc_spv_meas.nim:25-65): peo[dir][even/odd], a (4, 2) array, of g or of the resident field"""
+    if g is not None:
+        check(lib().qexhip_gauge_set(ctx._h, _p(g)))
+    out = np.zeros(8)
+    check(lib().qexhip_plaq_s4(ctx._h, _p(out)))
+    return out.reshape(4, 2)
+
+
 def ploops(ctx, g=None):
     """the four Polyakov loops [g.wline([mu+1] * L_mu) for mu in 0..3] (gauge_flow.nim:137-156 `meas_ploop`,
     staghmc_sh.nim:281-291 `ploop`) of g, or of the resident field, in one call"""

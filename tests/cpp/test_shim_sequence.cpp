@@ -89,6 +89,7 @@ static void hipGaugeSet(const Buf &g) { CHK(qexhip_gauge_set(h, g.data())); }
 static void hipGaugeGet(Buf &g) { CHK(qexhip_gauge_get(h, g.data())); }
 static void hipPlaq(double o[6]) { CHK(qexhip_plaq(h, o)); }
 static void hipFlowMeasure(double pl[6], double eq[3]) { CHK(qexhip_flow_measure(h, pl, eq)); }
+static void hipS4Gauge(double o[8]) { CHK(qexhip_plaq_s4(h, o)); }
 // hipPloops: (pls, plt) = (mean of the three spatial loops, the temporal one), as meas_ploop (gauge_flow.nim:137-156)
 static void hipPloops(double pls[2], double plt[2]) {
   double o[8];
@@ -228,6 +229,11 @@ int main() {
       }
       CHECK(std::fabs(pls[0] - ops[0]) < 1e-14 && std::fabs(pls[1] - ops[1]) < 1e-14 && std::fabs(plt[0] - opt[0]) < 1e-14 && std::fabs(plt[1] - opt[1]) < 1e-14,
             "flow t=%g Polyakov loops (%g,%g) (%g,%g) vs (%g,%g) (%g,%g)", t, pls[0], pls[1], plt[0], plt[1], ops[0], ops[1], opt[0], opt[1]);
+      // the fork's verbose plaquette measurement (staghmc_spv_meas.nim:25-65)
+      double s4[8], os4[8];
+      hipS4Gauge(s4);
+      qo_s4_gauge(lo, gr.data(), os4);
+      for (int i = 0; i < 8; i++) CHECK(std::fabs(s4[i] - os4[i]) < 1e-14, "flow t=%g s4_gauge[%d] %g %g", t, i, s4[i], os4[i]);
       nmeas++;
     });
     CHECK(nmeas == 3 && relerr(gf, gr) < 1e-12, "hipGaugeFlow: %d measurements, links %g", nmeas, relerr(gf, gr));

@@ -107,6 +107,11 @@ def test_gpu_md_building_blocks(oracle):
     for path in ([4] * lat[3], [1] * lat[0], [1, 2, -1, -2], [-3, 4, 4, 3, -4, -4], [2]):
         w = q.wline(ctx, path, g1)
         assert abs(w - o.wline(lo, g1, path)) < 1e-14
+    # s4_gauge (staghmc_spv_meas.nim:25-65): even/odd plaquette sums per direction; every plaquette is counted for its two
+    # directions, so the eight numbers add up to 8 x the sum of the six plaquettes of g.plaq
+    s4 = q.s4_gauge(ctx, g1)
+    assert np.abs(s4 - o.s4_gauge(lo, g1)).max() < 1e-14
+    assert abs(s4.sum() - 8.0 * q.plaq(ctx).sum()) < 1e-13
     # the four Polyakov loops in one call (meas_ploop, gauge_flow.nim:137-156): one lane per LINE instead of per site
     pl = q.ploops(ctx, g1)
     for d in range(4):
@@ -182,6 +187,7 @@ def test_gpu_gauge_sector_on_the_sharded_path(oracle):
     # Polyakov line in t is assembled from per-rank segments (all-gather); anything else is refused
     for path in ([4] * 8, [-4] * 8, [1] * 8, [1, 4, -1, -4], [4, 4, 4, 1, -4, -4, -4, -1], [-4, -4, 2, 4, 4, -2]):
         assert abs(q.wline(A, path, ga) - q.wline(B, path, gb)) < 1e-15
+    assert np.abs(q.s4_gauge(A) - q.s4_gauge(B)).max() < 1e-15 and np.abs(q.s4_gauge(A) - o.s4_gauge(lo, ga)).max() < 1e-14
     pa, pb = q.ploops(A), q.ploops(B)
     for d in range(4):
         assert abs(pa[d] - pb[d]) < 1e-15 and abs(pa[d] - o.wline(lo, ga, [d + 1] * 8)) < 1e-14

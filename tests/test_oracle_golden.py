@@ -275,3 +275,20 @@ def test_rsqrtPH_property_of_the_reference(oracle):
     u = np.stack([o.su3_fn("qo_projectU", xi) for xi in x])
     s, bound = _tmatfun_bound(u)
     assert s.max() < bound
+
+
+def test_s4_gauge_sums_to_the_plaquettes(oracle):
+    """s4_gauge (stagg_pv_hmc/staghmc_spv_meas.nim:25-65) adds every site plaquette to the even/odd bin of its two
+    directions and normalises by physVol * 0.5 * (nd - 1) * nc; g.plaq (pinned by G1) normalises by physVol * 6 * nc:
+    the eight numbers add up to 8 x the sum of the six plaquettes, and on the unit gauge every bin is 1."""
+    o = oracle
+    lo = o.Layout([8, 8, 8, 8])
+    g = o.gauge_random(lo)
+    s4 = o.s4_gauge(lo, g)
+    assert abs(s4.sum() - 8.0 * o.plaq(lo, g).sum()) < 1e-13
+    assert np.abs(o.s4_gauge(lo, o.gauge_unit(lo)) - 1.0).max() < 1e-15
+    # a field that depends on the parity of x_0 only through U_1 shows up in direction 0's even / odd split
+    lo2 = o.Layout([4, 6, 4, 2])
+    g2 = o.gauge_warm(lo2, 0.3, o.RngField(lo2, o.RNG_MILC6, 5))
+    s2 = o.s4_gauge(lo2, g2)
+    assert s2.shape == (4, 2) and abs(s2.sum() - 8.0 * o.plaq(lo2, g2).sum()) < 1e-13
