@@ -1,6 +1,8 @@
 """GPU parity of the flow observables: fmunu(loop) -> E_s, E_t, Q through the
 HIP kernels, against the reference's golden set G3 (tests/base/twflow_topo.nim:19-62) and the oracle.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -113,3 +115,44 @@ def test_flow_measure_is_plaq_and_EQ_in_one_pass(oracle, halo):
         c2.set_option("obs_clover", 0)             # without the dedicated kernel: two passes, same numbers
         pl2, eq2 = q.flowMeasure(c2)
         assert np.abs(pl2 - pl).max() < 1e-16 and np.allclose(eq2, eq, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_flow_loop_example_prints_the_reference_line(oracle):
+    """examples/gauge_flow.py = the loop of src/flow/gauge_flow.nim: its FLOW lines (tau, plaquette normalised to 3, clover E,
+    t^2 E, d t^2E / dt, the `check` column 12 t^2 (3 - plaq), Q, t^2 E_ss, t^2 E_st, Polyakov loops; gauge_flow.nim:385-470)
+    recomputed from the oracle's flow, plaquettes, clover observables and Wilson lines."""
+    import re
+    import subprocess
+    import sys
+
+    o = oracle
+    lat = [4, 6, 4, 8]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "examples", "gauge_flow.py"), "-lat"] + [str(v) for v in lat] +
+                       ["-warm", "0.3", "-dt", "0.02", "0.05", "-tmax", "0.06", "0.16", "-seed", "77"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows = [[float(v) for v in ln.split()[1:]] for ln in p.stdout.splitlines() if ln.startswith("FLOW ")]
+    assert len(rows) == 1 + 3 + 2
+    lo = o.Layout(lat)
+    g = o.gauge_warm(lo, 0.3, o.RngField(lo, o.RNG_MILC6, 77))
+    o.gauge_projectSU(lo, g)
+    tau, old = 0.0, 0.0
+    steps = [None, 0.02, 0.02, 0.02, 0.05, 0.05]
+    for row, dt in zip(rows, steps):
+        if dt is not None:
+            o.wflow(lo, g, 1, dt)
+            tau += dt
+        pl = o.plaq(lo, g)
+        es, et, qq = o.flow_EQ(lo, g, 1)
+        ss, st = 2.0 * pl[:3].sum(), 2.0 * pl[3:].sum()
+        p3 = (3.0 * ss + 3.0 * st) / 2.0
+        t2E = tau * tau * (es + et)
+        loops = [o.wline(lo, g, [d + 1] * lat[d]) for d in range(4)]
+        pls, plt = sum(loops[:3]) / 3.0, loops[3]
+        ref = [tau, p3, es + et, t2E, (t2E - old) / (dt or 0.02), 12.0 * tau * tau * (3.0 - p3), qq, tau * tau * es, tau * tau * et,
+               3.0 * plt.real, 3.0 * plt.imag, 3.0 * pls.real, 3.0 * pls.imag]
+        old = t2E
+        assert abs(row[0] - ref[0]) < 0.006                              # tau is printed with two decimals
+        for a, b in zip(row[1:], ref[1:]):
+            assert abs(a - b) < 2e-12 * max(1.0, abs(b)) + 6e-14, (tau, row, ref)   # 13 printed decimals
