@@ -102,6 +102,9 @@ int qexhip_stag_op_xx(qexhip_handle h, double *r, const double *x, double m2, in
 /* eoReconstruct (src/physics/stagD.nim:583-586): r.odd = (b.odd - D_oe r.even)/m, r.even kept */
 int qexhip_stag_eo_reconstruct(qexhip_handle h, double *r, const double *b, double m);
 
+/* eoReduce (src/physics/stagD.nim:575-581): r.even = (D^+ b).even = (m b - D b).even, r.odd kept */
+int qexhip_stag_eo_reduce(qexhip_handle h, double *r, const double *b, double m);
+
 /* Shifted outer product of the fermion force:
  *   f[mu](s) (+)= scale(parity of s) * x(s) (x) x(s+mu)^+     f: double[vol][4][3][3][2]
  * stagDeriv (src/physics/stagD.nim:634-664) is scale_even = +1, scale_odd = -1, accumulate = 1 (the

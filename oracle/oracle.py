@@ -64,6 +64,7 @@ def lib():
         L.qo_Ddag.argtypes = [vp, vp, vp, vp, vp, cd]
         L.qo_stagD2xx.argtypes = [vp, vp, vp, vp, vp, cd, ci]
         L.qo_eoReconstruct.argtypes = [vp, vp, vp, vp, vp, cd]
+        L.qo_eoReduce.argtypes = [vp, vp, vp, vp, vp, cd]
         L.qo_solveXX.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, ci, vp, ci, vp]
         L.qo_solve.argtypes = [vp, vp, vp, vp, vp, cd, cd, ci, vp]
         L.qo_fat7.argtypes = [vp, vp, vp, vp, vp, vp, cd]
@@ -315,6 +316,10 @@ def stagD2xx(lo, fat, lng, x, m2, par_even=True):
     r = np.zeros_like(x)
     lib().qo_stagD2xx(lo._h, _p(fat), _p(lng), _p(r), _p(x), m2, 1 if par_even else 0)
     return r
+
+
+def eoReduce(lo, fat, lng, r, b, m):
+    lib().qo_eoReduce(lo._h, _p(fat), _p(lng), _p(r), _p(b), m)
 
 
 def eoReconstruct(lo, fat, lng, r, b, m):

@@ -773,6 +773,10 @@ void qo_Ddag(const qo_layout *lo, const double *fat, const double *lng, double *
   qo_stagD(lo, fat, lng, r, x, 0, m, -1.0, 0.0);
   qo_stagD(lo, fat, lng, r, x, 1, m, -1.0, 0.0);
 }
+/* eoReduce (stagD.nim:575-581): r.even = (D^+ b).even -- stagD on the even subset with sc = -1 */
+void qo_eoReduce(const qo_layout *lo, const double *fat, const double *lng, double *r, const double *b, double m) {
+  qo_stagD(lo, fat, lng, r, b, 0, m, -1.0, 0.0);
+}
 /* eoReconstruct (stagD.nim:583-586): r.odd = (b.odd - D_oe r.even)/m */
 void qo_eoReconstruct(const qo_layout *lo, const double *fat, const double *lng,
                       double *r, const double *b, double m) {

@@ -122,6 +122,7 @@ void qo_Ddag(const qo_layout *lo, const double *fat, const double *lng, double *
 /* r[par] = 4 m2 x - (2D)(2D) x   (stagD.nim:434-469); par_even=1: ee, 0: oo */
 void qo_stagD2xx(const qo_layout *lo, const double *fat, const double *lng,
                  double *r, const double *x, double m2, int par_even);
+void qo_eoReduce(const qo_layout *lo, const double *fat, const double *lng, double *r, const double *b, double m);
 void qo_eoReconstruct(const qo_layout *lo, const double *fat, const double *lng,
                       double *r, const double *b, double m);
 

@@ -289,6 +289,16 @@ extern "C" int qexhip_stag_eo_reconstruct(qexhip_handle c, double *r, const doub
   return field_download(c, *fr, r);
 }
 
+extern "C" int qexhip_stag_eo_reduce(qexhip_handle c, double *r, const double *b, double m) {
+  if (!c || !r || !b) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fb, *fr;
+  CHK(host_in(c, WK_IN, b, &fb));
+  CHK(host_in(c, WK_OUT, r, &fr));       // the odd half of r is kept
+  CHK(op_eo_reduce_pub(c, *fr, *fb, m));
+  return field_download(c, *fr, r);
+}
+
 extern "C" int qexhip_stag_outer(qexhip_handle c, double *f, const double *x, double scale_even, double scale_odd,
                                  int accumulate) {
   if (!c || !f || !x) return QEXHIP_ERR_ARG;
@@ -700,6 +710,7 @@ extern "C" int qexhip_md_refresh_momenta(qexhip_handle c, qexhip_rng *rng) {
 }
 extern "C" int qexhip_dev_zero(qexhip_handle c, int id, int parity) {
   if (!c || parity < 0 || parity > 2) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
   DevField *f;
   CHK(find_field(c, id, &f));
   return blas_zero(c, *f, parity);
@@ -708,11 +719,19 @@ extern "C" int qexhip_dev_solve_batch(qexhip_handle c, int n, const int *x_ids, 
                                       const double *r2req, int maxits, int *iters, double *r2) {
   if (!c || !x_ids || !b_ids || !mass || !r2req || n < 1 || n > 64) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
+  // every solution is zeroed while its system is set up, in order: a solution field that is also a source (of ANY system of
+  // the call) or another system's solution would be destroyed silently -- refuse such aliases for the whole call
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++)
+      if (x_ids[i] == b_ids[j] || (i != j && x_ids[i] == x_ids[j])) {
+        qexhip_set_error("dev_solve_batch: solution field %d (system %d) aliases %s of system %d", x_ids[i], i,
+                         x_ids[i] == b_ids[j] ? "the source" : "the solution", j);
+        return QEXHIP_ERR_ARG;
+      }
   for (int k0 = 0; k0 < n; k0 += 4) {          // lock-step batches of four, as qexhip_stag_solve_batch
     const int k = std::min(4, n - k0);
     DevField *xs[4], *bs[4];
     for (int j = 0; j < k; j++) {
-      if (x_ids[k0 + j] == b_ids[k0 + j]) { qexhip_set_error("dev_solve_batch: solution and source are the same field"); return QEXHIP_ERR_ARG; }
       CHK(find_field(c, x_ids[k0 + j], &xs[j]));
       CHK(find_field(c, b_ids[k0 + j], &bs[j]));
     }

@@ -53,23 +53,42 @@ extern "C" int qexhip_comm_init(qexhip_handle c, const char id[QEXHIP_UNIQUE_ID_
   // stream they are on, i.e. an exchange queued behind an all-reduce that waits for a long kernel would wait too; with a
   // communicator of its own the exchange depends on ev_ready only.  ncclCommSplit is collective over the parent: every
   // rank is here.  QEXHIP_COMM2=0 keeps the single communicator (A/B).
+  // Whether the second communicator is used must be ONE decision for the whole job: ranks that disagreed would post the
+  // overlapped exchange on different communicators and never match.  So every step is agreed by a min-all-reduce over the
+  // parent: (1) the wish (QEXHIP_COMM2=0 on any rank keeps the single communicator everywhere -- no rank may skip the
+  // collective split on its own), (2) the outcome of the split (a rank-local failure drops comm2 on every rank).
+  auto agree_min = [&](int mine, int *all) -> int {
+    double *d = &c->dscal[60];
+    double h = (double)mine;
+    HIPCHK(hipMemcpyAsync(d, &h, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(ncclAllReduce(d, d, 1, ncclDouble, ncclMin, comm, c->stream));
+    HIPCHK(hipMemcpyAsync(&h, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *all = (int)h;
+    return 0;
+  };
   const char *e2 = getenv("QEXHIP_COMM2");
-  if (!e2 || atoi(e2) != 0) {
-    // not fatal: a communicator that cannot be split (every rank gets the same answer: the call is collective) leaves the
-    // context with the one communicator for both streams, which is what rounds 1-2 ran with
+  int want = (!e2 || atoi(e2) != 0) ? 1 : 0, want_all = 0;
+  CHK(agree_min(want, &want_all));
+  if (want_all) {
     ncclComm_t comm2 = nullptr;
     ncclResult_t r2 = ncclCommSplit(comm, 0, rank, &comm2, nullptr);
     int n2 = 0, k2 = -1;
     if (r2 == ncclSuccess && comm2) {
       if (ncclCommCount(comm2, &n2) != ncclSuccess || ncclCommUserRank(comm2, &k2) != ncclSuccess || n2 != nranks || k2 != rank) r2 = ncclInternalError;
     }
-    if (r2 == ncclSuccess && comm2) {
+    int ok = (r2 == ncclSuccess && comm2) ? 1 : 0, ok_all = 0;
+    CHK(agree_min(ok, &ok_all));
+    if (ok_all) {
       c->comm2 = comm2;
     } else {
-      fprintf(stderr, "libqexhip: rank %d: no second communicator for the comm stream (%s); using one communicator for both streams\n",
-              rank, r2 == ncclSuccess ? "split returned none" : ncclGetErrorString(r2));
+      // not fatal: the context keeps the one communicator for both streams, which is what rounds 1-2 ran with
+      fprintf(stderr, "libqexhip: rank %d: no second communicator for the comm stream (%s); every rank uses one communicator for both streams\n",
+              rank, ok ? "another rank could not split" : (r2 == ncclSuccess ? "split returned none" : ncclGetErrorString(r2)));
       if (comm2) (void)ncclCommDestroy(comm2);
     }
+  } else if (want) {
+    fprintf(stderr, "libqexhip: rank %d: QEXHIP_COMM2=0 on another rank: one communicator for both streams everywhere\n", rank);
   }
   return 0;
 }

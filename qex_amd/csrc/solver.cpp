@@ -71,6 +71,8 @@ static int op_eo_reconstruct(qexhip_ctx *c, DevField &r, DevField &b, double m) 
   return 0;
 }
 int op_eo_reconstruct_pub(qexhip_ctx *c, DevField &r, DevField &b, double m) { return op_eo_reconstruct(c, r, b, m); }
+// r.even = (D^+ b).even = (m b - D b).even  (eoReduce, stagD.nim:575-581: one stagD on the even subset with sc = -1)
+int op_eo_reduce_pub(qexhip_ctx *c, DevField &r, DevField &b, double m) { return op_stagD(c, r, b, 0, m, -1.0, 0.0); }
 
 static int ensure_hist(qexhip_ctx *c, int cap) {
   if (cap < 1) cap = 1;

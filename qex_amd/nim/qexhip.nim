@@ -54,6 +54,8 @@ proc qexhip_comm_init(h: QexhipHandle; id: ptr char; nranks, rank: cint): cint {
 proc qexhip_stag_set_links(h: QexhipHandle; fat, lng: ptr cdouble): cint {.qh.}
 proc qexhip_stag_dslash(h: QexhipHandle; r, x: ptr cdouble; parity: cint; a, b: cdouble): cint {.qh.}
 proc qexhip_stag_D(h: QexhipHandle; r, x: ptr cdouble; m, sc: cdouble): cint {.qh.}
+proc qexhip_stag_eo_reduce(h: QexhipHandle; r, b: ptr cdouble; m: cdouble): cint {.qh.}
+proc qexhip_stag_eo_reconstruct(h: QexhipHandle; r, b: ptr cdouble; m: cdouble): cint {.qh.}
 proc qexhip_stag_solve_xx(h: QexhipHandle; x, b: ptr cdouble; mass, r2req: cdouble;
                           maxits, parEven: cint; iters: ptr cint; r2: ptr cdouble;
                           hist: ptr cdouble; histcap: cint): cint {.qh.}
@@ -260,6 +262,22 @@ proc hipDdag*(s: Staggered; r, x: Field; m: SomeNumber) =
   toHost(x, xb)
   rb.setLen(xb.len)
   chk qexhip_stag_D(hipParam.h, rb.p, xb.p, m.cdouble, -1.0)
+  fromHost(r, rb)
+
+proc hipEoReduce*(s: Staggered; r, b: Field; m: SomeNumber) =
+  ## s.eoReduce(r, b, m) (stagD.nim:575-581): r.even = (D^+ b).even; r.odd is kept
+  var rb, bb: HostBuf
+  toHost(b, bb)
+  toHost(r, rb)
+  chk qexhip_stag_eo_reduce(hipParam.h, rb.p, bb.p, m.cdouble)
+  fromHost(r, rb)
+
+proc hipEoReconstruct*(s: Staggered; r, b: Field; m: SomeNumber) =
+  ## s.eoReconstruct(r, b, m) (stagD.nim:582-586): r.odd = (b.odd - D_oe r.even)/m; r.even is kept
+  var rb, bb: HostBuf
+  toHost(b, bb)
+  toHost(r, rb)
+  chk qexhip_stag_eo_reconstruct(hipParam.h, rb.p, bb.p, m.cdouble)
   fromHost(r, rb)
 
 # ---------------------------------------------------------------------------------------------------------------

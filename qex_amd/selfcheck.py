@@ -122,10 +122,17 @@ def compare(got, want):
     chk("history", "cg_hist", got["cg_hist"], w["cg_hist"])
     chk("history", "cg_x2", got["cg_x2"], w["cg_x2"])
     if "naik_x2" in got and "naik_x2" in w:
-        if got["naik_its"] != w["naik_its"]:
-            failed.append("naik_its: %d != %d" % (got["naik_its"], w["naik_its"]))
+        # another t-partition sums the all-reduced partials in another order: a residual within rounding of the stop
+        # threshold may end the loop one iteration earlier or later; the difference is reported, only |d| > 1 fails
+        res["naik_its_diff"] = int(got["naik_its"]) - int(w["naik_its"])
+        if abs(res["naik_its_diff"]) > 1:
+            failed.append("naik_its: %d vs %d" % (got["naik_its"], w["naik_its"]))
         chk("solution", "naik_x2", got["naik_x2"], w["naik_x2"])
-    return {"ok": not failed, "max_rel": {k: float("%.3e" % v) for k, v in res.items()}, "tolerance": dict(TOL), "failed": failed}
+    its_diff = res.pop("naik_its_diff", None)
+    out = {"ok": not failed, "max_rel": {k: float("%.3e" % v) for k, v in res.items()}, "tolerance": dict(TOL), "failed": failed}
+    if its_diff is not None:
+        out["naik_its_minus_fixture"] = its_diff
+    return out
 
 
 def load_fixture(lat, mass=0.1, path=None):

@@ -276,6 +276,10 @@ class Staggered:
         """f[mu][i][a,b] (:= | +=) scale * psi[i][a] * psi(i+mu)[b].adj  (staghmc_spv.nim:831-854)"""
         check(lib().qexhip_stag_outer(self.ctx._h, _p(f), _p(psi), float(scale), float(scale), 1 if accumulate else 0))
 
+    def eoReduce(self, r, b, m):
+        """r.even = (D^+ b).even  (stagD.nim:575-581); r.odd is kept"""
+        check(lib().qexhip_stag_eo_reduce(self.ctx._h, _p(r), _p(b), float(m)))
+
     def eoReconstruct(self, r, b, m):
         check(lib().qexhip_stag_eo_reconstruct(self.ctx._h, _p(r), _p(b), float(m)))
 

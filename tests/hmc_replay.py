@@ -600,6 +600,8 @@ class DeviceEndsReplay(Replay):
                 if lvl <= len(cfg.hmasses[k]):
                     psi[(k, lvl)] = ctx.field_new()
                     rng.dev_gaussian_vector(ctx, psi[(k, lvl)])
+        for old in getattr(self, "phi_ids", None) or []:      # the previous trajectory's pseudofermions (resident fields)
+            ctx.field_free(old)
         self.phi_ids = []
         a, b = self._tmp[-1], self._tmp[-2]
         for j, (k, i) in enumerate(cfg.fields):
@@ -646,6 +648,8 @@ class DeviceEndsReplay(Replay):
         xs = self._tmp[:2]
         its, _ = ctx.dev_solve_batch(xs, srcs, [PBPMASS, PBPMASS], RSQ)
         pbp = [PBPMASS * ctx.dev_norm2(x) / self.lo.vol for x in xs]
+        for s in srcs:
+            ctx.field_free(s)
         pl = q.plaq(ctx)
         ps, pt = 2.0 * sum(pl[:3]), 2.0 * sum(pl[3:])
         loops = q.ploops(ctx)                                  # the four g.wline([mu+1] * L_mu) of `ploop` in one call

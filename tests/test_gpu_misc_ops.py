@@ -307,8 +307,12 @@ def test_resident_field_entry_points_against_the_oracle(oracle):
         xr, oits, fin = o.solve(lo, g, None, b, m, 1e-14, 100000)
         got = ctx.field_download(xids[k])
         assert abs(its[k] - oits) <= 2 and r2[k] <= 1e-14 and np.linalg.norm(got - xr) / np.linalg.norm(xr) < 1e-7, (k, its[k], oits)
-    with pytest.raises(q.QexHipError, match="same field"):
+    with pytest.raises(q.QexHipError, match="aliases the source"):
         ctx.dev_solve_batch([bids[0]], [bids[0]], [0.1], 1e-10)
+    with pytest.raises(q.QexHipError, match="aliases the source"):        # x of system 0 is b of system 1
+        ctx.dev_solve_batch([bids[1], xids[1]], [bids[0], bids[1]], [0.1, 0.1], 1e-10)
+    with pytest.raises(q.QexHipError, match="aliases the solution"):      # the same solution field twice, across two lock-step batches
+        ctx.dev_solve_batch([xids[0]] + xids[1:5] + [xids[0]], bids, ms, 1e-10)
     # multi-shift on resident fields: aliased solution / source fields are refused, the workspace can be handed back
     sh = [0.2, 4 * (0.4 ** 2 - 0.2 ** 2)]
     with pytest.raises(q.QexHipError, match="source field"):

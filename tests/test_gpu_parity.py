@@ -139,6 +139,21 @@ def test_stagD2ee_oo(request, fix):
     assert relerr(r[h:], ref[h:]) < 1e-13
 
 
+@pytest.mark.parametrize("which", ["s8", "s8naik", "sodd"])
+def test_eoReduce(request, which):
+    """eoReduce (stagD.nim:575-581): r.even = (D^+ b).even, r.odd untouched; == the even half of Ddag"""
+    S = request.getfixturevalue(which)
+    h = S.lo.vol // 2
+    r = S.x.copy()
+    S.s.eoReduce(r, S.y, 0.1)
+    ref = S.x.copy()
+    S.o.eoReduce(S.lo, S.g, S.g3, ref, S.y, 0.1)
+    assert relerr(r, ref) < 1e-13 and np.array_equal(r[h:], S.x[h:])
+    dd = np.zeros_like(S.y)
+    S.s.Ddag(dd, S.y, 0.1)
+    assert relerr(r[:h], dd[:h]) < 1e-15
+
+
 def test_eoReconstruct(s8):
     S = s8
     r = S.x.copy()

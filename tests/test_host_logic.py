@@ -301,6 +301,10 @@ def test_shard_check_compare_logic():
         r = sc.compare(g, want)
         assert not r["ok"] and any(key in f for f in r["failed"]), (key, r)
     g = copy.deepcopy(v)
+    g["naik_its"] += 1                           # another partition may stop one iteration later: reported, not failed
+    r = sc.compare(g, want)
+    assert r["ok"] and r["naik_its_minus_fixture"] == 1
+    g = copy.deepcopy(v)
     g["cg_hist"][7] *= 1 + 1e-5
     assert not sc.compare(g, want)["ok"]
     g = copy.deepcopy(v)

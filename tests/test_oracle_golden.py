@@ -196,6 +196,16 @@ def test_operator_identities(oracle):
     A = o.stagD2xx(lo, g, None, xe, m * m, True)
     DdD = o.Ddag(lo, g, None, o.D(lo, g, None, xe, m), m)
     assert np.abs(A[:h] - 4 * DdD[:h]).max() < 1e-12
+    # eoReduce (stagD.nim:575-581) = the even half of Ddag, odd half of r untouched; eoReconstruct undoes the
+    # even-odd elimination: from r.even = (D^+ D)^-1_ee-solution the odd half follows from the odd row of D r = b
+    r = y.copy()
+    o.eoReduce(lo, g, None, r, x, m)
+    assert np.array_equal(r[h:], y[h:]) and np.abs(r[:h] - o.Ddag(lo, g, None, x, m)[:h]).max() < 1e-14
+    full = o.D(lo, g, None, x, m)                   # b = D x  =>  eoReconstruct(x.even, b) returns x.odd
+    r = x.copy()
+    r[h:] = 0
+    o.eoReconstruct(lo, g, None, r, full, m)
+    assert np.abs(r - x).max() < 1e-12
     # gauge covariance: U'_mu(s) = G(s) U_mu(s) G(s+mu)^+, x' = G x  =>  D'x' = G (D x)
     G = np.zeros((lo.vol, 3, 3, 2))
     for i in range(lo.vol):
