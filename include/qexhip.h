@@ -297,13 +297,24 @@ int qexhip_stag_solve_batch(qexhip_handle h, int n, double *const *x, const doub
  * chosen format.  Row 2 is rebuilt in registers.  QEXHIP_RECON=0|1|2 caps the format.  No counterpart in QEX (its
  * CPU Dslash always reads full links, stagD.nim:349-395); QUDA's reconstruct-12/13 is the precedent. */
 int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double *max_dev);
-/* Tuning switches, same names as the QEXHIP_<NAME> environment variables read at init: "recon" (link
- * compression on/off, effective at the next set_links), "swz", "ntstore", "overlap" (face exchange on the second stream
- * beside the interior sweep: -1 auto, 0, 1), "batch_multi", "multi_reduce" (take the sharded reduction branches on one
- * rank: test hook), "flow_exp" (1: closed-form exp in the Wilson-flow stage, the default; 0: the reference's Taylor +
- * 20 squarings, matexp.nim), "obs_clover" (1: the dedicated kernel for fmunu(loop = 1), the default; 0: the generic path
- * walker), "flow_ring" (1: the Wilson-flow stage as a loader / consumer kernel, csrc/flow_stage.hip -- a measured alternative,
- * slower than the default 0 on MI355X).  Unknown names are an error (QEXHIP_ERR_ARG). */
+/* Options of a context.  Unknown names are an error (QEXHIP_ERR_ARG).
+ *   "recon"        cap on the link compression (0 keep all 18 reals, 1 sign format only, 2 also the U(3) format; default 2),
+ *                  effective at the next set_links
+ *   "overlap"      face exchange on the second stream beside the interior sweep: -1 by interior size (default), 0 never, 1 always
+ *   "flow_exp"     1: closed-form exp(v) in the Wilson-flow stage (default; agrees with the reference's to ~1e-15 per element),
+ *                  0: the reference's algorithm, order-4 Taylor + 20 squarings (matexp.nim:80-85,634-649)
+ *   test hooks -- each selects, on any lattice, the code path that some lattices / ranks take by necessity:
+ *   "multi_reduce" 1: the sharded reduction branches (all-reduce of the partial vectors) on one rank
+ *   "batch_multi"  1: the same for the lock-step multi-system CG
+ *   "force_pair"   0: k_force_lds (one tile and parity per workgroup), what shapes without paired tile positions run
+ *   "obs_clover"   0: the generic path walker, what fmunu loops 3-5 run, for the clover loop as well
+ *
+ * Environment (read once, at qexhip_init / qexhip_comm_init) -- the complete list:
+ *   QEXHIP_RECON, QEXHIP_OVERLAP, QEXHIP_FLOW_EXP   initial values of the options of the same (lower-case) name
+ *   QEXHIP_COMM2=0   keep ONE RCCL communicator for both streams (default: the overlapped face exchange gets a communicator
+ *                    of its own); the ranks agree on this by a min-all-reduce, any rank's 0 wins
+ * Every other choice the kernels make (visiting orders, non-temporal accesses, LDS staging, launch shapes) is fixed to the
+ * variant that won its A/B measurement on MI355X (profiles/); the losers are not in the library. */
 int qexhip_set_option(qexhip_handle h, const char *name, int value);
 
 /* Smear on the device and hand the result straight to the operator (replaces smear -> rephase ->

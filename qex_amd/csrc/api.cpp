@@ -113,22 +113,24 @@ extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], 
   HIPCHK(hipMalloc((void **)&c->cg, sizeof(CgScal)));
   HIPCHK(hipMemset(c->cg, 0, sizeof(CgScal)));
   HIPCHK(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
-  if (const char *e = getenv("QEXHIP_SWZ")) c->opt_swz = atoi(e);
-  if (const char *e = getenv("QEXHIP_NTSTORE")) c->opt_ntstore = atoi(e);
+  // the environment switches of the library (include/qexhip.h "Environment"): these three and QEXHIP_COMM2 (comm.cpp)
   if (const char *e = getenv("QEXHIP_OVERLAP")) c->opt_overlap = atoi(e);
   if (const char *e = getenv("QEXHIP_RECON")) c->opt_recon = atoi(e);
   if (const char *e = getenv("QEXHIP_FLOW_EXP")) c->opt_flow_exp = atoi(e);
-  if (const char *e = getenv("QEXHIP_OBS_CLOVER")) c->opt_obs_clover = atoi(e);
-  if (const char *e = getenv("QEXHIP_FLOW_RING")) c->opt_flow_ring = atoi(e);
-  if (const char *e = getenv("QEXHIP_FORCE_PAIR")) c->opt_force_pair = atoi(e);
   {
-    // LDS a workgroup may ask for (160 KiB on gfx950): the large-LDS kernels (k_flow_stage 144 KiB, k_force_lds and
-    // k_flow_obs_clover 72 KiB) fall back to their plain forms when the device offers less
+    // the gauge kernels stage links through 144 KiB (k_force_lds2) / 72 KiB (k_force_lds, k_flow_obs_clover) of LDS per
+    // workgroup: gfx950 offers 160 KiB.  The library is built for that one target; anything smaller is refused here
+    // rather than at the first flow step.
     int a = 0, b = 0;
     (void)hipDeviceGetAttribute(&a, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
     (void)hipDeviceGetAttribute(&b, hipDeviceAttributeSharedMemPerBlockOptin, device);
     (void)hipGetLastError();
-    c->max_lds_optin = a > b ? a : b;
+    const int lds = a > b ? a : b;
+    if (lds < 147456) {
+      qexhip_set_error("device %d offers %d bytes of LDS per workgroup; libqexhip is built for gfx950 (160 KiB)", device, lds);
+      qexhip_finalize(c);
+      return QEXHIP_ERR_STATE;
+    }
   }
   c->nranks = 1;  // until qexhip_comm_init
   c->rank = 0;
@@ -562,14 +564,11 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   if (!c || !name) return QEXHIP_ERR_ARG;
   const std::string n(name);
   if (n == "recon") c->opt_recon = value;            // takes effect at the next set_links
-  else if (n == "swz") c->opt_swz = value;
-  else if (n == "ntstore") c->opt_ntstore = value;
   else if (n == "overlap") c->opt_overlap = value;
   else if (n == "batch_multi") c->opt_batch_multi = value;
   else if (n == "multi_reduce") c->opt_multi_reduce = value;
   else if (n == "flow_exp") c->opt_flow_exp = value;
   else if (n == "obs_clover") c->opt_obs_clover = value;
-  else if (n == "flow_ring") c->opt_flow_ring = value;
   else if (n == "force_pair") c->opt_force_pair = value;
   else { qexhip_set_error("unknown option"); return QEXHIP_ERR_ARG; }
   return 0;

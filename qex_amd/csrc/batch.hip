@@ -267,9 +267,9 @@ static int sweep_mrhs(qexhip_ctx *c, MrhsArgs &A, bool second, DevField *const *
   if (c->g.halo)
     for (int j = 0; j < A.nrhs; j++) CHK(comm_halo_exchange(c, *infield[j], inpar, 0));
   const int nb = (c->g.Vh + 255) / 256;
-  const int swz = c->opt_swz >= 0 ? c->opt_swz : (c->recon != 0);
+  const int swz = c->recon != 0;                     // as dslash.hip: on for compressed links
   A.swz = (swz && nb >= 64 && (nb & 7) == 0) ? nb : 0;
-  A.ntstore = c->opt_ntstore;
+  A.ntstore = 1;
   ScopedTimer tm(c, "dslash_batch", c->stream);
   if (c->ndir == 8) {
     if (c->recon == 1) launch_mrhs<8, 1>(c, A, second, nb);

@@ -165,9 +165,10 @@ static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool 
   A.c0 = c0; A.c1 = c1; A.d0 = d0; A.d1 = d1;
   A.nb1 = (c1 - c0 + 255) / 256;
   int nb = A.nb1 + (d1 > d0 ? (d1 - d0 + 255) / 256 : 0);
-  const int swz = c->opt_swz >= 0 ? c->opt_swz : (c->recon != 0);
-  A.swz = (swz && nb >= 64 && (nb & 7) == 0) ? nb : 0;
-  A.ntstore = c->opt_ntstore;
+  // XCD swizzle: measured on for compressed links, off for 18-real links (profiles/r01_tune_dslash.log); output stores are
+  // non-temporal (the result is read by the NEXT kernel, after 0.6 GB of links went through the caches)
+  A.swz = (c->recon != 0 && nb >= 64 && (nb & 7) == 0) ? nb : 0;
+  A.ntstore = 1;
   double *psave = A.partials;
   A.partials = psave ? psave + part_off : nullptr;
   dim3 grid(nb), block(256);

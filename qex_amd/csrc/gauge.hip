@@ -120,83 +120,16 @@ __global__ void __launch_bounds__(256) k_plaq_final(const double *partials, int 
   if (threadIdx.x == 0) out[k] = r / norm;
 }
 
-// force: one lane per (mu, site).  F_mu(x) = TAH( U_mu(x) [cp * sum_nu (fwd + bwd staples)]^+ )
-// A workgroup = one 64-site tile x 4 directions (wavefront w handles mu = w), so the four
-// wavefronts that share most of their neighbour links run together.  Which tile a workgroup takes comes from
-// tile_order_table (mode 3, the default: one contiguous (t,z) region per XCD, walked in compact blocks with both
-// parities adjacent -- every link is used by 19 staple terms, and tiles dealt round-robin over the XCDs would
-// each re-fetch it from beyond their own L2, cdna_hip_programming.md T1).  QEXHIP_FORCE_MODE keeps the older
-// mappings for A/B runs: 0 = mu-major lanes, 1 = tiles in storage order, 2 = storage order, contiguous per XCD.
-// flow mode (Pm != nullptr): the RK3 combination v = cf*f + cpm*p (wflow.nim:39,48,57) is formed here
-// and written over the momentum field, so the exp kernel reads one field less and F is not needed.
-// CLOSED: exp(v) in closed form (m3_exp_tah, su3.h) instead of the reference's Taylor + 20 squarings: option "flow_exp"
-template <bool CLOSED>
-__global__ void __launch_bounds__(256) k_force(Geom g, const double2 *__restrict__ G, double2 *F, double cp, int mode,
-                                               double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk) {
-  int mu, p, c;
-  if (mode == 3) {
-    const int e = order[(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)];
-    if (e < 0) return;
-    mu = threadIdx.x >> 6;
-    p = e & 1;
-    c = (e >> 1) * 64 + (threadIdx.x & 63);
-    if (c >= g.Vh) return;
-  } else if (mode == 0) {
-    int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= 4 * g.V) return;
-    mu = j / g.V;
-    int i = j - mu * g.V;
-    p = i >= g.Vh; c = i - p * g.Vh;
-  } else {
-    int bid = blockIdx.x, nb = gridDim.x;
-    if (mode == 2 && (nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
-    mu = threadIdx.x >> 6;
-    p = bid >= g.ntile;
-    c = (bid - p * g.ntile) * 64 + (threadIdx.x & 63);
-    if (c >= g.Vh) return;
-  }
-  int x[4], xpm[4], y[4], z[4];
-  coords_of(g, c, p, x);
-  shifted(g, x, mu, 1, xpm);
-  // the twelve staples are summed unscaled (accumulating products, no temporary matrix); cp, the same for all of
-  // them, is applied once to the projected force
-  M3 acc = m3_zero();
-#pragma unroll 1
-  for (int nu = 0; nu < 4; nu++) {
-    if (nu == mu) continue;
-    // forward: U_nu(x) U_mu(x+nu) U_nu(x+mu)^+          (stf[mu,nu], staples.nim:181-183)
-    shifted(g, x, nu, 1, y);
-    M3 t = m3_mul_na(m3_load(G + link_off(g, y, mu), 64), m3_load(G + link_off(g, xpm, nu), 64));
-    m3_mac(acc, m3_load(G + link_off(g, x, nu), 64), t);
-    // backward: U_nu(x-nu)^+ U_mu(x-nu) U_nu(x-nu+mu)   (stu[mu,nu] shifted down, staples.nim:184-186)
-    shifted(g, x, nu, -1, y);
-    shifted(g, y, mu, 1, z);
-    t = m3_mul_an(m3_load(G + link_off(g, y, nu), 64), m3_load(G + link_off(g, y, mu), 64));
-    m3_mac(acc, t, m3_load(G + link_off(g, z, nu), 64));
-  }
-  size_t o = link_off(g, x, mu);
-  M3 f = m3_tah(m3_mul_na(m3_load(G + o, 64), acc));
-  if (Pm) {
-    M3 v;
-    const double cfp = cf * cp;
-    if (cpm != 0.0) {
-      M3 pm = m3_load(Pm + o, 64);
-#pragma unroll
-      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x + cpm * pm.e[k].x, cfp * f.e[k].y + cpm * pm.e[k].y);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; k++) v.e[k] = make_double2(cfp * f.e[k].x, cfp * f.e[k].y);
-    }
-    m3_store(Pm + o, 64, v);
-    // fused second half of the RK3 stage (wflow.nim:40-43): U <- exp(v) U into the other buffer, so the
-    // compute-bound exp overlaps the L2-bound staple gathers of other waves and v, U are not re-read
-    if (Uout) m3_store(Uout + o, 64, m3_mul(CLOSED ? m3_exp_tah(v) : m3_exp(v), m3_load(G + o, 64)));
-  } else {
-#pragma unroll
-    for (int k = 0; k < 9; k++) { f.e[k].x *= cp; f.e[k].y *= cp; }
-    m3_store(F + o, 64, f);
-  }
-}
+// Plaquette force / Wilson-flow stage.  F_mu(x) = TAH( U_mu(x) [cp * sum_nu (fwd + bwd staples)]^+ ), one lane per (mu, site).
+// A workgroup = one 64-site tile x 4 directions (wavefront w handles mu = w), so the four wavefronts that share most of their
+// neighbour links run together.  Which tile a workgroup takes comes from tile_order_table: one contiguous (t,z) region per
+// XCD, walked in compact blocks with both parities adjacent -- every link is used by 19 staple terms, and tiles dealt
+// round-robin over the XCDs would each re-fetch it from beyond their own L2 (cdna_hip_programming.md T1).
+// flow mode (Pm != nullptr): the RK3 combination v = cf*f + cpm*p (wflow.nim:39,48,57) is formed here and written over the
+// momentum field, and U' = exp(v) U goes to the other link buffer in the same kernel (wflow.nim:40-43): the compute-bound
+// exp overlaps the L2-bound staple gathers of other waves and v, U are not re-read.
+// CLOSED: exp(v) in closed form (m3_exp_tah, su3.h) instead of the reference's Taylor + 20 squarings: option "flow_exp".
+// Momentum / force / new-link traffic is streamed past the caches (non-temporal): it is touched once per stage.
 
 // what k_force_lds and k_force_lds2 do with a link's staple sum: f = TAH(U acc^+) (gaugeUtils.nim:389-398), then either the
 // force itself (F = cp f) or the RK3 stage v = cf cp f + cpm p -> p, U' = exp(v) U (wflow.nim:36-62)
@@ -228,14 +161,14 @@ __device__ __forceinline__ void force_finish(const M3 &U, const M3 &acc, bool li
   }
 }
 
-// k_force with the links that the four directions of a tile share passed through LDS (mode 3 only).  The kernel pays for
+// The links that the four directions of a tile share are passed through LDS.  The kernel pays for
 // its gathers at the CU's L2->L1 rate (profiles/r02_kforce_experiments.md): of the 19 matrices a lane fetches, U_nu(x) and
 // U_nu(x-nu) (nu != mu) are the same for the three wavefronts with mu != nu -- and they are the workgroup's own links
 // U_mu(x), U_mu(x-mu) of wavefront nu.  Every wavefront therefore loads its own two once, puts them into LDS (8 x 9 KiB),
 // ONE barrier, and reads its six shared operands back from there: 14 global matrix loads per lane instead of 19.
 template <bool CLOSED, bool HALO>
 __global__ void __launch_bounds__(256) k_force_lds(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
-                                                   double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk, int nt) {
+                                                   double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk) {
   extern __shared__ double2 smU[];                    // [2 nu + (0: U_nu(x) | 1: U_nu(x-nu))][9][64]
   const int e = order[(blockIdx.x & 7) * chunk + (blockIdx.x >> 3)];
   if (e < 0) return;                                  // the whole workgroup together
@@ -272,7 +205,7 @@ __global__ void __launch_bounds__(256) k_force_lds(Geom g, const double2 *__rest
     m3_mac(acc, t, m3_load(G + link_off_t<HALO>(g, z, nu), 64));
   }
   const M3 U = m3_load(smU + (size_t)(2 * mu) * 576 + lane, 64);
-  force_finish<CLOSED>(U, acc, live, o, F, cp, Pm, cf, cpm, Uout, nt);
+  force_finish<CLOSED>(U, acc, live, o, F, cp, Pm, cf, cpm, Uout, 1);
 }
 
 // k_force_lds over BOTH parities of a tile position in one workgroup (8 wavefronts: parity x direction).  The two tiles
@@ -300,7 +233,7 @@ __device__ __forceinline__ M3 link_lds_or_global(const Geom &g, const double2 *_
 }
 template <bool CLOSED, bool HALO>
 __global__ void __launch_bounds__(512) k_force_lds2(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
-                                                    double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk, int nt) {
+                                                    double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk) {
   extern __shared__ double2 smU[];                    // [parity][2 nu + (0: U_nu(x) | 1: U_nu(x-nu))][9][64]
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int e = order[(blockIdx.x & 7) * chunk + 2 * (blockIdx.x >> 3) + (w >> 2)];   // the table holds (tile,0),(tile,1) adjacent
@@ -340,7 +273,7 @@ __global__ void __launch_bounds__(512) k_force_lds2(Geom g, const double2 *__res
     m3_mac(acc, t, link_lds_or_global<HALO>(g, G, smq, tile, xpm, nu, 1, z));     // U_nu(x+mu-nu) = slot 1 of site x+mu
   }
   const M3 U = m3_load(smp + (size_t)(2 * mu) * 576 + lane, 64);
-  force_finish<CLOSED>(U, acc, live, o, F, cp, Pm, cf, cpm, Uout, nt);
+  force_finish<CLOSED>(U, acc, live, o, F, cp, Pm, cf, cpm, Uout, 1);
 }
 
 // RK3 stage, second half: U <- exp(v) U with v already in the momentum field (wflow.nim:40-43)
@@ -638,7 +571,7 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3], double *plaq6) {
   double *part = nullptr;
   CHK(ordered_sites(c, &order, &chunk, &nb, &part));
   const size_t shb = (size_t)8 * 576 * sizeof(double2);
-  const bool clover = loop == 1 && c->opt_obs_clover && c->max_lds_optin >= (int)shb;
+  const bool clover = loop == 1 && c->opt_obs_clover;
   if (plaq6 && !clover) { qexhip_set_error("flow_measure: the fused pass is the clover kernel's (loop 1, option obs_clover)"); return -3; }
   if (clover) {
     if (!(c->lds_attr_done & 2)) {
@@ -881,8 +814,7 @@ int gauge_deriv_dev(qexhip_ctx *c, const double2 *G, double2 *F, double cplaq, d
   ScopedTimer tm(c, "staple", c->stream);
   const int *order = nullptr; int chunk = 0;
   CHK(tile_order_table(c, &order, &chunk));
-  static const int rectfast = [] { const char *e = getenv("QEXHIP_RECT_FAST"); return e ? atoi(e) : 1; }();
-  if (kind == 0 && c2 != 0.0 && rectfast && c->gn) {
+  if (kind == 0 && c2 != 0.0 && c->gn) {
     // rectangle action: the shared-factor kernel on the double links of G (the context's D2 buffer has the layout of any natural field)
     if (!c->gn->D2) HIPCHK(hipMalloc((void **)&c->gn->D2, c->gn->n2 * sizeof(double2)));
     if (c->g.halo) {
@@ -1049,40 +981,33 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
   CHK(gn_alloc_fp(c));
   CHK(gauge_ghosts(c, ghost_depth_for(c2, kind)));
   ScopedTimer tm(c, "staple", c->stream);
-  static const int mode = [] { const char *e = getenv("QEXHIP_FORCE_MODE"); return e ? atoi(e) : 3; }();   // process-wide tuning switch
-  int nb = mode == 0 ? (4 * c->g.V + 255) / 256 : 2 * c->g.ntile;
   const int *order = nullptr; int chunk = 0;
   CHK(tile_order_table(c, &order, &chunk));
-  if (mode == 3) nb = 8 * chunk;
+  const int nb = 8 * chunk;
+  const bool closed = Uout && c->opt_flow_exp;
   if (c2 != 0.0) {
     // kind 0: cr = c.rect/nc ; kind 1: ca = 2 c.adjplaq/nc^2
     const double k2 = kind == 0 ? c2 / 3.0 : 2.0 * c2 / 9.0;
-    static const int rectfast = [] { const char *e = getenv("QEXHIP_RECT_FAST"); return e ? atoi(e) : 1; }();
-    if (kind == 0 && rectfast) {
+    if (kind == 0) {
       // rectangle action: double links once per call, then the shared-factor kernel
       if (!c->gn->D2) HIPCHK(hipMalloc((void **)&c->gn->D2, c->gn->n2 * sizeof(double2)));
       if (c->g.halo) k_double_links<true><<<2 * c->g.etile, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->D2);
       else k_double_links<false><<<2 * c->g.ntile, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->D2);
       double2 *Pf = (flow || Uout) ? c->gn->P : nullptr;
-      const bool closed = Uout && c->opt_flow_exp;
-#define QX_FRECT(CL, HL) k_force_rect<CL, HL><<<8 * chunk, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->D2, c->gn->F, cplaq / 3.0, k2, Pf, cf, cpm, 0, Uout, order, chunk)
+#define QX_FRECT(CL, HL) k_force_rect<CL, HL><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->D2, c->gn->F, cplaq / 3.0, k2, Pf, cf, cpm, 0, Uout, order, chunk)
       if (closed) { if (c->g.halo) QX_FRECT(true, true); else QX_FRECT(true, false); }
       else { if (c->g.halo) QX_FRECT(false, true); else QX_FRECT(false, false); }
 #undef QX_FRECT
-    } else if (Uout && c->opt_flow_exp)
-      k_force_gen<true><<<8 * chunk, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind, c->gn->P, cf, cpm, 0, Uout, order, chunk);
+    } else if (closed)
+      k_force_gen<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind, c->gn->P, cf, cpm, 0, Uout, order, chunk);
     else
-      k_force_gen<false><<<8 * chunk, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind,
-                                                         flow ? c->gn->P : nullptr, cf, cpm, 0, Uout, order, chunk);
+      k_force_gen<false><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, k2, kind,
+                                                    flow ? c->gn->P : nullptr, cf, cpm, 0, Uout, order, chunk);
   } else {
     // (capping the registers for 3 or 4 waves/SIMD spills: 1460 / 2370 us against 1310 us fused at 2 waves/SIMD)
-    static const int lds = [] { const char *e = getenv("QEXHIP_FORCE_LDS"); return e ? atoi(e) : 1; }();
-    const bool closed = Uout && c->opt_flow_exp;
-    const size_t shb = (size_t)8 * 576 * sizeof(double2);         // 72 KiB: two workgroups per CU, as the registers allow anyway
-    // the Wilson-flow stage proper (staples -> v -> exp(v) U): loader / consumer kernel, flow_stage.hip (144 KiB of LDS)
-    if (flow && Uout && mode == 3 && c->opt_flow_ring && c->max_lds_optin >= (int)(16 * 576 * sizeof(double2))) {
-      CHK(flow_stage_launch(c, c->gn->U, c->gn->P, Uout, cplaq / 3.0, cf, cpm, order, chunk, closed));
-    } else if (lds && mode == 3 && c->opt_force_pair && c->tile_pairs_ok && c->max_lds_optin >= (int)(2 * shb)) {
+    const size_t shb = (size_t)8 * 576 * sizeof(double2);         // 72 KiB per parity of a tile position (qexhip_init checks the device offers 144)
+    double2 *Pf = (closed || flow) ? c->gn->P : nullptr;
+    if (c->opt_force_pair && c->tile_pairs_ok) {
       // both parities of a tile position per workgroup (k_force_lds2): 144 KiB of LDS, one workgroup of 8 wavefronts per CU
       if (!(c->lds_attr_done & 8)) {
         HIPCHK(hipFuncSetAttribute((const void *)k_force_lds2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * shb)));
@@ -1091,13 +1016,12 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
         HIPCHK(hipFuncSetAttribute((const void *)k_force_lds2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * shb)));
         c->lds_attr_done |= 8;
       }
-      double2 *Pf = (closed || flow) ? c->gn->P : nullptr;
-      static const int fnt = [] { const char *e = getenv("QEXHIP_FORCE_NT"); return e ? atoi(e) : 1; }();
-#define QX_FLDS2(CL, HL) k_force_lds2<CL, HL><<<nb / 2, 512, 2 * shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk, fnt)
+#define QX_FLDS2(CL, HL) k_force_lds2<CL, HL><<<nb / 2, 512, 2 * shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk)
       if (closed) { if (c->g.halo) QX_FLDS2(true, true); else QX_FLDS2(true, false); }
       else { if (c->g.halo) QX_FLDS2(false, true); else QX_FLDS2(false, false); }
 #undef QX_FLDS2
-    } else if (lds && mode == 3 && c->max_lds_optin >= (int)shb) {
+    } else {
+      // lattice shapes whose visiting order cannot pair the parities of a tile position: one (tile, parity) per workgroup
       if (!(c->lds_attr_done & 1)) {
         HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
         HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
@@ -1105,16 +1029,11 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
         HIPCHK(hipFuncSetAttribute((const void *)k_force_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
         c->lds_attr_done |= 1;
       }
-      double2 *Pf = (closed || flow) ? c->gn->P : nullptr;
-      static const int fnt = [] { const char *e = getenv("QEXHIP_FORCE_NT"); return e ? atoi(e) : 1; }();
-#define QX_FLDS(CL, HL) k_force_lds<CL, HL><<<nb, 256, shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk, fnt)
+#define QX_FLDS(CL, HL) k_force_lds<CL, HL><<<nb, 256, shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk)
       if (closed) { if (c->g.halo) QX_FLDS(true, true); else QX_FLDS(true, false); }
       else { if (c->g.halo) QX_FLDS(false, true); else QX_FLDS(false, false); }
 #undef QX_FLDS
-    } else if (closed)
-      k_force<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, c->gn->P, cf, cpm, Uout, order, chunk);
-    else
-      k_force<false><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, mode, flow ? c->gn->P : nullptr, cf, cpm, Uout, order, chunk);
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -1131,28 +1050,18 @@ int gauge_wflow(qexhip_ctx *c, int nsteps, double eps, double cplaq, double c2, 
   if (kind == 0 && c2 != 0.0) for (int d = 0; d < 4; d++) if (c->g.X[d] < 4) { qexhip_set_error("rectangle action needs extents >= 4"); return -1; }
   CHK(gn_alloc_fp(c));
   const double epsnc = eps * 3.0;
-  const size_t ltiles = (size_t)2 * c->g.ntile * 4;
-  const int nb = (int)((ltiles * 64 + 255) / 256);
   const double cf[3] = {(-1.0 / 4.0) * epsnc, (-8.0 / 9.0) * epsnc, (-3.0 / 4.0) * epsnc};
   const double cpm[3] = {0.0, -17.0 / 9.0, -1.0};
-  static const int fused = [] { const char *e = getenv("QEXHIP_FLOW_FUSED"); return e ? atoi(e) : 1; }();
-  if (fused && !c->gn->U2) {
+  // one kernel per RK3 stage (staples -> v -> U' = exp(v) U into the second link buffer), then the buffers swap
+  if (!c->gn->U2) {
     HIPCHK(hipMalloc((void **)&c->gn->U2, c->gn->n2 * sizeof(double2)));
     HIPCHK(hipMemsetAsync(c->gn->U2, 0, c->gn->n2 * sizeof(double2), c->stream));
   }
   for (int s = 0; s < nsteps; s++)
     for (int st = 0; st < 3; st++) {
-      if (fused) {
-        CHK(force_dev(c, cplaq, 1, cf[st], cpm[st], c2, kind, c->gn->U2));
-        std::swap(c->gn->U, c->gn->U2);
-        c->gn->ghost_valid = 0;
-      } else {
-        CHK(force_dev(c, cplaq, 1, cf[st], cpm[st], c2, kind));
-        ScopedTimer tm(c, "expupdate", c->stream);
-        k_exp_update<<<nb, 256, 0, c->stream>>>(ltiles, c->gn->U, c->gn->P, 1.0, (size_t)c->g.ntile * 4, (size_t)c->g.etile * 4);
-        HIPCHK(hipGetLastError());
-        c->gn->ghost_valid = 0;
-      }
+      CHK(force_dev(c, cplaq, 1, cf[st], cpm[st], c2, kind, c->gn->U2));
+      std::swap(c->gn->U, c->gn->U2);
+      c->gn->ghost_valid = 0;
     }
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
@@ -1627,8 +1536,7 @@ int gauge_wline(qexhip_ctx *c, const int *path, int n, double out[2]) {
     bool straight = true;
     for (int k = 1; k < n; k++) if (path[k] != path[0]) straight = false;
     const int d = std::abs(path[0]) - 1;
-    static const int fast = [] { const char *e = getenv("QEXHIP_WLINE_LINES"); return e ? atoi(e) : 1; }();
-    if (fast && straight && n == g.X[d] && !(g.halo && d == 3)) {
+    if (straight && n == g.X[d] && !(g.halo && d == 3)) {
       const int nl = g.V / g.X[d];
       const int nbl = std::min((nl + 63) / 64, 1024);
       if (d == 0) launch_xlines(c, nbl, c->partials);

@@ -339,12 +339,9 @@ int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk_out) {
   const Geom &g = c->g;
   const int n = 2 * g.ntile, chunk = (n + 7) / 8;
   if (c->tile_order && c->tile_order_n == 8 * chunk) { *tab = c->tile_order; *chunk_out = chunk; return 0; }
-  static const int by = [] { const char *e = getenv("QEXHIP_ORD_Y"); return e ? atoi(e) : 8; }();
-  static const int bz = [] { const char *e = getenv("QEXHIP_ORD_Z"); return e ? atoi(e) : 4; }();
-  static const int bt = [] { const char *e = getenv("QEXHIP_ORD_T"); return e ? atoi(e) : 4; }();
-  // QEXHIP_ORD_RZ (1, 2, 4, 8): the XCD regions are split in z as well as t (measurement knob; 1 = t-ranges only)
-  static const int rz_env = [] { const char *e = getenv("QEXHIP_ORD_RZ"); return e ? atoi(e) : 1; }();
-  const int rz = ((rz_env == 2 || rz_env == 4 || rz_env == 8) && g.X[3] % (8 / rz_env) == 0 && g.X[2] % rz_env == 0) ? rz_env : 1;
+  // block extents in (y, z, t) of the walk inside an XCD's region: the winner of the sweep in
+  // profiles/r03_flow_stage_order_sweep.log (XCD regions split in z as well as t lost there and are gone)
+  constexpr int by = 8, bz = 4, bt = 4;
   struct Ent { unsigned long long key0, key1; int e; };
   std::vector<Ent> v(n);
   for (int p = 0; p < 2; p++)
@@ -355,10 +352,6 @@ int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk_out) {
       Ent &a = v[(size_t)p * g.ntile + tile];
       a.e = 2 * tile + p;
       a.key0 = (((long)t * g.X[2] + z) * g.X[1] + y) * 2 + p;         // plain order: splits the lattice into 8 (t,z) regions
-      if (rz > 1) {                                                    // regions = (8/rz t-ranges) x (rz z-ranges)
-        const int tr = t / (g.X[3] / (8 / rz)), zr = z / (g.X[2] / rz);
-        a.key0 += (unsigned long long)(tr * rz + zr) << 44;
-      }
       // six 10-bit fields + parity = 61 bits (extents <= 1024, geom_init)
       a.key1 = ((((((unsigned long long)(t / bt) * 1024u + z / bz) * 1024u + y / by) * 1024u + t % bt) * 1024u + z % bz) * 1024u + (y % by)) * 2 + p;
     }
@@ -449,8 +442,7 @@ static void tile_order_plane_host(const Geom &g, int mu, int nu, std::vector<int
 int tile_order_plane(qexhip_ctx *c, int mu, int nu, const int **tab, int *chunk_out) {
   const Geom &g = c->g;
   const int n = 2 * g.ntile, chunk = (n + 7) / 8;
-  static const int use = [] { const char *e = getenv("QEXHIP_ORD_PLANE"); return e ? atoi(e) : 1; }();
-  if (!use || mu == nu || mu < 0 || nu < 0 || mu > 3 || nu > 3) return tile_order_table(c, tab, chunk_out);
+  if (mu == nu || mu < 0 || nu < 0 || mu > 3 || nu > 3) return tile_order_table(c, tab, chunk_out);
   int *&slot = c->tile_order_pl[mu * 4 + nu];
   if (slot) { *tab = slot; *chunk_out = chunk; return 0; }
   std::vector<int> h;

@@ -98,17 +98,13 @@ struct qexhip_ctx {
   // timers
   int timers_on = 0;
   std::map<std::string, TimerSlot> timers;
-  // tuning switches (env QEXHIP_SWZ / QEXHIP_NTSTORE, read at init)
-  int opt_swz = -1, opt_ntstore = 1;   // swz: -1 = on for compressed links, off for 18-real links (measured)
   // compressed links (recon = 1: rows 0,1 + sign mask; 2: rows 0,1 + det; row 2 rebuilt in the kernel)
   double2 *Wc = nullptr; unsigned long long *Ws = nullptr; size_t Wc_rows = 0; int recon = 0; double recon_dev = 0;
   int opt_batch_multi = 0; // test hook: take the multi-rank reduction branch of the batched CG on one rank
   int opt_multi_reduce = 0; // test hook: take the multi-rank reduction branches of CG / multi-shift CG / norms on one rank
                             // (with a one-rank RCCL communicator the all-reduces are real collectives)
-  int opt_force_pair = 1; // QEXHIP_FORCE_PAIR / option "force_pair": both parities of a tile position per workgroup in the plaquette force / flow stage (k_force_lds2)
-  int opt_flow_ring = 0;  // QEXHIP_FLOW_RING / option "flow_ring": 1 = the loader / consumer flow stage (flow_stage.hip: measured alternative,
-                          // 850-900 us against 720-780, profiles/r03_flow_stage_experiments.md); 0 = k_force_lds, the default
-  int opt_obs_clover = 1; // QEXHIP_OBS_CLOVER / option "obs_clover": 1 = the tile-per-workgroup clover kernel for fmunu(loop = 1); 0 = the path walker
+  int opt_force_pair = 1; // option "force_pair" (test hook): 0 takes k_force_lds, the form lattice shapes without paired tile positions get, on any shape
+  int opt_obs_clover = 1; // option "obs_clover" (test hook): 0 takes the generic path walker, the form fmunu loops 3-5 get, for loop 1 as well
   int opt_flow_exp = 1;   // QEXHIP_FLOW_EXP / option "flow_exp": 1 = closed-form exp(v) in the fused Wilson-flow stage (same function,
                           // another algorithm than the reference's; agrees with it to ~1e-15 per element; the default); 0 = the reference's
                           // Taylor + 20 squarings (matexp.nim), which the MD link updates always use
@@ -125,8 +121,7 @@ struct qexhip_ctx {
   int *tile_order_pl[16]{};                          // the same for kernels that shift in the (mu, nu) plane only (layout.hip)
   void *obs_table = nullptr;                         // ObsTable of gauge_flow_obs (gauge.hip)
   void *batch = nullptr;                             // BatchState of the lock-step multi-system CG (batch.hip)
-  int lds_attr_done = 0;                             // per context (= per device): which kernels had MaxDynamicSharedMemorySize raised (bit 0 k_force_lds, 1 k_flow_obs_clover, 2 k_flow_stage, 3 k_force_lds2)
-  int max_lds_optin = 0;                             // hipDeviceAttributeMaxSharedMemoryPerBlock(Optin): the large-LDS kernels fall back when it is too small
+  int lds_attr_done = 0;                             // per context (= per device): which kernels had MaxDynamicSharedMemorySize raised (bit 0 k_force_lds, 1 k_flow_obs_clover, 3 k_force_lds2)
   void *cgm_scal = nullptr;                          // CgmScal of the multi-shift solver (multishift.hip)
 };
 
@@ -294,6 +289,3 @@ const double2 *gauge_links_dev(qexhip_ctx *c);   // resident natural-layout link
 struct qexhip_rng;
 int rng_dev_generate(qexhip_ctx *c, qexhip_rng *R, int what, DevField *f, double2 *P);   // what: 0 gaussian vector, 1 u1 vector, 2 randomTAH -> P
 int md_momenta_dev(qexhip_ctx *c, double2 **M);                                          // resident MD momenta (allocated on demand)
-// ---- flow_stage.hip ----
-int flow_stage_launch(qexhip_ctx *c, const double2 *U, double2 *P, double2 *Uout, double cp, double cf, double cpm,
-                      const int *order, int chunk, bool closed);

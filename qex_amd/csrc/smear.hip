@@ -61,11 +61,9 @@ __device__ __forceinline__ void shift_sm(const Geom &g, const int x[4], int mu, 
   if (g.halo) shift_sm_t<true>(g, x, mu, d, y); else shift_sm_t<false>(g, x, mu, d, y);
 }
 
-// blocked visiting order for the gather kernels (tile_order_table, layout.hip); QEXHIP_SMEAR_ORD=0 falls back to the plain order
+// blocked visiting order for the gather kernels (tile_order_table / tile_order_plane, layout.hip)
 static int smear_order(qexhip_ctx *c, const Geom &g, const int **order, int *chunk, int *nblk, int mu = -1, int nu = -1) {
-  static const int use = [] { const char *e = getenv("QEXHIP_SMEAR_ORD"); return e ? atoi(e) : 1; }();
   *order = nullptr; *chunk = 0; *nblk = (g.V + 255) / 256;
-  if (!use) return 0;
   CHK(tile_order_plane(c, mu, nu, order, chunk));     // mu < 0: the generic blocked order
   *nblk = 8 * ((*chunk + 3) / 4);
   return 0;
@@ -635,15 +633,15 @@ struct Smear {
   int staple(MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, MView init = MView{nullptr, 0}, double cinit = 0.0,
              MViewW proj = MViewW{nullptr, 0}) {
     ScopedTimer tm(c, "smear", c->stream);
-    static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
+    constexpr int swz = 1;     // XCD-aware block remap of the gather kernels (measured winner, profiles/r02_pmc_staple_kernels_order.log)
     const int *order; int chunk, nblk;
     CHK(smear_order(c, g, &order, &chunk, &nblk, mu, nu));
     // Dynamic LDS the kernel never touches, as an occupancy limiter: 60 KB per workgroup admits two workgroups (8
     // wavefronts = 8 tiles) per CU instead of the 3-4 its registers allow.  The kernel is bound by what misses the XCD's
     // 4 MB L2, and fewer tiles in flight keep the lines its wavefronts share alive: nHYP smearing 7.27 -> 6.70 ms at 32^4
-    // (45 KB: 7.14, 100 KB = one workgroup per CU: 7.41).  QEXHIP_STAPLE_LDS=0 switches it off.
-    static const int ldsb = [] { const char *e = getenv("QEXHIP_STAPLE_LDS"); return e ? atoi(e) : 60000; }();
-    static const int gnt = [] { const char *e = getenv("QEXHIP_STAPLE_NT"); return e ? atoi(e) : 1; }();
+    // (45 KB: 7.14, 100 KB = one workgroup per CU: 7.41; none: 7.27).
+    constexpr int ldsb = 60000;
+    constexpr int gnt = 1;     // non-temporal stores of the staple / accumulator (written once, read by a later kernel)
     if (g.halo) k_gen_staple<true><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk, gnt);
     else k_gen_staple<false><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk, gnt);
     HIPCHK(hipGetLastError());
@@ -689,7 +687,7 @@ struct Smear {
     return 0;
   }
   int sderiv(MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu, double coef) {
-    static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
+    constexpr int swz = 1;     // XCD-aware block remap of the gather kernels (measured winner, profiles/r02_pmc_staple_kernels_order.log)
     ScopedTimer tm(c, "smear_deriv", c->stream);
     // (scheduling fences cost 3 % here: 48.5 vs 46.9 ms per HISQ force, A/B on one GPU)
     const int *order; int chunk, nblk;
@@ -897,32 +895,13 @@ int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, doub
   return 0;
 }
 // smearedForce(f, chain) on the device field st->F (in: chain, out: f)   (hypsmear.nim:146-245)
-static int staple_deriv(qexhip_ctx *c, const Geom &g, MViewW f1, MViewW f2, MView g1, MView g2, MView cf, int mu, int nu,
-                        int z1 = 0, int z2 = 0) {
-  static const int swz = [] { const char *e = getenv("QEXHIP_SMEAR_SWZ"); return e ? atoi(e) : 1; }();
-  const int *order; int chunk, nblk;
-  CHK(smear_order(c, g, &order, &chunk, &nblk, mu, nu));
-  // in-place accumulating form: scheduling fences between the products bring it from 256 VGPRs / 1 wave per SIMD
-  // to 216 / 2 (192 in the sharded form) and the nHYP chain from 24.2 to 23.2 ms (sharded, 48^3x12: 31.2 -> 26.1 ms)
-  static const int wpe = [] { const char *e = getenv("QEXHIP_SDERIV_WPE"); return e ? atoi(e) : 2; }();
-  if (g.halo) k_staple_deriv<false, true, true><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2, 1.0, order, chunk);
-  else if (wpe == 3) k_staple_deriv<false, false, true, 3><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2, 1.0, order, chunk);
-  else k_staple_deriv<false, false, true><<<nblk, 256, 0, c->stream>>>(g, f1, f2, g1, g2, cf, mu, nu, swz, z1, z2, 1.0, order, chunk);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-// the (mu, nu) and (nu, mu) symStapleDerivs of a level in one pass (k_staple_deriv_pair); QEXHIP_SDERIV_PAIR=0: two single calls
+// the (mu, nu) and (nu, mu) symStapleDerivs of a level in one pass (k_staple_deriv_pair)
 static int staple_deriv_pair(qexhip_ctx *c, const Geom &g, MViewW F1, MViewW F2, MView g1, MView g2, MView cA, MView cB, int mu, int nu,
                              int z1, int z2) {
-  static const int pair = [] { const char *e = getenv("QEXHIP_SDERIV_PAIR"); return e ? atoi(e) : 1; }();
   const int *order; int chunk, nblk;
   CHK(smear_order(c, g, &order, &chunk, &nblk, mu, nu));
-  if (!pair || !order) {
-    CHK(staple_deriv(c, g, F1, F2, g1, g2, cA, mu, nu, z1, z2));
-    return staple_deriv(c, g, F2, F1, g2, g1, cB, nu, mu, 0, 0);
-  }
   const int nb2 = 8 * ((chunk + 1) / 2);         // two wavefronts per tile: 2 table slots per 256-thread workgroup
-  static const int nt = [] { const char *e = getenv("QEXHIP_SDERIV_NT"); return e ? atoi(e) : 1; }();
+  constexpr int nt = 1;
   if (g.halo) k_staple_deriv_pair<true><<<nb2, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk, nt);
   else k_staple_deriv_pair<false><<<nb2, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk, nt);
   HIPCHK(hipGetLastError());
@@ -934,25 +913,19 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
   const int nblk = S.nb();
   const double alp1 = st->a1 / 2.0, alp2 = st->a2 / 4.0, alp3 = st->a3 / 6.0;
   const double ma1 = 1 - st->a1, ma2 = 1 - st->a2, ma3 = 1 - st->a3;
-  const MView noU{nullptr, 0};
   ScopedTimer tm(c, "nhyp_force", c->stream);
   // fl1 / fl2 are sums of several staple derivatives: the first contribution to each writes, the rest accumulate
   bool t1[4][4] = {}, t2[4][4] = {};
-  static const int batch = getenv("QEXHIP_PROJ_BATCH") ? atoi(getenv("QEXHIP_PROJ_BATCH")) : 1;
+  // the projectUderiv calls of one level in ONE launch (k_projUderiv_batch: grid.y = direction, up to three fields each)
   ProjBatch PB;
-  PB.nt = getenv("QEXHIP_PROJ_NT") ? atoi(getenv("QEXHIP_PROJ_NT")) : 1;
-  if (batch) {
+  PB.nt = 1;
+  {
     for (int mu = 0; mu < 4; mu++) {
       PB.dst[mu][0] = S.gvw(st->fc, mu); PB.X[mu][0] = S.gv(st->K.flx, mu); PB.C[mu][0] = S.gv(st->F, mu);
       PB.f[mu] = S.gvw(st->F, mu);
     }
     PB.nn = 1; PB.accumulate = 0; PB.ma = ma3; PB.alp = alp3;
     k_projUderiv_batch<<<dim3(nblk, 4), 256, 0, c->stream>>>(g, PB);
-  } else {
-    for (int mu = 0; mu < 4; mu++) {
-      k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.gvw(st->fc, mu), noU, S.gv(st->K.flx, mu), S.gv(st->F, mu),
-                                                S.gvw(st->F, mu), ma3, alp3, 0);
-    }
   }
   HIPCHK(hipGetLastError());
   CHK(S.ghosts_g(st->fc));          // t-sharded: a chain field is read at shifted sites by the staple derivative
@@ -963,7 +936,7 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
       t2[nu][mu] = t2[mu][nu] = true;
     }
   HIPCHK(hipGetLastError());
-  if (batch) {
+  {
     for (int mu = 0; mu < 4; mu++) {
       int j = 0;
       for (int nu = 0; nu < 4; nu++) {
@@ -979,14 +952,6 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++)
         if (nu != mu) CHK(S.ghosts_f(st->fl2[mu][nu]));
-  } else {
-    for (int mu = 0; mu < 4; mu++)
-      for (int nu = 0; nu < 4; nu++) {
-        if (nu == mu) continue;
-        k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[mu][nu]), S.fv(st->K.l2x[mu][nu]),
-                                                  S.fv(st->fl2[mu][nu]), S.gvw(st->F, mu), ma2, alp2, 1);
-        CHK(S.ghosts_f(st->fl2[mu][nu]));
-      }
   }
   HIPCHK(hipGetLastError());
   // the call (mu, nu, a) and its partner (a, nu, mu) share b = 6 - mu - nu - a and exchange the roles of their fields
@@ -1000,7 +965,7 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
         t1[a][b] = t1[mu][b] = true;
       }
   HIPCHK(hipGetLastError());
-  if (batch) {
+  {
     for (int mu = 0; mu < 4; mu++) {
       int j = 0;
       for (int nu = 0; nu < 4; nu++) {
@@ -1016,14 +981,6 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++)
         if (nu != mu) CHK(S.ghosts_f(st->fl1[mu][nu]));
-  } else {
-    for (int mu = 0; mu < 4; mu++)
-      for (int nu = 0; nu < 4; nu++) {
-        if (nu == mu) continue;
-        k_projUderiv<<<nblk, 256, 0, c->stream>>>(g, S.fvw(st->fl1[mu][nu]), S.fv(st->K.l1[mu][nu]), S.fv(st->K.l1x[mu][nu]),
-                                                  S.fv(st->fl1[mu][nu]), S.gvw(st->F, mu), ma1, alp1, 1);
-        CHK(S.ghosts_f(st->fl1[mu][nu]));
-      }
   }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)

@@ -150,17 +150,6 @@ def test_gpu_gauge_sector_on_the_sharded_path(oracle):
         for loop in (1, 3, 4, 5):
             ea, eb = q.flowEQ(A, loop), q.flowEQ(B, loop)          # of the resident (flowed) fields
             assert np.allclose(ea, eb, rtol=0, atol=0)
-    # the loader / consumer form of the Wilson-flow stage (option flow_ring, csrc/flow_stage.hip), periodic and sharded: another
-    # summation order of the same staples, so equal to rounding, and bit for bit between its two forms
-    ga, gb, gc = g.copy(), g.copy(), g.copy()
-    q.gaugeFlow(A, ga, 2, 0.01)
-    for X in (A, B):
-        X.set_option("flow_ring", 1)
-    q.gaugeFlow(A, gb, 2, 0.01)
-    q.gaugeFlow(B, gc, 2, 0.01)
-    for X in (A, B):
-        X.set_option("flow_ring", 0)
-    assert np.array_equal(gb, gc) and np.abs(ga - gb).max() < 1e-14
     # both parities of a tile position per workgroup (option force_pair, k_force_lds2: neighbours inside the tile position
     # come from LDS) against one tile per workgroup (k_force_lds): the same products in the same order, so bit for bit
     ga, gb, gc = g.copy(), g.copy(), g.copy()

@@ -355,14 +355,12 @@ def test_gauge_force(oracle):
     assert relerr(f, oracle.gauge_force(lo, g)) < 1e-13
 
 
-@pytest.mark.parametrize("flow_ring", [0, 1])
 @pytest.mark.parametrize("flow_exp", [1, 0])
-def test_wflow_golden(oracle, flow_exp, flow_ring):
+def test_wflow_golden(oracle, flow_exp):
     """G2 (src/gauge/wflow.nim:92-99,124-149): plaquettes after gaugeFlow(6, 0.01), rel 2e-14 -- the reference's own
     tolerance -- with the flow's default closed-form exp(v) (flow_exp = 1: the same matrix function by Cayley-Hamilton,
     csrc/su3.h m3_exp_tah) and with the reference's algorithm (flow_exp = 0: order-4 Taylor at v/2^20 + 20 squarings,
-    matexp.nim), which is also what the oracle runs; the flowed links agree with the oracle's to 1e-12 either way.
-    flow_ring = 1: the stage as the loader / consumer kernel (csrc/flow_stage.hip, the measured alternative to k_force_lds)."""
+    matexp.nim), which is also what the oracle runs; the flowed links agree with the oracle's to 1e-12 either way."""
     import qex_amd as q
 
     lo = oracle.Layout([8, 8, 8, 8])
@@ -370,7 +368,6 @@ def test_wflow_golden(oracle, flow_exp, flow_ring):
     gref = g.copy()
     ctx = q.Context([8, 8, 8, 8])
     ctx.set_option("flow_exp", flow_exp)
-    ctx.set_option("flow_ring", flow_ring)
     q.gaugeFlow(ctx, g, 6, 0.01)
     p0 = np.array([0.01960725848281519, 0.01982378149813489, 0.01938877647467847,
                    0.0185899778070918, 0.0180821938831715, 0.01876842496122964])
@@ -692,10 +689,9 @@ def test_multi_rank_code_path_on_one_rank(oracle, naik):
     assert np.max(np.abs(q.plaq(ctx, g0) - q.plaq(A.ctx, g0))) < 1e-15
 
 
-@pytest.mark.parametrize("flow_ring", [0, 1])
 @pytest.mark.parametrize("flow_exp", [1, 0])
 @pytest.mark.parametrize("lat", [[4, 6, 10, 6], [6, 6, 6, 8]])
-def test_force_and_flow_on_a_lattice_with_a_ragged_last_tile(oracle, flow_exp, flow_ring, lat):
+def test_force_and_flow_on_a_lattice_with_a_ragged_last_tile(oracle, flow_exp, lat):
     """4 x 6 x 10 x 6: 720 sites per parity = 11 tiles of 64 and a quarter.  The force / flow kernels give a whole
     workgroup (four directions, shared links through LDS, one barrier) to every tile, so the padding lanes of the last
     tile must go through the barrier and store nothing: force and three flow steps against the oracle.
@@ -708,7 +704,6 @@ def test_force_and_flow_on_a_lattice_with_a_ragged_last_tile(oracle, flow_exp, f
     g = oracle.gauge_random(lo, seed=SEED)
     ctx = q.Context(lat)
     ctx.set_option("flow_exp", flow_exp)
-    ctx.set_option("flow_ring", flow_ring)
     assert relerr(q.gaugeForce(ctx, g), oracle.gauge_force(lo, g)) < 1e-13
     assert ("tile_pairs=%d" % (1 if lat[0] == 6 else 0)) in ctx.info()
     gref = g.copy()
