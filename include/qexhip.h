@@ -75,6 +75,11 @@ int qexhip_comm_info(qexhip_handle h, int *nranks, int *rank, int *device, char 
  * and ghost refreshes, one -- ncclCommSplit of the first -- for the face exchanges posted on the second stream beside the
  * interior sweep, so that neither queues behind the other), 1 with QEXHIP_COMM2=0. */
 int qexhip_comm_count(qexhip_handle h, int *ncomms);
+/* How a one-parity sweep runs on this context's (t-sharded) field: out[0] = 1 if t-hops across the slab boundary go through
+ * ghost zones, out[1] = 1 if the face exchange is posted on the second stream beside an interior launch (option "overlap";
+ * by default only when the interior is >= 131072 sites and a face >= 1 MiB), out[2] = interior sites of one parity,
+ * out[3] = bytes of one face message.  bench.py prints it so that a scaling run explains its own launch structure. */
+int qexhip_stag_sweep_info(qexhip_handle h, int out[4]);
 /* test hook: with one rank, route the t-direction hops through the halo path
  * (pack -> RCCL self send/recv -> boundary sweep) instead of the periodic wrap. */
 int qexhip_comm_force_halo(qexhip_handle h, int on);
@@ -453,7 +458,10 @@ int qexhip_io_metadata(const char *path, char *file_md, int file_cap, char *reco
 /* ---------------- kernel timers ----------------
  * hipEvent pairs around launches of the named kernel class on the context stream
  * (the tic/toc hooks of src/physics/stagD.nim:354-395, src/solvers/cg.nim:175-241).
- * names: "dslash" (one-parity sweep), "blas", "reduce", "staple", "expupdate", "plaq". */
+ * names: "dslash" (one-parity sweep; the faces of an overlapped sweep are "dslash_bnd"), "blas", "reduce", "staple",
+ * "expupdate", "plaq", "exchange" (the RCCL face exchange, on the stream it is posted on), "allreduce".
+ * on = 1: every class; 2: the Dslash sweeps only (least perturbation of a timed region); 3: the anatomy of a sharded
+ * iteration -- Dslash sweeps, exchange, allreduce; 0: off. */
 int qexhip_timers_enable(qexhip_handle h, int on);
 int qexhip_timers_reset(qexhip_handle h);
 int qexhip_timers_get(qexhip_handle h, const char *name, long *count, double *total_ms);

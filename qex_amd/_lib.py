@@ -26,6 +26,7 @@ SYMBOLS = [
     ("qexhip_comm_force_halo", _ci, [_vp, _ci]),
     ("qexhip_comm_info", _ci, [_vp, _pi, _pi, _pi, C.c_char_p, _ci]),
     ("qexhip_comm_count", _ci, [_vp, _pi]),
+    ("qexhip_stag_sweep_info", _ci, [_vp, _pi]),
     ("qexhip_stag_set_links", _ci, [_vp, _vp, _vp]),
     ("qexhip_stag_dslash", _ci, [_vp, _vp, _vp, _ci, _cd, _cd]),
     ("qexhip_stag_D", _ci, [_vp, _vp, _vp, _cd, _cd]),

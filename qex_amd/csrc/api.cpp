@@ -21,11 +21,18 @@ void qexhip_set_error(const char *fmt, ...) {
 extern "C" const char *qexhip_last_error(void) { return g_err; }
 
 // ---- timers ----
+// levels: 1 everything; 2 only the Dslash sweeps (the dominant kernel), so that the event records perturb a timed region as
+// little as possible; 3 the sharded iteration's anatomy: Dslash sweeps (interior "dslash", faces "dslash_bnd"), the face
+// exchange ("exchange": events on the stream the RCCL group is posted on) and the all-reduces ("allreduce")
+static bool timer_class_on(const qexhip_ctx *c, const char *name) {
+  if (!c->timers_on) return false;
+  if (c->timers_on == 2) return strncmp(name, "dslash", 6) == 0;
+  if (c->timers_on == 3) return strncmp(name, "dslash", 6) == 0 || strcmp(name, "exchange") == 0 || strcmp(name, "allreduce") == 0;
+  return true;
+}
 ScopedTimer::ScopedTimer(qexhip_ctx *c_, const char *name, hipStream_t st_) : c(c_), st(st_) {
   if (!c->timers_on) return;
-  // on == 2: only the Dslash sweeps (the dominant kernel) are bracketed, so that the event
-  // records perturb the timed region as little as possible
-  if (c->timers_on == 2 && strncmp(name, "dslash", 6) != 0) return;
+  if (!timer_class_on(c, name)) return;
   s = &c->timers[name];
   if (s->used + 2 > s->ev.size()) {
     size_t old = s->ev.size();
@@ -40,8 +47,7 @@ ScopedTimer::~ScopedTimer() {
   s->used += 2;
 }
 bool timer_event_pair(qexhip_ctx *c, const char *name, hipEvent_t *e0, hipEvent_t *e1) {
-  if (!c->timers_on) return false;
-  if (c->timers_on == 2 && strncmp(name, "dslash", 6) != 0) return false;
+  if (!timer_class_on(c, name)) return false;
   TimerSlot *s = &c->timers[name];
   if (s->used + 2 > s->ev.size()) {
     size_t old = s->ev.size();
@@ -55,6 +61,7 @@ bool timer_event_pair(qexhip_ctx *c, const char *name, hipEvent_t *e0, hipEvent_
 }
 int timers_collect(qexhip_ctx *c) {
   HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(c->cstream));   // "exchange" events of an overlapped sweep live there
   for (auto &kv : c->timers) {
     TimerSlot &s = kv.second;
     for (size_t i = 0; i + 1 < s.used; i += 2) {
@@ -289,6 +296,17 @@ extern "C" int qexhip_stag_eo_reconstruct(qexhip_handle c, double *r, const doub
   CHK(host_in(c, WK_OUT, r, &fr));
   CHK(op_eo_reconstruct_pub(c, *fr, *fb, m));
   return field_download(c, *fr, r);
+}
+
+extern "C" int qexhip_stag_sweep_info(qexhip_handle c, int out[4]) {
+  if (!c || !out) return QEXHIP_ERR_ARG;
+  int lo_end = 0, hi_beg = 0, overlap = 0;
+  sweep_plan(c, &lo_end, &hi_beg, &overlap);
+  out[0] = c->g.halo;
+  out[1] = overlap;
+  out[2] = c->g.halo ? hi_beg - lo_end : c->g.Vh;
+  out[3] = c->g.halo ? c->g.depth * c->g.F * 48 : 0;
+  return 0;
 }
 
 extern "C" int qexhip_stag_eo_reduce(qexhip_handle c, double *r, const double *b, double m) {

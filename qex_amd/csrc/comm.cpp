@@ -157,6 +157,7 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
   double2 *ghost_hi = base + (size_t)g.ntile * 192;
   double2 *ghost_lo = ghost_hi + face2;
   if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+  ScopedTimer tm(c, "exchange", cs);            // on the stream the group is posted on: transport + waiting for the neighbours
   if (c->comm) {
     // the overlapped exchange has the second communicator to itself (comm_init)
     ncclComm_t comm = (ncclComm_t)((overlap && c->comm2) ? c->comm2 : c->comm);
@@ -171,7 +172,7 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
     HIPCHK(hipMemcpyAsync(ghost_hi, bottom, nd * sizeof(double), hipMemcpyDeviceToDevice, cs));
     HIPCHK(hipMemcpyAsync(ghost_lo, top, nd * sizeof(double), hipMemcpyDeviceToDevice, cs));
   }
-  if (overlap) HIPCHK(hipEventRecord(c->ev_halo, c->cstream));
+  if (overlap) HIPCHK(hipEventRecord(c->ev_halo, c->cstream));    // (recorded before tm's closing event: ev_halo does not wait for it)
   return 0;
 }
 
@@ -230,6 +231,7 @@ int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n) {
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
   CHK(need_comm(c));
   if (!multi_rank(c) || !c->comm) return 0;    // one rank without the rehearsal hook, or no communicator: nothing to sum
+  ScopedTimer tm(c, "allreduce", c->stream);
   NCCLCHK(ncclAllReduce(dptr, dptr, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
   return 0;
 }

@@ -188,6 +188,22 @@ static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool 
   return 0;
 }
 
+// How a sweep over a t-sharded field is laid out: boundary sites [0, lo_end) and [hi_beg, Vh), interior between them, and
+// whether the face exchange goes to the second stream beside the interior launch.
+// Overlap only when the interior is long enough to hide the exchange (measured on one MI355X with a one-rank communicator:
+// the two cross-stream dependencies cost ~20 us per sweep; an interior of 128k sites runs ~30 us) and a face is big enough
+// for its transfer to cost more than the split does: in the one-rank rehearsal (no transport time at all) the interior /
+// boundary split with its two cross-stream events costs ~15 us per sweep (48^3 x 12: 417 vs 388 us per iteration; 32^3 x 16:
+// 253 vs 218); a 48^3 face is 2.65 MB per direction (tens of microseconds on an xGMI link), a 32^3 face 0.79 MB.
+void sweep_plan(const qexhip_ctx *c, int *lo_end_out, int *hi_beg_out, int *overlap_out) {
+  const Geom &g = c->g;
+  int lo_end = g.depth * g.F; if (lo_end > g.Vh) lo_end = g.Vh;
+  int hi_beg = g.Vh - g.depth * g.F; if (hi_beg < lo_end) hi_beg = lo_end;
+  const size_t face_bytes = (size_t)g.depth * g.F * 48;
+  *lo_end_out = lo_end; *hi_beg_out = hi_beg;
+  *overlap_out = !g.halo ? 0 : (c->opt_overlap >= 0 ? (c->opt_overlap != 0) : ((hi_beg - lo_end) >= 131072 && face_bytes >= ((size_t)1 << 20)));
+}
+
 int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const DslashOpts &o) {
   const Geom &g = c->g;
   if (!c->W) { qexhip_set_error("staggered links not set (qexhip_stag_set_links)"); return -3; }
@@ -220,17 +236,8 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
     nparts = (g.Vh + 255) / 256;
   } else {
     // halo: exchange faces of `in` on the comm stream, interior sweep meanwhile, then boundary
-    int lo_end = g.depth * g.F; if (lo_end > g.Vh) lo_end = g.Vh;
-    int hi_beg = g.Vh - g.depth * g.F; if (hi_beg < lo_end) hi_beg = lo_end;
-    // overlap the exchange with the interior sweep on a second stream only when the interior is
-    // long enough to hide it (measured on one MI355X with a one-rank communicator: the two
-    // cross-stream dependencies cost ~20 us per sweep; an interior of 128k sites runs ~30 us)
-    // ... and only when a face is big enough for its transfer to cost more than the split does: in the one-rank
-    // rehearsal (no transport time at all) the interior / boundary split with its two cross-stream events costs ~15 us
-    // per sweep (48^3 x 12: 417 vs 388 us per iteration; 32^3 x 16: 253 vs 218); a 48^3 face is 2.65 MB per direction
-    // (tens of microseconds on an xGMI link), a 32^3 face 0.79 MB
-    const size_t face_bytes = (size_t)g.depth * g.F * 48;
-    const int overlap = c->opt_overlap >= 0 ? c->opt_overlap : ((hi_beg - lo_end) >= 131072 && face_bytes >= ((size_t)1 << 20));
+    int lo_end, hi_beg, overlap;
+    sweep_plan(c, &lo_end, &hi_beg, &overlap);
     if (overlap) HIPCHK(hipEventRecord(c->ev_ready, c->stream));
     CHK(comm_halo_exchange(c, in, 1 - parity, overlap));
     if (!overlap) {

@@ -199,6 +199,7 @@ struct DslashOpts {
   const int *done = nullptr;       // device flag: skip when set
 };
 int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const DslashOpts &o);
+void sweep_plan(const qexhip_ctx *c, int *lo_end, int *hi_beg, int *overlap);   // boundary / interior ranges and the overlap decision
 
 // ---- blas.hip ----
 int blas_zero(qexhip_ctx *c, DevField &f, int parity);

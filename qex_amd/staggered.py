@@ -116,6 +116,12 @@ class Context:
         check(lib().qexhip_comm_count(self._h, C.byref(n)))
         return n.value
 
+    def sweep_info(self):
+        """{"halo", "overlap", "interior_sites", "face_bytes"}: how a one-parity sweep is launched on this context"""
+        o = (C.c_int * 4)()
+        check(lib().qexhip_stag_sweep_info(self._h, o))
+        return {"halo": bool(o[0]), "overlap": bool(o[1]), "interior_sites": int(o[2]), "face_bytes": int(o[3])}
+
     def force_halo(self, on=True):
         check(lib().qexhip_comm_force_halo(self._h, 1 if on else 0))
 

@@ -1,8 +1,8 @@
 """Record of what the history-parity tests actually measured (round-2 verdict, "parity transparency").
 
 Every test that compares a residual history of the HIP path with the oracle's calls `record(...)`; at the end of the
-session the records are written to gpurun_out/r03_parity_devs.json (gpurun merges that directory back; the file is then
-committed as profiles/r03_parity_devs.json).  Nothing is written when no record was made (the CPU suite).
+session the records are written to gpurun_out/r04_parity_devs.json (gpurun merges that directory back; the file is then
+committed as profiles/r04_parity_devs.json).  Nothing is written when no record was made (the CPU suite).
 
 `tolerance(...)` is the bound those tests enforce on the WHOLE history: CG amplifies the rounding differences between two
 equivalent summation orders, so the yardstick is the CPU path against itself when only its reduction order changes
@@ -41,7 +41,7 @@ def spread_over_threads(o, solve_hist, hist_ref, counts=None):
 
 def tolerance(spread):
     """FACTOR x the CPU path's own spread, at least FLOOR, at most CAP -- except where the CPU path deviates from ITSELF by
-    more than CAP / 2.  Measured on the GPU box (profiles/r03_parity_devs.json): only the 4 x 6 x 10 x 6 fixtures `sodd` / `soddw`
+    more than CAP / 2.  Measured on the GPU box (profiles/r04_parity_devs.json): only the 4 x 6 x 10 x 6 fixtures `sodd` / `soddw`
     (CPU self-spread 1.5e-2 ... 6e-2 over 1, 2, 3, 8 threads; the HIP path 0.3 ... 2.8 times that) and the light-mass Naik
     multi-shift ladder on the same lattice (400 iterations, 3e-2).  Both quantities are single samples of a chaotic drift, so a
     bound below ~3 x the oracle's own reproducibility would test the oracle's luck, not the HIP path: there the bound is OVER = 4
@@ -76,7 +76,7 @@ def flush():
         return None
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    path = os.path.join(d, "r03_parity_devs.json")
+    path = os.path.join(d, "r04_parity_devs.json")
     with open(path, "w") as f:
         json.dump({"rule": "whole history < min(%g, max(%g, %g x CPU self-spread over thread counts)), or %g x that spread where the "
                            "CPU path deviates from itself by more than %g (flag cpu_spread_exceeds_cap); first 100 iterations < 1e-10"

@@ -1,0 +1,82 @@
+"""Real RCCL between DISTINCT GPUs: skipped on a one-GPU box, decisive on anything larger.
+
+The ranks are started by torch.distributed.run as fresh processes (nothing is re-exec'ed, this pytest process never hands
+its GPU state to them); every rank checks its t-slab of each result against the GLOBAL oracle result
+(tests/two_rank_worker.py).  Replaces shifts.nim:67-94,254-285 / qshifts.nim:51-131 (paired send/recv of the faces) and
+commsUtils.nim:195-204 (rank sums) -- the one part of the product a single-GPU box cannot exercise.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ngpu():
+    import torch
+
+    return torch.cuda.device_count()          # counts without initialising the GPU on this image
+
+
+def _launch(nranks, script_args, port, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+needs2 = pytest.mark.skipif(_ngpu() < 2, reason="needs two GPUs: real RCCL transport between distinct devices")
+
+
+@needs2
+@pytest.mark.parametrize("lat,overlap", [([8, 8, 8, 8], -1), ([8, 8, 8, 8], 1), ([16, 16, 16, 32], -1), ([16, 16, 16, 32], 1)])
+def test_two_ranks_against_the_global_oracle(lat, overlap):
+    """8^4 (slabs of 4 slices: Naik ghost depth 3 of 4) and 16^3 x 32; overlap = 1 forces the interior / boundary split with
+    the exchange on the second stream and its own communicator, -1 is the size-based default (one launch at these sizes)."""
+    p = _launch(2, [os.path.join(ROOT, "tests", "two_rank_worker.py")] + [str(v) for v in lat] + ["--overlap", str(overlap)], 29541)
+    ok = [ln for ln in p.stdout.splitlines() if ln.startswith("TWO_RANK_OK")]
+    assert p.returncode == 0 and len(ok) == 2, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    devs = {json.loads(ln.split(" ", 3)[3])["pci_bus"] for ln in ok}
+    assert len(devs) == 2, devs                                    # two distinct devices
+
+
+@needs2
+def test_four_ranks_against_the_global_oracle():
+    if _ngpu() < 4:
+        pytest.skip("needs four GPUs")
+    p = _launch(4, [os.path.join(ROOT, "tests", "two_rank_worker.py"), "8", "8", "8", "16", "--skip-gauge"], 29542)
+    assert p.returncode == 0 and sum(ln.startswith("TWO_RANK_OK") for ln in p.stdout.splitlines()) == 4, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+@needs2
+def test_bench_two_ranks_real_rccl():
+    """the driver's N = 2 launch line: self-verification green through real transport, and the line explains itself"""
+    p = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5", "--repeats", "2"], 29543, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    ln = json.loads([x for x in p.stdout.splitlines() if x.startswith("{")][-1])
+    assert "error" not in ln and ln["rccl_nranks"] == 2 and ln["shard_check"]["ok"] is True, ln.get("shard_check")
+    assert len({r["pci_bus"] for r in ln["ranks"]}) == 2
+    d = ln["multi_gpu"]
+    for k in ("interior_us", "boundary_us", "exchange_us", "allreduce_us", "comm_count", "overlap", "per_rank"):
+        assert k in d, k
+    leg = ln["cg_48x48x48x96"]
+    assert leg["shard_check"]["ok"] is True and "multi_gpu" in leg
+
+
+@pytest.mark.parametrize("lat,overlap", [([8, 8, 8, 8], 1), ([16, 16, 16, 32], -1)])
+def test_worker_script_one_rank_rehearsal(lat, overlap):
+    """The worker itself, run with ONE rank on the one GPU a test box has (sharded code path through a one-rank communicator):
+    so that the first time two GPUs are available, what can fail is the transport and not the script."""
+    p = _launch(1, [os.path.join(ROOT, "tests", "two_rank_worker.py")] + [str(v) for v in lat] + ["--overlap", str(overlap)], 29540)
+    assert p.returncode == 0 and sum(ln.startswith("TWO_RANK_OK") for ln in p.stdout.splitlines()) == 1, (p.stdout[-1500:], p.stderr[-3000:])
+
+
+def test_two_rank_tests_skip_cleanly_on_one_gpu():
+    """this file must never fail for lack of hardware: on one GPU the launches above are skipped, not attempted"""
+    assert _ngpu() >= 1
+    if _ngpu() < 2:
+        assert needs2.args[0] is True

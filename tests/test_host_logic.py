@@ -246,6 +246,11 @@ def test_bench_launch_path_two_ranks():
                 "dtype", "data", "config", "ranks"):
         assert key in ln, key
     assert ln["n_gpus"] == 2 and ln["dry_run"] is True and ln["value"] is None
+    # the self-diagnosing part of an N > 1 line: every key, max / min over the ranks, one entry per rank
+    mg = ln["multi_gpu"]
+    for k in ("interior_us", "boundary_us", "exchange_us", "allreduce_us", "comm_count", "overlap", "per_rank", "min_over_ranks"):
+        assert k in mg, k
+    assert mg["interior_us"] == 1.0 and mg["min_over_ranks"]["interior_us"] == 0.0 and sorted(r["rank"] for r in mg["per_rank"]) == [0, 1]
     assert sorted(r["rank"] for r in ln["ranks"]) == [0, 1]
 
 

@@ -1,0 +1,164 @@
+"""Worker of tests/test_gpu_two_ranks.py: one process per GPU, launched by torch.distributed.run BEFORE anything touches a
+GPU, real RCCL between two (or more) distinct devices.
+
+Every rank builds the same GLOBAL problem with the oracle (gauge field, sources), hands its t-slab to
+libqexhip -- context with rankGeom {1,1,1,N}, communicator from qexhip_comm_init -- and checks ITS slab of every result
+against the global oracle result:
+
+  stagD2 on the three subsets / D           <= 1e-13   (faces through ncclSend/ncclRecv, shifts.nim:67-94,254-285, qshifts.nim:51-131)
+  CG residual history (solveEE)             first 100 iterations 1e-10, iteration count +-1, solution 1e-6 (cg.nim:174-217:
+                                            both reductions end in a rank sum, commsUtils.nim:195-204)
+  Naik 3-mass multi-shift CG                the same bars, ghost depth 3
+  plaquettes, one Wilson-flow step          1e-13 / 1e-12 (ghost links refreshed per stage)
+  nHYP smearing + smeared gauge force       1e-11
+
+usage (by the test): python -m torch.distributed.run --nproc-per-node N two_rank_worker.py LX LY LZ LT [--overlap K]
+Exit status 0 and a line `TWO_RANK_OK rank r ...` per rank, non-zero on the first failed check.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SEED = 987654321
+
+
+def relerr(a, b):
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("lat", type=int, nargs=4)
+    ap.add_argument("--overlap", type=int, default=-1, help="option overlap of the context: -1 by size, 0 never, 1 always")
+    ap.add_argument("--skip-gauge", action="store_true", help="operator and solvers only")
+    args = ap.parse_args()
+    rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only (unique id, final barrier)
+    import qex_amd as q
+    from oracle import oracle as o
+
+    glat = list(args.lat)
+    olo = o.Layout(glat)
+    rf = o.RngField(olo, o.RNG_MILC6, SEED)
+    g0 = o.gauge_random(olo, rf)                                      # unphased: the gauge sector's input
+    g = g0.copy()
+    o.rephase(olo, g)
+    g3 = o.gauge_random(olo, rf)
+    o.rephase(olo, g3)
+    g3 *= 0.3
+    x, y = o.vector_gaussian(olo, rf), o.vector_gaussian(olo, rf)
+    loc, idx = q.Layout(glat).shard_indices(world, rank)
+    vh = loc.vol // 2
+
+    if world > 1:
+        ctx = q.Context(loc.lat, device=local_rank, rank_geom=(1, 1, 1, world), rank_coord=(0, 0, 0, rank))
+    else:
+        ctx = q.Context(loc.lat, device=local_rank)                    # one-GPU rehearsal of this script: the sharded code path ...
+    uid = [q.Context.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    ctx.comm_init(uid[0], world, rank)
+    if world == 1:
+        ctx.force_halo(True)                                           # ... ghost zones filled through a one-rank communicator,
+        ctx.set_option("multi_reduce", 1)                              # reductions through real (one-rank) all-reduces
+    info = ctx.comm_info()
+    assert info[0] == world and info[1] == rank, info                  # RCCL's own count and rank
+    if args.overlap >= 0:
+        ctx.set_option("overlap", args.overlap)
+    res = {"rank": rank, "device": info[2], "pci_bus": info[3], "comms": ctx.comm_count()}
+
+    def sl(a):
+        return np.ascontiguousarray(a[idx])
+
+    # ---- one-hop operator ----
+    s = q.newStag(ctx, sl(g))
+    worst = 0.0
+    for subset, par in (("even", 0), ("odd", 1), ("all", 2)):
+        for a, b in ((0.0, 0.0), (0.3, 0.7)):
+            ref = y.copy()
+            o.stagD2(olo, g, None, ref, x, par, a, b)
+            r = sl(y)
+            s.stagD2(r, sl(x), subset, a, b)
+            worst = max(worst, relerr(r, sl(ref)))
+    r = np.zeros_like(sl(x))
+    s.D(r, sl(x), 0.1)
+    worst = max(worst, relerr(r, sl(o.D(olo, g, None, x, 0.1))))
+    res["stagD2_D"] = worst
+    assert worst < 1e-13, worst
+
+    # ---- CG (solveEE): history, count, solution ----
+    sp = q.SolverParams(r2req=1e-12, maxits=5000, verbosity=0)
+    xs = np.zeros_like(sl(x))
+    s.solveEE(xs, sl(x), 0.1, sp, histcap=8192)
+    xr, its, fin, hist = o.solveXX(olo, g, None, x, 0.1, 1e-12, 5000, True, histcap=8192)
+    n = min(len(hist), len(sp.r2hist))
+    dev = np.abs(sp.r2hist[:n] / hist[:n] - 1)
+    res["cg"] = {"its": sp.iterations, "oracle_its": int(its), "dev100": float(dev[:100].max()), "dev_all": float(dev.max()),
+                 "x": relerr(xs[:vh], sl(xr)[:vh])}
+    assert abs(sp.iterations - its) <= 1 and res["cg"]["dev100"] < 1e-10 and res["cg"]["x"] < 1e-6, res["cg"]
+
+    # ---- Naik: stagD2 and the 3-mass multi-shift CG (ghost depth 3) ----
+    if loc.lat[3] >= 4:
+        s3 = q.newStag3(ctx, sl(g), sl(g3))
+        ref = y.copy()
+        o.stagD2(olo, g, g3, ref, x, 2, 0.3, 0.7)
+        r = sl(y)
+        s3.stagD2(r, sl(x), "all", 0.3, 0.7)
+        res["naik_stagD2"] = relerr(r, sl(ref))
+        assert res["naik_stagD2"] < 1e-13, res["naik_stagD2"]
+        masses = [0.1, 0.2, 0.4]
+        shifts = [masses[0]] + [4.0 * (m * m - masses[0] ** 2) for m in masses[1:]]      # stagSolve.nim:391-394
+        ys = [np.zeros_like(sl(x)) for _ in masses]
+        spm = q.SolverParams(r2req=1e-12, maxits=5000, verbosity=0)
+        s3.solveXX_multi(ys, sl(x), shifts, spm, histcap=8192)
+        yr, mits, mhist = o.solveXX_multi(olo, g, g3, x, shifts, 1e-12, 5000, True, histcap=8192)
+        n = min(len(mhist), len(spm.r2hist))
+        dev = np.abs(spm.r2hist[:n] / mhist[:n] - 1)
+        res["naik_multishift"] = {"its": spm.iterations, "oracle_its": int(mits), "dev100": float(dev[:100].max()),
+                                  "x": max(relerr(a[:vh], sl(b)[:vh]) for a, b in zip(ys, yr))}
+        assert abs(spm.iterations - mits) <= 1 and res["naik_multishift"]["dev100"] < 1e-10 and res["naik_multishift"]["x"] < 1e-6, res["naik_multishift"]
+
+    # ---- gauge sector: plaquettes, one flow step, nHYP smear + smeared gauge force ----
+    if not args.skip_gauge:
+        pl = q.plaq(ctx, sl(g0))
+        res["plaq"] = float(np.abs(pl - o.plaq(olo, g0)).max())
+        assert res["plaq"] < 1e-13, res["plaq"]
+        gf = sl(g0)
+        q.gaugeFlow(ctx, gf, 1, 0.01)
+        gr = g0.copy()
+        o.wflow(olo, gr, 1, 0.01)
+        res["wflow_links"] = relerr(gf, sl(gr))
+        res["wflow_plaq"] = float(np.abs(q.plaq(ctx) - o.plaq(olo, gr)).max())
+        assert res["wflow_links"] < 1e-12 and res["wflow_plaq"] < 1e-13, res
+        gw = o.gauge_warm(olo, 0.5, rf)
+        sg = np.zeros_like(sl(gw))
+        sf = q.HypCoefs(0.4, 0.5, 0.5).smearGetForce(ctx, sl(gw), sg)
+        sgr = o.nhyp_smear(olo, gw, 0.4, 0.5, 0.5)
+        sgr = sgr[0] if isinstance(sgr, tuple) else sgr
+        res["nhyp_smear"] = relerr(sg, sl(sgr))
+        f = np.zeros_like(sg)
+        sf.gforce(f, plaq=1.0)
+        chain = o.gauge_deriv_general(olo, sgr, 1.0, 0.0, 0)
+        _, fr = o.nhyp_force(olo, gw, chain, 0.4, 0.5, 0.5)
+        o.force_projTAH(olo, fr, gw, adj=True)
+        res["nhyp_gforce"] = relerr(f, sl(fr))
+        sf.release()
+        assert res["nhyp_smear"] < 1e-12 and res["nhyp_gforce"] < 1e-11, res
+
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("TWO_RANK_OK rank %d %s" % (rank, json.dumps(res)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
