@@ -158,3 +158,71 @@ def test_config4_rank_share_48x12_properties():
     assert abs(sols["periodic"][1] - sols["halo"][1]) <= 2
     for k in range(len(masses)):
         assert relerr(sols["halo"][0][k], sols["periodic"][0][k]) < 1e-7, k
+
+
+def test_config4_rank_share_48x12_trajectory_pieces():
+    """The rest of one rank's share of BASELINE configs[4] (an nHYP-smeared stagg_pv_hmc trajectory on 48^3 x 96 over 8 GPUs =
+    a 48^3 x 12 slab with ghost zones): nHYP smearing with its closure, the smeared-force chain, the gauge and the fermion MD
+    force (hypsmear.nim:145-247, staghmc_spv.nim:716-868), the HISQ link build and its force -- every kernel in its sharded
+    form (forced ghost zones, faces through the exchange path) against the periodic kernels on the same slab wrapped onto
+    itself: identical to rounding (1e-15).  No CPU reference at this size, so the chain is ALSO held to its definition on the
+    sharded path: d Re tr(C^+ V(U)) = Re tr(dU^+ F) for single-link perturbations on both boundary slices."""
+    import qex_amd as q
+
+    lat = [48, 48, 48, 12]
+    lo = q.Layout(lat)
+    rf = q.RngField(lat, q.RngMilc6, SEED)
+    g = rf.warm(0.5)
+    gp = g.copy()
+    q.rephase(lo, gp)
+    rng = np.random.default_rng(11)
+    Cf = rng.standard_normal(g.shape)
+    psis = [rf.gaussian_vector(), rf.gaussian_vector()]
+    hc = q.HypCoefs(0.4, 0.5, 0.5)
+    res = {}
+    for mode in ("periodic", "halo"):
+        ctx = q.Context(lat)
+        if mode == "halo":
+            ctx.force_halo(True)
+        r = {}
+        sg = np.zeros_like(g)
+        sf = hc.smearGetForce(ctx, g, sg)
+        r["nhyp_links"] = sg
+        f = np.zeros_like(g)
+        sf(f, Cf)
+        r["chain"] = f.copy()
+        sf.gforce(f, plaq=1.0)
+        r["gforce"] = f.copy()
+        sf.fforce(f, psis, [0.37, -1.9], bc="aaaa")
+        r["fforce"] = f.copy()
+        if mode == "halo":
+            # the chain is the gradient, on the sharded kernels: one link on the first and one on the last local t-slice
+            S = lambda gg: float((Cf * _nhyp(q, hc, ctx, gg)).sum())
+            for t in (0, lat[3] - 1):
+                i = int(lo.index([5, 7, 11, t]))
+                d = np.zeros((3, 3, 2))
+                d[:] = 1e-5 * rng.standard_normal((3, 3, 2))
+                gpl, gmi = g.copy(), g.copy()
+                gpl[i, 3] += d
+                gmi[i, 3] -= d
+                num, ana = (S(gpl) - S(gmi)) / 2, float((d * r["chain"][i, 3]).sum())
+                assert abs(num - ana) < 1e-6 * abs(ana), (t, num, ana)
+                del gpl, gmi
+        sf.release()
+        fl, ll = np.zeros_like(g), np.zeros_like(g)
+        q.HisqCoefs().init().smear(ctx, gp, fl, ll)
+        r["hisq_fat"], r["hisq_long"] = fl, ll
+        r["hisq_force"] = q.HisqCoefs().init().force(ctx, gp, Cf, 0.5 * Cf)
+        ctx.close()
+        if mode == "periodic":
+            res = r
+            continue
+        for k in sorted(res):
+            a, b = res.pop(k), r.pop(k)
+            assert np.linalg.norm((a - b).ravel()) <= 1e-15 * np.linalg.norm(a.ravel()), k
+
+
+def _nhyp(q, hc, ctx, g):
+    sg = np.zeros_like(g)
+    hc.smear(ctx, g, sg)
+    return sg
