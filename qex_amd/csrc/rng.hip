@@ -151,7 +151,14 @@ struct qexhip_rng : RngField {};
 extern "C" int qexhip_rng_new(qexhip_rng **out, int kind, unsigned long long seed, const int lat[4], const int glat[4], int t_offset) {
   if (!out || !lat || kind < 0 || kind > 1) return QEXHIP_ERR_ARG;
   const int *G = glat ? glat : lat;
-  auto *R = new qexhip_rng();
+  for (int i = 0; i < 4; i++)
+    if (lat[i] < 2 || (lat[i] & 1) || lat[i] > 1024 || G[i] < lat[i] || (i < 3 && G[i] != lat[i])) {
+      qexhip_set_error("rng_new: local extents must be even, 2..1024, and equal the global ones except in t (dim %d: local %d, global %d)", i, lat[i], G[i]);
+      return QEXHIP_ERR_ARG;
+    }
+  if (t_offset < 0 || t_offset + lat[3] > G[3]) { qexhip_set_error("rng_new: slab [%d, %d) outside the global t extent %d", t_offset, t_offset + lat[3], G[3]); return QEXHIP_ERR_ARG; }
+  auto *R = new (std::nothrow) qexhip_rng();
+  if (!R) return QEXHIP_ERR_ARG;
   R->kind = kind;
   for (int i = 0; i < 4; i++) R->lat[i] = lat[i];
   R->vol = (size_t)lat[0] * lat[1] * lat[2] * lat[3];

@@ -164,6 +164,15 @@ int main() {
     hipDdag(r, x, 0.1);
     qo_Ddag(lo, g.data(), nullptr, ref.data(), x.data(), 0.1);
     CHECK(relerr(r, ref) < 1e-13, "hipDdag: %g", relerr(r, ref));
+    // hipEoReduce / hipEoReconstruct (stagD.nim:575-586): r is read and written (the other parity is kept)
+    Buf e = y, eref = y;
+    CHK(qexhip_stag_eo_reduce(h, e.data(), x.data(), 0.1));
+    qo_eoReduce(lo, g.data(), nullptr, eref.data(), x.data(), 0.1);
+    CHECK(relerr(e, eref) < 1e-13, "hipEoReduce: %g", relerr(e, eref));
+    e = y; eref = y;
+    CHK(qexhip_stag_eo_reconstruct(h, e.data(), x.data(), 0.1));
+    qo_eoReconstruct(lo, g.data(), nullptr, eref.data(), x.data(), 0.1);
+    CHECK(relerr(e, eref) < 1e-13, "hipEoReconstruct: %g", relerr(e, eref));
   }
   // ---- hipSolveEE / hipSolveOO / hipSolve ----
   for (int pe = 1; pe >= 0; pe--) {
