@@ -8,6 +8,7 @@
 // all lanes agree), which keeps the host out of the iteration loop.
 #include "qexhip_internal.h"
 #include "reduce.h"
+#include "cg_device.h"
 
 static inline int grid_for(size_t n2) {
   size_t nb = (n2 + 255) / 256;
@@ -70,6 +71,8 @@ __global__ void __launch_bounds__(256) k_reduce_final(const double *partials, in
   double r = block_sum_256(acc);
   if (threadIdx.x == 0) *out = r;
 }
+
+int blas_grid(const qexhip_ctx *c, int) { return grid_for(body2(c)); }   // workgroups (= partial sums) of the CG's BLAS kernels
 
 int blas_zero(qexhip_ctx *c, DevField &f, int parity) {
   size_t n = body2(c);
@@ -155,26 +158,6 @@ int read_scalars(qexhip_ctx *c, const double *dev, int n, double *host) {
 // next k_cg_xpay that slot k&1 is already written).
 // Sharded, the partial VECTORS are all-reduced (a few KB: the same latency as one double), which keeps the two one-block
 // reduction launches out of the iteration as well.
-__device__ __forceinline__ double cg_sum_parts(const double *parts, int n) {
-  double a = 0;
-  for (int i = threadIdx.x; i < n; i += 256) a += parts[i];
-  return block_sum_256_all(a);
-}
-__device__ __forceinline__ void cg_roll(CgScal *s, int k, double r2k, double *hist, int histcap) {
-  const int cur = k & 1;
-  s->r2s[cur] = r2k;
-  s->itns[cur] = k;
-  s->dones[cur] = !(k < s->maxits && r2k > s->r2stop);
-  if (k < histcap) hist[k] = r2k / s->b2;
-  s->agree[0] = r2k; s->agree[1] = -r2k; s->agree[2] = (double)k; s->agree[3] = -(double)k;
-}
-__device__ __forceinline__ void cg_carry(CgScal *s, int k) {   // finished earlier: carry the final state forward
-  const int cur = k & 1, prv = cur ^ 1;
-  s->r2s[cur] = s->r2s[prv];
-  s->itns[cur] = s->itns[prv];
-  s->dones[cur] = 1;
-  s->agree[0] = s->r2s[prv]; s->agree[1] = -s->r2s[prv]; s->agree[2] = (double)s->itns[prv]; s->agree[3] = -(double)s->itns[prv];
-}
 // q := z (itn 0) | q := z + beta*q, beta = rz/rzo   (cg.nim:186-193; cpNone: z=r, q=p)
 __global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, size_t n, CgScal *s, int k, int rolled,
                                                 const double *r2parts, int nparts, double *hist, int histcap) {
@@ -199,7 +182,7 @@ __global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, s
     if (first) p[i] = rv;
     else {
       double2 pv = p[i];
-      p[i] = make_double2(rv.x + beta * pv.x, rv.y + beta * pv.y);
+      p[i] = make_double2(fma(beta, pv.x, rv.x), fma(beta, pv.y, rv.y));   // explicit fma (what the compiler contracted this to anyway)
     }
   }
 }

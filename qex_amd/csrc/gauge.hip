@@ -231,6 +231,16 @@ __device__ __forceinline__ M3 link_lds_or_global(const Geom &g, const double2 *_
   if ((cs >> 6) == tile) return m3_load(smq + (size_t)(2 * a + slot) * 576 + (cs & 63), 64);
   return m3_load(G + link_off_t<HALO>(g, gs, a), 64);
 }
+// the same choice as an ADDRESS (generic pointer: the flat load that follows serves either aperture): one load sequence per
+// operand instead of a divergent branch around two, which is what keeps k_flow_obs_clover2 inside its register budget
+template <bool HALO>
+__device__ __forceinline__ const double2 *link_ptr_lds_or_global(const Geom &g, const double2 *__restrict__ G, const double2 *smq, int tile,
+                                                                 const int s[4], int a, int slot, const int gs[4]) {
+  const int cs = site_cidx<HALO>(g, s);
+  const double2 *pl = smq + (size_t)(2 * a + slot) * 576 + (cs & 63);
+  const double2 *pg = G + link_off_t<HALO>(g, gs, a);
+  return (cs >> 6) == tile ? pl : pg;
+}
 template <bool CLOSED, bool HALO>
 __global__ void __launch_bounds__(512) k_force_lds2(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
                                                     double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk) {
@@ -499,6 +509,128 @@ __global__ void __launch_bounds__(384, 3) k_flow_obs_clover(Geom g, const double
     partials[(size_t)(3 + ip) * gridDim.x + blockIdx.x] = red[3][wv];
   }
 }
+// k_flow_obs_clover over BOTH parities of a tile position in one workgroup (12 wavefronts: parity x plane), as k_force_lds2:
+// the two tiles are the same 128 consecutive lattice sites (whole x rows), so every operand of a leaf that sits one hop in
+// x -- and in y for three rows of four -- from the lane's site is a link the OTHER parity group already holds in LDS:
+// U_d(s) = slot 0 of site s, U_d(s - d) = slot 1.  All eight gathered operands of a plane can be named that way through a
+// one-hop neighbour (x+-a or x+-b); on a 32-wide lattice 21 of the 48 per site then come from LDS: 27 + 8 global matrix loads
+// per site instead of 48 + 8.  Same products in the same order as k_flow_obs_clover: bit-identical F, E, Q, plaquettes.
+template <bool HALO>
+__global__ void __launch_bounds__(768) k_flow_obs_clover2(Geom g, const double2 *__restrict__ G, double *partials,
+                                                             const int *order, int chunk) {
+  extern __shared__ double2 smO[];                    // [parity][2 mu + (0: U_mu(x) | 1: U_mu(x-mu))][9][64], later F[parity][plane][9][64]
+  __shared__ double red[4][12];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pgrp = wv / 6, w = wv - 6 * pgrp;         // parity group, plane
+  const int slot0 = (blockIdx.x & 7) * chunk + 2 * (blockIdx.x >> 3);   // the table holds (tile,0),(tile,1) adjacent
+  double es = 0, et = 0, q = 0, pl = 0;
+  if (order[slot0] >= 0) {                            // padding pair: the whole workgroup together
+    const int e = order[slot0 + pgrp];
+    const int p = e & 1, tile = e >> 1;
+    const int c0 = tile * 64 + lane;
+    const bool live = c0 < g.Vh;
+    const int c = live ? c0 : g.Vh - 1;
+    int x[4], xma[4], xmb[4], xpa[4], xpb[4], z[4];
+    coords_of(g, c, p, x);
+    double2 *smp = smO + (size_t)p * 8 * 576;
+    const double2 *smq = smO + (size_t)(1 - p) * 8 * 576;
+    for (int id = w; id < 8; id += 6) {
+      const int mu = id >> 1;
+      shifted_dyn<HALO>(g, x, mu, (id & 1) ? -1 : 0, z);
+      const M3 m = m3_load(G + link_off_t<HALO>(g, z, mu), 64);
+      double2 *d = smp + (size_t)id * 576 + lane;
+#pragma unroll
+      for (int k = 0; k < 9; k++) d[k * 64] = m.e[k];
+    }
+    __syncthreads();
+    const int a = (w & 1) ? 3 : (w == 0 ? 1 : 2);     // planes (1,0) (3,2) (2,0) (3,1) (2,1) (3,0)
+    const int b = (w == 0 || w == 2 || w == 5) ? 0 : (w == 1 ? 2 : 1);
+    const double2 *Ua = smp + (size_t)(2 * a) * 576 + lane, *Ub = smp + (size_t)(2 * b) * 576 + lane;
+    shifted_dyn<HALO>(g, x, a, -1, xma);
+    shifted_dyn<HALO>(g, x, b, -1, xmb);
+    shifted_dyn<HALO>(g, x, a, 1, xpa);
+    shifted_dyn<HALO>(g, x, b, 1, xpb);
+    M3 acc = m3_zero();
+    {                                                 // {-a,-b,a,b}: U_a(x-a)^+ U_b(x-a-b)^+ U_a(x-a-b) U_b(x-b)
+      M3 m = m3_adj(m3_load(Ua + 576, 64));
+      shifted_dyn<HALO>(g, xma, b, -1, z);
+      m = m3_mul_na(m, m3_load(link_ptr_lds_or_global<HALO>(g, G, smq, tile, xma, b, 1, z), 64));     // U_b(x-a-b) = slot 1 of site x-a
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul(m, m3_load(link_ptr_lds_or_global<HALO>(g, G, smq, tile, xmb, a, 1, z), 64));        // U_a(x-a-b) = slot 1 of site x-b
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul(m, m3_load(Ub + 576, 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m3_axpy(acc, 0.25, m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {                                                 // {-b,a,b,-a}: U_b(x-b)^+ U_a(x-b) U_b(x-b+a) U_a(x)^+
+      M3 m = m3_adj(m3_load(Ub + 576, 64));
+      shifted_dyn<HALO>(g, xmb, a, 1, z);
+      m = m3_mul(m, m3_load(link_ptr_lds_or_global<HALO>(g, G, smq, tile, xmb, a, 0, xmb), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul(m, m3_load(link_ptr_lds_or_global<HALO>(g, G, smq, tile, xpa, b, 1, z), 64));        // U_b(x+a-b) = slot 1 of site x+a
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul_na(m, m3_load(Ua, 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m3_axpy(acc, 0.25, m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {                                                 // {a,b,-a,-b}: U_a(x) U_b(x+a) U_a(x+b)^+ U_b(x)^+
+      M3 m = m3_load(Ua, 64);
+      m = m3_mul(m, m3_load(link_ptr_lds_or_global<HALO>(g, G, smq, tile, xpa, b, 0, xpa), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul_na(m, m3_load(link_ptr_lds_or_global<HALO>(g, G, smq, tile, xpb, a, 0, xpb), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul_na(m, m3_load(Ub, 64));
+      __builtin_amdgcn_sched_barrier(0);
+      if (live) pl = m.e[0].x + m.e[4].x + m.e[8].x;  // this leaf is the plaquette of plaq (gaugeUtils.nim:213-282)
+      m3_axpy(acc, 0.25, m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {                                                 // {b,-a,-b,a}: U_b(x) U_a(x+b-a)^+ U_b(x-a)^+ U_a(x-a)
+      M3 m = m3_load(Ub, 64);
+      shifted_dyn<HALO>(g, xpb, a, -1, z);
+      m = m3_mul_na(m, m3_load(link_ptr_lds_or_global<HALO>(g, G, smq, tile, xpb, a, 1, z), 64));     // U_a(x+b-a) = slot 1 of site x+b
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul_na(m, m3_load(link_ptr_lds_or_global<HALO>(g, G, smq, tile, xma, b, 0, xma), 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m = m3_mul(m, m3_load(Ua + 576, 64));
+      __builtin_amdgcn_sched_barrier(0);
+      m3_axpy(acc, 0.25, m);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const M3 F = m3_tah(acc);
+    const double ff = m3_retr_mul(F, F);
+    __syncthreads();                                  // every wavefront is done with the links
+    {
+      double2 *d = smO + (size_t)wv * 576 + lane;
+#pragma unroll
+      for (int k = 0; k < 9; k++) d[k * 64] = F.e[k];
+    }
+    __syncthreads();
+    if (live) {
+      if (w & 1) et = ff;                             // the partner of a pair always has mu = 3
+      else {
+        es = ff;
+        const M3 fb = m3_load(smO + (size_t)(wv + 1) * 576 + lane, 64);
+        q = (w == 2 ? -1.0 : 1.0) * m3_retr_mul(F, fb);   // Q = -(1/4pi^2) (F10 F32 - F20 F31 + F21 F30)
+      }
+    }
+  }
+  es = wave_sum(es); et = wave_sum(et); q = wave_sum(q); pl = wave_sum(pl);
+  if (lane == 0) { red[0][wv] = es; red[1][wv] = et; red[2][wv] = q; red[3][wv] = pl; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const double *r = red[threadIdx.x];
+    partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+        (((r[0] + r[1]) + (r[2] + r[3])) + (r[4] + r[5])) + (((r[6] + r[7]) + (r[8] + r[9])) + (r[10] + r[11]));
+  } else if (threadIdx.x < 9) {
+    // planes of wavefronts 0..5: (1,0) (3,2) (2,0) (3,1) (2,1) (3,0) -> plaq's index mu (mu - 1) / 2 + nu: 0 5 1 4 2 3
+    const int k = threadIdx.x - 3;
+    const int ip = k == 0 ? 0 : (k == 1 ? 5 : (k == 2 ? 1 : (k == 3 ? 4 : (k == 4 ? 2 : 3))));
+    partials[(size_t)(3 + ip) * gridDim.x + blockIdx.x] = red[3][k] + red[3][k + 6];
+  }
+}
 __global__ void __launch_bounds__(256) k_obs_final(const double *partials, int nb, double vol, double *out) {
   const int k = blockIdx.x;                    // one workgroup per observable
   double acc = 0;
@@ -579,10 +711,22 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3], double *plaq6) {
       HIPCHK(hipFuncSetAttribute((const void *)k_flow_obs_clover<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb));
       c->lds_attr_done |= 2;
     }
-    nb = 8 * chunk;                                   // one workgroup per tile
     ScopedTimer tm(c, "flowobs", c->stream);
-    if (c->g.halo) k_flow_obs_clover<true><<<nb, 384, shb, c->stream>>>(c->g, c->gn->U, part, order, chunk);
-    else k_flow_obs_clover<false><<<nb, 384, shb, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+    if (c->opt_force_pair && c->tile_pairs_ok) {
+      // both parities of a tile position per workgroup: 144 KiB of LDS, one workgroup of 12 wavefronts per CU
+      if (!(c->lds_attr_done & 4)) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_flow_obs_clover2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * shb)));
+        HIPCHK(hipFuncSetAttribute((const void *)k_flow_obs_clover2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * shb)));
+        c->lds_attr_done |= 4;
+      }
+      nb = 4 * chunk;                                 // one workgroup per tile position
+      if (c->g.halo) k_flow_obs_clover2<true><<<nb, 768, 2 * shb, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+      else k_flow_obs_clover2<false><<<nb, 768, 2 * shb, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+    } else {
+      nb = 8 * chunk;                                 // one workgroup per tile
+      if (c->g.halo) k_flow_obs_clover<true><<<nb, 384, shb, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+      else k_flow_obs_clover<false><<<nb, 384, shb, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+    }
     HIPCHK(hipGetLastError());
   } else {
     ScopedTimer tm(c, "flowobs", c->stream);

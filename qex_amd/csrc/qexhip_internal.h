@@ -68,6 +68,8 @@ struct TimerSlot {
 
 struct GaugeNat;  // natural-layout gauge field for plaquette / flow (gauge.hip)
 
+enum { WK_SLOTS = 16 };   // >= WK_N (below)
+
 struct qexhip_ctx {
   int device = 0;
   Geom g{};
@@ -94,7 +96,7 @@ struct qexhip_ctx {
   double *hist = nullptr; int histcap = 0;           // device residual history
   void *pinned = nullptr;                            // pinned host scratch (4 KiB)
   // work vectors (lazily allocated, like the {.global.} temp of stagD.nim:437-442)
-  int wk[12]{0};
+  int wk[WK_SLOTS]{0};
   // timers
   int timers_on = 0;
   std::map<std::string, TimerSlot> timers;

@@ -111,14 +111,17 @@ int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2
   int chunk = 32, k = 0, rolled = 1;              // k_cg_init wrote slot 0
   bool done = st.dones[0];
   double r2 = st.r2s[0];
+  // (Round 4 tried forming p = r + beta p inside the first sweep -- every output site builds it for its eight neighbours, one of
+  // them stores it -- to drop k_cg_xpay and a launch boundary: the sweep grew by 17 us, the iteration did not move (267.9 vs
+  // 267.6 us, profiles/r04_cg_fuse_ab.log), so the separate launch stays.)
   while (!done) {
     int n = std::min(chunk, st.maxits - k);
     if (n <= 0) break;
     for (int i = 0; i < n; i++, k++) {
       CHK(cg_xpay(c, *p, *r, par, k, rolled));                        // cg.nim:186-193 (+ bookkeeping of k-1)
       rolled = 0;
-      int ndot = 0;                                                   // <p,Ap> partials are summed inside
-      CHK(op_xx(c, *Ap, *p, m2, par_even, 1, &c->cg->dones[k & 1], &ndot));   // cg_update; cg.nim:200, qLAp :206
+      int ndot = 0;                                                   // <p,Ap> partials are summed inside cg_update
+      CHK(op_xx(c, *Ap, *p, m2, par_even, 1, &c->cg->dones[k & 1], &ndot));   // cg.nim:200, qLAp :206
       CHK(cg_update(c, x, *r, *p, *Ap, par, k, ndot));                // cg.nim:208-213
     }
     CHK(cg_close(c, k));

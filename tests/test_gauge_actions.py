@@ -154,10 +154,16 @@ def test_gpu_gauge_sector_on_the_sharded_path(oracle):
     # come from LDS) against one tile per workgroup (k_force_lds): the same products in the same order, so bit for bit
     ga, gb, gc = g.copy(), g.copy(), g.copy()
     fa = q.gaugeForce(A, g, cplaq=1.0)
+    ma, mb = q.flowMeasure(A, g), q.flowMeasure(B, g)           # clover E, Q + plaquettes, paired kernel (k_flow_obs_clover2)
     q.gaugeFlow(A, ga, 2, 0.01)
     for X in (A, B):
         X.set_option("force_pair", 0)
     assert np.array_equal(fa, q.gaugeForce(A, g, cplaq=1.0)) and np.array_equal(fa, q.gaugeForce(B, g, cplaq=1.0))
+    # ... and the one-tile clover kernel: same leaves in the same order, only the workgroup partials are grouped differently
+    for m2 in (q.flowMeasure(A, g), q.flowMeasure(B, g)):
+        for m1 in (ma, mb):
+            assert np.abs(np.asarray(m1[0]) - np.asarray(m2[0])).max() < 1e-15 and np.allclose(m1[1], m2[1], rtol=1e-13, atol=1e-13)
+    assert np.abs(np.asarray(ma[0]) - o.plaq(lo, g)).max() < 1e-14 and np.allclose(ma[1], o.flow_EQ(lo, g, 1), rtol=1e-11, atol=1e-12)
     q.gaugeFlow(A, gb, 2, 0.01)
     q.gaugeFlow(B, gc, 2, 0.01)
     for X in (A, B):
