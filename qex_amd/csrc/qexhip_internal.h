@@ -123,7 +123,7 @@ struct qexhip_ctx {
   int *tile_order_pl[16]{};                          // the same for kernels that shift in the (mu, nu) plane only (layout.hip)
   void *obs_table = nullptr;                         // ObsTable of gauge_flow_obs (gauge.hip)
   void *batch = nullptr;                             // BatchState of the lock-step multi-system CG (batch.hip)
-  int lds_attr_done = 0;                             // per context (= per device): which kernels had MaxDynamicSharedMemorySize raised (bit 0 k_force_lds, 1 k_flow_obs_clover, 3 k_force_lds2)
+  int lds_attr_done = 0;                             // per context (= per device): which kernels had MaxDynamicSharedMemorySize raised (bit 0 k_force_lds, 1 k_flow_obs_clover, 2 k_flow_obs_clover2, 3 k_force_lds2, 4 k_projUderiv_batch)
   void *cgm_scal = nullptr;                          // CgmScal of the multi-shift solver (multishift.hip)
 };
 

@@ -270,6 +270,39 @@ __device__ __forceinline__ M3 m3_projectUderiv(const M3 &x, const M3 &chain) {
   for (int k = 0; k < 9; k++) r.e[k] = csub(r.e[k], xt.e[k]);
   return r;
 }
+// the same with x parked in LDS (xl: this lane's column, stride 64): x is needed at the start (z, u) and for the very last
+// product only, and 36 VGPRs is what separates the function from two wavefronts per SIMD
+__device__ __forceinline__ M3 m3_projectUderiv_parked(const double2 *xl, const M3 &chain) {
+  M3 z, u;
+  {
+    const M3 x = m3_load(xl, 64);
+    z = m3_rsqrt_xdx(x);
+    u = m3_mul(x, z);
+  }
+  const double2 *q = z.e;
+  const double2 det0 = cm2(q[0], q[4], q[1], q[3]), det1 = cm2(q[2], q[3], q[0], q[5]), det2 = cm2(q[1], q[5], q[2], q[4]);
+  const double2 idet = cinv(cadd(cadd(cmul(det0, q[8]), cmul(det1, q[7])), cmul(det2, q[6])));
+  M3 y, ady;
+  y.e[0] = cmul(idet, cm2(q[4], q[8], q[5], q[7])); y.e[1] = cmul(idet, cm2(q[7], q[2], q[8], q[1])); y.e[2] = cmul(idet, det2);
+  y.e[3] = cmul(idet, cm2(q[5], q[6], q[3], q[8])); y.e[4] = cmul(idet, cm2(q[8], q[0], q[6], q[2])); y.e[5] = cmul(idet, det1);
+  y.e[6] = cmul(idet, cm2(q[3], q[7], q[4], q[6])); y.e[7] = cmul(idet, cm2(q[6], q[1], q[7], q[0])); y.e[8] = cmul(idet, det0);
+#pragma unroll
+  for (int k = 0; k < 9; k++) ady.e[k] = cmul(idet, z.e[k]);
+  M3 r = m3_mul(chain, z);
+  const M3 t1 = m3_mul_an(u, r);
+  M3 ch;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      ch.e[3 * i + j] = make_double2(t1.e[3 * i + j].x + t1.e[3 * j + i].x, t1.e[3 * i + j].y - t1.e[3 * j + i].y);
+  const M3 t2 = m3_sylsolve_herm(y, ady, ch);
+  __builtin_amdgcn_sched_barrier(0);
+  const M3 xt = m3_mul(m3_load(xl, 64), t2);
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.e[k] = csub(r.e[k], xt.e[k]);
+  return r;
+}
 // r = projectUderiv(U or projectU(X), X, C);  f (=|+=) ma * r;  dst = alp * r      (dst may alias C)
 // -- the projection's chain rule fused with the bookkeeping that follows it at every level
 // (hypsmear.nim:166-173,196-205,224-233: `f[mu] += ma*fl; fl *= alp`)
@@ -302,34 +335,46 @@ struct ProjBatch {
   MViewW dst[4][3];
   MView X[4][3], C[4][3];
   MViewW f[4];
-  int nn, accumulate, nt;
+  int nn, accumulate;
   double ma, alp;
 };
-// (Round 3: prefetching the operands of constituent j + 1 by LDS-DMA into 18 KiB of LDS per wavefront while constituent j is
-// worked on changed nothing -- chain 11.64-11.76 ms with and without, A/B on one GPU -- and was removed again.)
-__global__ void __launch_bounds__(256) k_projUderiv_batch(Geom g, ProjBatch B) {
+// The accumulator o and the operand x of a lane are PARKED in LDS (2 x 9 KiB per wavefront, 72 KiB per workgroup): x is
+// needed at the start (rsqrt, projection) and for the very last product only, o once per constituent, and their 72 VGPRs are
+// what separates the function (256 + 56 registers with everything live) from two wavefronts per SIMD.  Round 4, A/B on
+// one GPU (profiles/r04_projuderiv_parked_ab.log): chain 11.64-11.71 ms -> 10.90-10.92; capping the registers at 256
+// instead (55 spilled to scratch) made it 12.2-12.3.  (Round 3: prefetching the operands of constituent j + 1 by LDS-DMA
+// changed nothing and was removed again.)
+__global__ void __launch_bounds__(256, 2) k_projUderiv_batch(Geom g, ProjBatch B) {
+  extern __shared__ double2 smPB[];                 // [wavefront][o | x][9][64]
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= g.V) return;
   const int mu = blockIdx.y;
   const int p = i >= g.Vh, c = i - p * g.Vh;
   const size_t t = (size_t)p * g.etile + (c >> 6);
   const int l = c & 63;
+  double2 *ol = smPB + (size_t)(threadIdx.x >> 6) * 2 * 576 + l, *xl = ol + 576;
   const MViewW f = B.f[mu];
-  const int nt = B.nt;
-  M3 o = B.accumulate ? (nt ? m3_load_nt(f.p + t * f.tstride + l, 64) : m3_load(f.p + t * f.tstride + l, 64)) : m3_zero();
+  {
+    const M3 o = B.accumulate ? m3_load_nt(f.p + t * f.tstride + l, 64) : m3_zero();
+    m3_store(ol, 64, o);
+  }
 #pragma unroll 1
   for (int j = 0; j < B.nn; j++) {
     const MView X = B.X[mu][j], C = B.C[mu][j];
     const MViewW dst = B.dst[mu][j];
-    const M3 x = nt ? m3_load_nt(X.p + t * X.tstride + l, 64) : m3_load(X.p + t * X.tstride + l, 64);
-    const M3 ch = nt ? m3_load_nt(C.p + t * C.tstride + l, 64) : m3_load(C.p + t * C.tstride + l, 64);
-    M3 r = m3_projectUderiv(x, ch);
-    m3_axpy(o, B.ma, r);
+    m3_store(xl, 64, m3_load_nt(X.p + t * X.tstride + l, 64));
+    const M3 ch = m3_load_nt(C.p + t * C.tstride + l, 64);
+    M3 r = m3_projectUderiv_parked(xl, ch);
+    {
+      M3 o = m3_load(ol, 64);
+      m3_axpy(o, B.ma, r);
+      m3_store(ol, 64, o);
+    }
 #pragma unroll
     for (int k = 0; k < 9; k++) { r.e[k].x *= B.alp; r.e[k].y *= B.alp; }
-    if (nt) m3_store_nt(dst.p + t * dst.tstride + l, 64, r); else m3_store(dst.p + t * dst.tstride + l, 64, r);
+    m3_store_nt(dst.p + t * dst.tstride + l, 64, r);
   }
-  if (nt) m3_store_nt(f.p + t * f.tstride + l, 64, o); else m3_store(f.p + t * f.tstride + l, 64, o);
+  m3_store_nt(f.p + t * f.tstride + l, 64, m3_load(ol, 64));
 }
 // symStapleDeriv (smearutil.nim:22-50) gathered per site:
 //   f1(x) += g2(x) g1(x+mu) c(x+nu)^+ + c(x) g1(x+mu) g2(x+nu)^+ + [g2^+ g1 c(+nu) + c^+ g1 g2(+nu)](x-mu)
@@ -916,16 +961,20 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
   ScopedTimer tm(c, "nhyp_force", c->stream);
   // fl1 / fl2 are sums of several staple derivatives: the first contribution to each writes, the rest accumulate
   bool t1[4][4] = {}, t2[4][4] = {};
+  if (!(c->lds_attr_done & 16)) {
+    HIPCHK(hipFuncSetAttribute((const void *)k_projUderiv_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
+    c->lds_attr_done |= 16;
+  }
+#define QX_PB_LAUNCH k_projUderiv_batch<<<dim3(nblk, 4), 256, 73728, c->stream>>>(g, PB)
   // the projectUderiv calls of one level in ONE launch (k_projUderiv_batch: grid.y = direction, up to three fields each)
   ProjBatch PB;
-  PB.nt = 1;
   {
     for (int mu = 0; mu < 4; mu++) {
       PB.dst[mu][0] = S.gvw(st->fc, mu); PB.X[mu][0] = S.gv(st->K.flx, mu); PB.C[mu][0] = S.gv(st->F, mu);
       PB.f[mu] = S.gvw(st->F, mu);
     }
     PB.nn = 1; PB.accumulate = 0; PB.ma = ma3; PB.alp = alp3;
-    k_projUderiv_batch<<<dim3(nblk, 4), 256, 0, c->stream>>>(g, PB);
+    QX_PB_LAUNCH;
   }
   HIPCHK(hipGetLastError());
   CHK(S.ghosts_g(st->fc));          // t-sharded: a chain field is read at shifted sites by the staple derivative
@@ -947,7 +996,7 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
       PB.f[mu] = S.gvw(st->F, mu);
     }
     PB.nn = 3; PB.accumulate = 1; PB.ma = ma2; PB.alp = alp2;
-    k_projUderiv_batch<<<dim3(nblk, 4), 256, 0, c->stream>>>(g, PB);
+    QX_PB_LAUNCH;
     HIPCHK(hipGetLastError());
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++)
@@ -976,7 +1025,7 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
       PB.f[mu] = S.gvw(st->F, mu);
     }
     PB.nn = 3; PB.accumulate = 1; PB.ma = ma1; PB.alp = alp1;
-    k_projUderiv_batch<<<dim3(nblk, 4), 256, 0, c->stream>>>(g, PB);
+    QX_PB_LAUNCH;
     HIPCHK(hipGetLastError());
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++)
