@@ -140,11 +140,11 @@ if rd and cp_w:
         ("k_cg_xpay", None, 144 * Vh, "p = r + beta p: 2 reads + 1 write of 48 B"),
         ("k_cg_update", None, 288 * Vh, "x, r updates: 4 reads + 2 writes of 48 B"),
         ("k_cgm_update", None, (48 + 96 + 9 * 192) * Vh, "r in, ps[0] in/out, 9 x (xs, ps in/out), 10 shifts"),
-        ("k_flow_stage", None, (4 * M * 3 + 4 * M * 2.0 / 3.0) * VOL, "U in, U' out, momentum out, momentum in for stages 2-3 (2112 B/site average)"),
         ("k_force_lds", None, (4 * M * 3 + 4 * M * 2.0 / 3.0) * VOL, "U in, U' out, momentum out, momentum in for stages 2-3 (2112 B/site average)"),
         ("k_force_lds2", None, (4 * M * 3 + 4 * M * 2.0 / 3.0) * VOL, "U in, U' out, momentum out, momentum in for stages 2-3 (2112 B/site average); both parities of a tile position per workgroup"),
         ("k_plaq", None, 4 * M * VOL, "4 links per site read once (576 B)"),
         ("k_flow_obs_clover", None, 4 * M * VOL, "4 links per site read once (576 B)"),
+        ("k_flow_obs_clover2", None, 4 * M * VOL, "4 links per site read once (576 B): plaquettes + clover E, Q in one pass, both parities of a tile position per workgroup"),
         ("k_flow_obs_all", None, 4 * M * VOL, "4 links per site read once (576 B): plaquette + clover E, Q in one pass"),
         ("k_gen_staple", None, 4 * M * VOL, "two input matrices read once, accumulator read + written: 576 B/site unique"),
         ("k_staple_deriv_pair", None, 10 * M * VOL, "a (mu,nu)/(nu,mu) pair: 6 matrices read, 2 read and written back = 1440 B/site (rounds 2-3 quoted the 8 reads alone, 1152 B, against read + write traffic)"),
