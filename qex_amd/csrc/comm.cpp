@@ -139,7 +139,7 @@ static inline int upper(const qexhip_ctx *c) { return (c->rank + 1) % c->nranks;
 static inline int lower(const qexhip_ctx *c) { return (c->rank - 1 + c->nranks) % c->nranks; }
 
 // Exchange the t-faces of one parity half of f.  Runs on the comm stream after ev_ready (the
-// producer of f on the compute stream); records ev_halo.  Message order is the same on every
+// producer of f on the compute stream); the caller records ev_halo behind whatever it posts after the exchange.  Message order is the same on every
 // rank -- sends {bottom->lower, top->upper}, receives {ghost_hi<-upper, ghost_lo<-lower} -- so
 // that with two ranks (upper == lower) or one rank (self) the k-th send pairs with the k-th recv.
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
@@ -172,7 +172,7 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
     HIPCHK(hipMemcpyAsync(ghost_hi, bottom, nd * sizeof(double), hipMemcpyDeviceToDevice, cs));
     HIPCHK(hipMemcpyAsync(ghost_lo, top, nd * sizeof(double), hipMemcpyDeviceToDevice, cs));
   }
-  if (overlap) HIPCHK(hipEventRecord(c->ev_halo, c->cstream));    // (recorded before tm's closing event: ev_halo does not wait for it)
+  // overlap: the caller (dslash_sweep) posts its boundary launch behind the group on cstream and records ev_halo after it
   return 0;
 }
 

@@ -151,15 +151,16 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
 // (hipExtLaunchKernelGGL): the pair brackets exactly the kernel's execution, like the duration
 // rocprofv3 reports, instead of the record-to-record interval of two stream markers.
 template <class K>
-static void launch_timed(qexhip_ctx *c, const char *tname, K kernel, dim3 grid, dim3 block, DslashArgs &A) {
+static void launch_timed(qexhip_ctx *c, const char *tname, K kernel, dim3 grid, dim3 block, DslashArgs &A, hipStream_t st) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (timer_event_pair(c, tname, &e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, 0, c->stream, e0, e1, 0, A);
-  else hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, A);
+  if (timer_event_pair(c, tname, &e0, &e1)) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0, e1, 0, A);
+  else hipLaunchKernelGGL(kernel, grid, block, 0, st, A);
 }
 
 template <int NDIR, bool HALO>
 static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool dot, int part_off,
-                  int d0 = 0, int d1 = 0, const char *tname = "dslash") {
+                  int d0 = 0, int d1 = 0, const char *tname = "dslash", hipStream_t st = nullptr) {
+  if (!st) st = c->stream;
   if (c1 <= c0 && d1 <= d0) return 0;
   if (c1 <= c0) { c0 = d0; c1 = d1; d0 = d1 = 0; }
   A.c0 = c0; A.c1 = c1; A.d0 = d0; A.d1 = d1;
@@ -174,10 +175,10 @@ static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool 
   dim3 grid(nb), block(256);
 #define QX_LAUNCH(R) \
   do { \
-    if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true, R>, grid, block, A); \
-    else if (init) launch_timed(c, tname, k_dslash<NDIR, HALO, true, false, R>, grid, block, A); \
-    else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true, R>, grid, block, A); \
-    else launch_timed(c, tname, k_dslash<NDIR, HALO, false, false, R>, grid, block, A); \
+    if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true, R>, grid, block, A, st); \
+    else if (init) launch_timed(c, tname, k_dslash<NDIR, HALO, true, false, R>, grid, block, A, st); \
+    else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true, R>, grid, block, A, st); \
+    else launch_timed(c, tname, k_dslash<NDIR, HALO, false, false, R>, grid, block, A, st); \
   } while (0)
   if (c->recon == 1) QX_LAUNCH(1);
   else if (c->recon == 2) QX_LAUNCH(2);
@@ -250,10 +251,14 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
       int nb_int = (hi_beg - lo_end + 255) / 256, nb_lo = (lo_end + 255) / 256;
       if (c->ndir == 8) CHK((launch<8, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
       else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
+      // Both t-faces in ONE launch, posted on the COMM stream right behind the exchange: it needs the ghost zones and nothing
+      // of the interior launch, so it starts the moment the faces have arrived and runs beside the interior's tail instead of
+      // after it (round 4; one-rank rehearsal of a 48^3 x 12 slab: 403 -> see profiles/r04_notes.md).  Everything later on the
+      // compute stream waits for ev_halo, recorded behind it.
+      if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream)));
+      else CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream)));
+      HIPCHK(hipEventRecord(c->ev_halo, c->cstream));
       HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
-      // both t-faces in ONE launch (fewer launches per sweep)
-      if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd")));
-      else CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd")));
       nparts = nb_int + nb_lo + (g.Vh - hi_beg + 255) / 256;
     }
   }

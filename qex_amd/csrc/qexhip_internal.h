@@ -176,7 +176,7 @@ int solve_batch_host(qexhip_ctx *c, int n, double *const *x, const double *const
 inline bool multi_rank(const qexhip_ctx *c) { return c->nranks > 1 || c->opt_multi_reduce; }
 
 // ---- comm.cpp ----
-int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready, records ev_halo
+int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready; the caller records ev_halo behind what it posts next
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
 int comm_agree_post(qexhip_ctx *c);                               // max-reduce c->cg->agree over the ranks (on stream)
 int comm_agree_check(qexhip_ctx *c, const CgScal &host);          // after the state was read back: all ranks hold the same residual and count

@@ -352,7 +352,9 @@ __global__ void __launch_bounds__(256, 2) k_projUderiv_batch(Geom g, ProjBatch B
   const int p = i >= g.Vh, c = i - p * g.Vh;
   const size_t t = (size_t)p * g.etile + (c >> 6);
   const int l = c & 63;
-  double2 *ol = smPB + (size_t)(threadIdx.x >> 6) * 2 * 576 + l, *xl = ol + 576;
+  // LDS column = the LANE, not the site's position in its tile: where the parity halves meet inside a wavefront (Vh not a
+  // multiple of 64) two lanes hold sites with the same tile position
+  double2 *ol = smPB + (size_t)(threadIdx.x >> 6) * 2 * 576 + (threadIdx.x & 63), *xl = ol + 576;
   const MViewW f = B.f[mu];
   {
     const M3 o = B.accumulate ? m3_load_nt(f.p + t * f.tstride + l, 64) : m3_zero();
