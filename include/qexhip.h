@@ -76,10 +76,13 @@ int qexhip_comm_info(qexhip_handle h, int *nranks, int *rank, int *device, char 
  * interior sweep, so that neither queues behind the other), 1 with QEXHIP_COMM2=0. */
 int qexhip_comm_count(qexhip_handle h, int *ncomms);
 /* How a one-parity sweep runs on this context's (t-sharded) field: out[0] = 1 if t-hops across the slab boundary go through
- * ghost zones, out[1] = 1 if the face exchange is posted on the second stream beside an interior launch (option "overlap";
- * by default only when the interior is >= 131072 sites and a face >= 1 MiB), out[2] = interior sites of one parity,
- * out[3] = bytes of one face message.  bench.py prints it so that a scaling run explains its own launch structure. */
-int qexhip_stag_sweep_info(qexhip_handle h, int out[4]);
+ * ghost zones, out[1] = 1 if the face exchange is posted on the second stream beside an interior launch, out[2] = interior
+ * sites of one parity, out[3] = bytes of one face message, out[4] = 1 if out[1] was MEASURED: with a communicator of more
+ * than one rank, set_links times a few sweeps in either form (collective; the slowest rank decides, so all ranks agree) --
+ * out[5], out[6] = microseconds per sweep it saw exchange-first / overlapped; otherwise out[1] follows option "overlap" or,
+ * at -1, the rule of the one-rank rehearsals (overlap when the interior is >= 131072 sites and a face >= 1 MiB);
+ * out[7] = the option's value.  bench.py prints it so that a scaling run explains its own launch structure. */
+int qexhip_stag_sweep_info(qexhip_handle h, int out[8]);
 /* test hook: with one rank, route the t-direction hops through the halo path
  * (pack -> RCCL self send/recv -> boundary sweep) instead of the periodic wrap. */
 int qexhip_comm_force_halo(qexhip_handle h, int on);
@@ -305,7 +308,9 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
 /* Options of a context.  Unknown names are an error (QEXHIP_ERR_ARG).
  *   "recon"        cap on the link compression (0 keep all 18 reals, 1 sign format only, 2 also the U(3) format; default 2),
  *                  effective at the next set_links
- *   "overlap"      face exchange on the second stream beside the interior sweep: -1 by interior size (default), 0 never, 1 always
+ *   "overlap"      face exchange on the second stream beside the interior sweep: 0 never, 1 always, -1 (default) measured at
+ *                  set_links when the communicator has more than one rank (qexhip_stag_sweep_info), else by interior / face
+ *                  size; -2: measure on one rank too (test hook)
  *   "flow_exp"     1: closed-form exp(v) in the Wilson-flow stage (default; agrees with the reference's to ~1e-15 per element),
  *                  0: the reference's algorithm, order-4 Taylor + 20 squarings (matexp.nim:80-85,634-649)
  *   test hooks -- each selects, on any lattice, the code path that some lattices / ranks take by necessity:

@@ -298,14 +298,19 @@ extern "C" int qexhip_stag_eo_reconstruct(qexhip_handle c, double *r, const doub
   return field_download(c, *fr, r);
 }
 
-extern "C" int qexhip_stag_sweep_info(qexhip_handle c, int out[4]) {
+extern "C" int qexhip_stag_sweep_info(qexhip_handle c, int out[8]) {
   if (!c || !out) return QEXHIP_ERR_ARG;
   int lo_end = 0, hi_beg = 0, overlap = 0;
   sweep_plan(c, &lo_end, &hi_beg, &overlap);
+  const int slot = c->ndir == 16;
   out[0] = c->g.halo;
   out[1] = overlap;
   out[2] = c->g.halo ? hi_beg - lo_end : c->g.Vh;
   out[3] = c->g.halo ? c->g.depth * c->g.F * 48 : 0;
+  out[4] = c->overlap_auto[slot] >= 0;
+  out[5] = (int)(c->overlap_tune_us[slot][0] + 0.5);
+  out[6] = (int)(c->overlap_tune_us[slot][1] + 0.5);
+  out[7] = c->opt_overlap;
   return 0;
 }
 

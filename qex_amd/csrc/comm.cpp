@@ -236,6 +236,17 @@ int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
   return 0;
 }
 
+int comm_allreduce_max(qexhip_ctx *c, double *host, int n) {
+  if (n > 4) return QEXHIP_ERR_ARG;
+  if (!c->comm || c->nranks < 2) return 0;
+  double *d = &c->dscal[56];
+  HIPCHK(hipMemcpyAsync(d, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  NCCLCHK(ncclAllReduce(d, d, n, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));
+  HIPCHK(hipMemcpyAsync(host, d, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // The CG loops run their control flow on every rank separately (loop condition on the rank's own copy of the all-reduced
 // residual, as the reference does after its QMP sum, cg.nim:174): if two ranks ever held different bits they would leave
 // the loop at different iterations and the next collective would never complete.  At the end of every chunk of iterations

@@ -11,6 +11,9 @@
 #include "site_index.h"
 #include "reduce.h"
 #include <hip/hip_ext.h>
+#include <chrono>
+
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct DslashArgs {
   Geom g;
@@ -202,7 +205,50 @@ void sweep_plan(const qexhip_ctx *c, int *lo_end_out, int *hi_beg_out, int *over
   int hi_beg = g.Vh - g.depth * g.F; if (hi_beg < lo_end) hi_beg = lo_end;
   const size_t face_bytes = (size_t)g.depth * g.F * 48;
   *lo_end_out = lo_end; *hi_beg_out = hi_beg;
-  *overlap_out = !g.halo ? 0 : (c->opt_overlap >= 0 ? (c->opt_overlap != 0) : ((hi_beg - lo_end) >= 131072 && face_bytes >= ((size_t)1 << 20)));
+  const int tuned = c->overlap_auto[c->ndir == 16];
+  *overlap_out = !g.halo || hi_beg <= lo_end ? 0
+                 : (c->opt_overlap >= 0 ? (c->opt_overlap != 0)
+                    : (tuned >= 0 ? tuned : ((hi_beg - lo_end) >= 131072 && face_bytes >= ((size_t)1 << 20))));
+}
+
+// The static rule above was set from one-rank rehearsals, where an exchange costs one RCCL kernel and no transport.  With a real
+// communicator (nranks > 1) the decision is MEASURED once per operator shape, right after the links are in place: a few
+// sweeps in either mode on scratch fields, the slower rank's time decides (max-all-reduce, so every rank takes the same
+// branch).  Collective over the communicator, like set_links itself (ghost links).  Option "overlap" = 0 / 1 switches the
+// measurement off, -2 asks for it on one rank too (test hook).
+int sweep_autotune(qexhip_ctx *c) {
+  const Geom &g = c->g;
+  const int slot = c->ndir == 16;
+  if (!g.halo || !c->W || c->overlap_auto[slot] >= 0) return 0;
+  if (!(c->opt_overlap == -2 || (c->opt_overlap == -1 && c->nranks > 1 && c->comm))) return 0;
+  int lo_end, hi_beg, dummy;
+  sweep_plan(c, &lo_end, &hi_beg, &dummy);
+  if (hi_beg <= lo_end) { c->overlap_auto[slot] = 0; return 0; }        // no interior to overlap with
+  DevField a, b;
+  CHK(field_alloc(c, a));
+  CHK(field_alloc(c, b));
+  const int saved = c->opt_overlap, saved_timers = c->timers_on;
+  c->timers_on = 0;
+  double t[2] = {0, 0};
+  int rc = 0;
+  for (int mode = 0; mode < 2 && !rc; mode++) {
+    c->opt_overlap = mode;
+    for (int k = 0; k < 12 && !rc; k++) {
+      if (k == 2) { rc = hipStreamSynchronize(c->stream) != hipSuccess ? -2 : 0; t[mode] = -now_us(); }
+      DslashOpts o;
+      if (!rc) rc = dslash_sweep(c, (k & 1) ? a : b, (k & 1) ? b : a, k & 1, o);
+    }
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = -2;
+    t[mode] += now_us();
+  }
+  c->opt_overlap = saved;
+  c->timers_on = saved_timers;
+  (void)hipFree(a.d); (void)hipFree(b.d);
+  if (rc) return rc;
+  if (c->comm && c->nranks > 1) CHK(comm_allreduce_max(c, t, 2));
+  c->overlap_auto[slot] = t[1] < t[0] ? 1 : 0;
+  c->overlap_tune_us[slot][0] = t[0] / 10.0; c->overlap_tune_us[slot][1] = t[1] / 10.0;
+  return 0;
 }
 
 int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const DslashOpts &o) {
@@ -253,7 +299,7 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
       else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
       // Both t-faces in ONE launch, posted on the COMM stream right behind the exchange: it needs the ghost zones and nothing
       // of the interior launch, so it starts the moment the faces have arrived and runs beside the interior's tail instead of
-      // after it (round 4; one-rank rehearsal of a 48^3 x 12 slab: 403 -> see profiles/r04_notes.md).  Everything later on the
+      // after it (round 4: 1-6 % of an iteration on thin slabs in the one-rank rehearsal, profiles/r04_notes.md).  Everything later on the
       // compute stream waits for ev_halo, recorded behind it.
       if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream)));
       else CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream)));

@@ -161,7 +161,8 @@ int links_upload(qexhip_ctx *c, const double *fat, const double *lng) {
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipStreamSynchronize(c->stream));
-  return links_compress(c);
+  CHK(links_compress(c));
+  return sweep_autotune(c);
 }
 
 // ---- link compression --------------------------------------------------------------------------
@@ -299,7 +300,8 @@ int links_from_natural(qexhip_ctx *c, const double2 *fat, const double2 *lng) {
   if (lng) k_links_from_nat<<<(g.V + 255) / 256, 256, 0, c->stream>>>(g, lng, c->W, ndir, 8, 3);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
-  return links_compress(c);
+  CHK(links_compress(c));
+  return sweep_autotune(c);
 }
 
 // ---- host-callable test hooks for the index arithmetic (no GPU needed) ----

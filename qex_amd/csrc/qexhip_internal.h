@@ -111,7 +111,10 @@ struct qexhip_ctx {
                           // another algorithm than the reference's; agrees with it to ~1e-15 per element; the default); 0 = the reference's
                           // Taylor + 20 squarings (matexp.nim), which the MD link updates always use
   int opt_recon = 2;      // QEXHIP_RECON: 0 keeps the 18-real links always, 1 sign format only, 2 also the U(3) format
-  int opt_overlap = -1;  // QEXHIP_OVERLAP: 1 always use the comm stream, 0 never, -1 by interior size
+  int opt_overlap = -1;  // QEXHIP_OVERLAP / option "overlap": 1 always use the comm stream, 0 never, -1 measured once per operator shape when the
+                         // communicator has more than one rank (sweep_autotune), by interior / face size otherwise; -2: measure on one rank too
+  int overlap_auto[2]{-1, -1};          // the measured decision for 8- and 16-link operators (-1: not measured)
+  double overlap_tune_us[2][2]{};       // us per sweep the measurement saw: [8 | 16 links][exchange first | overlapped], max over ranks
   // natural gauge (flow)
   GaugeNat *gn = nullptr;
   void *nhyp = nullptr;   // NhypState (smear.hip): the smearGetForce closure
@@ -178,6 +181,7 @@ inline bool multi_rank(const qexhip_ctx *c) { return c->nranks > 1 || c->opt_mul
 // ---- comm.cpp ----
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready; the caller records ev_halo behind what it posts next
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
+int comm_allreduce_max(qexhip_ctx *c, double *host, int n);      // host values -> max over the ranks, back on the host (n <= 4, synchronous)
 int comm_agree_post(qexhip_ctx *c);                               // max-reduce c->cg->agree over the ranks (on stream)
 int comm_agree_check(qexhip_ctx *c, const CgScal &host);          // after the state was read back: all ranks hold the same residual and count
 int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n);
@@ -201,6 +205,7 @@ struct DslashOpts {
   const int *done = nullptr;       // device flag: skip when set
 };
 int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const DslashOpts &o);
+int sweep_autotune(qexhip_ctx *c);      // measure exchange-first against overlapped once per operator shape (collective)
 void sweep_plan(const qexhip_ctx *c, int *lo_end, int *hi_beg, int *overlap);   // boundary / interior ranges and the overlap decision
 
 // ---- blas.hip ----

@@ -118,9 +118,13 @@ class Context:
 
     def sweep_info(self):
         """{"halo", "overlap", "interior_sites", "face_bytes"}: how a one-parity sweep is launched on this context"""
-        o = (C.c_int * 4)()
+        o = (C.c_int * 8)()
         check(lib().qexhip_stag_sweep_info(self._h, o))
-        return {"halo": bool(o[0]), "overlap": bool(o[1]), "interior_sites": int(o[2]), "face_bytes": int(o[3])}
+        r = {"halo": bool(o[0]), "overlap": bool(o[1]), "interior_sites": int(o[2]), "face_bytes": int(o[3]), "overlap_measured": bool(o[4]),
+             "option_overlap": int(o[7])}
+        if o[4]:
+            r["measured_us_per_sweep"] = {"exchange_first": int(o[5]), "overlapped": int(o[6])}
+        return r
 
     def force_halo(self, on=True):
         check(lib().qexhip_comm_force_halo(self._h, 1 if on else 0))

@@ -326,3 +326,41 @@ def test_resident_field_entry_points_against_the_oracle(oracle):
     assert n1 == n2 and all(np.array_equal(u, ctx.field_download(i)) for u, i in zip(a, xids[:2]))
     ctx.comm_init(q.Context.unique_id(), 1, 0)
     assert ctx.comm_count() in (1, 2)
+
+
+def test_overlap_decision_is_measured_when_asked(oracle):
+    """With a communicator of more than one rank the library times exchange-first against overlapped sweeps at set_links and
+    takes the faster (collective, the slowest rank decides).  Option overlap = -2 asks for the same measurement on one rank:
+    the decision is reported with the two timings, a second set_links reuses it, and the operator is unchanged by it."""
+    import qex_amd as q
+
+    o = oracle
+    lat = [16, 16, 16, 16]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 5)
+    g = o.gauge_random(lo, rf)
+    o.rephase(lo, g)
+    x = o.vector_gaussian(lo, rf)
+    ref = o.D(lo, g, None, x, 0.1)
+    ctx = q.Context(lat)
+    ctx.comm_init(q.Context.unique_id(), 1, 0)
+    ctx.force_halo(True)
+    s = q.newStag(ctx, g)
+    assert ctx.sweep_info()["overlap_measured"] is False          # one rank, default option: the static rule
+    ctx.set_option("overlap", -2)
+    s = q.newStag(ctx, g)
+    si = ctx.sweep_info()
+    assert si["overlap_measured"] is True and si["halo"] and si["option_overlap"] == -2
+    m = si["measured_us_per_sweep"]
+    assert m["exchange_first"] > 0 and m["overlapped"] > 0 and si["overlap"] == (m["overlapped"] < m["exchange_first"])
+    r = np.zeros_like(x)
+    s.D(r, x, 0.1)
+    assert np.linalg.norm(r - ref) / np.linalg.norm(ref) < 1e-13
+    s = q.newStag(ctx, g)                                          # measured once per operator shape
+    assert ctx.sweep_info()["measured_us_per_sweep"] == m
+    for forced in (0, 1):
+        ctx.set_option("overlap", forced)
+        assert ctx.sweep_info()["overlap"] == bool(forced)
+        s.D(r, x, 0.1)
+        assert np.linalg.norm(r - ref) / np.linalg.norm(ref) < 1e-13
+    ctx.close()

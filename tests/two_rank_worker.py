@@ -93,6 +93,7 @@ def main():
     s.D(r, sl(x), 0.1)
     worst = max(worst, relerr(r, sl(o.D(olo, g, None, x, 0.1))))
     res["stagD2_D"] = worst
+    res["sweep"] = ctx.sweep_info()                                    # incl. the measured overlap decision (world > 1, option -1)
     assert worst < 1e-13, worst
 
     # ---- CG (solveEE): history, count, solution ----
