@@ -109,7 +109,14 @@ extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], 
   if (geom_init(c->g, latLocal, 1, halo)) { delete c; return QEXHIP_ERR_ARG; }
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+  {
+    // the comm stream carries the face exchange and the boundary launch that waits for it: at the highest priority, so that the
+    // RCCL kernel is dispatched at once and not behind the thousands of interior workgroups the compute stream has queued
+    // (one-rank rehearsal, where nothing has to be hidden: no difference either way, profiles/r04_prio_ab.log)
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) HIPCHK(hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, hi));
+    else HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+  }
   HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
   c->part2_off = std::max(6144, (c->g.Vh + 255) / 256 + 8);   // >= 6*1024 for the plaquette partials
