@@ -378,7 +378,7 @@ extern "C" int qexhip_tune_fma64(qexhip_handle c, int kind, int chains, int wps,
 
 
 // ---- what the CU's L2 -> L1 path delivers for the Wilson-flow stage's operand stream (round 3) ----
-// The 48 operand matrices of a 64-site tile (flow_stage.hip: 8 own/back links, 36 plane operands, 4 momenta ~ here all taken
+// The 48 operand matrices of a 64-site tile (the loader / consumer flow stage of round 3, removed: 8 own/back links, 36 plane operands, 4 momenta ~ here all taken
 // from U), gathered by NW wavefronts per workgroup into REGISTERS, D matrices in flight per wavefront, nothing else: no LDS,
 // no barrier, 18 integer ops per matrix to keep the loads alive.  Persistent workgroups walk tile_order_table.
 #include "gauge_index.h"

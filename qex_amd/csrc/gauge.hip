@@ -749,7 +749,7 @@ int gauge_flow_obs(qexhip_ctx *c, int loop, double out[3], double *plaq6) {
 // ---------------- general gauge actions: plaq + rect, plaq + adjplaq (completes row a14) ----------------
 // gaugeActionDeriv with c.rect (src/gauge/gaugeAction.nim:205-241,275-331) and gaugeADeriv / forceA
 // (:683-747), as used by the action-selectable flow of src/flow/flow.nim:22-90.  Same lane
-// mapping as k_force.  The 18 rectangle staples of a link are walked as 5-link paths.
+// mapping as k_force_lds.  The 18 rectangle staples of a link are walked as 5-link paths.
 __device__ const signed char RECT_STEPS[6][5] = {
     {2, 2, 1, -2, -2}, {2, 1, 1, -2, -1}, {-1, 2, 1, 1, -2},          // +nu
     {-2, -2, 1, 2, 2}, {-2, 1, 1, 2, -1}, {-1, -2, 1, 1, 2}};         // -nu

@@ -1,5 +1,5 @@
 // gauge_index.h -- site / link addressing of the natural-layout gauge field G[parity][tile][mu][9][64] (double2), shared by the
-// gauge kernels (gauge.hip, flow_stage.hip).  Site numbering: checkerboard index c = lex/2 of the rank-local lattice
+// gauge kernels (gauge.hip; the FsSite helpers serve the gather calibration of dslash_tune.hip).  Site numbering: checkerboard index c = lex/2 of the rank-local lattice
 // (src/layout/qlayout.nim:110-131 with V = 1); t-sharded fields carry ghost tiles addressed as virtual slices.
 #pragma once
 #include "qexhip_internal.h"
