@@ -32,6 +32,8 @@ struct MrhsArgs {
   double *partials[QX_MAXRHS];
   const CgScal *st;            // st[j].done switches system j off
   int parity, nrhs, swz, ntstore;
+  int c0, c1, d0, d1, nb1;     // site range [c0, c1) for workgroups < nb1, [d0, d1) for the rest (both t-faces in one launch)
+  int part_off;                // first <xs, out> partial this launch writes
 };
 
 // SECOND = false: out_j = +sum_mu (U in_j(+mu) - U^+ in_j(-mu))              (stagDP, first half of stagD2ee)
@@ -45,9 +47,10 @@ __global__ void __launch_bounds__(256) k_dslash_mrhs(MrhsArgs A) {
   if (!any) return;
   int bid = blockIdx.x;
   if (A.swz) bid = (bid & 7) * (A.swz >> 3) + (bid >> 3);
-  const int c = bid * 256 + threadIdx.x;
+  int c = A.c0 + bid * 256 + threadIdx.x, clim = A.c1;
+  if (bid >= A.nb1) { c = A.d0 + (bid - A.nb1) * 256 + threadIdx.x; clim = A.d1; }
   double dotv[QX_MAXRHS] = {0, 0, 0, 0};
-  if (c < A.g.Vh) {
+  if (c < clim) {
     const Geom &g = A.g;
     SiteXYZT s = site_coord(g, c, A.parity);
     double2 acc[QX_MAXRHS][3], xsv[QX_MAXRHS][3];
@@ -133,7 +136,7 @@ __global__ void __launch_bounds__(256) k_dslash_mrhs(MrhsArgs A) {
     for (int j = 0; j < QX_MAXRHS; j++) {
       if (!act[j]) continue;             // uniform over the grid
       double r = block_sum_256(dotv[j]);
-      if (threadIdx.x == 0) A.partials[j][blockIdx.x] = r;
+      if (threadIdx.x == 0) A.partials[j][A.part_off + blockIdx.x] = r;
     }
   }
 }
@@ -252,33 +255,57 @@ void batch_state_free(qexhip_ctx *c) {
 }
 
 template <int NDIR, int RECON>
-static void launch_mrhs(qexhip_ctx *c, MrhsArgs &A, bool second, int nb) {
+static void launch_mrhs(qexhip_ctx *c, MrhsArgs &A, bool second, int nb, hipStream_t st) {
   if (c->g.halo) {
-    if (second) hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, true, true>), dim3(nb), dim3(256), 0, c->stream, A);
-    else hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, false, true>), dim3(nb), dim3(256), 0, c->stream, A);
+    if (second) hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, true, true>), dim3(nb), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, false, true>), dim3(nb), dim3(256), 0, st, A);
   } else {
-    if (second) hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, true, false>), dim3(nb), dim3(256), 0, c->stream, A);
-    else hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, false, false>), dim3(nb), dim3(256), 0, c->stream, A);
+    if (second) hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, true, false>), dim3(nb), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((k_dslash_mrhs<NDIR, RECON, false, false>), dim3(nb), dim3(256), 0, st, A);
   }
 }
-// t-sharded: the faces of every system's input field are exchanged first (on the compute stream), then ONE launch
-// covers the slab -- the exchange-then-sweep order of dslash_sweep's non-overlapped branch
-static int sweep_mrhs(qexhip_ctx *c, MrhsArgs &A, bool second, DevField *const *infield = nullptr, int inpar = 0) {
-  if (c->g.halo)
-    for (int j = 0; j < A.nrhs; j++) CHK(comm_halo_exchange(c, *infield[j], inpar, 0));
-  const int nb = (c->g.Vh + 255) / 256;
-  const int swz = c->recon != 0;                     // as dslash.hip: on for compressed links
-  A.swz = (swz && nb >= 64 && (nb & 7) == 0) ? nb : 0;
+// one launch over [c0, c1) (+ [d0, d1)); returns the number of workgroups = <xs, out> partials it writes from part_off on
+static int launch_range(qexhip_ctx *c, MrhsArgs &A, bool second, int c0, int c1, int d0, int d1, int part_off, hipStream_t st) {
+  A.c0 = c0; A.c1 = c1; A.d0 = d0; A.d1 = d1;
+  A.nb1 = (c1 - c0 + 255) / 256;
+  const int nb = A.nb1 + (d1 > d0 ? (d1 - d0 + 255) / 256 : 0);
+  A.part_off = part_off;
+  const bool whole = (c0 == 0 && c1 == c->g.Vh && d1 <= d0);
+  A.swz = (whole && c->recon != 0 && nb >= 64 && (nb & 7) == 0) ? nb : 0;     // as dslash.hip: on for compressed links
   A.ntstore = 1;
-  ScopedTimer tm(c, "dslash_batch", c->stream);
   if (c->ndir == 8) {
-    if (c->recon == 1) launch_mrhs<8, 1>(c, A, second, nb);
-    else if (c->recon == 2) launch_mrhs<8, 2>(c, A, second, nb);
-    else launch_mrhs<8, 0>(c, A, second, nb);
+    if (c->recon == 1) launch_mrhs<8, 1>(c, A, second, nb, st);
+    else if (c->recon == 2) launch_mrhs<8, 2>(c, A, second, nb, st);
+    else launch_mrhs<8, 0>(c, A, second, nb, st);
   } else {
-    if (c->recon == 1) launch_mrhs<16, 1>(c, A, second, nb);
-    else if (c->recon == 2) launch_mrhs<16, 2>(c, A, second, nb);
-    else launch_mrhs<16, 0>(c, A, second, nb);
+    if (c->recon == 1) launch_mrhs<16, 1>(c, A, second, nb, st);
+    else if (c->recon == 2) launch_mrhs<16, 2>(c, A, second, nb, st);
+    else launch_mrhs<16, 0>(c, A, second, nb, st);
+  }
+  return nb;
+}
+// t-sharded: the faces of every system's input field travel in ONE RCCL group; either exchange-first and one launch over the
+// slab, or -- where dslash_sweep overlaps (sweep_plan) -- the group and the boundary launch on the comm stream beside the
+// interior launch, exactly the structure of dslash_sweep.  *ndot = number of <xs, out> partials the sweep wrote.
+static int sweep_mrhs(qexhip_ctx *c, MrhsArgs &A, bool second, int *ndot, DevField *const *infield = nullptr, int inpar = 0) {
+  const Geom &g = c->g;
+  int lo_end = 0, hi_beg = g.Vh, overlap = 0;
+  if (g.halo) sweep_plan(c, &lo_end, &hi_beg, &overlap);
+  // the decision of sweep_plan is for ONE system's faces; a batch moves nrhs times as much per exchange, and between distinct
+  // GPUs that transfer is what the overlap is for: with a real communicator, overlap from 1 MiB of faces per direction on
+  if (g.halo && !overlap && c->opt_overlap < 0 && c->nranks > 1 && hi_beg > lo_end &&
+      (size_t)A.nrhs * g.depth * g.F * 48 >= ((size_t)1 << 20)) overlap = 1;
+  if (g.halo && overlap) HIPCHK(hipEventRecord(c->ev_ready, c->stream));
+  if (g.halo) CHK(comm_halo_exchange_multi(c, A.nrhs, infield, inpar, overlap));
+  ScopedTimer tm(c, "dslash_batch", c->stream);
+  if (!overlap) {
+    *ndot = launch_range(c, A, second, 0, g.Vh, 0, 0, 0, c->stream);
+  } else {
+    const int nb_int = launch_range(c, A, second, lo_end, hi_beg, 0, 0, 0, c->stream);
+    const int nb_bnd = launch_range(c, A, second, 0, lo_end, hi_beg, g.Vh, nb_int, c->cstream);
+    HIPCHK(hipEventRecord(c->ev_halo, c->cstream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    *ndot = nb_int + nb_bnd;
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -300,7 +327,7 @@ int solve_xx_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const d
   }
   if (!B->st) HIPCHK(hipMalloc((void **)&B->st, sizeof(CgScal) * QX_MAXRHS));
   if (!B->glob) { HIPCHK(hipMalloc((void **)&B->glob, sizeof(double) * 8)); HIPCHK(hipMemsetAsync(B->glob, 0, sizeof(double) * 8, c->stream)); }
-  const int nbd = (g.Vh + 255) / 256;                 // Dslash workgroups = <p,Ap> partials per system
+  const int nbd = (g.Vh + 255) / 256 + 4;             // room for the <p,Ap> partials of a sweep per system (a split sweep rounds up per range)
   const size_t nvec = (size_t)g.ntile * 192;
   const int nbb = (int)std::min<size_t>((nvec + 255) / 256, 2048);
   const size_t per = (size_t)nbd + nbb;
@@ -364,13 +391,15 @@ int solve_xx_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const d
         ScopedTimer tm(c, "blas", c->stream);
         k_cgb_xpay<<<dim3(nbb, n), 256, 0, c->stream>>>(L, nvec);
       }
-      CHK(sweep_mrhs(c, A1, false, pf, par));
-      CHK(sweep_mrhs(c, A2, true, tf, 1 - par));
+      int nd1 = 0, ndots = 0;
+      CHK(sweep_mrhs(c, A1, false, &nd1, pf, par));
+      CHK(sweep_mrhs(c, A2, true, &ndots, tf, 1 - par));
+      if (!multi && deferred) L.ndot = ndots;
       if (multi) {
-        k_cgb_local_sum<<<n, 256, 0, c->stream>>>(L, nbd, 0);
+        k_cgb_local_sum<<<n, 256, 0, c->stream>>>(L, ndots, 0);
         CHK(comm_allreduce(c, B->glob, n));
       } else if (!deferred) {
-        k_cgb_reduce_dot<<<n, 256, 0, c->stream>>>(L, nbd);
+        k_cgb_reduce_dot<<<n, 256, 0, c->stream>>>(L, ndots);
       }
       {
         ScopedTimer tm(c, "blas", c->stream);

@@ -176,6 +176,40 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
   return 0;
 }
 
+// The same for the input fields of the n systems of a lock-step batch in ONE RCCL group (one kernel instead of n): per field
+// the message order of comm_halo_exchange, fields in ascending order on every rank.
+int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parity, int overlap) {
+  CHK(need_comm(c));
+  hipStream_t cs = overlap ? c->cstream : c->stream;
+  const Geom &g = c->g;
+  const size_t face2 = (size_t)g.depth * g.F * 3;
+  const size_t nd = face2 * 2;
+  if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+  ScopedTimer tm(c, "exchange", cs);
+  if (c->comm) {
+    ncclComm_t comm = (ncclComm_t)((overlap && c->comm2) ? c->comm2 : c->comm);
+    NCCLCHK(ncclGroupStart());
+    for (int j = 0; j < n; j++) {
+      double2 *base = f[j]->par(parity);
+      NCCLCHK(ncclSend(base, nd, ncclDouble, lower(c), comm, cs));
+      NCCLCHK(ncclSend(base + (size_t)(g.ntile) * 192 - face2, nd, ncclDouble, upper(c), comm, cs));
+    }
+    for (int j = 0; j < n; j++) {
+      double2 *ghost_hi = f[j]->par(parity) + (size_t)g.ntile * 192;
+      NCCLCHK(ncclRecv(ghost_hi, nd, ncclDouble, upper(c), comm, cs));
+      NCCLCHK(ncclRecv(ghost_hi + face2, nd, ncclDouble, lower(c), comm, cs));
+    }
+    NCCLCHK(ncclGroupEnd());
+  } else {
+    for (int j = 0; j < n; j++) {
+      double2 *base = f[j]->par(parity), *ghost_hi = base + (size_t)g.ntile * 192;
+      HIPCHK(hipMemcpyAsync(ghost_hi, base, nd * sizeof(double), hipMemcpyDeviceToDevice, cs));
+      HIPCHK(hipMemcpyAsync(ghost_hi + face2, base + (size_t)(g.ntile) * 192 - face2, nd * sizeof(double), hipMemcpyDeviceToDevice, cs));
+    }
+  }
+  return 0;
+}
+
 // send `bytes` to the upper neighbour, receive the same amount from the lower one (stream-ordered)
 int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st) {
   CHK(need_comm(c));

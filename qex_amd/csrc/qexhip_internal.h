@@ -180,6 +180,7 @@ inline bool multi_rank(const qexhip_ctx *c) { return c->nranks > 1 || c->opt_mul
 
 // ---- comm.cpp ----
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready; the caller records ev_halo behind what it posts next
+int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parity, int overlap);   // n fields, one RCCL group
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
 int comm_allreduce_max(qexhip_ctx *c, double *host, int n);      // host values -> max over the ranks, back on the host (n <= 4, synchronous)
 int comm_agree_post(qexhip_ctx *c);                               // max-reduce c->cg->agree over the ranks (on stream)
