@@ -8,6 +8,7 @@ against the global oracle result:
   stagD2 on the three subsets / D           <= 1e-13   (faces through ncclSend/ncclRecv, shifts.nim:67-94,254-285, qshifts.nim:51-131)
   CG residual history (solveEE)             first 100 iterations 1e-10, iteration count +-1, solution 1e-6 (cg.nim:174-217:
                                             both reductions end in a rank sum, commsUtils.nim:195-204)
+  lock-step batched CG (3 systems)          iteration counts +-1, solutions 1e-6 (all faces in one RCCL group)
   Naik 3-mass multi-shift CG                the same bars, ghost depth 3
   plaquettes, one Wilson-flow step          1e-13 / 1e-12 (ghost links refreshed per stage)
   nHYP smearing + smeared gauge force       1e-11
@@ -70,6 +71,7 @@ def main():
     if world == 1:
         ctx.force_halo(True)                                           # ... ghost zones filled through a one-rank communicator,
         ctx.set_option("multi_reduce", 1)                              # reductions through real (one-rank) all-reduces
+        ctx.set_option("batch_multi", 1)                               # ... in the lock-step batched CG too
     info = ctx.comm_info()
     assert info[0] == world and info[1] == rank, info                  # RCCL's own count and rank
     if args.overlap >= 0:
@@ -106,6 +108,21 @@ def main():
     res["cg"] = {"its": sp.iterations, "oracle_its": int(its), "dev100": float(dev[:100].max()), "dev_all": float(dev.max()),
                  "x": relerr(xs[:vh], sl(xr)[:vh])}
     assert abs(sp.iterations - its) <= 1 and res["cg"]["dev100"] < 1e-10 and res["cg"]["x"] < 1e-6, res["cg"]
+
+    # ---- lock-step batched CG (the HMC's Hasenbusch solves): all systems' faces in one RCCL group, n scalars per all-reduce ----
+    bms = [0.1, 0.2, 0.4]
+    bbs = [sl(x), sl(y), sl(x) + sl(y)]
+    for b in bbs:
+        b[vh:] = 0
+    bxs = [np.zeros_like(b) for b in bbs]
+    bits, _ = s.solveXX_batch(bxs, bbs, bms, 1e-12, 5000, True)
+    worst = 0.0
+    for k, (src, m) in enumerate(zip((x, y, x + y), bms)):
+        xr_k, its_k, _, _ = o.solveXX(olo, g, None, src, m, 1e-12, 5000, True)
+        assert abs(bits[k] - its_k) <= 1, (k, bits[k], its_k)
+        worst = max(worst, relerr(bxs[k][:vh], sl(xr_k)[:vh]))
+    res["batch"] = {"its": list(bits), "x": worst}
+    assert worst < 1e-6, res["batch"]
 
     # ---- Naik: stagD2 and the 3-mass multi-shift CG (ghost depth 3) ----
     if loc.lat[3] >= 4:
