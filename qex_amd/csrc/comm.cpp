@@ -225,27 +225,32 @@ int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, 
   return 0;
 }
 
-// faces of up to two buffers (the two parity halves of a matrix field) in ONE group, both directions:
-// bottom[k] -> lower neighbour's ghost_hi, top[k] -> upper neighbour's ghost_lo   (same message order as above)
+// faces of several buffers (the two parity halves of one or more matrix fields) in ONE group, both directions:
+// bottom[k] -> lower neighbour's ghost_hi, top[k] -> upper neighbour's ghost_lo   (same message order as above).
+// async: on the comm stream (second communicator) after ev_ready, which the caller recorded behind the producer of the
+// buffers; nothing waits for it here -- the caller joins (records ev_halo on the comm stream, lets the compute stream wait)
+// before the first kernel that reads the ghosts.
 int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double *const top[], double *const ghost_hi[],
-                        double *const ghost_lo[], size_t ndoubles) {
+                        double *const ghost_lo[], size_t ndoubles, int async) {
   CHK(need_comm(c));
+  hipStream_t st = async ? c->cstream : c->stream;
+  if (async) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   if (c->comm) {
-    ncclComm_t comm = (ncclComm_t)c->comm;
+    ncclComm_t comm = (ncclComm_t)((async && c->comm2) ? c->comm2 : c->comm);
     NCCLCHK(ncclGroupStart());
     for (int k = 0; k < nbuf; k++) {
-      NCCLCHK(ncclSend(bottom[k], ndoubles, ncclDouble, lower(c), comm, c->stream));
-      NCCLCHK(ncclSend(top[k], ndoubles, ncclDouble, upper(c), comm, c->stream));
+      NCCLCHK(ncclSend(bottom[k], ndoubles, ncclDouble, lower(c), comm, st));
+      NCCLCHK(ncclSend(top[k], ndoubles, ncclDouble, upper(c), comm, st));
     }
     for (int k = 0; k < nbuf; k++) {
-      NCCLCHK(ncclRecv(ghost_hi[k], ndoubles, ncclDouble, upper(c), comm, c->stream));
-      NCCLCHK(ncclRecv(ghost_lo[k], ndoubles, ncclDouble, lower(c), comm, c->stream));
+      NCCLCHK(ncclRecv(ghost_hi[k], ndoubles, ncclDouble, upper(c), comm, st));
+      NCCLCHK(ncclRecv(ghost_lo[k], ndoubles, ncclDouble, lower(c), comm, st));
     }
     NCCLCHK(ncclGroupEnd());
   } else {
     for (int k = 0; k < nbuf; k++) {
-      HIPCHK(hipMemcpyAsync(ghost_hi[k], bottom[k], ndoubles * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      HIPCHK(hipMemcpyAsync(ghost_lo[k], top[k], ndoubles * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(ghost_hi[k], bottom[k], ndoubles * sizeof(double), hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(ghost_lo[k], top[k], ndoubles * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
   }
   return 0;

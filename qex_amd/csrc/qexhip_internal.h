@@ -187,7 +187,7 @@ int comm_agree_post(qexhip_ctx *c);                               // max-reduce 
 int comm_agree_check(qexhip_ctx *c, const CgScal &host);          // after the state was read back: all ranks hold the same residual and count
 int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n);
 int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double *const top[], double *const ghost_hi[],
-                        double *const ghost_lo[], size_t ndoubles);
+                        double *const ghost_lo[], size_t ndoubles, int async = 0);   // async: on the comm stream after ev_ready, no join
 int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st);
 void comm_destroy(qexhip_ctx *c);
 

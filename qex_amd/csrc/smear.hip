@@ -640,19 +640,33 @@ struct Smear {
   int nb() const { return (g.V + 255) / 256; }
   // t-sharded: refresh the ghost slices of a field (tstride 576: one matrix field, 2304: gauge-shaped) to `depth`;
   // the caller does this for every field that is about to be read at shifted sites.  No-op on one GPU without ghosts.
-  int ghosts(const double2 *field, int tstride, int depth = 1) {
+  int ghosts(const double2 *field, int tstride, int depth = 1) { return ghosts_many(&field, 1, tstride, depth, 0); }
+  // the same for n fields of one shape in ONE RCCL group.  async = 1: posted on the comm stream behind what the compute
+  // stream has produced so far, and NOT waited for: the compute stream goes on with kernels that do not read these ghosts
+  // (the next field of the same smearing level), ghosts_join() comes before the first kernel that does.
+  int ghosts_many(const double2 *const *fields, int n, int tstride, int depth, int async) {
     if (!g.halo) return 0;
+    if (n < 1 || n > 12) { qexhip_set_error("internal: ghosts_many takes 1..12 fields"); return -3; }
     const size_t tile2 = (size_t)tstride * 2, ft = (size_t)g.F / 64;
-    double *bottom[2], *top[2], *ghi[2], *glo[2];
-    for (int p = 0; p < 2; p++) {
-      double *base = (double *)field + (size_t)p * g.etile * tile2;
-      bottom[p] = base;
-      top[p] = base + ((size_t)g.ntile - depth * ft) * tile2;
-      ghi[p] = base + (size_t)g.ntile * tile2;
-      glo[p] = base + ((size_t)g.ntile + 3 * ft + (3 - depth) * ft) * tile2;
-    }
-    ScopedTimer tm(c, "smear_halo", c->stream);
-    return comm_faces_exchange(c, 2, bottom, top, ghi, glo, (size_t)depth * ft * tile2);
+    double *bottom[24], *top[24], *ghi[24], *glo[24];
+    for (int k = 0; k < n; k++)
+      for (int p = 0; p < 2; p++) {
+        double *base = (double *)fields[k] + (size_t)p * g.etile * tile2;
+        bottom[2 * k + p] = base;
+        top[2 * k + p] = base + ((size_t)g.ntile - depth * ft) * tile2;
+        ghi[2 * k + p] = base + (size_t)g.ntile * tile2;
+        glo[2 * k + p] = base + ((size_t)g.ntile + 3 * ft + (3 - depth) * ft) * tile2;
+      }
+    if (async) HIPCHK(hipEventRecord(c->ev_ready, c->stream));
+    ScopedTimer tm(c, "smear_halo", async ? c->cstream : c->stream);
+    return comm_faces_exchange(c, 2 * n, bottom, top, ghi, glo, (size_t)depth * ft * tile2, async);
+  }
+  int ghosts_f_async(const double2 *f) { return ghosts_many(&f, 1, 576, 1, 1); }
+  int ghosts_join() {
+    if (!g.halo) return 0;
+    HIPCHK(hipEventRecord(c->ev_halo, c->cstream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    return 0;
   }
   int ghosts_f(const double2 *f, int depth = 1) { return ghosts(f, 576, depth); }
   int ghosts_g(const double2 *G, int depth = 1) { return ghosts(G, 4 * 576, depth); }
@@ -865,8 +879,9 @@ struct Smear {
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
         CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(K.l1x[mu][nu]), alp1, gv(G, mu), 1 - a1, fvw(K.l1[mu][nu])));
-        CHK(ghosts_f(K.l1[mu][nu]));
+        CHK(ghosts_f_async(K.l1[mu][nu]));                  // travels while the next (mu, nu) is computed
       }
+    CHK(ghosts_join());
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
@@ -879,8 +894,9 @@ struct Smear {
                      last ? fvw(K.l2[mu][nu]) : none));
           cnt++;
         }
-        CHK(ghosts_f(K.l2[mu][nu]));
+        CHK(ghosts_f_async(K.l2[mu][nu]));
       }
+    CHK(ghosts_join());
     for (int mu = 0; mu < 4; mu++) {
       const MViewW x3 = keep ? gvw(K.flx, mu) : fvw(tmp);
       int cnt = 0;
@@ -1000,9 +1016,13 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
     PB.nn = 3; PB.accumulate = 1; PB.ma = ma2; PB.alp = alp2;
     QX_PB_LAUNCH;
     HIPCHK(hipGetLastError());
-    for (int mu = 0; mu < 4; mu++)
-      for (int nu = 0; nu < 4; nu++)
-        if (nu != mu) CHK(S.ghosts_f(st->fl2[mu][nu]));
+    {
+      const double2 *fs[12]; int nf = 0;
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++)
+          if (nu != mu) fs[nf++] = st->fl2[mu][nu];
+      CHK(S.ghosts_many(fs, nf, 576, 1, 0));      // the twelve chain fields of the level in ONE group
+    }
   }
   HIPCHK(hipGetLastError());
   // the call (mu, nu, a) and its partner (a, nu, mu) share b = 6 - mu - nu - a and exchange the roles of their fields
@@ -1029,9 +1049,13 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
     PB.nn = 3; PB.accumulate = 1; PB.ma = ma1; PB.alp = alp1;
     QX_PB_LAUNCH;
     HIPCHK(hipGetLastError());
-    for (int mu = 0; mu < 4; mu++)
-      for (int nu = 0; nu < 4; nu++)
-        if (nu != mu) CHK(S.ghosts_f(st->fl1[mu][nu]));
+    {
+      const double2 *fs[12]; int nf = 0;
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++)
+          if (nu != mu) fs[nf++] = st->fl1[mu][nu];
+      CHK(S.ghosts_many(fs, nf, 576, 1, 0));
+    }
   }
   HIPCHK(hipGetLastError());
   for (int mu = 0; mu < 4; mu++)
