@@ -26,6 +26,8 @@
 #ifndef QEXHIP_H
 #define QEXHIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -459,6 +461,10 @@ int qexhip_io_read_field(const char *path, const int lat[4], void *data, int sit
  * *file_len / *record_len = the sizes needed (incl. the 0). */
 int qexhip_io_metadata(const char *path, char *file_md, int file_cap, char *record_md, int record_cap, int *file_len,
                        int *record_len);
+/* crc32 of src/io/crc32.nim:35-37 (reflected 0xedb88320, start and final complement 0xffffffff): what the SciDAC checksum pair
+ * is built from, suma ^= rotl(crc32(site), rank % 29), sumb ^= rotl(crc32(site), rank % 31).  The reference's own known
+ * answer: crc32("The quick brown fox jumps over the lazy dog") == 0x414FA339 (crc32.nim:103-106). */
+int qexhip_io_crc32(const void *data, size_t nbytes, unsigned *crc);
 
 /* ---------------- kernel timers ----------------
  * hipEvent pairs around launches of the named kernel class on the context stream

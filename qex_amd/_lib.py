@@ -122,6 +122,7 @@ SYMBOLS = [
     ("qexhip_md_save_links", _ci, [_vp]),
     ("qexhip_md_restore_links", _ci, [_vp]),
     ("qexhip_io_metadata", _ci, [C.c_char_p, C.c_char_p, _ci, C.c_char_p, _ci, _pi, _pi]),
+    ("qexhip_io_crc32", _ci, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint)]),   # data pointer, not a handle
     ("qexhip_io_gauge_info", _ci, [C.c_char_p, _pi, C.c_char_p, _pi]),
     ("qexhip_io_read_gauge", _ci, [C.c_char_p, _pi, _vp, _vp, _vp]),
     ("qexhip_io_read_gauge_slab", _ci, [C.c_char_p, _pi, _ci, _ci, _vp]),

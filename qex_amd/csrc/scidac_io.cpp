@@ -32,18 +32,21 @@
 void qexhip_set_error(const char *fmt, ...);
 
 namespace {
-uint32_t crc_table[256];
-bool crc_ready = false;
-void crc_init() {
-  for (uint32_t i = 0; i < 256; i++) {
-    uint32_t c = i;
-    for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-    crc_table[i] = c;
+// CRC-32 as src/io/crc32.nim: reflected polynomial 0xedb88320 (:5), table of the 256 byte remainders (:8-16), start
+// 0xffffffff, final complement (:25-37).  The reference's own known answer (crc32.nim:103-106) is held in tests/test_scidac_io.py.
+struct CrcTable {
+  uint32_t t[256];
+  CrcTable() {
+    for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      t[i] = c;
+    }
   }
-  crc_ready = true;
-}
+};
 uint32_t crc32(const unsigned char *p, size_t n) {
-  if (!crc_ready) crc_init();
+  static const CrcTable tab;                 // thread-safe one-time initialisation
+  const uint32_t *crc_table = tab.t;
   uint32_t c = 0xFFFFFFFFu;
   for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
   return c ^ 0xFFFFFFFFu;
@@ -497,3 +500,10 @@ extern "C" int qexhip_io_write_field(const char *path, const int lat[4], const v
 extern "C" int qexhip_io_read_field(const char *path, const int lat[4], void *data, int site_bytes, int word_bytes, char datatype[64]) { return guarded([&] { return io_read_field_impl(path, lat, data, site_bytes, word_bytes, datatype); }); }
 extern "C" int qexhip_io_metadata(const char *path, char *file_md, int file_cap, char *record_md, int record_cap, int *file_len,
                                   int *record_len) { return guarded([&] { return io_metadata_impl(path, file_md, file_cap, record_md, record_cap, file_len, record_len); }); }
+
+// the CRC-32 the checksums are built from (crc32 of src/io/crc32.nim:35-37), for hosts that want to verify records themselves
+extern "C" int qexhip_io_crc32(const void *data, size_t nbytes, unsigned *crc) {
+  if ((!data && nbytes) || !crc) return QEXHIP_ERR_ARG;
+  *crc = crc32((const unsigned char *)data, nbytes);
+  return 0;
+}
