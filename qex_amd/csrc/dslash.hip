@@ -226,7 +226,7 @@ int sweep_autotune(qexhip_ctx *c) {
   if (hi_beg <= lo_end) { c->overlap_auto[slot] = 0; return 0; }        // no interior to overlap with
   DevField a, b;
   CHK(field_alloc(c, a));
-  CHK(field_alloc(c, b));
+  if (int e = field_alloc(c, b)) { (void)hipFree(a.d); return e; }
   const int saved = c->opt_overlap, saved_timers = c->timers_on;
   c->timers_on = 0;
   double t[2] = {0, 0};
