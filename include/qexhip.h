@@ -163,6 +163,8 @@ int qexhip_stag_solve_multi(qexhip_handle h, double *const *xs, const double *b,
  * elementwise updates CG uses (fieldET.nim:547-598).  On host vectors; for tests. */
 int qexhip_norm2(qexhip_handle h, const double *x, int parity, double *out);
 int qexhip_redot(qexhip_handle h, const double *x, const double *y, int parity, double *out);
+/* dotP (src/field/fieldET.nim:677-693): the complex inner product sum_s x(s)^+ y(s); out[0] = Re, out[1] = Im */
+int qexhip_dot(qexhip_handle h, const double *x, const double *y, int parity, double out[2]);
 /* y[parity] += a*x */
 int qexhip_axpy(qexhip_handle h, double a, const double *x, double *y, int parity);
 /* y[parity] = x + a*y */
@@ -198,6 +200,7 @@ int qexhip_release_workspace(qexhip_handle h);
  * on resident fields: what a caller that keeps its vectors in HBM uses for true residuals and solution norms. */
 int qexhip_dev_norm2(qexhip_handle h, int x_id, int parity, double *out);
 int qexhip_dev_redot(qexhip_handle h, int x_id, int y_id, int parity, double *out);
+int qexhip_dev_dot(qexhip_handle h, int x_id, int y_id, int parity, double out[2]);     /* dotP on resident fields */
 int qexhip_dev_D(qexhip_handle h, int r_id, int x_id, double m, double sc);
 /* r[parity] := 0 (the `phi.odd := 0` of the pseudofermion refresh, staghmc_sh.nim:748-755) */
 int qexhip_dev_zero(qexhip_handle h, int id, int parity);

@@ -20,6 +20,7 @@
 #include "qexhip.h"
 #include <array>
 #include <chrono>
+#include <complex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -291,6 +292,16 @@ inline double norm2(Context &c, const Field &x, int subset = QEXHIP_ALL) {
   double r = 0;
   check(qexhip_norm2(c.h, x.data(), subset, &r));
   return r;
+}
+inline double redot(Context &c, const Field &x, const Field &y, int subset = QEXHIP_ALL) {      // fieldET.nim:704-724
+  double r = 0;
+  check(qexhip_redot(c.h, x.data(), y.data(), subset, &r));
+  return r;
+}
+inline std::complex<double> dot(Context &c, const Field &x, const Field &y, int subset = QEXHIP_ALL) {   // fieldET.nim:677-693
+  double r[2] = {0, 0};
+  check(qexhip_dot(c.h, x.data(), y.data(), subset, r));
+  return {r[0], r[1]};
 }
 
 }  // namespace qex

@@ -27,6 +27,8 @@ SYMBOLS = [
     ("qexhip_comm_info", _ci, [_vp, _pi, _pi, _pi, C.c_char_p, _ci]),
     ("qexhip_comm_count", _ci, [_vp, _pi]),
     ("qexhip_stag_sweep_info", _ci, [_vp, _pi]),
+    ("qexhip_dot", _ci, [_vp, _vp, _vp, _ci, _pd]),
+    ("qexhip_dev_dot", _ci, [_vp, _ci, _ci, _ci, _pd]),
     ("qexhip_stag_set_links", _ci, [_vp, _vp, _vp]),
     ("qexhip_stag_dslash", _ci, [_vp, _vp, _vp, _ci, _cd, _cd]),
     ("qexhip_stag_D", _ci, [_vp, _vp, _vp, _cd, _cd]),

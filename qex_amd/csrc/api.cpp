@@ -418,6 +418,15 @@ extern "C" int qexhip_redot(qexhip_handle c, const double *x, const double *y, i
   CHK(blas_redot(c, *fx, *fy, parity, &c->dscal[8]));
   return read_scalars(c, &c->dscal[8], 1, out);
 }
+extern "C" int qexhip_dot(qexhip_handle c, const double *x, const double *y, int parity, double out[2]) {
+  if (!c || !x || !y || !out || parity < 0 || parity > 2) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx, *fy;
+  CHK(host_in(c, WK_IN, x, &fx));
+  CHK(host_in(c, WK_IN2, y, &fy));
+  CHK(blas_cdot(c, *fx, *fy, parity, &c->dscal[8]));
+  return read_scalars(c, &c->dscal[8], 2, out);
+}
 extern "C" int qexhip_axpy(qexhip_handle c, double a, const double *x, double *y, int parity) {
   if (!c || !x || !y) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
@@ -563,6 +572,15 @@ extern "C" int qexhip_dev_redot(qexhip_handle c, int x_id, int y_id, int parity,
   CHK(find_field(c, y_id, &fy));
   CHK(blas_redot(c, *fx, *fy, parity, &c->dscal[8]));
   return read_scalars(c, &c->dscal[8], 1, out);
+}
+extern "C" int qexhip_dev_dot(qexhip_handle c, int x_id, int y_id, int parity, double out[2]) {
+  if (!c || !out || parity < 0 || parity > 2) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx, *fy;
+  CHK(find_field(c, x_id, &fx));
+  CHK(find_field(c, y_id, &fy));
+  CHK(blas_cdot(c, *fx, *fy, parity, &c->dscal[8]));
+  return read_scalars(c, &c->dscal[8], 2, out);
 }
 extern "C" int qexhip_dev_D(qexhip_handle c, int r_id, int x_id, double m, double sc) {
   if (!c || r_id == x_id) return QEXHIP_ERR_ARG;

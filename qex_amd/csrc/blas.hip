@@ -137,6 +137,45 @@ int blas_redot(qexhip_ctx *c, const DevField &x, const DevField &y, int parity, 
   }
   return reduce_partials(c, tot, dev_out);
 }
+// dotP (fieldET.nim:677-693): sum_s x(s)^+ y(s), complex -> dev_out[0] = Re, dev_out[1] = Im (rank-global)
+__global__ void __launch_bounds__(256) k_cdot(const double2 *x, const double2 *y, size_t n, double *pre, double *pim) {
+  double ar = 0, ai = 0;
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const double2 xv = x[i], yv = y[i];
+    ar = fma(xv.x, yv.x, fma(xv.y, yv.y, ar));
+    ai = fma(xv.x, yv.y, fma(-xv.y, yv.x, ai));
+  }
+  double r = block_sum_256(ar);
+  if (threadIdx.x == 0) pre[blockIdx.x] = r;
+  r = block_sum_256(ai);
+  if (threadIdx.x == 0) pim[blockIdx.x] = r;
+}
+__global__ void __launch_bounds__(256) k_reduce_final2(const double *pre, const double *pim, int n, double *out) {
+  const double *p = blockIdx.x ? pim : pre;
+  double acc = 0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += p[i];
+  double r = block_sum_256(acc);
+  if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+int blas_cdot(qexhip_ctx *c, const DevField &x, const DevField &y, int parity, double *dev_out) {
+  size_t n = body2(c);
+  const int nb = grid_for(n);
+  int tot = 0;
+  double *pre = c->partials, *pim = c->partials + 2 * nb;       // up to 2 x 2 x 2048 partials: the buffer holds part2_off (>= 6144) + 2048 + 64
+  if (4 * nb > c->part2_off + 2048) { qexhip_set_error("internal: partial buffer too small for cdot"); return -3; }
+  {
+    ScopedTimer tm(c, "blas", c->stream);
+    FOR_PAR(parity, p) {
+      k_cdot<<<nb, 256, 0, c->stream>>>(x.par(p), y.par(p), n, pre + tot, pim + tot);
+      tot += nb;
+    }
+    k_reduce_final2<<<2, 256, 0, c->stream>>>(pre, pim, tot, dev_out);
+    HIPCHK(hipGetLastError());
+  }
+  if (multi_rank(c)) CHK(comm_allreduce(c, dev_out, 2));
+  return 0;
+}
+
 int blas_norm2(qexhip_ctx *c, const DevField &x, int parity, double *dev_out) {
   return blas_redot(c, x, x, parity, dev_out);
 }

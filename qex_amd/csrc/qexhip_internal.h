@@ -218,6 +218,7 @@ int blas_scale(qexhip_ctx *c, double a, DevField &y, int parity);
 int blas_axpby(qexhip_ctx *c, double a, const DevField &x, double b, const DevField &y, DevField &z, int parity);  // z = a x + b y
 int blas_norm2(qexhip_ctx *c, const DevField &x, int parity, double *dev_out);   // rank-global
 int blas_redot(qexhip_ctx *c, const DevField &x, const DevField &y, int parity, double *dev_out);
+int blas_cdot(qexhip_ctx *c, const DevField &x, const DevField &y, int parity, double *dev_out);    // dev_out[0..1] = Re, Im of <x, y>
 int tile_order_table(qexhip_ctx *c, const int **tab, int *chunk);   // blocked (tile, parity) visiting order, layout.hip
 int tile_order_plane(qexhip_ctx *c, int mu, int nu, const int **tab, int *chunk);   // order for kernels whose gathers stay in the (mu, nu) plane
 int reduce_partials(qexhip_ctx *c, int n, double *dev_out);  // sum partials[0..n) -> dev_out (+ allreduce)

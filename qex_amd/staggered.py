@@ -215,6 +215,12 @@ class Context:
         check(lib().qexhip_dev_redot(self._h, x_id, y_id, _SUBSET[subset], C.byref(out)))
         return out.value
 
+    def dev_dot(self, x_id, y_id, subset="all"):
+        """dot(x, y) = sum x^+ y of resident fields (fieldET.nim:677-693), complex"""
+        out = (C.c_double * 2)()
+        check(lib().qexhip_dev_dot(self._h, x_id, y_id, _SUBSET[subset], out))
+        return complex(out[0], out[1])
+
     def dev_D(self, r_id, x_id, m, sc=1.0):
         """r = m x + sc D x on resident fields (Staggered.D: sc = 1, Ddag: sc = -1)"""
         check(lib().qexhip_dev_D(self._h, r_id, x_id, float(m), float(sc)))
@@ -229,6 +235,12 @@ class Context:
         out = C.c_double(0)
         check(lib().qexhip_redot(self._h, _p(x), _p(y), _SUBSET[subset], C.byref(out)))
         return out.value
+
+    def dot(self, x, y, subset="all"):
+        """dot(x, y) = sum x^+ y (fieldET.nim:677-693), complex"""
+        out = (C.c_double * 2)()
+        check(lib().qexhip_dot(self._h, _p(x), _p(y), _SUBSET[subset], out))
+        return complex(out[0], out[1])
 
     def axpy(self, a, x, y, subset="all"):
         check(lib().qexhip_axpy(self._h, a, _p(x), _p(y), _SUBSET[subset]))

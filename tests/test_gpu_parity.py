@@ -102,6 +102,21 @@ def test_blas_hooks(s8):
     assert relerr(y2, ref) < 1e-15
 
 
+def test_dotP(s8, sodd):
+    """dot(x, y) = sum x^+ y, complex (fieldET.nim:677-693), host and resident fields, all subsets, incl. a lattice with a ragged last tile"""
+    for S in (s8, sodd):
+        cx = lambda a: a[..., 0] + 1j * a[..., 1]
+        h = S.lo.vol // 2
+        ix, iy = S.ctx.field_new(S.x), S.ctx.field_new(S.y)
+        for sub, sl in (("even", slice(0, h)), ("odd", slice(h, None)), ("all", slice(None))):
+            want = np.vdot(cx(S.x[sl]), cx(S.y[sl]))
+            for got in (S.ctx.dot(S.x, S.y, sub), S.ctx.dev_dot(ix, iy, sub)):
+                assert abs(got - want) < 1e-12 * abs(want), (sub, got, want)
+            assert abs(S.ctx.dot(S.x, S.x, sub).imag) < 1e-12 and abs(S.ctx.dot(S.x, S.x, sub).real - S.ctx.norm2(S.x, sub)) < 1e-9
+            assert abs(S.ctx.dot(S.x, S.y, sub).real - S.ctx.redot(S.x, S.y, sub)) < 1e-9
+        S.ctx.field_free(ix); S.ctx.field_free(iy)
+
+
 @pytest.mark.parametrize("fix", ["s8", "sodd", "s8naik", "s8w", "soddw", "s8naikw"])
 @pytest.mark.parametrize("sub,par", [("even", 0), ("odd", 1), ("all", 2)])
 def test_stagD2(request, fix, sub, par):
