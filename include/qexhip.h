@@ -102,6 +102,10 @@ int qexhip_stag_dslash(qexhip_handle h, double *r, const double *x, int parity, 
  * Staggered.Ddag (sc=-1, :569-571):  r = m*x + sc*D*x */
 int qexhip_stag_D(qexhip_handle h, double *r, const double *x, double m, double sc);
 
+/* stagD itself (src/physics/stagD.nim:406-409) on ONE subset (parity QEXHIP_EVEN / ODD / ALL): r[subset] = a*r + m*x + sc*D*x,
+ * the rest of r kept.  stagDb (:425-427, no final scale) is qexhip_stag_dslash(h, r, x, parity, 0, m / (0.5 sc)). */
+int qexhip_stag_stagD(qexhip_handle h, double *r, const double *x, int parity, double m, double sc, double a);
+
 /* stagD with the accumulate coefficient: r = a*r + m*x + sc*D*x on both parities; a = 1, sc = -1 is
  * Staggered.peqDdag (src/physics/stagD.nim:572-574) */
 int qexhip_stag_D_acc(qexhip_handle h, double *r, const double *x, double m, double sc, double a);

@@ -149,6 +149,7 @@ class Staggered {
   int linkFormat() const { int n = 0, f = 0; double d = 0; check(qexhip_stag_links_info(c_.h, &n, &f, &d)); return f; }
   void D(Field &r, const Field &x, double m) { check(qexhip_stag_D(c_.h, r.data(), x.data(), m, 1.0)); }
   void Ddag(Field &r, const Field &x, double m) { check(qexhip_stag_D(c_.h, r.data(), x.data(), m, -1.0)); }
+  void stagD(Field &r, const Field &x, int subset, double m, double sc = 1.0, double a = 0.0) { check(qexhip_stag_stagD(c_.h, r.data(), x.data(), subset, m, sc, a)); }
   void eoReduce(Field &r, const Field &b, double m) { check(qexhip_stag_eo_reduce(c_.h, r.data(), b.data(), m)); }
   void eoReconstruct(Field &r, const Field &b, double m) { check(qexhip_stag_eo_reconstruct(c_.h, r.data(), b.data(), m)); }
   void stagD2(Field &r, const Field &x, int subset, double a, double b) { check(qexhip_stag_dslash(c_.h, r.data(), x.data(), subset, a, b)); }

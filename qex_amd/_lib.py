@@ -36,6 +36,7 @@ SYMBOLS = [
     ("qexhip_stag_op_xx", _ci, [_vp, _vp, _vp, _cd, _ci]),
     ("qexhip_stag_eo_reconstruct", _ci, [_vp, _vp, _vp, _cd]),
     ("qexhip_stag_eo_reduce", _ci, [_vp, _vp, _vp, _cd]),
+    ("qexhip_stag_stagD", _ci, [_vp, _vp, _vp, _ci, _cd, _cd, _cd]),
     ("qexhip_stag_outer", _ci, [_vp, _vp, _vp, _cd, _cd, _ci]),
     ("qexhip_stag_solve_xx", _ci, [_vp, _vp, _vp, _cd, _cd, _ci, _ci, _pi, _pd, _vp, _ci]),
     ("qexhip_stag_solve", _ci, [_vp, _vp, _vp, _cd, _cd, _ci, _pi, _pd]),

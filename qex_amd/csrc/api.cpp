@@ -321,6 +321,16 @@ extern "C" int qexhip_stag_sweep_info(qexhip_handle c, int out[8]) {
   return 0;
 }
 
+extern "C" int qexhip_stag_stagD(qexhip_handle c, double *r, const double *x, int parity, double m, double sc, double a) {
+  if (!c || !r || !x || parity < 0 || parity > 2 || sc == 0.0) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx, *fr;
+  CHK(host_in(c, WK_IN, x, &fx));
+  CHK(host_in(c, WK_OUT, r, &fr));       // r is read when a != 0; the other subset is kept
+  for (int p = (parity == 2 ? 0 : parity); p <= (parity == 2 ? 1 : parity); p++) CHK(op_stagD_pub(c, *fr, *fx, p, m, sc, a));
+  return field_download(c, *fr, r);
+}
+
 extern "C" int qexhip_stag_eo_reduce(qexhip_handle c, double *r, const double *b, double m) {
   if (!c || !r || !b) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));

@@ -166,6 +166,7 @@ int links_from_natural(qexhip_ctx *c, const double2 *fat, const double2 *lng);
 int links_compress(qexhip_ctx *c);
 int op_eo_reconstruct_pub(qexhip_ctx *c, DevField &r, DevField &b, double m);
 int op_eo_reduce_pub(qexhip_ctx *c, DevField &r, DevField &b, double m);
+int op_stagD_pub(qexhip_ctx *c, DevField &r, DevField &x, int parity, double m, double sc, double a);   // one subset of stagD
 void batch_state_free(qexhip_ctx *c);
 int batch_io_fields(qexhip_ctx *c, int n, DevField **xs, DevField **bs);
 int solve_full_batch_dev(qexhip_ctx *c, int n, DevField **x, DevField **b, const double *mass, const double *r2req,

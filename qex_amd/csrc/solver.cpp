@@ -71,6 +71,7 @@ static int op_eo_reconstruct(qexhip_ctx *c, DevField &r, DevField &b, double m) 
   return 0;
 }
 int op_eo_reconstruct_pub(qexhip_ctx *c, DevField &r, DevField &b, double m) { return op_eo_reconstruct(c, r, b, m); }
+int op_stagD_pub(qexhip_ctx *c, DevField &r, DevField &x, int parity, double m, double sc, double a) { return op_stagD(c, r, x, parity, m, sc, a); }
 // r.even = (D^+ b).even = (m b - D b).even  (eoReduce, stagD.nim:575-581: one stagD on the even subset with sc = -1)
 int op_eo_reduce_pub(qexhip_ctx *c, DevField &r, DevField &b, double m) { return op_stagD(c, r, b, 0, m, -1.0, 0.0); }
 

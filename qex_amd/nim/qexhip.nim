@@ -54,6 +54,7 @@ proc qexhip_comm_init(h: QexhipHandle; id: ptr char; nranks, rank: cint): cint {
 proc qexhip_stag_set_links(h: QexhipHandle; fat, lng: ptr cdouble): cint {.qh.}
 proc qexhip_stag_dslash(h: QexhipHandle; r, x: ptr cdouble; parity: cint; a, b: cdouble): cint {.qh.}
 proc qexhip_stag_D(h: QexhipHandle; r, x: ptr cdouble; m, sc: cdouble): cint {.qh.}
+proc qexhip_stag_stagD(h: QexhipHandle; r, x: ptr cdouble; parity: cint; m, sc, a: cdouble): cint {.qh.}
 proc qexhip_stag_eo_reduce(h: QexhipHandle; r, b: ptr cdouble; m: cdouble): cint {.qh.}
 proc qexhip_stag_eo_reconstruct(h: QexhipHandle; r, b: ptr cdouble; m: cdouble): cint {.qh.}
 proc qexhip_stag_solve_xx(h: QexhipHandle; x, b: ptr cdouble; mass, r2req: cdouble;
@@ -262,6 +263,14 @@ proc hipDdag*(s: Staggered; r, x: Field; m: SomeNumber) =
   toHost(x, xb)
   rb.setLen(xb.len)
   chk qexhip_stag_D(hipParam.h, rb.p, xb.p, m.cdouble, -1.0)
+  fromHost(r, rb)
+
+proc hipStagD*(s: Staggered; r, x: Field; m: SomeNumber; sc: SomeNumber = 1.0; a: SomeNumber = 0.0; subset = "all") =
+  ## stagD(s.se | s.so, r, s.g, x, m, sc, a) (stagD.nim:406-409): r[subset] = a r + m x + sc D x; the rest of r is kept
+  var rb, xb: HostBuf
+  toHost(x, xb)
+  toHost(r, rb)
+  chk qexhip_stag_stagD(hipParam.h, rb.p, xb.p, subsetCode(subset), m.cdouble, sc.cdouble, a.cdouble)
   fromHost(r, rb)
 
 proc hipEoReduce*(s: Staggered; r, b: Field; m: SomeNumber) =

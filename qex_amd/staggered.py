@@ -298,6 +298,10 @@ class Staggered:
         """f[mu][i][a,b] (:= | +=) scale * psi[i][a] * psi(i+mu)[b].adj  (staghmc_spv.nim:831-854)"""
         check(lib().qexhip_stag_outer(self.ctx._h, _p(f), _p(psi), float(scale), float(scale), 1 if accumulate else 0))
 
+    def stagD(self, r, x, subset, m, sc=1.0, a=0.0):
+        """stagD(s.se | s.so, r, s.g, x, m, sc, a) (stagD.nim:406-409): r[subset] = a*r + m*x + sc*D*x"""
+        check(lib().qexhip_stag_stagD(self.ctx._h, _p(r), _p(x), _SUBSET[subset], float(m), float(sc), float(a)))
+
     def eoReduce(self, r, b, m):
         """r.even = (D^+ b).even  (stagD.nim:575-581); r.odd is kept"""
         check(lib().qexhip_stag_eo_reduce(self.ctx._h, _p(r), _p(b), float(m)))

@@ -164,6 +164,11 @@ int main() {
     hipDdag(r, x, 0.1);
     qo_Ddag(lo, g.data(), nullptr, ref.data(), x.data(), 0.1);
     CHECK(relerr(r, ref) < 1e-13, "hipDdag: %g", relerr(r, ref));
+    // hipStagD (stagD.nim:406-409) on one subset with the accumulate term
+    Buf sd = y, sdref = y;
+    CHK(qexhip_stag_stagD(h, sd.data(), x.data(), QEXHIP_ODD, 0.2, -0.5, 0.7));
+    qo_stagD(lo, g.data(), nullptr, sdref.data(), x.data(), 1, 0.2, -0.5, 0.7);
+    CHECK(relerr(sd, sdref) < 1e-13, "hipStagD: %g", relerr(sd, sdref));
     // hipEoReduce / hipEoReconstruct (stagD.nim:575-586): r is read and written (the other parity is kept)
     Buf e = y, eref = y;
     CHK(qexhip_stag_eo_reduce(h, e.data(), x.data(), 0.1));

@@ -169,6 +169,20 @@ def test_eoReduce(request, which):
     assert relerr(r[:h], dd[:h]) < 1e-15
 
 
+@pytest.mark.parametrize("which", ["s8", "s8naik", "sodd"])
+def test_stagD_one_subset(request, which):
+    """stagD(sd, r, g, x, m, sc, a) (stagD.nim:406-409) on one subset: r[subset] = a r + m x + sc D x, the rest of r untouched"""
+    S = request.getfixturevalue(which)
+    h = S.lo.vol // 2
+    for subset, par, keep in (("even", 0, slice(h, None)), ("odd", 1, slice(0, h)), ("all", 2, slice(0, 0))):
+        for m, sc, a in ((0.1, 1.0, 0.0), (0.3, -1.0, 0.0), (0.2, -0.5, 0.7)):
+            r = S.y.copy()
+            S.s.stagD(r, S.x, subset, m, sc, a)
+            ref = S.y.copy()
+            S.o.stagD(S.lo, S.g, S.g3, ref, S.x, par, m, sc, a)
+            assert relerr(r, ref) < 1e-13 and np.array_equal(r[keep], S.y[keep]), (subset, m, sc, a)
+
+
 def test_eoReconstruct(s8):
     S = s8
     r = S.x.copy()
