@@ -237,7 +237,7 @@ int links_compress(qexhip_ctx *c) {
     HIPCHK(hipMalloc((void **)&c->Ws, nrows * sizeof(unsigned long long)));
     c->Wc_rows = nrows;
   }
-  unsigned int *flag = (unsigned int *)&c->dscal[30];
+  unsigned int *flag = (unsigned int *)&c->dscal[62];    // a slot of its own (qexhip_internal.h)
   const unsigned nblk = (unsigned)((nrows * 64 + 255) / 256);
   for (int fmt = 1; fmt <= 2; fmt++) {
     if (fmt == 2 && c->opt_recon == 1) break;          // QEXHIP_RECON=1: sign format only

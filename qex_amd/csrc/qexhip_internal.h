@@ -91,7 +91,11 @@ struct qexhip_ctx {
   double *stage = nullptr; size_t stage_bytes = 0;   // host-format staging on device
   double *partials = nullptr; int npartials = 0;     // block partial sums: [0,part2_off) Dslash / redot, then 2048 for the CG update
   int part2_off = 0;
-  double *dscal = nullptr;                           // device scalars (reductions)
+  double *dscal = nullptr;                           // 64 device scalars (reductions), by owner: [0..4] solvers (b2, r2, norms of
+                                                     // the full solve), [8..9] the BLAS entry points, [16..21] plaquettes, [24..32]
+                                                     // flow observables / action / line sums, [40..51]
+                                                     // s4 / Polyakov sums, [56..59] comm_allreduce_max, [60] comm_init's agreement,
+                                                     // [62] link-compression test
   CgScal *cg = nullptr;                              // device CG state
   double *hist = nullptr; int histcap = 0;           // device residual history
   void *pinned = nullptr;                            // pinned host scratch (4 KiB)
