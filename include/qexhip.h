@@ -327,6 +327,10 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *   "batch_multi"  1: the same for the lock-step multi-system CG
  *   "force_pair"   0: k_force_lds (one tile and parity per workgroup), what shapes without paired tile positions run
  *   "obs_clover"   0: the generic path walker, what fmunu loops 3-5 run, for the clover loop as well
+ *   "emu_exchange_us", "emu_allreduce_us"   transport emulation for one-GPU rehearsals: every face exchange / all-reduce is preceded,
+ *                  on its stream, by a wait of that many microseconds -- the time the transfer would take between distinct
+ *                  GPUs.  Results must not depend on it (a consumer that does not wait for its ghosts would show); iteration
+ *                  times under it are what bench.py --halo --emulate-transport reports
  *
  * Environment (read once, at qexhip_init / qexhip_comm_init) -- the complete list:
  *   QEXHIP_RECON, QEXHIP_OVERLAP, QEXHIP_FLOW_EXP   initial values of the options of the same (lower-case) name

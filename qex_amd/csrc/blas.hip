@@ -72,6 +72,24 @@ __global__ void __launch_bounds__(256) k_reduce_final(const double *partials, in
   if (threadIdx.x == 0) *out = r;
 }
 
+// Transport emulation (options "emu_exchange_us" / "emu_allreduce_us", comm.cpp): one lane waits `us` microseconds of the
+// constant-rate wall clock (100 MHz on gfx950) on the stream a collective is about to be posted on -- so that a one-GPU
+// rehearsal sees exchanges / all-reduces that take as long as they would between distinct GPUs.  Bounded by construction:
+// the loop ends when the clock has advanced, and at the latest after 2^22 polls (~0.1 s).
+__global__ void k_delay(long long ticks) {
+  const long long t0 = wall_clock64();
+  for (int i = 0; i < (1 << 22); i++) {
+    if (wall_clock64() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+int blas_delay(hipStream_t st, int us) {
+  if (us <= 0) return 0;
+  k_delay<<<1, 1, 0, st>>>((long long)us * 100);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int blas_grid(const qexhip_ctx *c, int) { return grid_for(body2(c)); }   // workgroups (= partial sums) of the CG's BLAS kernels
 
 int blas_zero(qexhip_ctx *c, DevField &f, int parity) {

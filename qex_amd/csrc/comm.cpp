@@ -158,6 +158,7 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
   double2 *ghost_lo = ghost_hi + face2;
   if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   ScopedTimer tm(c, "exchange", cs);            // on the stream the group is posted on: transport + waiting for the neighbours
+  CHK(blas_delay(cs, c->emu_exchange_us));
   if (c->comm) {
     // the overlapped exchange has the second communicator to itself (comm_init)
     ncclComm_t comm = (ncclComm_t)((overlap && c->comm2) ? c->comm2 : c->comm);
@@ -186,6 +187,7 @@ int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parit
   const size_t nd = face2 * 2;
   if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   ScopedTimer tm(c, "exchange", cs);
+  CHK(blas_delay(cs, c->emu_exchange_us));
   if (c->comm) {
     ncclComm_t comm = (ncclComm_t)((overlap && c->comm2) ? c->comm2 : c->comm);
     NCCLCHK(ncclGroupStart());
@@ -235,6 +237,7 @@ int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double 
   CHK(need_comm(c));
   hipStream_t st = async ? c->cstream : c->stream;
   if (async) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+  CHK(blas_delay(st, c->emu_exchange_us));
   if (c->comm) {
     ncclComm_t comm = (ncclComm_t)((async && c->comm2) ? c->comm2 : c->comm);
     NCCLCHK(ncclGroupStart());
@@ -271,6 +274,7 @@ int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
   CHK(need_comm(c));
   if (!multi_rank(c) || !c->comm) return 0;    // one rank without the rehearsal hook, or no communicator: nothing to sum
   ScopedTimer tm(c, "allreduce", c->stream);
+  CHK(blas_delay(c->stream, c->emu_allreduce_us));
   NCCLCHK(ncclAllReduce(dptr, dptr, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
   return 0;
 }

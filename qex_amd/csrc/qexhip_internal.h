@@ -117,6 +117,8 @@ struct qexhip_ctx {
   int opt_recon = 2;      // QEXHIP_RECON: 0 keeps the 18-real links always, 1 sign format only, 2 also the U(3) format
   int opt_overlap = -1;  // QEXHIP_OVERLAP / option "overlap": 1 always use the comm stream, 0 never, -1 measured once per operator shape when the
                          // communicator has more than one rank (sweep_autotune), by interior / face size otherwise; -2: measure on one rank too
+  int emu_exchange_us = 0, emu_allreduce_us = 0;   // options of the same names (test / rehearsal hooks): delay posted in front of every face
+                                                   // exchange / all-reduce, as long as the transfer would take between distinct GPUs
   int overlap_auto[2]{-1, -1};          // the measured decision for 8- and 16-link operators (-1: not measured)
   double overlap_tune_us[2][2]{};       // us per sweep the measurement saw: [8 | 16 links][exchange first | overlapped], max over ranks
   // natural gauge (flow)
@@ -229,6 +231,7 @@ int tile_order_plane(qexhip_ctx *c, int mu, int nu, const int **tab, int *chunk)
 int reduce_partials(qexhip_ctx *c, int n, double *dev_out);  // sum partials[0..n) -> dev_out (+ allreduce)
 int read_scalars(qexhip_ctx *c, const double *dev, int n, double *host);  // sync readback
 int blas_grid(const qexhip_ctx *c, int parity_count);
+int blas_delay(hipStream_t st, int us);      // transport emulation: a one-lane kernel that waits `us` microseconds on st
 // CG fused kernels
 int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity, int k, int rolled);
 int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity, int k, int ndot);

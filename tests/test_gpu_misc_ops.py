@@ -364,3 +364,81 @@ def test_overlap_decision_is_measured_when_asked(oracle):
         s.D(r, x, 0.1)
         assert np.linalg.norm(r - ref) / np.linalg.norm(ref) < 1e-13
     ctx.close()
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_sharded_paths_under_emulated_transport_latency(oracle, overlap):
+    """Between distinct GPUs a face exchange takes tens to hundreds of microseconds; in the one-rank rehearsal it is almost
+    free, so a consumer that forgot to wait for its ghosts could go unnoticed.  Options emu_exchange_us / emu_allreduce_us put
+    a wait in front of every exchange / all-reduce on its stream -- longer than any kernel of this lattice -- and every
+    sharded path must still reproduce the periodic kernels: the overlapped sweep with its boundary launch on the comm
+    stream, CG and multi-shift histories, the lock-step batch (one RCCL group, overlapped), nHYP smearing with its
+    asynchronous level refreshes, and the force chain."""
+    import qex_amd as q
+
+    o = oracle
+    lat = [16, 16, 16, 8]
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 77)
+    g = o.gauge_warm(lo, 0.5, rf)
+    gp = g.copy()
+    o.rephase(lo, gp)
+    g3 = 0.3 * gp
+    x, y = o.vector_gaussian(lo, rf), o.vector_gaussian(lo, rf)
+    chain = o.gauge_random_tah(lo, rf)
+    h = lo.vol // 2
+    res = {}
+    for mode in ("periodic", "emulated"):
+        ctx = q.Context(lat)
+        if mode == "emulated":
+            ctx.comm_init(q.Context.unique_id(), 1, 0)
+            ctx.force_halo(True)
+            ctx.set_option("multi_reduce", 1)
+            ctx.set_option("batch_multi", 1)
+            ctx.set_option("overlap", overlap)
+            ctx.set_option("emu_exchange_us", 400)
+            ctx.set_option("emu_allreduce_us", 60)
+        r = {}
+        for naik in (False, True):
+            s = q.newStag3(ctx, gp, g3) if naik else q.newStag(ctx, gp)
+            d = np.zeros_like(x)
+            s.D(d, x, 0.1)
+            r["D%d" % naik] = d.copy()
+            sp = q.SolverParams(r2req=1e-10, maxits=400, verbosity=0)
+            xs = np.zeros_like(x)
+            s.solveEE(xs, x, 0.2, sp, histcap=512)
+            r["cg%d" % naik] = (sp.iterations, sp.r2hist.copy(), xs.copy())
+        masses = [0.2, 0.4, 0.8]
+        ys = [np.zeros_like(x) for _ in masses]
+        spm = q.SolverParams(r2req=1e-10, maxits=400, verbosity=0)
+        s.solveXX_multi(ys, x, [masses[0]] + [4 * (m * m - masses[0] ** 2) for m in masses[1:]], spm, histcap=512)
+        r["multi"] = (spm.iterations, spm.r2hist.copy(), [v.copy() for v in ys])
+        bs = [x.copy(), y.copy(), x + y]
+        for b in bs:
+            b[h:] = 0
+        bx = [np.zeros_like(b) for b in bs]
+        its, _ = s.solveXX_batch(bx, bs, [0.2, 0.3, 0.5], 1e-10, 400, True)
+        r["batch"] = (its, [v.copy() for v in bx])
+        sg = np.zeros_like(g)
+        sf = q.HypCoefs(0.4, 0.5, 0.5).smearGetForce(ctx, g, sg)
+        f = np.zeros_like(g)
+        sf(f, chain)
+        r["nhyp"], r["chain"] = sg.copy(), f.copy()
+        sf.release()
+        r["plaq"] = q.plaq(ctx, g)
+        gf = g.copy()
+        q.gaugeFlow(ctx, gf, 1, 0.01)
+        r["flow"] = gf
+        ctx.close()
+        res[mode] = r
+    a, b = res["periodic"], res["emulated"]
+    rel = lambda u, v: np.linalg.norm((u - v).ravel()) / np.linalg.norm(u.ravel())
+    for k in ("D0", "D1", "nhyp", "chain", "flow"):
+        assert rel(a[k], b[k]) < 1e-14, k
+    assert np.abs(a["plaq"] - b["plaq"]).max() < 1e-15
+    for k in ("cg0", "cg1", "multi"):
+        assert abs(a[k][0] - b[k][0]) <= 1, k
+        n = min(len(a[k][1]), len(b[k][1]), 100)
+        assert np.abs(b[k][1][:n] / a[k][1][:n] - 1).max() < 1e-9, k
+    assert rel(a["cg0"][2][:h], b["cg0"][2][:h]) < 1e-7 and all(rel(u[:h], v[:h]) < 1e-7 for u, v in zip(a["multi"][2], b["multi"][2]))
+    assert all(abs(i - j) <= 1 for i, j in zip(a["batch"][0], b["batch"][0])) and all(rel(u[:h], v[:h]) < 1e-7 for u, v in zip(a["batch"][1], b["batch"][1]))
