@@ -169,6 +169,15 @@ def main():
         _, fr = o.nhyp_force(olo, gw, chain, 0.4, 0.5, 0.5)
         o.force_projTAH(olo, fr, gw, adj=True)
         res["nhyp_gforce"] = relerr(f, sl(fr))
+        # the operator on the closure's links, BC + staggered phases put on by the DEVICE (k_rephase: the t boundary condition
+        # lives on the last rank only -- the one piece of rank-coordinate logic a one-rank run cannot reach)
+        sn = q.Staggered(ctx, None, smear=q.HypCoefs(0.4, 0.5, 0.5), bc="pppa")
+        sgp = sgr.copy()
+        o.rephase(olo, sgp)
+        r = np.zeros_like(sl(x))
+        sn.D(r, sl(x), 0.1)
+        res["D_on_device_rephased_nhyp_links"] = relerr(r, sl(o.D(olo, sgp, None, x, 0.1)))
+        assert res["D_on_device_rephased_nhyp_links"] < 1e-12, res
         sf.release()
         assert res["nhyp_smear"] < 1e-12 and res["nhyp_gforce"] < 1e-11, res
 
