@@ -61,10 +61,23 @@ int qexhip_sync(qexhip_handle h);
 /* library / device description, for logs */
 int qexhip_device_info(qexhip_handle h, char *buf, int buflen);
 
-/* ---------------- communicator (RCCL over xGMI) ----------------
+/* ---------------- communicator (RCCL over xGMI, or peer-mapped memory) ----------------
  * Replaces the QMP send/recv pairs of the shifts (src/layout/qshifts.nim:51-131) and
  * threadRankSum's QMP_sum (src/comms/commsUtils.nim:195-204, commsQmp.nim:127-128).
- * Rank 0 obtains an id, the host broadcasts it (QMP_broadcast in QEX), every rank calls init. */
+ * Rank 0 obtains an id, the host broadcasts it (QMP_broadcast in QEX), every rank calls init (collective; an id serves ONE
+ * comm_init).  Two transports sit behind the same entry points (QEXHIP_TRANSPORT / option "transport", one value for the
+ * whole job):
+ *   rccl   ncclSend/ncclRecv groups and ncclAllReduce between DISTINCT devices -- the default whenever every rank has a GPU
+ *          of its own; works across nodes
+ *   peer   every rank maps its neighbours' receive arenas and every rank's mailbox through hipIpc; a face exchange is one
+ *          kernel that pushes into the neighbour's HBM and unpacks what arrived, an all-reduce one single-workgroup kernel
+ *          that sums the ranks' mailboxes in rank order (bit-identical on every rank).  One node only (<= 16 ranks).  It is
+ *          the only transport that lets several ranks share ONE device, which RCCL refuses
+ *   auto   (default) the ranks of the node meet in a POSIX shared-memory segment named after the id and take `peer` if any
+ *          two of them are bound to the same device, `rccl` otherwise.  A job that spans nodes sets QEXHIP_TRANSPORT=rccl
+ *          (no rendezvous).  QEXHIP_RENDEZVOUS_TIMEOUT (s, default 120) bounds the wait for the other ranks,
+ *          QEXHIP_PEER_TIMEOUT (s, default 30) every device-side wait of the peer transport: a rank that never arrives
+ *          becomes QEXHIP_ERR_COMM on the others, never a hang. */
 #define QEXHIP_UNIQUE_ID_BYTES 128
 int qexhip_comm_unique_id(char id[QEXHIP_UNIQUE_ID_BYTES]);
 int qexhip_comm_init(qexhip_handle h, const char id[QEXHIP_UNIQUE_ID_BYTES], int nranks, int rank);
@@ -73,9 +86,13 @@ int qexhip_comm_init(qexhip_handle h, const char id[QEXHIP_UNIQUE_ID_BYTES], int
  * Without a communicator nranks = 0, rank = -1.  Any output pointer may be NULL.
  * A context with rankGeom[3] > 1 refuses every exchange / reduction until qexhip_comm_init has run (QEXHIP_ERR_STATE). */
 int qexhip_comm_info(qexhip_handle h, int *nranks, int *rank, int *device, char *busid, int buslen);
+/* which transport the communicator runs on: name = "none" | "rccl" | "peer"; stats (may be NULL) = peer-transport counters
+ * {face exchanges posted, all-reduces posted, arena (re)allocations, bytes of receive arena}, zeros otherwise */
+int qexhip_comm_transport(qexhip_handle h, char *name, int len, long stats[4]);
 /* number of RCCL communicators the context holds: 0 before comm_init, 2 afterwards (one for the compute stream's all-reduces
  * and ghost refreshes, one -- ncclCommSplit of the first -- for the face exchanges posted on the second stream beside the
- * interior sweep, so that neither queues behind the other), 1 with QEXHIP_COMM2=0. */
+ * interior sweep, so that neither queues behind the other), 1 with QEXHIP_COMM2=0.  Peer transport: 2 (the two streams'
+ * channels are independent by construction). */
 int qexhip_comm_count(qexhip_handle h, int *ncomms);
 /* How a one-parity sweep runs on this context's (t-sharded) field: out[0] = 1 if t-hops across the slab boundary go through
  * ghost zones, out[1] = 1 if the face exchange is posted on the second stream beside an interior launch, out[2] = interior
@@ -320,6 +337,10 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *   "overlap"      face exchange on the second stream beside the interior sweep: 0 never, 1 always, -1 (default) measured at
  *                  set_links when the communicator has more than one rank (qexhip_stag_sweep_info), else by interior / face
  *                  size; -2: measure on one rank too (test hook)
+ *                  0 / 1 also pin the launch structure, and with it the bits of a sharded residual history, from run to run
+ *                  (the measurement takes the overlapped form only on a > 5 % win).  Must be the same on every rank (checked
+ *                  at set_links)
+ *   "transport"    before qexhip_comm_init: 0 auto, 1 rccl, 2 peer (see "communicator"); the same on every rank
  *   "flow_exp"     1: closed-form exp(v) in the Wilson-flow stage (default; agrees with the reference's to ~1e-15 per element),
  *                  0: the reference's algorithm, order-4 Taylor + 20 squarings (matexp.nim:80-85,634-649)
  *   test hooks -- each selects, on any lattice, the code path that some lattices / ranks take by necessity:
@@ -334,6 +355,7 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *
  * Environment (read once, at qexhip_init / qexhip_comm_init) -- the complete list:
  *   QEXHIP_RECON, QEXHIP_OVERLAP, QEXHIP_FLOW_EXP   initial values of the options of the same (lower-case) name
+ *   QEXHIP_TRANSPORT=auto|rccl|peer, QEXHIP_RENDEZVOUS_TIMEOUT, QEXHIP_PEER_TIMEOUT   see "communicator"
  *   QEXHIP_COMM2=0   keep ONE RCCL communicator for both streams (default: the overlapped face exchange gets a communicator
  *                    of its own); the ranks agree on this by a min-all-reduce, any rank's 0 wins
  * Every other choice the kernels make (visiting orders, non-temporal accesses, LDS staging, launch shapes) is fixed to the

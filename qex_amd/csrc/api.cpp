@@ -196,7 +196,7 @@ extern "C" int qexhip_sync(qexhip_handle c) {
   if (!c) return QEXHIP_ERR_ARG;
   HIPCHK(hipStreamSynchronize(c->cstream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  return 0;
+  return peer_check(c);
 }
 
 extern "C" int qexhip_device_info(qexhip_handle c, char *buf, int buflen) {
@@ -236,7 +236,7 @@ extern "C" int qexhip_comm_force_halo(qexhip_handle c, int on) {
 extern "C" int qexhip_stag_set_links(qexhip_handle c, const double *fat, const double *lng) {
   if (!c || !fat) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(c->device));
-  if (c->rankGeom[3] > 1 && !c->comm) { qexhip_set_error("rankGeom[3] = %d but qexhip_comm_init was not called", c->rankGeom[3]); return QEXHIP_ERR_STATE; }
+  if (c->rankGeom[3] > 1 && !comm_ready(c)) { qexhip_set_error("rankGeom[3] = %d but qexhip_comm_init was not called", c->rankGeom[3]); return QEXHIP_ERR_STATE; }
   if (c->g.halo) {
     int depth = lng ? 3 : 1;
     if (c->g.X[3] < depth) { qexhip_set_error("local t extent %d < hop length %d", c->g.X[3], depth); return QEXHIP_ERR_ARG; }
@@ -623,6 +623,11 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   const std::string n(name);
   if (n == "recon") c->opt_recon = value;            // takes effect at the next set_links
   else if (n == "overlap") c->opt_overlap = value;
+  else if (n == "transport") {
+    if (comm_ready(c)) { qexhip_set_error("option transport must be set before qexhip_comm_init"); return QEXHIP_ERR_STATE; }
+    if (value < 0 || value > 2) { qexhip_set_error("option transport: 0 auto, 1 rccl, 2 peer"); return QEXHIP_ERR_ARG; }
+    c->opt_transport = value;
+  }
   else if (n == "batch_multi") c->opt_batch_multi = value;
   else if (n == "multi_reduce") c->opt_multi_reduce = value;
   else if (n == "flow_exp") c->opt_flow_exp = value;

@@ -201,6 +201,7 @@ int blas_norm2(qexhip_ctx *c, const DevField &x, int parity, double *dev_out) {
 int read_scalars(qexhip_ctx *c, const double *dev, int n, double *host) {
   HIPCHK(hipMemcpyAsync(c->pinned, dev, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  CHK(peer_check(c));        // a bounded device-side wait of the peer transport gave up: the numbers below would be garbage
   for (int i = 0; i < n; i++) host[i] = ((double *)c->pinned)[i];
   return 0;
 }

@@ -1,4 +1,4 @@
-// comm.cpp -- RCCL (over xGMI) communicator: t-face halo exchange and scalar all-reduce.
+// comm.cpp -- the communicator: t-face halo exchange and scalar all-reduce, over RCCL (xGMI) or over peer-mapped memory (peer.hip).
 //
 // Replaces (a) the persistent QMP send/recv pairs behind startSB/boundarySB2
 // (src/layout/shifts.nim:67-94,254-285; src/layout/qshifts.nim:51-131) and (b) the
@@ -8,6 +8,7 @@
 // (qexhip_internal.h), so there is no pack or unpack kernel: RCCL sends straight out of the
 // field and receives straight into the ghost tiles.
 #include "qexhip_internal.h"
+#include "peer_shm.h"
 #include "../../include/qexhip.h"
 #include <rccl/rccl.h>
 #include <cstring>
@@ -32,14 +33,73 @@ extern "C" int qexhip_comm_unique_id(char id[QEXHIP_UNIQUE_ID_BYTES]) {
   return 0;
 }
 
+// QEXHIP_TRANSPORT / option "transport": which transport a communicator uses.  One decision for the whole job:
+//   rccl (1)  RCCL between distinct devices, the north star's transport; no rendezvous, works across nodes
+//   peer (2)  peer-mapped memory (peer.hip); one node; the only choice when ranks share a device
+//   auto (0, default)  the ranks meet in a shared-memory segment named after the id, compare devices, and take `peer` if
+//             any two of them share one (RCCL refuses that), `rccl` otherwise
+static int transport_wish(const qexhip_ctx *c) {
+  if (c->opt_transport >= 0) return c->opt_transport;
+  const char *e = getenv("QEXHIP_TRANSPORT");
+  if (!e || !*e) return 0;
+  if (!strcmp(e, "rccl") || !strcmp(e, "1")) return 1;
+  if (!strcmp(e, "peer") || !strcmp(e, "2")) return 2;
+  return 0;
+}
+
+// Decide the transport (collective over the node's ranks unless the wish is rccl).  *use_peer = 1: `host` stays open for peer_init.
+static int choose_transport(qexhip_ctx *c, const char *id, int nranks, int rank, PeerHost *host, int *use_peer) {
+  *use_peer = 0;
+  const int wish = transport_wish(c);
+  if (wish == 1 || nranks > PEER_MAXR) return 0;
+  double tmo = 120.0;
+  if (const char *e = getenv("QEXHIP_RENDEZVOUS_TIMEOUT")) { const double v = atof(e); if (v > 0) tmo = v; }
+  CHK(peer_host_open(host, (const unsigned char *)id, nranks, rank, tmo));
+  PeerShmSlot &me = host->shm->s[rank];
+  me.device = c->device;
+  me.wish = wish;
+  me.bus[0] = 0;
+  if (hipDeviceGetPCIBusId(me.bus, (int)sizeof me.bus, c->device) != hipSuccess) { (void)hipGetLastError(); snprintf(me.bus, sizeof me.bus, "dev%d", c->device); }
+  if (int e = peer_host_barrier(host)) { peer_host_close(host); return e; }
+  int any_peer = 0, shared = 0;
+  for (int r = 0; r < nranks; r++) {
+    const PeerShmSlot &a = host->shm->s[r];
+    if (a.wish == 2) any_peer = 1;
+    for (int q = 0; q < r; q++) {
+      const PeerShmSlot &b = host->shm->s[q];
+      if (!strncmp(a.bus, b.bus, sizeof a.bus) && !strncmp(a.host, b.host, sizeof a.host)) shared = 1;
+    }
+  }
+  *use_peer = (any_peer || shared) ? 1 : 0;
+  if (!*use_peer) {
+    // every rank has read the table (it decided the same): a second barrier keeps rank 0 from unmapping under a slow reader
+    int e = peer_host_barrier(host);
+    peer_host_close(host);
+    return e;
+  }
+  return 0;
+}
+
 extern "C" int qexhip_comm_init(qexhip_handle c, const char id[QEXHIP_UNIQUE_ID_BYTES], int nranks, int rank) {
-  if (!c) return QEXHIP_ERR_ARG;
+  if (!c || !id) return QEXHIP_ERR_ARG;
   if (nranks != c->rankGeom[3] || rank != c->rankCoord[3]) {
     qexhip_set_error("comm_init: nranks/rank (%d/%d) must equal rankGeom[3]/rankCoord[3] (%d/%d)", nranks, rank,
                      c->rankGeom[3], c->rankCoord[3]);
     return QEXHIP_ERR_ARG;
   }
-  if (c->comm) { qexhip_set_error("communicator already initialised"); return QEXHIP_ERR_STATE; }
+  if (comm_ready(c)) { qexhip_set_error("communicator already initialised"); return QEXHIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(c->device));
+  {
+    PeerHost host;
+    int use_peer = 0;
+    CHK(choose_transport(c, id, nranks, rank, &host, &use_peer));
+    if (use_peer) {
+      c->nranks = nranks;
+      c->rank = rank;
+      if (int e = peer_init(c, host)) { peer_destroy(c); c->nranks = 1; c->rank = 0; return e; }
+      return 0;
+    }
+  }
   HIPCHK(hipSetDevice(c->device));
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
@@ -94,13 +154,14 @@ extern "C" int qexhip_comm_init(qexhip_handle c, const char id[QEXHIP_UNIQUE_ID_
 }
 
 void comm_destroy(qexhip_ctx *c) {
+  peer_destroy(c);
   if (c->comm2) { ncclCommDestroy((ncclComm_t)c->comm2); c->comm2 = nullptr; }
   if (c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
 }
 
 extern "C" int qexhip_comm_count(qexhip_handle c, int *ncomms) {
   if (!c || !ncomms) return QEXHIP_ERR_ARG;
-  *ncomms = (c->comm ? 1 : 0) + (c->comm2 ? 1 : 0);
+  *ncomms = c->peer ? 2 : (c->comm ? 1 : 0) + (c->comm2 ? 1 : 0);      // peer transport: the two stream classes are independent channels
   return 0;
 }
 
@@ -108,7 +169,7 @@ extern "C" int qexhip_comm_count(qexhip_handle c, int *ncomms) {
 // the copy fallbacks below could do is wrap that slab onto itself, i.e. silently compute the physics of a different
 // (periodic, smaller) lattice.  Every exchange / reduction entry refuses instead.
 static int need_comm(const qexhip_ctx *c) {
-  if (!c->comm && c->rankGeom[3] > 1) {
+  if (!comm_ready(c) && c->rankGeom[3] > 1) {
     qexhip_set_error("rankGeom[3] = %d but qexhip_comm_init was not called: refusing to wrap the local slab periodically",
                      c->rankGeom[3]);
     return QEXHIP_ERR_STATE;
@@ -116,10 +177,18 @@ static int need_comm(const qexhip_ctx *c) {
   return 0;
 }
 
+extern "C" int qexhip_comm_transport(qexhip_handle c, char *name, int len, long stats[4]) {
+  if (!c) return QEXHIP_ERR_ARG;
+  if (name && len > 0) snprintf(name, len, "%s", c->peer ? "peer" : (c->comm ? "rccl" : "none"));
+  if (stats) peer_info(c, stats);
+  return 0;
+}
+
 // what RCCL itself says about the communicator (bench.py reports it so that "N ranks" is RCCL's count, not ours)
 extern "C" int qexhip_comm_info(qexhip_handle c, int *nranks, int *rank, int *device, char *busid, int buslen) {
   if (!c) return QEXHIP_ERR_ARG;
   int n = 0, r = -1, d = c->device;
+  if (c->peer) { n = c->nranks; r = c->rank; }
   if (c->comm) {
     NCCLCHK(ncclCommCount((ncclComm_t)c->comm, &n));
     NCCLCHK(ncclCommUserRank((ncclComm_t)c->comm, &r));
@@ -159,7 +228,11 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
   if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   ScopedTimer tm(c, "exchange", cs);            // on the stream the group is posted on: transport + waiting for the neighbours
   CHK(blas_delay(cs, c->emu_exchange_us));
-  if (c->comm) {
+  if (c->peer) {
+    const void *dn = bottom, *up = top;
+    void *from_up = ghost_hi, *from_dn = ghost_lo;
+    CHK(peer_exchange(c, cs, 1, &dn, 1, &up, &from_up, &from_dn, nd * sizeof(double)));
+  } else if (c->comm) {
     // the overlapped exchange has the second communicator to itself (comm_init)
     ncclComm_t comm = (ncclComm_t)((overlap && c->comm2) ? c->comm2 : c->comm);
     NCCLCHK(ncclGroupStart());
@@ -188,7 +261,16 @@ int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parit
   if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   ScopedTimer tm(c, "exchange", cs);
   CHK(blas_delay(cs, c->emu_exchange_us));
-  if (c->comm) {
+  if (c->peer) {
+    std::vector<const void *> dn(n), up(n);
+    std::vector<void *> from_up(n), from_dn(n);
+    for (int j = 0; j < n; j++) {
+      double2 *base = f[j]->par(parity);
+      dn[j] = base; up[j] = base + (size_t)(g.ntile) * 192 - face2;
+      from_up[j] = base + (size_t)g.ntile * 192; from_dn[j] = base + (size_t)g.ntile * 192 + face2;
+    }
+    CHK(peer_exchange(c, cs, n, dn.data(), n, up.data(), from_up.data(), from_dn.data(), nd * sizeof(double)));
+  } else if (c->comm) {
     ncclComm_t comm = (ncclComm_t)((overlap && c->comm2) ? c->comm2 : c->comm);
     NCCLCHK(ncclGroupStart());
     for (int j = 0; j < n; j++) {
@@ -215,7 +297,9 @@ int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parit
 // send `bytes` to the upper neighbour, receive the same amount from the lower one (stream-ordered)
 int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st) {
   CHK(need_comm(c));
-  if (c->comm) {
+  if (c->peer) {
+    CHK(peer_exchange(c, st, 0, nullptr, 1, &send_up, nullptr, &recv_from_down, bytes));
+  } else if (c->comm) {
     ncclComm_t comm = (ncclComm_t)c->comm;
     NCCLCHK(ncclGroupStart());
     NCCLCHK(ncclSend(send_up, bytes, ncclChar, upper(c), comm, st));
@@ -238,7 +322,10 @@ int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double 
   hipStream_t st = async ? c->cstream : c->stream;
   if (async) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   CHK(blas_delay(st, c->emu_exchange_us));
-  if (c->comm) {
+  if (c->peer) {
+    CHK(peer_exchange(c, st, nbuf, (const void *const *)bottom, nbuf, (const void *const *)top, (void *const *)ghost_hi, (void *const *)ghost_lo,
+                      ndoubles * sizeof(double)));
+  } else if (c->comm) {
     ncclComm_t comm = (ncclComm_t)((async && c->comm2) ? c->comm2 : c->comm);
     NCCLCHK(ncclGroupStart());
     for (int k = 0; k < nbuf; k++) {
@@ -262,6 +349,7 @@ int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double 
 // rank-ordered concatenation of `n` doubles per rank (one rank / no communicator: a copy)
 int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n) {
   CHK(need_comm(c));
+  if (c->peer && c->nranks > 1) return peer_allgather(c, send, recv, n);
   if (c->comm && c->nranks > 1) {
     NCCLCHK(ncclAllGather(send, recv, n, ncclDouble, (ncclComm_t)c->comm, c->stream));
   } else {
@@ -272,16 +360,18 @@ int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n) {
 
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
   CHK(need_comm(c));
-  if (!multi_rank(c) || !c->comm) return 0;    // one rank without the rehearsal hook, or no communicator: nothing to sum
+  if (!multi_rank(c) || !comm_ready(c)) return 0;    // one rank without the rehearsal hook, or no communicator: nothing to sum
   ScopedTimer tm(c, "allreduce", c->stream);
   CHK(blas_delay(c->stream, c->emu_allreduce_us));
+  if (c->peer) return peer_allreduce(c, dptr, n, 0);
   NCCLCHK(ncclAllReduce(dptr, dptr, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
   return 0;
 }
 
 int comm_allreduce_max(qexhip_ctx *c, double *host, int n) {
   if (n > 4) return QEXHIP_ERR_ARG;
-  if (!c->comm || c->nranks < 2) return 0;
+  if (!comm_ready(c) || c->nranks < 2) return 0;
+  if (c->peer) return peer_host_reduce(c, host, n, 0);     // host operands: through the rendezvous segment, no GPU involved
   double *d = &c->dscal[56];
   HIPCHK(hipMemcpyAsync(d, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   NCCLCHK(ncclAllReduce(d, d, n, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));
@@ -296,12 +386,14 @@ int comm_allreduce_max(qexhip_ctx *c, double *host, int n) {
 // the state the host is about to read is therefore max-reduced as {r2, -r2, itn, -itn}; max and min must coincide.
 int comm_agree_post(qexhip_ctx *c) {
   CHK(need_comm(c));
-  if (!multi_rank(c) || !c->comm) return 0;
+  if (!multi_rank(c) || !comm_ready(c)) return 0;
+  if (c->peer) return peer_allreduce(c, c->cg->agree, 4, 1);
   NCCLCHK(ncclAllReduce(c->cg->agree, c->cg->agree, 4, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));
   return 0;
 }
 int comm_agree_check(qexhip_ctx *c, const CgScal &h) {
-  if (!multi_rank(c) || !c->comm) return 0;
+  if (!multi_rank(c) || !comm_ready(c)) return 0;
+  CHK(peer_check(c));
   const bool both_nan = std::isnan(h.agree[0]) && std::isnan(h.agree[1]);     // a NaN residual ends the loop on every rank alike
   if ((!both_nan && h.agree[0] != -h.agree[1]) || h.agree[2] != -h.agree[3]) {
     qexhip_set_error("sharded CG: the ranks disagree on the residual (%.17g .. %.17g) or the iteration count (%g .. %g) -- "

@@ -219,18 +219,29 @@ void sweep_plan(const qexhip_ctx *c, int *lo_end_out, int *hi_beg_out, int *over
 int sweep_autotune(qexhip_ctx *c) {
   const Geom &g = c->g;
   const int slot = c->ndir == 16;
-  if (!g.halo || !c->W || c->overlap_auto[slot] >= 0) return 0;
-  if (!(c->opt_overlap == -2 || (c->opt_overlap == -1 && c->nranks > 1 && c->comm))) return 0;
+  if (!g.halo || !c->W) return 0;
+  const bool multi = c->nranks > 1 && comm_ready(c);
+  if (multi) {
+    // The overlap decision selects the stream (and, on RCCL, the communicator) an exchange is posted on: ranks that disagreed
+    // would never match.  set_links is collective, so this is the place to find out (QEXHIP_OVERLAP / option "overlap").
+    double v[2] = {(double)c->opt_overlap, -(double)c->opt_overlap};
+    CHK(comm_allreduce_max(c, v, 2));
+    if (v[0] != -v[1]) {
+      qexhip_set_error("option overlap / QEXHIP_OVERLAP differs between the ranks (%g .. %g): it must be the same everywhere", -v[1], v[0]);
+      return -3;
+    }
+  }
+  if (c->overlap_auto[slot] >= 0) return 0;
+  if (!(c->opt_overlap == -2 || (c->opt_overlap == -1 && multi))) return 0;
   int lo_end, hi_beg, dummy;
   sweep_plan(c, &lo_end, &hi_beg, &dummy);
   if (hi_beg <= lo_end) { c->overlap_auto[slot] = 0; return 0; }        // no interior to overlap with
   DevField a, b;
-  CHK(field_alloc(c, a));
-  if (int e = field_alloc(c, b)) { (void)hipFree(a.d); return e; }
+  int rc = field_alloc(c, a);
+  if (!rc) rc = field_alloc(c, b);
   const int saved = c->opt_overlap, saved_timers = c->timers_on;
   c->timers_on = 0;
   double t[2] = {0, 0};
-  int rc = 0;
   for (int mode = 0; mode < 2 && !rc; mode++) {
     c->opt_overlap = mode;
     for (int k = 0; k < 12 && !rc; k++) {
@@ -243,11 +254,21 @@ int sweep_autotune(qexhip_ctx *c) {
   }
   c->opt_overlap = saved;
   c->timers_on = saved_timers;
-  (void)hipFree(a.d); (void)hipFree(b.d);
+  if (a.d) (void)hipFree(a.d);
+  if (b.d) (void)hipFree(b.d);
+  // every rank reaches the collective, a failed one with a sentinel, so that all fail together instead of one hanging the others
+  double v[3] = {t[0], t[1], rc ? 1.0 : 0.0};
+  if (multi) {
+    const int e = comm_allreduce_max(c, v, 3);
+    if (e && !rc) rc = e;
+  }
   if (rc) return rc;
-  if (c->comm && c->nranks > 1) CHK(comm_allreduce_max(c, t, 2));
-  c->overlap_auto[slot] = t[1] < t[0] ? 1 : 0;
-  c->overlap_tune_us[slot][0] = t[0] / 10.0; c->overlap_tune_us[slot][1] = t[1] / 10.0;
+  if (v[2] != 0.0) { qexhip_set_error("sweep_autotune: another rank failed while measuring"); return -4; }
+  // Overlap only on a clear win (> 5 %): the two forms group the deferred dot partials differently, so a decision that flips
+  // between runs on timing noise would cost run-to-run bit-reproducibility of the residual history for nothing.
+  // Option overlap = 0 / 1 pins the form (and the bits) outright.
+  c->overlap_auto[slot] = v[1] < 0.95 * v[0] ? 1 : 0;
+  c->overlap_tune_us[slot][0] = v[0] / 10.0; c->overlap_tune_us[slot][1] = v[1] / 10.0;
   return 0;
 }
 

@@ -1,0 +1,432 @@
+// peer.hip -- the peer-memory transport: faces pushed straight into the neighbour's HBM through hipIpc-mapped memory,
+// sequence-numbered flags instead of a collective library, rank-ordered mailbox all-reduce.
+//
+// Replaces, like comm.cpp's RCCL arm, the QMP send/recv pairs of the shifts (src/layout/qshifts.nim:51-131,
+// src/layout/shifts.nim:67-94,254-285) and the rank sum of threadRankSum (src/comms/commsUtils.nim:195-204).  Two reasons
+// for a second transport next to RCCL:
+//   * RCCL refuses two ranks on one device; this transport does not care which device a peer's memory lives on, so
+//     N processes sharing ONE MI355X run the real multi-rank protocol (rank > 0 kernels, real neighbours) on the one-GPU
+//     boxes the test suite gets;
+//   * latency: a CG iteration on a thin slab is dominated by fixed costs.  A mailbox all-reduce is one
+//     single-workgroup launch (3.5-4.5 us measured against ~21 us for ncclAllReduce of the same scalar,
+//     profiles/r05_ipc_probe.log), a face exchange one launch with no proxy thread in the path.
+//
+// Protocol (every rank runs the same sequence of calls, as with any collective library):
+//   channel  = (stream class s: 0 compute stream, 1 comm stream; direction d).  Each rank owns, per class, an inbound
+//              ARENA with two halves (messages from the lower / from the upper neighbour) and, in its CONTROL block, one
+//              `data` word per inbound channel and one `credit` word per outbound channel.
+//   exchange n on a channel, ONE kernel per rank (k_peer_exchange):
+//     push    wait until my credit word says the receiver has unpacked message n-1 (its arena half is free), copy the
+//             faces into the receiver's arena half, system-scope release, then data := n in the receiver's control block;
+//     unpack  wait until my data word says n, system-scope acquire, copy my arena half into the ghost tiles (or any other
+//             destination: nothing has to be registered), then credit := n in the sender's control block.
+//     The push of exchange n needs only the peer's unpack n-1, which needs only my push n-1 (an earlier kernel on the same
+//     stream): no cycle, whatever the residency of the workgroups.
+//   all-reduce k (k_peer_allreduce, one workgroup): copy my operand into slot k&3 of EVERY rank's mailbox, flag := k; wait
+//     for the N flags of my own mailbox; sum the N operands in rank order -- the same bits on every rank, whatever the
+//     arrival order.  A rank can be at most one all-reduce ahead of the slowest one, so four slots never collide.
+// Every device-side wait is bounded (timeout -> error word in pinned host memory -> QEXHIP_ERR_COMM at the next host
+// sync): both processes may share the CUs, and a wave that never exits would take the box down.
+#include "qexhip_internal.h"
+#include "peer_shm.h"
+#include "../../include/qexhip.h"
+#include <cstring>
+#include <cstdlib>
+#include <algorithm>
+
+static_assert(sizeof(hipIpcMemHandle_t) <= PEER_HANDLE_BYTES, "ipc handle size");
+
+typedef unsigned long long u64;
+enum { PEER_MAXSEG = 32, PEER_CHUNK = 2048, PEER_NSLOT = 4, PEER_MBOX_N = 4096 };
+// control block, in 8-byte words: every polled word on a 128-byte line of its own
+enum { CW_DATA = 0 /* + (s*2+d)*16 */, CW_CREDIT = 64 /* + (s*2+dir)*16 */, CW_MFLAG = 256 /* + slot*PEER_MAXR + src */,
+       CTRL_MBOX_BYTE = 8192, CTRL_BYTES = CTRL_MBOX_BYTE + PEER_NSLOT * PEER_MAXR * PEER_MBOX_N * 8 };
+
+struct PeerComm {
+  PeerHost host;
+  int nranks = 1, rank = 0;
+  char *ctrl = nullptr;
+  char *arena[2]{nullptr, nullptr};      // per stream class: [from lower: cap | from upper: cap]
+  size_t cap[2]{0, 0};                   // bytes of ONE half
+  char *pctrl[PEER_MAXR]{};              // every rank's control block as mapped here (own pointer at [rank])
+  char *parena[2][PEER_MAXR]{};          // arenas of the two neighbours as mapped here
+  unsigned int *done = nullptr;          // device: [class][push | unpack] completion counters
+  u64 *err = nullptr;                    // pinned host word the kernels write on a timeout
+  u64 seq_out[2][2]{}, seq_in[2][2]{}, seq_red = 0;
+  long long ticks = 0;                   // timeout in wall_clock64 ticks
+  long exchanges = 0, allreduces = 0, grows = 0;
+};
+
+static inline int upper(const PeerComm *p) { return (p->rank + 1) % p->nranks; }
+static inline int lower(const PeerComm *p) { return (p->rank - 1 + p->nranks) % p->nranks; }
+
+// ---------------- device side ----------------
+__device__ inline bool peer_poll_ge(const u64 *p, u64 want, u64 *err, long long ticks, u64 code) {
+  if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
+  const long long t0 = wall_clock64();
+  for (unsigned it = 1;; it++) {
+    __builtin_amdgcn_s_sleep(4);
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
+    if ((it & 255) == 0) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;    // somebody gave up already
+      if (wall_clock64() - t0 > ticks) {
+        __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return false;
+      }
+    }
+  }
+}
+
+struct PeerXfer {
+  const uint4 *src[2][PEER_MAXSEG];   // pieces to [lower | upper]
+  uint4 *dst[2][PEER_MAXSEG];         // destinations of the pieces from [lower | upper]
+  uint4 *out_arena[2];                // peer-mapped: [lower's from-upper half | upper's from-lower half]
+  const uint4 *in_arena[2];           // own: [from-lower half | from-upper half]
+  u64 *out_flag[2];                   // peer-mapped data words
+  const u64 *credit[2];               // own credit words of the two outbound channels
+  const u64 *in_flag[2];              // own data words
+  u64 *credit_out[2];                 // peer-mapped credit words of the two senders
+  u64 seq_out[2], seq_in[2];
+  u64 *err;
+  unsigned int *done;                 // [0] push, [1] unpack
+  long long ticks;
+  u64 n16;                            // 16-byte units per piece
+  int ns[2], nr[2];
+};
+
+__device__ inline void peer_copy_chunk(uint4 *__restrict__ d, const uint4 *__restrict__ s, unsigned n) {
+  // n <= PEER_CHUNK units, 256 lanes.  Whole chunks: 8 loads in flight per lane before the first store
+  if (n == PEER_CHUNK) {
+    uint4 v0 = s[threadIdx.x], v1 = s[threadIdx.x + 256], v2 = s[threadIdx.x + 512], v3 = s[threadIdx.x + 768];
+    uint4 v4 = s[threadIdx.x + 1024], v5 = s[threadIdx.x + 1280], v6 = s[threadIdx.x + 1536], v7 = s[threadIdx.x + 1792];
+    d[threadIdx.x] = v0; d[threadIdx.x + 256] = v1; d[threadIdx.x + 512] = v2; d[threadIdx.x + 768] = v3;
+    d[threadIdx.x + 1024] = v4; d[threadIdx.x + 1280] = v5; d[threadIdx.x + 1536] = v6; d[threadIdx.x + 1792] = v7;
+  } else {
+    for (unsigned i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
+  __shared__ int ok;
+  const unsigned cpp = (unsigned)((X.n16 + PEER_CHUNK - 1) / PEER_CHUNK);   // chunks per piece
+  // ---- push ----
+  const unsigned nout = (unsigned)(X.ns[0] + X.ns[1]) * cpp;
+  if (threadIdx.x == 0) {
+    int good = 1;
+    for (int dir = 0; dir < 2; dir++)
+      if (X.ns[dir] > 0 && !peer_poll_ge(X.credit[dir], X.seq_out[dir] - 1, X.err, X.ticks, 0x100 + dir)) good = 0;
+    ok = good;
+  }
+  __syncthreads();
+  if (!ok) return;
+  for (unsigned ch = blockIdx.x; ch < nout; ch += gridDim.x) {
+    const unsigned q = ch / cpp, j = ch - q * cpp;
+    const int dir = q >= (unsigned)X.ns[0];
+    const unsigned k = dir ? q - X.ns[0] : q;
+    const u64 off = (u64)j * PEER_CHUNK;
+    const unsigned n = (unsigned)(X.n16 - off < PEER_CHUNK ? X.n16 - off : PEER_CHUNK);
+    peer_copy_chunk(X.out_arena[dir] + (u64)k * X.n16 + off, X.src[dir][k] + off, n);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: its stores have reached L2 / the fabric
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope: this XCD's dirty lines are written back ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ... before the counter / flag (MI355X_MICROARCH: the compiler may drop this wait)
+    const unsigned a = __hip_atomic_fetch_add(&X.done[0], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (a == gridDim.x - 1) {
+      __hip_atomic_store(&X.done[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int dir = 0; dir < 2; dir++)
+        if (X.ns[dir] > 0) __hip_atomic_store(X.out_flag[dir], X.seq_out[dir], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  // ---- unpack ----
+  const unsigned nin = (unsigned)(X.nr[0] + X.nr[1]) * cpp;
+  if (threadIdx.x == 0) {
+    int good = 1;
+    for (int d = 0; d < 2; d++)
+      if (X.nr[d] > 0 && !peer_poll_ge(X.in_flag[d], X.seq_in[d], X.err, X.ticks, 0x200 + d)) good = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ok = good;
+  }
+  __syncthreads();
+  if (!ok) return;
+  for (unsigned ch = blockIdx.x; ch < nin; ch += gridDim.x) {
+    const unsigned q = ch / cpp, j = ch - q * cpp;
+    const int d = q >= (unsigned)X.nr[0];
+    const unsigned k = d ? q - X.nr[0] : q;
+    const u64 off = (u64)j * PEER_CHUNK;
+    const unsigned n = (unsigned)(X.n16 - off < PEER_CHUNK ? X.n16 - off : PEER_CHUNK);
+    peer_copy_chunk(X.dst[d][k] + off, X.in_arena[d] + (u64)k * X.n16 + off, n);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every load of the arena has returned before the credit goes out
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned a = __hip_atomic_fetch_add(&X.done[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (a == gridDim.x - 1) {
+      __hip_atomic_store(&X.done[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int d = 0; d < 2; d++)
+        if (X.nr[d] > 0) __hip_atomic_store(X.credit_out[d], X.seq_in[d], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+struct PeerMbox {
+  double *box[PEER_MAXR];     // mailbox payload of every rank as mapped here: [slot][src][PEER_MBOX_N]
+  u64 *flag[PEER_MAXR];       // mailbox flags of every rank: [slot][src]
+  u64 *err;
+  long long ticks;
+  int nranks, me;
+};
+
+// OP 0: sum, 1: max.  x[0..n) := reduction over the ranks, in rank order
+template <int OP>
+__global__ void __launch_bounds__(512) k_peer_allreduce(double *x, int n, const PeerMbox M, u64 seq) {
+  __shared__ int ok;
+  const int slot = (int)(seq & (PEER_NSLOT - 1));
+  const size_t mine = ((size_t)slot * PEER_MAXR + M.me) * PEER_MBOX_N;
+  for (int i = threadIdx.x; i < n; i += 512) {
+    const double v = x[i];
+    for (int r = 0; r < M.nranks; r++) M.box[r][mine + i] = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) ok = 1;
+  __syncthreads();
+  if ((int)threadIdx.x < M.nranks) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&M.flag[threadIdx.x][slot * PEER_MAXR + M.me], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!peer_poll_ge(&M.flag[M.me][slot * PEER_MAXR + threadIdx.x], seq, M.err, M.ticks, 0x300 + threadIdx.x)) ok = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (!ok) return;
+  const double *my = M.box[M.me] + (size_t)slot * PEER_MAXR * PEER_MBOX_N;
+  for (int i = threadIdx.x; i < n; i += 512) {
+    double acc = my[i];
+    for (int r = 1; r < M.nranks; r++) {
+      const double v = my[(size_t)r * PEER_MBOX_N + i];
+      if (OP == 0) acc += v;
+      else acc = (v > acc || v != v) ? v : acc;
+    }
+    x[i] = acc;
+  }
+}
+
+// ---------------- host side ----------------
+static u64 *ctrl_word(char *ctrl, int w) { return (u64 *)ctrl + w; }
+
+static int peer_check_err(PeerComm *p) {
+  const u64 e = __atomic_load_n(p->err, __ATOMIC_ACQUIRE);
+  if (e) {
+    const char *what = (e & 0xF00) == 0x100 ? "credit of an outbound channel" : (e & 0xF00) == 0x200 ? "data of an inbound channel" : "all-reduce contribution";
+    qexhip_set_error("peer transport: rank %d timed out waiting for the %s (code 0x%llx): a neighbour is gone, or the ranks "
+                     "did not issue the same sequence of exchanges", p->rank, what, e);
+    peer_host_fail(&p->host);
+    return QEXHIP_ERR_COMM;
+  }
+  return 0;
+}
+int peer_check(qexhip_ctx *c) { return c->peer ? peer_check_err(c->peer) : 0; }
+
+static void fill_mbox(const PeerComm *p, PeerMbox &M) {
+  for (int r = 0; r < p->nranks; r++) {
+    M.box[r] = (double *)(p->pctrl[r] + CTRL_MBOX_BYTE);
+    M.flag[r] = ctrl_word(p->pctrl[r], CW_MFLAG);
+  }
+  M.err = p->err; M.ticks = p->ticks; M.nranks = p->nranks; M.me = p->rank;
+}
+
+int peer_init(qexhip_ctx *c, PeerHost &host) {
+  PeerComm *p = new PeerComm();
+  p->host = host;
+  p->nranks = host.nranks; p->rank = host.rank;
+  c->peer = p;                                   // from here comm_destroy owns it
+  double tmo = 30.0;
+  if (const char *e = getenv("QEXHIP_PEER_TIMEOUT")) { const double v = atof(e); if (v > 0) tmo = v; }
+  int khz = 0;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device);
+  if (khz <= 0) khz = 100000;
+  p->ticks = (long long)(tmo * 1000.0 * khz);
+  HIPCHK(hipMalloc((void **)&p->ctrl, CTRL_BYTES));
+  HIPCHK(hipMemset(p->ctrl, 0, CTRL_BYTES));
+  HIPCHK(hipMalloc((void **)&p->done, 64));
+  HIPCHK(hipMemset(p->done, 0, 64));
+  HIPCHK(hipHostMalloc((void **)&p->err, 64, hipHostMallocDefault));
+  *p->err = 0;
+  HIPCHK(hipDeviceSynchronize());
+  PeerShmSlot &me = p->host.shm->s[p->rank];
+  if (p->nranks > 1) {
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, p->ctrl));
+    memcpy(me.handle[0], &h, sizeof h);
+    me.cap[0] = CTRL_BYTES;
+  }
+  CHK(peer_host_barrier(&p->host));
+  for (int r = 0; r < p->nranks; r++) {
+    if (r == p->rank) { p->pctrl[r] = p->ctrl; continue; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const void *)p->host.shm->s[r].handle[0], sizeof h);
+    HIPCHK(hipIpcOpenMemHandle((void **)&p->pctrl[r], h, hipIpcMemLazyEnablePeerAccess));
+  }
+  CHK(peer_host_barrier(&p->host));
+  peer_host_unlink(&p->host);          // every rank has mapped the segment: the name can go (nothing is left behind if the job dies)
+  return 0;
+}
+
+// the inbound arena of stream class s must hold `bytes` per half.  Growing is COLLECTIVE: by symmetry (equal local
+// volumes, same call sequence) every rank is in this call with the same size
+static int peer_ensure_arena(qexhip_ctx *c, int s, size_t bytes) {
+  PeerComm *p = c->peer;
+  if (bytes <= p->cap[s]) return 0;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(c->cstream));
+  CHK(peer_check_err(p));
+  CHK(peer_host_barrier(&p->host));               // nobody is writing into anybody's old arena any more
+  const int nb[2] = {lower(p), upper(p)};
+  for (int k = 0; k < 2; k++) {
+    const int r = nb[k];
+    if (r != p->rank && p->parena[s][r]) { (void)hipIpcCloseMemHandle(p->parena[s][r]); }
+    p->parena[s][r] = nullptr;
+  }
+  CHK(peer_host_barrier(&p->host));               // nobody maps my old arena any more
+  if (p->arena[s]) HIPCHK(hipFree(p->arena[s]));
+  p->arena[s] = nullptr;
+  size_t cap = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20);
+  cap = (cap + 4095) & ~(size_t)4095;
+  HIPCHK(hipMalloc((void **)&p->arena[s], 2 * cap));
+  PeerShmSlot &me = p->host.shm->s[p->rank];
+  if (p->nranks > 1) {
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, p->arena[s]));
+    memcpy(me.handle[1 + s], &h, sizeof h);
+  }
+  me.cap[1 + s] = cap;
+  CHK(peer_host_barrier(&p->host));
+  for (int k = 0; k < 2; k++) {
+    const int r = nb[k];
+    if (p->host.shm->s[r].cap[1 + s] != cap) {
+      qexhip_set_error("peer transport: rank %d sized its arena %llu bytes, rank %d %zu: the ranks' messages differ in size", r,
+                       (unsigned long long)p->host.shm->s[r].cap[1 + s], p->rank, cap);
+      peer_host_fail(&p->host);
+      return QEXHIP_ERR_COMM;
+    }
+    if (r == p->rank) { p->parena[s][r] = p->arena[s]; continue; }
+    if (p->parena[s][r]) continue;               // two ranks: lower == upper, opened once
+    hipIpcMemHandle_t h;
+    memcpy(&h, (const void *)p->host.shm->s[r].handle[1 + s], sizeof h);
+    HIPCHK(hipIpcOpenMemHandle((void **)&p->parena[s][r], h, hipIpcMemLazyEnablePeerAccess));
+  }
+  CHK(peer_host_barrier(&p->host));
+  p->cap[s] = cap;
+  p->grows++;
+  return 0;
+}
+
+// One exchange on stream st: ns_dn pieces to the lower neighbour (they arrive in ITS from-upper half), ns_up pieces to the upper
+// one; by symmetry ns_up pieces arrive from the lower neighbour (-> dst_from_dn) and ns_dn from the upper one (-> dst_from_up).
+// Every piece is `bytes` long (a multiple of 16).
+int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *src_dn, int ns_up, const void *const *src_up,
+                  void *const *dst_from_up, void *const *dst_from_dn, size_t bytes) {
+  PeerComm *p = c->peer;
+  if (bytes % 16 != 0) { qexhip_set_error("peer transport: message of %zu bytes is not a multiple of 16", bytes); return QEXHIP_ERR_ARG; }
+  if (ns_dn < 0 || ns_up < 0 || (ns_dn == 0 && ns_up == 0) || bytes == 0) return 0;
+  const int s = (st == c->cstream) ? 1 : 0;
+  CHK(peer_check_err(p));
+  for (int k0 = 0; k0 < std::max(ns_dn, ns_up); k0 += (int)PEER_MAXSEG) {
+    const int nd = std::max(0, std::min((int)PEER_MAXSEG, ns_dn - k0)), nu = std::max(0, std::min((int)PEER_MAXSEG, ns_up - k0));
+    CHK(peer_ensure_arena(c, s, (size_t)std::max(nd, nu) * bytes));
+    PeerXfer X;
+    memset(&X, 0, sizeof X);
+    const int lo = lower(p), up = upper(p);
+    for (int k = 0; k < nd; k++) { X.src[0][k] = (const uint4 *)src_dn[k0 + k]; X.dst[1][k] = (uint4 *)dst_from_up[k0 + k]; }
+    for (int k = 0; k < nu; k++) { X.src[1][k] = (const uint4 *)src_up[k0 + k]; X.dst[0][k] = (uint4 *)dst_from_dn[k0 + k]; }
+    X.ns[0] = nd; X.ns[1] = nu; X.nr[0] = nu; X.nr[1] = nd;
+    X.n16 = bytes / 16;
+    X.out_arena[0] = (uint4 *)(p->parena[s][lo] + p->cap[s]);       // the lower neighbour's from-upper half
+    X.out_arena[1] = (uint4 *)(p->parena[s][up]);                   // the upper neighbour's from-lower half
+    X.in_arena[0] = (const uint4 *)p->arena[s];
+    X.in_arena[1] = (const uint4 *)(p->arena[s] + p->cap[s]);
+    X.out_flag[0] = ctrl_word(p->pctrl[lo], CW_DATA + (s * 2 + 1) * 16);
+    X.out_flag[1] = ctrl_word(p->pctrl[up], CW_DATA + (s * 2 + 0) * 16);
+    X.credit[0] = ctrl_word(p->ctrl, CW_CREDIT + (s * 2 + 0) * 16);
+    X.credit[1] = ctrl_word(p->ctrl, CW_CREDIT + (s * 2 + 1) * 16);
+    X.in_flag[0] = ctrl_word(p->ctrl, CW_DATA + (s * 2 + 0) * 16);
+    X.in_flag[1] = ctrl_word(p->ctrl, CW_DATA + (s * 2 + 1) * 16);
+    X.credit_out[0] = ctrl_word(p->pctrl[lo], CW_CREDIT + (s * 2 + 1) * 16);   // the lower neighbour's to-upper channel
+    X.credit_out[1] = ctrl_word(p->pctrl[up], CW_CREDIT + (s * 2 + 0) * 16);   // the upper neighbour's to-lower channel
+    for (int d = 0; d < 2; d++) {
+      if (X.ns[d] > 0) X.seq_out[d] = ++p->seq_out[s][d];
+      if (X.nr[d] > 0) X.seq_in[d] = ++p->seq_in[s][d];
+    }
+    X.err = p->err; X.done = p->done + s * 2; X.ticks = p->ticks;
+    const size_t cpp = (X.n16 + PEER_CHUNK - 1) / PEER_CHUNK;
+    const size_t nch = (size_t)(nd + nu) * cpp;
+    const int grid = (int)std::min<size_t>(nch, 256);
+    hipLaunchKernelGGL(k_peer_exchange, dim3(grid), dim3(256), 0, st, X);
+    HIPCHK(hipGetLastError());
+    p->exchanges++;
+  }
+  return 0;
+}
+
+int peer_allreduce(qexhip_ctx *c, double *dptr, int n, int op) {
+  PeerComm *p = c->peer;
+  CHK(peer_check_err(p));
+  PeerMbox M;
+  fill_mbox(p, M);
+  for (int i0 = 0; i0 < n; i0 += PEER_MBOX_N) {
+    const int m = std::min<int>(PEER_MBOX_N, n - i0);
+    const u64 seq = ++p->seq_red;
+    if (op == 0) hipLaunchKernelGGL(k_peer_allreduce<0>, dim3(1), dim3(512), 0, c->stream, dptr + i0, m, M, seq);
+    else hipLaunchKernelGGL(k_peer_allreduce<1>, dim3(1), dim3(512), 0, c->stream, dptr + i0, m, M, seq);
+    p->allreduces++;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int peer_host_reduce(qexhip_ctx *c, double *host, int n, int op) { return peer_host_allreduce(&c->peer->host, host, n, op); }
+
+// rank-ordered concatenation by a ring of N-1 one-way exchanges: step k forwards the segment of rank (me - k) upwards
+int peer_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n) {
+  PeerComm *p = c->peer;
+  HIPCHK(hipMemcpyAsync(recv + (size_t)p->rank * n, send, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  for (int k = 0; k + 1 < p->nranks; k++) {
+    const int have = (p->rank - k + p->nranks) % p->nranks, get = (p->rank - k - 1 + p->nranks) % p->nranks;
+    const void *src = recv + (size_t)have * n;
+    void *dst = recv + (size_t)get * n;
+    CHK(peer_exchange(c, c->stream, 0, nullptr, 1, &src, nullptr, &dst, n * sizeof(double)));
+  }
+  return 0;
+}
+
+void peer_info(const qexhip_ctx *c, long out[4]) {
+  const PeerComm *p = c->peer;
+  out[0] = p ? p->exchanges : 0; out[1] = p ? p->allreduces : 0; out[2] = p ? p->grows : 0;
+  out[3] = p ? (long)(p->cap[0] + p->cap[1]) * 2 : 0;
+}
+
+void peer_destroy(qexhip_ctx *c) {
+  PeerComm *p = c->peer;
+  if (!p) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  // nobody unmaps or frees while a neighbour may still be writing; a short bounded wait -- a peer that died is not waited for
+  p->host.timeout_s = std::min(p->host.timeout_s, 10.0);
+  const bool all_here = p->host.shm && peer_host_barrier(&p->host) == 0;
+  for (int r = 0; r < p->nranks; r++) {
+    if (r == p->rank) continue;
+    if (p->pctrl[r]) (void)hipIpcCloseMemHandle(p->pctrl[r]);
+    for (int s = 0; s < 2; s++) if (p->parena[s][r]) (void)hipIpcCloseMemHandle(p->parena[s][r]);
+  }
+  if (all_here) (void)peer_host_barrier(&p->host);
+  for (int s = 0; s < 2; s++) if (p->arena[s]) (void)hipFree(p->arena[s]);
+  if (p->ctrl) (void)hipFree(p->ctrl);
+  if (p->done) (void)hipFree(p->done);
+  if (p->err) (void)hipHostFree(p->err);
+  peer_host_close(&p->host);
+  delete p;
+  c->peer = nullptr;
+}

@@ -67,6 +67,7 @@ struct TimerSlot {
 };
 
 struct GaugeNat;  // natural-layout gauge field for plaquette / flow (gauge.hip)
+struct PeerComm;  // peer-memory transport (peer.hip)
 
 enum { WK_SLOTS = 16 };   // >= WK_N (below)
 
@@ -79,6 +80,8 @@ struct qexhip_ctx {
   // communicator
   void *comm = nullptr;  // ncclComm_t: everything posted on the compute stream (all-reduces, ghost refreshes, non-overlapped faces)
   void *comm2 = nullptr; // ncclComm_t split off comm: the face exchanges posted on cstream beside the interior sweep
+  PeerComm *peer = nullptr; // the other transport: faces and reductions through hipIpc-mapped peer memory (peer.hip); never both
+  int opt_transport = -1;   // option "transport" (before comm_init): -1 QEXHIP_TRANSPORT decides, 0 auto, 1 rccl, 2 peer
   int nranks = 1, rank = 0;
   int force_halo = 0;
   // staggered links
@@ -197,6 +200,19 @@ int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double 
                         double *const ghost_lo[], size_t ndoubles, int async = 0);   // async: on the comm stream after ev_ready, no join
 int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st);
 void comm_destroy(qexhip_ctx *c);
+inline bool comm_ready(const qexhip_ctx *c) { return c->comm != nullptr || c->peer != nullptr; }
+
+// ---- peer.hip: the peer-memory transport behind the same comm_* entry points ----
+struct PeerHost;
+int peer_init(qexhip_ctx *c, PeerHost &host);          // after the host rendezvous chose this transport (collective)
+void peer_destroy(qexhip_ctx *c);
+int peer_check(qexhip_ctx *c);                          // a device-side wait timed out since the last check -> QEXHIP_ERR_COMM
+int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *src_dn, int ns_up, const void *const *src_up,
+                  void *const *dst_from_up, void *const *dst_from_dn, size_t bytes);
+int peer_allreduce(qexhip_ctx *c, double *dptr, int n, int op);      // on the compute stream; op 0 sum, 1 max; rank order
+int peer_host_reduce(qexhip_ctx *c, double *host, int n, int op);    // host operands (op 0 max, 1 min, 2 sum), synchronous
+int peer_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n);
+void peer_info(const qexhip_ctx *c, long out[4]);                    // exchanges, all-reduces, arena growths, arena bytes
 
 // ---- dslash.hip ----
 // out[parity] = ca*rin + cb*xs + sgn * sum_mu [ U x(+) - U^+ x(-) ]; optional dot = Re<xs,out> partials

@@ -110,6 +110,13 @@ class Context:
         check(lib().qexhip_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d), bus, 64))
         return n.value, r.value, d.value, bus.value.decode()
 
+    def comm_transport(self):
+        """("none" | "rccl" | "peer", {exchanges, allreduces, arena_allocs, arena_bytes}) -- which transport comm_init chose"""
+        buf = C.create_string_buffer(16)
+        st = (C.c_long * 4)()
+        check(lib().qexhip_comm_transport(self._h, buf, 16, st))
+        return buf.value.decode(), dict(zip(("exchanges", "allreduces", "arena_allocs", "arena_bytes"), [int(v) for v in st]))
+
     def comm_count(self):
         """communicators held: 2 after comm_init (compute stream + overlapped face exchange), 1 with QEXHIP_COMM2=0"""
         n = C.c_int(0)

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("lat", type=int, nargs=4)
     ap.add_argument("--overlap", type=int, default=-1, help="option overlap of the context: -1 by size, 0 never, 1 always")
     ap.add_argument("--skip-gauge", action="store_true", help="operator and solvers only")
+    ap.add_argument("--share-device", action="store_true", help="every rank binds device 0: the peer-memory transport between processes "
+                    "that share one GPU (RCCL refuses that), i.e. real neighbours on a one-GPU box")
     args = ap.parse_args()
     rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -60,11 +62,12 @@ def main():
     x, y = o.vector_gaussian(olo, rf), o.vector_gaussian(olo, rf)
     loc, idx = q.Layout(glat).shard_indices(world, rank)
     vh = loc.vol // 2
+    dev = 0 if args.share_device else local_rank
 
     if world > 1:
-        ctx = q.Context(loc.lat, device=local_rank, rank_geom=(1, 1, 1, world), rank_coord=(0, 0, 0, rank))
+        ctx = q.Context(loc.lat, device=dev, rank_geom=(1, 1, 1, world), rank_coord=(0, 0, 0, rank))
     else:
-        ctx = q.Context(loc.lat, device=local_rank)                    # one-GPU rehearsal of this script: the sharded code path ...
+        ctx = q.Context(loc.lat, device=dev)                    # one-GPU rehearsal of this script: the sharded code path ...
     uid = [q.Context.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, src=0)
     ctx.comm_init(uid[0], world, rank)
@@ -74,9 +77,11 @@ def main():
         ctx.set_option("batch_multi", 1)                               # ... in the lock-step batched CG too
     info = ctx.comm_info()
     assert info[0] == world and info[1] == rank, info                  # RCCL's own count and rank
+    transport = ctx.comm_transport()[0]
+    assert transport == ("peer" if (args.share_device and world > 1) or os.environ.get("QEXHIP_TRANSPORT") == "peer" else "rccl"), transport
     if args.overlap >= 0:
         ctx.set_option("overlap", args.overlap)
-    res = {"rank": rank, "device": info[2], "pci_bus": info[3], "comms": ctx.comm_count()}
+    res = {"rank": rank, "device": info[2], "pci_bus": info[3], "comms": ctx.comm_count(), "transport": transport}
 
     def sl(a):
         return np.ascontiguousarray(a[idx])
@@ -181,6 +186,7 @@ def main():
         sf.release()
         assert res["nhyp_smear"] < 1e-12 and res["nhyp_gforce"] < 1e-11, res
 
+    res["transport_stats"] = ctx.comm_transport()[1]
     ctx.close()
     dist.barrier()
     dist.destroy_process_group()
