@@ -8,7 +8,7 @@ from ._lib import QexHipError, LIB_PATH, lib  # noqa: F401
 from .layout import Layout  # noqa: F401
 from .gauge import setBC, stagPhase, rephase, unit, synthetic_random_su3, synthetic_gaussian_vector  # noqa: F401
 from .staggered import (  # noqa: F401
-    Context, Staggered, SolverParams, newStag, newStag3, plaq, gaugeForce, gaugeFlow, gaugeSet, gaugeFlowResident, flowEQ, flowMeasure, gaugeAction, gaugeUpdate, reunit, wline, ploops, s4_gauge, ResidentMD, HisqCoefs, HypCoefs, makeImpLinks, fat7lDeriv, EVEN, ODD, ALL,
+    Context, device_count, Staggered, SolverParams, newStag, newStag3, plaq, gaugeForce, gaugeFlow, gaugeSet, gaugeFlowResident, flowEQ, flowMeasure, gaugeAction, gaugeUpdate, reunit, wline, ploops, s4_gauge, ResidentMD, HisqCoefs, HypCoefs, makeImpLinks, fat7lDeriv, EVEN, ODD, ALL,
 )
 from .io import loadGauge, loadGaugeSlab, saveGauge, getFileLattice, gaugeFileInfo, writeField, readField, fileMetadata  # noqa: F401
 from .rng import RngField, RngMilc6, MRG32k3a  # noqa: F401

@@ -62,6 +62,13 @@ class SolverParams:
         return f"its: {self.iterations}  secs: {self.seconds:.6g}  Gf/s: {gf:.6g}  r2: {self.r2:.6g}"
 
 
+def device_count():
+    """HIP devices this process can bind (qexhip_device_count): a host picks device = (rank on its node) mod this count"""
+    n = C.c_int(0)
+    check(lib().qexhip_device_count(C.byref(n)))
+    return int(n.value)
+
+
 class Context:
     """One GPU / one rank (qexhip_init).  rank_geom must be (1,1,1,N)."""
 

@@ -85,3 +85,18 @@ def test_closed_form_exp_against_the_reference_algorithm_and_long_double(tmp_pat
     p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     print(p.stdout)
     assert p.returncode == 0 and "0 scale(s) out of bounds" in p.stdout, p.stdout
+
+
+def test_peer_transport_host_rendezvous(tmp_path):
+    """qex_amd/csrc/peer_shm.cpp, the out-of-band channel of the peer-memory transport (what QMP's init / barrier / max give
+    QEX, src/comms/commsQmp.nim:14-33,127-140), CPU only: 1-8 forked ranks meet in the shm segment, pass 1000 barriers, agree
+    bit for bit on max / min / rank-ordered sum; a rank that never arrives or reports a failure is an ERROR on the others
+    within the timeout, never a hang; a slot is taken once."""
+    exe = str(tmp_path / "test_peer_shm")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_peer_shm.cpp"), os.path.join(ROOT, "qex_amd", "csrc", "peer_shm.cpp"),
+                           "-o", exe, "-lrt", "-lpthread"])
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    print(p.stdout)
+    assert p.returncode == 0 and "peer rendezvous: Passed" in p.stdout, p.stdout
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("qexhip_")], "a rendezvous segment was left behind"
