@@ -33,6 +33,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <algorithm>
+#include <vector>
 
 static_assert(sizeof(hipIpcMemHandle_t) <= PEER_HANDLE_BYTES, "ipc handle size");
 
@@ -55,6 +56,7 @@ struct PeerComm {
   u64 seq_out[2][2]{}, seq_in[2][2]{}, seq_red = 0;
   long long ticks = 0;                   // timeout in wall_clock64 ticks
   long exchanges = 0, allreduces = 0, grows = 0;
+  std::vector<char *> retired;           // outgrown arenas: freed at destroy only (see peer_ensure_arena)
 };
 
 static inline int upper(const PeerComm *p) { return (p->rank + 1) % p->nranks; }
@@ -90,7 +92,7 @@ struct PeerXfer {
   u64 *err;
   unsigned int *done;                 // [0] push, [1] unpack
   long long ticks;
-  u64 n16;                            // 16-byte units per piece
+  unsigned n16;                       // 16-byte units per piece (< 2^32: pieces below 64 GiB)
   int ns[2], nr[2];
 };
 
@@ -108,7 +110,10 @@ __device__ inline void peer_copy_chunk(uint4 *__restrict__ d, const uint4 *__res
 
 __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
   __shared__ int ok;
-  const unsigned cpp = (unsigned)((X.n16 + PEER_CHUNK - 1) / PEER_CHUNK);   // chunks per piece
+  // NOTE all chunk arithmetic is 32-bit on purpose: with a 64-bit `n16 - off < PEER_CHUNK ? n16 - off : PEER_CHUNK` hipcc
+  // (ROCm 7.2, gfx950) selected the tail length on a stale SCC (s_cselect_b32 behind a VALU v_cmp_lt_u64): piece 0 of a
+  // multi-piece message copied a whole chunk and ran over its neighbour in the arena (profiles/r05_notes.md)
+  const unsigned cpp = (X.n16 + PEER_CHUNK - 1) / PEER_CHUNK;   // chunks per piece
   // ---- push ----
   const unsigned nout = (unsigned)(X.ns[0] + X.ns[1]) * cpp;
   if (threadIdx.x == 0) {
@@ -123,8 +128,8 @@ __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
     const unsigned q = ch / cpp, j = ch - q * cpp;
     const int dir = q >= (unsigned)X.ns[0];
     const unsigned k = dir ? q - X.ns[0] : q;
-    const u64 off = (u64)j * PEER_CHUNK;
-    const unsigned n = (unsigned)(X.n16 - off < PEER_CHUNK ? X.n16 - off : PEER_CHUNK);
+    const unsigned off = j * PEER_CHUNK;
+    const unsigned n = min(X.n16 - off, (unsigned)PEER_CHUNK);
     peer_copy_chunk(X.out_arena[dir] + (u64)k * X.n16 + off, X.src[dir][k] + off, n);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: its stores have reached L2 / the fabric
@@ -155,8 +160,8 @@ __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
     const unsigned q = ch / cpp, j = ch - q * cpp;
     const int d = q >= (unsigned)X.nr[0];
     const unsigned k = d ? q - X.nr[0] : q;
-    const u64 off = (u64)j * PEER_CHUNK;
-    const unsigned n = (unsigned)(X.n16 - off < PEER_CHUNK ? X.n16 - off : PEER_CHUNK);
+    const unsigned off = j * PEER_CHUNK;
+    const unsigned n = min(X.n16 - off, (unsigned)PEER_CHUNK);
     peer_copy_chunk(X.dst[d][k] + off, X.in_arena[d] + (u64)k * X.n16 + off, n);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every load of the arena has returned before the credit goes out
@@ -291,9 +296,13 @@ static int peer_ensure_arena(qexhip_ctx *c, int s, size_t bytes) {
     p->parena[s][r] = nullptr;
   }
   CHK(peer_host_barrier(&p->host));               // nobody maps my old arena any more
-  if (p->arena[s]) HIPCHK(hipFree(p->arena[s]));
+  // An outgrown arena is RETIRED, not freed: on this driver (dmabuf IPC) hipIpcGetMemHandle fails with "invalid argument" on
+  // a fresh allocation once exported memory has been freed and its address range re-used -- 4 processes, 10th growth,
+  // reproduced outside the library (scratch/ipc_probe.cpp regrow mode 1 against mode 2, profiles/r05_ipc_probe.log).
+  // Capacities at least double, so everything retired together is smaller than the arena in use.
+  if (p->arena[s]) p->retired.push_back(p->arena[s]);
   p->arena[s] = nullptr;
-  size_t cap = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20);
+  size_t cap = std::max<size_t>(std::max<size_t>(bytes + bytes / 4, 2 * p->cap[s]), (size_t)1 << 20);
   cap = (cap + 4095) & ~(size_t)4095;
   HIPCHK(hipMalloc((void **)&p->arena[s], 2 * cap));
   PeerShmSlot &me = p->host.shm->s[p->rank];
@@ -343,7 +352,8 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
     for (int k = 0; k < nd; k++) { X.src[0][k] = (const uint4 *)src_dn[k0 + k]; X.dst[1][k] = (uint4 *)dst_from_up[k0 + k]; }
     for (int k = 0; k < nu; k++) { X.src[1][k] = (const uint4 *)src_up[k0 + k]; X.dst[0][k] = (uint4 *)dst_from_dn[k0 + k]; }
     X.ns[0] = nd; X.ns[1] = nu; X.nr[0] = nu; X.nr[1] = nd;
-    X.n16 = bytes / 16;
+    if (bytes / 16 >= ((size_t)1 << 32) - PEER_CHUNK) { qexhip_set_error("peer transport: a piece of %zu bytes is too large", bytes); return QEXHIP_ERR_ARG; }
+    X.n16 = (unsigned)(bytes / 16);
     X.out_arena[0] = (uint4 *)(p->parena[s][lo] + p->cap[s]);       // the lower neighbour's from-upper half
     X.out_arena[1] = (uint4 *)(p->parena[s][up]);                   // the upper neighbour's from-lower half
     X.in_arena[0] = (const uint4 *)p->arena[s];
@@ -361,7 +371,7 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
       if (X.nr[d] > 0) X.seq_in[d] = ++p->seq_in[s][d];
     }
     X.err = p->err; X.done = p->done + s * 2; X.ticks = p->ticks;
-    const size_t cpp = (X.n16 + PEER_CHUNK - 1) / PEER_CHUNK;
+    const size_t cpp = ((size_t)X.n16 + PEER_CHUNK - 1) / PEER_CHUNK;
     const size_t nch = (size_t)(nd + nu) * cpp;
     const int grid = (int)std::min<size_t>(nch, 256);
     hipLaunchKernelGGL(k_peer_exchange, dim3(grid), dim3(256), 0, st, X);
@@ -423,6 +433,7 @@ void peer_destroy(qexhip_ctx *c) {
   }
   if (all_here) (void)peer_host_barrier(&p->host);
   for (int s = 0; s < 2; s++) if (p->arena[s]) (void)hipFree(p->arena[s]);
+  for (char *a : p->retired) (void)hipFree(a);
   if (p->ctrl) (void)hipFree(p->ctrl);
   if (p->done) (void)hipFree(p->done);
   if (p->err) (void)hipHostFree(p->err);

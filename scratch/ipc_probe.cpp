@@ -127,6 +127,39 @@ __global__ void k_allreduce(double *x, int n, int nranks, int me, double *const 
   }
 }
 
+// regrow mode: what peer_ensure_arena does, 24 times with growing sizes: close peers' mappings, free (mode 1) or keep (mode 2) the old
+// arena, allocate a bigger one, export, open the neighbours'
+static int regrow(int rank, int n, int mode, Shm *shm) {
+  g_rank = rank;
+  CK(hipSetDevice(0));
+  char *arena = nullptr, *peer[MAXR] = {nullptr};
+  size_t sz = (size_t)1 << 20;
+  int rc = 0;
+  for (int it = 0; it < 24; it++, sz = sz + sz / 2 + 4096 * (size_t)it) {
+    hbarrier(shm, n, rank, 100);
+    for (int r = 0; r < n; r++) if (peer[r]) { hipError_t e = hipIpcCloseMemHandle(peer[r]); if (e != hipSuccess) printf("[%d] it %d close(%d): %s\n", rank, it, r, hipGetErrorString(e)); peer[r] = nullptr; }
+    hbarrier(shm, n, rank, 101);
+    if (arena && mode == 1) CK(hipFree(arena));
+    arena = nullptr;
+    CK(hipMalloc((void **)&arena, 2 * sz));
+    hipError_t e = hipIpcGetMemHandle(&shm->h[rank], arena);
+    if (e != hipSuccess) { printf("[%d] it %d size %zu ptr %p: hipIpcGetMemHandle: %s\n", rank, it, 2 * sz, (void *)arena, hipGetErrorString(e)); fflush(stdout); rc = 6; (void)hipGetLastError(); }
+    hbarrier(shm, n, rank, 102);
+    if (rc) return rc;
+    for (int k = -1; k <= 1; k += 2) {
+      const int r = (rank + k + n) % n;
+      if (r == rank || peer[r]) continue;
+      e = hipIpcOpenMemHandle((void **)&peer[r], shm->h[r], hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) { printf("[%d] it %d open(%d): %s\n", rank, it, r, hipGetErrorString(e)); fflush(stdout); return 7; }
+    }
+    CK(hipMemset(peer[(rank + 1) % n], rank + 1, 2 * sz));
+    CK(hipDeviceSynchronize());
+    hbarrier(shm, n, rank, 103);
+  }
+  printf("[%d] regrow mode %d: 24 growths up to %zu bytes ok\n", rank, mode, 2 * sz);
+  return 0;
+}
+
 static int child(int rank, int n, int iters, size_t bytes, int memkind, Shm *shm) {
   g_rank = rank;
   CK(hipSetDevice(0));
@@ -247,6 +280,7 @@ int main(int argc, char **argv) {
   int n = argc > 1 ? atoi(argv[1]) : 2, iters = argc > 2 ? atoi(argv[2]) : 200;
   size_t bytes = argc > 3 ? (size_t)atol(argv[3]) : (size_t)1 << 20;
   int memkind = argc > 4 ? atoi(argv[4]) : 0;
+  const int regrow_mode = argc > 5 ? atoi(argv[5]) : 0;
   if (n < 1 || n > MAXR) return 2;
   char name[64];
   snprintf(name, sizeof name, "/qexprobe_%d", (int)getpid());
@@ -257,7 +291,7 @@ int main(int argc, char **argv) {
   pid_t pids[MAXR];
   for (int r = 0; r < n; r++) {
     pids[r] = fork();
-    if (pids[r] == 0) { int rc = child(r, n, iters, bytes, memkind, shm); fflush(stdout); _exit(rc); }
+    if (pids[r] == 0) { int rc = regrow_mode ? regrow(r, n, regrow_mode, shm) : child(r, n, iters, bytes, memkind, shm); fflush(stdout); _exit(rc); }
   }
   int worst = 0;
   for (int r = 0; r < n; r++) { int stt = 0; waitpid(pids[r], &stt, 0); int rc = WIFEXITED(stt) ? WEXITSTATUS(stt) : 100 + WTERMSIG(stt); if (rc > worst) worst = rc; }

@@ -54,7 +54,10 @@ def test_ranks_sharing_one_device_against_the_global_oracle(nranks, lat, overlap
     p = _launch(nranks, [os.path.join(ROOT, "tests", "two_rank_worker.py")] + [str(v) for v in lat] + ["--overlap", str(overlap), "--share-device"],
                 extra_env={"QEXHIP_PEER_TIMEOUT": "60"})
     ok = [ln for ln in p.stdout.splitlines() if ln.startswith("TWO_RANK_OK")]
-    assert p.returncode == 0 and len(ok) == nranks, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    if p.returncode != 0 or len(ok) != nranks:
+        print(p.stdout[-4000:])
+        print(p.stderr[-8000:])
+    assert p.returncode == 0 and len(ok) == nranks, (p.returncode, len(ok))
     res = [json.loads(ln.split(" ", 3)[3]) for ln in ok]
     assert {r["transport"] for r in res} == {"peer"} and len({r["pci_bus"] for r in res}) == 1
     assert all(r["transport_stats"]["exchanges"] > 100 and r["transport_stats"]["allreduces"] > 100 for r in res), res[0]["transport_stats"]

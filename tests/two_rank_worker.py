@@ -101,6 +101,8 @@ def main():
     worst = max(worst, relerr(r, sl(o.D(olo, g, None, x, 0.1))))
     res["stagD2_D"] = worst
     res["sweep"] = ctx.sweep_info()                                    # incl. the measured overlap decision (world > 1, option -1)
+    if os.environ.get("QEX_WORKER_VERBOSE"):
+        print("rank %d sweep %s" % (rank, json.dumps(res["sweep"])), file=sys.stderr, flush=True)
     assert worst < 1e-13, worst
 
     # ---- CG (solveEE): history, count, solution ----
@@ -124,7 +126,7 @@ def main():
     worst = 0.0
     for k, (src, m) in enumerate(zip((x, y, x + y), bms)):
         xr_k, its_k, _, _ = o.solveXX(olo, g, None, src, m, 1e-12, 5000, True)
-        assert abs(bits[k] - its_k) <= 1, (k, bits[k], its_k)
+        assert abs(bits[k] - its_k) <= 1, (k, list(bits), its_k, res.get("sweep"))
         worst = max(worst, relerr(bxs[k][:vh], sl(xr_k)[:vh]))
     res["batch"] = {"its": list(bits), "x": worst}
     assert worst < 1e-6, res["batch"]
@@ -189,8 +191,12 @@ def main():
     res["transport_stats"] = ctx.comm_transport()[1]
     ctx.close()
     dist.barrier()
+    for r in range(world):                      # one rank at a time: lines of concurrent writers run into each other
+        if r == rank:
+            sys.stdout.write("\nTWO_RANK_OK rank %d %s\n" % (rank, json.dumps(res)))
+            sys.stdout.flush()
+        dist.barrier()
     dist.destroy_process_group()
-    print("TWO_RANK_OK rank %d %s" % (rank, json.dumps(res)), flush=True)
 
 
 if __name__ == "__main__":
