@@ -633,6 +633,7 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "flow_exp") c->opt_flow_exp = value;
   else if (n == "emu_exchange_us") c->emu_exchange_us = value;
   else if (n == "emu_allreduce_us") c->emu_allreduce_us = value;
+  else if (n == "emu_link_gbs") c->emu_link_gbs = value;
   else if (n == "obs_clover") c->opt_obs_clover = value;
   else if (n == "force_pair") c->opt_force_pair = value;
   else { qexhip_set_error("unknown option"); return QEXHIP_ERR_ARG; }

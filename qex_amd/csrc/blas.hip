@@ -291,7 +291,7 @@ int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity, int k, in
   size_t n = body2(c);
   ScopedTimer tm(c, "blas", c->stream);
   k_cg_xpay<<<grid_for(n), 256, 0, c->stream>>>(p.par(parity), r.par(parity), n, c->cg, k, rolled,
-                                               c->partials + c->part2_off, grid_for(n), c->hist, c->histcap);
+                                               c->partials + c->part2_off, rolled ? grid_for(n) : c->cg_r2parts, c->hist, c->histcap);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -301,18 +301,18 @@ int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const 
   size_t n = body2(c);
   int nb = grid_for(n);
   double *r2p = c->partials + c->part2_off;
-  if (multi_rank(c) && ndot > 0) CHK(comm_allreduce(c, c->partials, ndot));
+  if (ndot > 0) CHK(comm_allreduce_parts(c, c->partials, ndot, &ndot));
   {
     ScopedTimer tm(c, "blas", c->stream);
     k_cg_update<<<nb, 256, 0, c->stream>>>(x.par(parity), r.par(parity), p.par(parity), Ap.par(parity), n, c->cg, k, r2p,
                                            c->partials, ndot);
     HIPCHK(hipGetLastError());
   }
-  if (multi_rank(c)) CHK(comm_allreduce(c, r2p, nb));
+  CHK(comm_allreduce_parts(c, r2p, nb, &c->cg_r2parts));     // how many values the next k_cg_xpay / k_cg_close has to sum
   return 0;
 }
 int cg_close(qexhip_ctx *c, int k) {
-  k_cg_close<<<1, 256, 0, c->stream>>>(c->cg, k, c->partials + c->part2_off, grid_for(body2(c)), c->hist, c->histcap);
+  k_cg_close<<<1, 256, 0, c->stream>>>(c->cg, k, c->partials + c->part2_off, c->cg_r2parts, c->hist, c->histcap);
   HIPCHK(hipGetLastError());
   return comm_agree_post(c);
 }

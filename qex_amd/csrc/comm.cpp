@@ -204,6 +204,21 @@ extern "C" int qexhip_comm_info(qexhip_handle c, int *nranks, int *rank, int *de
   return 0;
 }
 
+// transport emulation (one-GPU rehearsals): what an exchange of `bytes` per direction would cost between distinct GPUs --
+// a fixed latency (option emu_exchange_us) plus, with option emu_link_gbs > 0, bytes / bandwidth of one xGMI direction
+static double emu_exchange_time(const qexhip_ctx *c, size_t bytes) {
+  double us = c->emu_exchange_us;
+  if (c->emu_link_gbs > 0) us += (double)bytes / (1e3 * c->emu_link_gbs);
+  return us;
+}
+// RCCL arm: a wait in front of the group (the one-rank self-copy that follows stands in for nothing: it is extra).
+// Peer arm: the time goes INTO the exchange kernel (peer.hip): data counts as arrived no earlier than that long after the
+// kernel started, the local copy that stands in for the remote push runs inside the window -- as the real push would.
+static int emu_exchange(qexhip_ctx *c, hipStream_t st, size_t bytes) {
+  if (c->peer) return 0;
+  return blas_delay(st, (int)(emu_exchange_time(c, bytes) + 0.5));
+}
+
 static inline int upper(const qexhip_ctx *c) { return (c->rank + 1) % c->nranks; }
 static inline int lower(const qexhip_ctx *c) { return (c->rank - 1 + c->nranks) % c->nranks; }
 
@@ -227,11 +242,11 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
   double2 *ghost_lo = ghost_hi + face2;
   if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   ScopedTimer tm(c, "exchange", cs);            // on the stream the group is posted on: transport + waiting for the neighbours
-  CHK(blas_delay(cs, c->emu_exchange_us));
+  CHK(emu_exchange(c, cs, nd * sizeof(double)));
   if (c->peer) {
     const void *dn = bottom, *up = top;
     void *from_up = ghost_hi, *from_dn = ghost_lo;
-    CHK(peer_exchange(c, cs, 1, &dn, 1, &up, &from_up, &from_dn, nd * sizeof(double)));
+    CHK(peer_exchange(c, cs, 1, &dn, 1, &up, &from_up, &from_dn, nd * sizeof(double), emu_exchange_time(c, nd * sizeof(double))));
   } else if (c->comm) {
     // the overlapped exchange has the second communicator to itself (comm_init)
     ncclComm_t comm = (ncclComm_t)((overlap && c->comm2) ? c->comm2 : c->comm);
@@ -260,7 +275,7 @@ int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parit
   const size_t nd = face2 * 2;
   if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   ScopedTimer tm(c, "exchange", cs);
-  CHK(blas_delay(cs, c->emu_exchange_us));
+  CHK(emu_exchange(c, cs, (size_t)n * nd * sizeof(double)));
   if (c->peer) {
     std::vector<const void *> dn(n), up(n);
     std::vector<void *> from_up(n), from_dn(n);
@@ -269,7 +284,8 @@ int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parit
       dn[j] = base; up[j] = base + (size_t)(g.ntile) * 192 - face2;
       from_up[j] = base + (size_t)g.ntile * 192; from_dn[j] = base + (size_t)g.ntile * 192 + face2;
     }
-    CHK(peer_exchange(c, cs, n, dn.data(), n, up.data(), from_up.data(), from_dn.data(), nd * sizeof(double)));
+    CHK(peer_exchange(c, cs, n, dn.data(), n, up.data(), from_up.data(), from_dn.data(), nd * sizeof(double),
+                      emu_exchange_time(c, (size_t)n * nd * sizeof(double))));
   } else if (c->comm) {
     ncclComm_t comm = (ncclComm_t)((overlap && c->comm2) ? c->comm2 : c->comm);
     NCCLCHK(ncclGroupStart());
@@ -297,8 +313,9 @@ int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parit
 // send `bytes` to the upper neighbour, receive the same amount from the lower one (stream-ordered)
 int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st) {
   CHK(need_comm(c));
+  CHK(emu_exchange(c, st, bytes));
   if (c->peer) {
-    CHK(peer_exchange(c, st, 0, nullptr, 1, &send_up, nullptr, &recv_from_down, bytes));
+    CHK(peer_exchange(c, st, 0, nullptr, 1, &send_up, nullptr, &recv_from_down, bytes, emu_exchange_time(c, bytes)));
   } else if (c->comm) {
     ncclComm_t comm = (ncclComm_t)c->comm;
     NCCLCHK(ncclGroupStart());
@@ -321,10 +338,11 @@ int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double 
   CHK(need_comm(c));
   hipStream_t st = async ? c->cstream : c->stream;
   if (async) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
-  CHK(blas_delay(st, c->emu_exchange_us));
+  ScopedTimer tm(c, "faces", st);               // after the wait for the producer: transport only (the same span as "exchange" above)
+  CHK(emu_exchange(c, st, (size_t)nbuf * ndoubles * sizeof(double)));
   if (c->peer) {
     CHK(peer_exchange(c, st, nbuf, (const void *const *)bottom, nbuf, (const void *const *)top, (void *const *)ghost_hi, (void *const *)ghost_lo,
-                      ndoubles * sizeof(double)));
+                      ndoubles * sizeof(double), emu_exchange_time(c, (size_t)nbuf * ndoubles * sizeof(double))));
   } else if (c->comm) {
     ncclComm_t comm = (ncclComm_t)((async && c->comm2) ? c->comm2 : c->comm);
     NCCLCHK(ncclGroupStart());
@@ -362,10 +380,25 @@ int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
   CHK(need_comm(c));
   if (!multi_rank(c) || !comm_ready(c)) return 0;    // one rank without the rehearsal hook, or no communicator: nothing to sum
   ScopedTimer tm(c, "allreduce", c->stream);
+  if (c->peer) return peer_allreduce(c, dptr, n, 0);       // (emulated latency: inside the kernel)
   CHK(blas_delay(c->stream, c->emu_allreduce_us));
-  if (c->peer) return peer_allreduce(c, dptr, n, 0);
   NCCLCHK(ncclAllReduce(dptr, dptr, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
   return 0;
+}
+
+// The workgroup partials parts[0..n) of a dot product, summed over the ranks, for a consumer that sums *n_out values itself:
+//   RCCL  the partial VECTOR is all-reduced in place (a few KB: the latency of one double), *n_out = n
+//   peer  one single-workgroup launch sums the vector in the consumers' own order (cg_sum_parts), passes the scalar through
+//         the mailboxes and leaves the rank-ordered total in parts[0], *n_out = 1
+// commsUtils.nim:195-204 (threadRankSum) is what both replace.
+int comm_allreduce_parts(qexhip_ctx *c, double *parts, int n, int *n_out) {
+  *n_out = n;
+  CHK(need_comm(c));
+  if (!multi_rank(c) || !comm_ready(c) || n <= 0) return 0;
+  if (!c->peer) return comm_allreduce(c, parts, n);
+  ScopedTimer tm(c, "allreduce", c->stream);
+  *n_out = 1;
+  return peer_allreduce_parts(c, parts, n);
 }
 
 int comm_allreduce_max(qexhip_ctx *c, double *host, int n) {

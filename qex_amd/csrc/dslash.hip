@@ -318,6 +318,16 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
       int nb_int = (hi_beg - lo_end + 255) / 256, nb_lo = (lo_end + 255) / 256;
       if (c->ndir == 8) CHK((launch<8, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
       else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
+      if (c->peer) {
+        // Peer transport: as below -- both t-faces in one launch on the comm stream right behind the exchange, beside the
+        // interior's tail -- but the join back to the compute stream is a device-side counter (a one-lane signal kernel behind
+        // the boundary launch, a one-wave wait kernel on the compute stream) instead of an event: the runtime's cross-queue
+        // dependency alone was ~20 us of dead time per sweep (profiles/r05_timeline_*.txt).
+        if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream)));
+        else CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream)));
+        CHK(peer_stream_signal(c, c->cstream));
+        CHK(peer_stream_join(c, c->stream, c->cstream));
+      } else {
       // Both t-faces in ONE launch, posted on the COMM stream right behind the exchange: it needs the ghost zones and nothing
       // of the interior launch, so it starts the moment the faces have arrived and runs beside the interior's tail instead of
       // after it (round 4: 1-6 % of an iteration on thin slabs in the one-rank rehearsal, profiles/r04_notes.md).  Everything later on the
@@ -326,6 +336,7 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
       else CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream)));
       HIPCHK(hipEventRecord(c->ev_halo, c->cstream));
       HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+      }
       nparts = nb_int + nb_lo + (g.Vh - hi_beg + 255) / 256;
     }
   }

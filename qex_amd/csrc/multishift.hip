@@ -215,17 +215,18 @@ int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, 
       CHK(op_xx(c, *Ap, *ps[0], m2, par_even, 1, &c->cg->done, &ndot));
       // sharded: the workgroup partials themselves are all-reduced (a few KB, the latency of one double), so the
       // iteration needs no one-block reduction launches; ndot == 0: big local volume, op_xx has reduced <p,Ap> already
-      if (sharded && ndot > 0) CHK(comm_allreduce(c, c->partials, ndot));
+      if (sharded && ndot > 0) CHK(comm_allreduce_parts(c, c->partials, ndot, &ndot));
       {
         ScopedTimer tm(c, "blas", c->stream);
         k_cgm_base<<<nb, 256, 0, c->stream>>>(xs[0]->par(par), r->par(par), ps[0]->par(par), Ap->par(par), n, c->cg, r2p,
                                               c->partials, ndot);
         HIPCHK(hipGetLastError());
       }
-      if (sharded) CHK(comm_allreduce(c, r2p, nb));
+      int nr2 = nb;
+      if (sharded) CHK(comm_allreduce_parts(c, r2p, nb, &nr2));
       {
         ScopedTimer tm(c, "reduce", c->stream);
-        k_cgm_close<<<1, 256, 0, c->stream>>>(r2p, nb, c->partials, ndot, c->cg, g_cgm_dev, c->hist, c->histcap);
+        k_cgm_close<<<1, 256, 0, c->stream>>>(r2p, nr2, c->partials, ndot, c->cg, g_cgm_dev, c->hist, c->histcap);
         HIPCHK(hipGetLastError());
       }
       ScopedTimer tm(c, "cgm_update", c->stream);

@@ -29,6 +29,7 @@
 // sync): both processes may share the CUs, and a wave that never exits would take the box down.
 #include "qexhip_internal.h"
 #include "peer_shm.h"
+#include "cg_device.h"
 #include "../../include/qexhip.h"
 #include <cstring>
 #include <cstdlib>
@@ -38,10 +39,13 @@
 static_assert(sizeof(hipIpcMemHandle_t) <= PEER_HANDLE_BYTES, "ipc handle size");
 
 typedef unsigned long long u64;
-enum { PEER_MAXSEG = 32, PEER_CHUNK = 2048, PEER_NSLOT = 4, PEER_MBOX_N = 4096 };
+enum { PEER_MAXSEG = 32, PEER_CHUNK = 4096, PEER_NSLOT = 4, PEER_MBOX_N = 4096 };
 // control block, in 8-byte words: every polled word on a 128-byte line of its own
 enum { CW_DATA = 0 /* + (s*2+d)*16 */, CW_CREDIT = 64 /* + (s*2+dir)*16 */, CW_MFLAG = 256 /* + slot*PEER_MAXR + src */,
-       CTRL_MBOX_BYTE = 8192, CTRL_BYTES = CTRL_MBOX_BYTE + PEER_NSLOT * PEER_MAXR * PEER_MBOX_N * 8 };
+       PEER_GRAN_N = 32,                          // doubles per small all-reduce: 2 tagged 8-byte granules each
+       CW_GRAN = 1024 /* + ((slot*PEER_MAXR + src)*PEER_GRAN_N + i)*2 */,
+       CTRL_MBOX_BYTE = 65536, CTRL_BYTES = CTRL_MBOX_BYTE + PEER_NSLOT * PEER_MAXR * PEER_MBOX_N * 8 };
+static_assert((CW_GRAN + PEER_NSLOT * PEER_MAXR * PEER_GRAN_N * 2) * 8 <= CTRL_MBOX_BYTE, "control block layout");
 
 struct PeerComm {
   PeerHost host;
@@ -54,7 +58,11 @@ struct PeerComm {
   unsigned int *done = nullptr;          // device: [class][push | unpack] completion counters
   u64 *err = nullptr;                    // pinned host word the kernels write on a timeout
   u64 seq_out[2][2]{}, seq_in[2][2]{}, seq_red = 0;
+  u64 *ready = nullptr;                  // device, local: ready[class] = number of exchanges of that class whose unpack has completed
+  u64 ready_seq[2]{};                    // exchanges posted per class
+  u64 join_seq[2]{};                     // peer_stream_signal / _join counters (ready + 32 + k*16)
   long long ticks = 0;                   // timeout in wall_clock64 ticks
+  double timeout_s = 30.0;
   long exchanges = 0, allreduces = 0, grows = 0;
   std::vector<char *> retired;           // outgrown arenas: freed at destroy only (see peer_ensure_arena)
 };
@@ -91,18 +99,30 @@ struct PeerXfer {
   u64 seq_out[2], seq_in[2];
   u64 *err;
   unsigned int *done;                 // [0] push, [1] unpack
+  u64 *ready;                         // own, device-local: := ready_val once every workgroup has unpacked (peer_wait_ready)
+  u64 ready_val;
   long long ticks;
+  long long emu_ticks;                // transport emulation: the inbound data counts as arrived no earlier than this long after the kernel started
   unsigned n16;                       // 16-byte units per piece (< 2^32: pieces below 64 GiB)
   int ns[2], nr[2];
 };
 
-__device__ inline void peer_copy_chunk(uint4 *__restrict__ d, const uint4 *__restrict__ s, unsigned n) {
-  // n <= PEER_CHUNK units, 256 lanes.  Whole chunks: 8 loads in flight per lane before the first store
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline void peer_copy_chunk(uint4 *__restrict__ d4, const uint4 *__restrict__ s4, unsigned n) {
+  // n <= PEER_CHUNK units, 256 lanes.  Whole chunks: 16 loads (256 B) in flight per lane before the first store -- beside an
+  // HBM-saturating sweep a copy gets bandwidth in proportion to the requests it keeps outstanding
+  u32x4 *__restrict__ d = (u32x4 *)d4;
+  const u32x4 *__restrict__ s = (const u32x4 *)s4;
   if (n == PEER_CHUNK) {
-    uint4 v0 = s[threadIdx.x], v1 = s[threadIdx.x + 256], v2 = s[threadIdx.x + 512], v3 = s[threadIdx.x + 768];
-    uint4 v4 = s[threadIdx.x + 1024], v5 = s[threadIdx.x + 1280], v6 = s[threadIdx.x + 1536], v7 = s[threadIdx.x + 1792];
-    d[threadIdx.x] = v0; d[threadIdx.x + 256] = v1; d[threadIdx.x + 512] = v2; d[threadIdx.x + 768] = v3;
-    d[threadIdx.x + 1024] = v4; d[threadIdx.x + 1280] = v5; d[threadIdx.x + 1536] = v6; d[threadIdx.x + 1792] = v7;
+    u32x4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = s[threadIdx.x + 256 * j];
+    // all 16 loads issued before the first store: hipcc otherwise sinks every load to its store (one 16-byte request in flight
+    // per lane; seen in the ISA).  An empty asm that "modifies" the values pins them in registers at this point.
+#pragma unroll
+    for (int j = 0; j < 16; j++) asm volatile("" : "+v"(v[j]));
+#pragma unroll
+    for (int j = 0; j < 16; j++) d[threadIdx.x + 256 * j] = v[j];
   } else {
     for (unsigned i = threadIdx.x; i < n; i += 256) d[i] = s[i];
   }
@@ -110,6 +130,7 @@ __device__ inline void peer_copy_chunk(uint4 *__restrict__ d, const uint4 *__res
 
 __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
   __shared__ int ok;
+  const long long t_start = X.emu_ticks > 0 ? wall_clock64() : 0;
   // NOTE all chunk arithmetic is 32-bit on purpose: with a 64-bit `n16 - off < PEER_CHUNK ? n16 - off : PEER_CHUNK` hipcc
   // (ROCm 7.2, gfx950) selected the tail length on a stale SCC (s_cselect_b32 behind a VALU v_cmp_lt_u64): piece 0 of a
   // multi-piece message copied a whole chunk and ran over its neighbour in the arena (profiles/r05_notes.md)
@@ -148,6 +169,9 @@ __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
   const unsigned nin = (unsigned)(X.nr[0] + X.nr[1]) * cpp;
   if (threadIdx.x == 0) {
     int good = 1;
+    // rehearsal on one GPU: between distinct GPUs the push above would have taken bytes / link bandwidth, and so would the
+    // neighbour's -- nothing arrives before that (the local copy that stands in for the push runs inside this window)
+    if (X.emu_ticks > 0) while (wall_clock64() - t_start < X.emu_ticks) __builtin_amdgcn_s_sleep(8);
     for (int d = 0; d < 2; d++)
       if (X.nr[d] > 0 && !peer_poll_ge(X.in_flag[d], X.seq_in[d], X.err, X.ticks, 0x200 + d)) good = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -172,8 +196,17 @@ __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
       __hip_atomic_store(&X.done[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int d = 0; d < 2; d++)
         if (X.nr[d] > 0) __hip_atomic_store(X.credit_out[d], X.seq_in[d], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      // every workgroup's acq_rel add above released its ghost stores: a kernel of ANOTHER stream that sees this value may read them
+      __hip_atomic_store(X.ready, X.ready_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// One wave on the consumer's stream: returns once the exchange number `want` of a stream class has been unpacked.  Replaces
+// the cross-stream event join (record on the comm stream, wait on the compute stream: ~20 us of dead time per sweep on this
+// runtime, profiles/r05_timeline_*.txt) by a device-side flag; the kernel boundary behind it is the consumer's acquire.
+__global__ void k_peer_wait(const u64 *ready, u64 want, u64 *err, long long ticks) {
+  if (threadIdx.x == 0) (void)peer_poll_ge(ready, want, err, ticks, 0x400);
 }
 
 struct PeerMbox {
@@ -219,6 +252,81 @@ __global__ void __launch_bounds__(512) k_peer_allreduce(double *x, int n, const 
   }
 }
 
+// Small all-reduces (the CG's scalars): the payload travels INSIDE the flags.  A double is cut into two 8-byte granules
+// {32 data bits, 32-bit tag = low half of the sequence number}; an aligned 8-byte store is one transaction, so a granule is
+// either the old one (tag of all-reduce k-4 in this slot) or the new one, never a mixture -- no release before, no acquire
+// after, no separate flag (MI355X_MICROARCH "handoff-1to1": data-tagged granules).  Lane (r, i) sends value i to rank r and
+// collects value i of rank r; the sums run over the ranks in rank order.
+__device__ inline void gran_send(u64 *dst, double v, unsigned tag) {
+  const u64 b = (u64)__double_as_longlong(v);
+  __hip_atomic_store(dst, (b & 0xffffffff00000000ULL) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(dst + 1, (b << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline bool gran_recv(const u64 *src, unsigned tag, double *v, u64 *err, long long ticks, u64 code) {
+  u64 hi = 0, lo = 0;
+  const long long t0 = wall_clock64();
+  for (unsigned it = 1;; it++) {
+    hi = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    lo = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned)hi == tag && (unsigned)lo == tag) break;
+    __builtin_amdgcn_s_sleep(2);
+    if ((it & 255) == 0) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+      if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+    }
+  }
+  *v = __longlong_as_double((long long)((hi & 0xffffffff00000000ULL) | (lo >> 32)));
+  return true;
+}
+
+struct PeerGran {
+  u64 *gran[PEER_MAXR];       // granule area of every rank as mapped here: [slot][src][PEER_GRAN_N][2]
+  u64 *err;
+  long long ticks, emu_ticks;
+  int nranks, me;
+};
+
+// x[0..n) := reduction over the ranks (OP 0 sum, 1 max), n <= PEER_GRAN_N.  PARTS: x[0..nparts) are workgroup partials whose sum
+// (in cg_sum_parts order, the order in which the consumers would have summed the vector themselves) is this rank's ONE operand.
+template <int OP, bool PARTS>
+__global__ void __launch_bounds__(256) k_peer_allreduce_small(double *x, int n, int nparts, const PeerGran G, u64 seq) {
+  __shared__ double val[PEER_MAXR * PEER_GRAN_N];
+  __shared__ int ok;
+  const long long t_start = G.emu_ticks > 0 ? wall_clock64() : 0;
+  double local = 0;
+  if (PARTS) { local = cg_sum_parts(x, nparts); n = 1; }
+  const int slot = (int)(seq & (PEER_NSLOT - 1));
+  const unsigned tag = (unsigned)seq;
+  if (threadIdx.x == 0) ok = 1;
+  __syncthreads();
+  const int r = threadIdx.x / PEER_GRAN_N, i = threadIdx.x % PEER_GRAN_N;      // 256 lanes >= 8 ranks x 32 values; more ranks loop
+  for (int rr = r; rr < G.nranks; rr += 256 / PEER_GRAN_N) {
+    if (i < n) {
+      const double mine = PARTS ? local : x[i];
+      gran_send(G.gran[rr] + ((size_t)(slot * PEER_MAXR + G.me) * PEER_GRAN_N + i) * 2, mine, tag);
+    }
+  }
+  if (G.emu_ticks > 0) while (wall_clock64() - t_start < G.emu_ticks) __builtin_amdgcn_s_sleep(2);    // rehearsal: the peers' granules cross xGMI
+  for (int rr = r; rr < G.nranks; rr += 256 / PEER_GRAN_N) {
+    if (i < n) {
+      double v = 0;
+      if (!gran_recv(G.gran[G.me] + ((size_t)(slot * PEER_MAXR + rr) * PEER_GRAN_N + i) * 2, tag, &v, G.err, G.ticks, 0x300 + rr)) ok = 0;
+      val[rr * PEER_GRAN_N + i] = v;
+    }
+  }
+  __syncthreads();
+  if (!ok) return;
+  if ((int)threadIdx.x < n) {
+    double acc = val[threadIdx.x];
+    for (int q = 1; q < G.nranks; q++) {
+      const double v = val[q * PEER_GRAN_N + threadIdx.x];
+      if (OP == 0) acc += v;
+      else acc = (v > acc || v != v) ? v : acc;
+    }
+    x[threadIdx.x] = acc;
+  }
+}
+
 // ---------------- host side ----------------
 static u64 *ctrl_word(char *ctrl, int w) { return (u64 *)ctrl + w; }
 
@@ -243,6 +351,12 @@ static void fill_mbox(const PeerComm *p, PeerMbox &M) {
   M.err = p->err; M.ticks = p->ticks; M.nranks = p->nranks; M.me = p->rank;
 }
 
+static void fill_gran(const PeerComm *p, PeerGran &G) {
+  for (int r = 0; r < p->nranks; r++) G.gran[r] = ctrl_word(p->pctrl[r], CW_GRAN);
+  G.err = p->err; G.ticks = p->ticks; G.nranks = p->nranks; G.me = p->rank;
+  G.emu_ticks = 0;
+}
+
 int peer_init(qexhip_ctx *c, PeerHost &host) {
   PeerComm *p = new PeerComm();
   p->host = host;
@@ -254,10 +368,13 @@ int peer_init(qexhip_ctx *c, PeerHost &host) {
   (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device);
   if (khz <= 0) khz = 100000;
   p->ticks = (long long)(tmo * 1000.0 * khz);
+  p->timeout_s = tmo;
   HIPCHK(hipMalloc((void **)&p->ctrl, CTRL_BYTES));
   HIPCHK(hipMemset(p->ctrl, 0, CTRL_BYTES));
   HIPCHK(hipMalloc((void **)&p->done, 64));
   HIPCHK(hipMemset(p->done, 0, 64));
+  HIPCHK(hipMalloc((void **)&p->ready, 512));
+  HIPCHK(hipMemset(p->ready, 0, 512));
   HIPCHK(hipHostMalloc((void **)&p->err, 64, hipHostMallocDefault));
   *p->err = 0;
   HIPCHK(hipDeviceSynchronize());
@@ -337,7 +454,7 @@ static int peer_ensure_arena(qexhip_ctx *c, int s, size_t bytes) {
 // one; by symmetry ns_up pieces arrive from the lower neighbour (-> dst_from_dn) and ns_dn from the upper one (-> dst_from_up).
 // Every piece is `bytes` long (a multiple of 16).
 int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *src_dn, int ns_up, const void *const *src_up,
-                  void *const *dst_from_up, void *const *dst_from_dn, size_t bytes) {
+                  void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us) {
   PeerComm *p = c->peer;
   if (bytes % 16 != 0) { qexhip_set_error("peer transport: message of %zu bytes is not a multiple of 16", bytes); return QEXHIP_ERR_ARG; }
   if (ns_dn < 0 || ns_up < 0 || (ns_dn == 0 && ns_up == 0) || bytes == 0) return 0;
@@ -371,9 +488,16 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
       if (X.nr[d] > 0) X.seq_in[d] = ++p->seq_in[s][d];
     }
     X.err = p->err; X.done = p->done + s * 2; X.ticks = p->ticks;
+    X.emu_ticks = (long long)(emu_us * 1e-6 * (double)p->ticks / p->timeout_s);
+    X.ready = p->ready + s * 16; X.ready_val = ++p->ready_seq[s];
     const size_t cpp = ((size_t)X.n16 + PEER_CHUNK - 1) / PEER_CHUNK;
     const size_t nch = (size_t)(nd + nu) * cpp;
-    const int grid = (int)std::min<size_t>(nch, 256);
+    // Few, fat workgroups: between distinct GPUs the push is bound by one xGMI direction (~45 GB/s: a couple of workgroups
+    // saturate it), and beside an interior sweep every workgroup here queues behind that sweep's and slows it down
+    // (162 workgroups for two 2.65 MB faces cost 30 us per iteration at 48^3 x 12, profiles/r05_emulated_scaling.log).
+    // One workgroup per 64 KiB chunk of either phase, 2..128.
+    const size_t tot = (size_t)(nd + nu) * bytes;
+    const int grid = (int)std::min<size_t>(nch, std::max<size_t>(2, std::min<size_t>(128, tot >> 16)));
     hipLaunchKernelGGL(k_peer_exchange, dim3(grid), dim3(256), 0, st, X);
     HIPCHK(hipGetLastError());
     p->exchanges++;
@@ -381,9 +505,49 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
   return 0;
 }
 
+__global__ void k_peer_set(u64 *flag, u64 val) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Device-side join of two streams of this context without an event: `signal` raises a counter behind everything posted on
+// `from` so far (a one-lane kernel: the kernel boundary in front of it is the release), `join` makes `waiter` wait for the
+// latest value (a one-wave kernel with a bounded poll: the boundary behind it is the acquire).  One counter per direction.
+int peer_stream_signal(qexhip_ctx *c, hipStream_t from) {
+  PeerComm *p = c->peer;
+  const int k = (from == c->cstream) ? 1 : 0;
+  hipLaunchKernelGGL(k_peer_set, dim3(1), dim3(64), 0, from, p->ready + 32 + k * 16, ++p->join_seq[k]);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int peer_stream_join(qexhip_ctx *c, hipStream_t waiter, hipStream_t from) {
+  PeerComm *p = c->peer;
+  const int k = (from == c->cstream) ? 1 : 0;
+  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, waiter, p->ready + 32 + k * 16, p->join_seq[k], p->err, p->ticks);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// on stream `waiter`: everything posted so far on the stream class of `posted_on` has arrived in the ghost zones
+int peer_wait_ready(qexhip_ctx *c, hipStream_t waiter, hipStream_t posted_on) {
+  PeerComm *p = c->peer;
+  const int s = (posted_on == c->cstream) ? 1 : 0;
+  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, waiter, p->ready + s * 16, p->ready_seq[s], p->err, p->ticks);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int peer_allreduce(qexhip_ctx *c, double *dptr, int n, int op) {
   PeerComm *p = c->peer;
   CHK(peer_check_err(p));
+  if (n <= PEER_GRAN_N) {
+    PeerGran G;
+    fill_gran(p, G);
+    G.emu_ticks = (long long)(c->emu_allreduce_us * 1e-6 * (double)p->ticks / p->timeout_s);
+    if (op == 0) hipLaunchKernelGGL((k_peer_allreduce_small<0, false>), dim3(1), dim3(256), 0, c->stream, dptr, n, 0, G, ++p->seq_red);
+    else hipLaunchKernelGGL((k_peer_allreduce_small<1, false>), dim3(1), dim3(256), 0, c->stream, dptr, n, 0, G, ++p->seq_red);
+    p->allreduces++;
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   PeerMbox M;
   fill_mbox(p, M);
   for (int i0 = 0; i0 < n; i0 += PEER_MBOX_N) {
@@ -393,6 +557,18 @@ int peer_allreduce(qexhip_ctx *c, double *dptr, int n, int op) {
     else hipLaunchKernelGGL(k_peer_allreduce<1>, dim3(1), dim3(512), 0, c->stream, dptr + i0, m, M, seq);
     p->allreduces++;
   }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int peer_allreduce_parts(qexhip_ctx *c, double *parts, int n) {
+  PeerComm *p = c->peer;
+  CHK(peer_check_err(p));
+  PeerGran G;
+  fill_gran(p, G);
+  G.emu_ticks = (long long)(c->emu_allreduce_us * 1e-6 * (double)p->ticks / p->timeout_s);
+  hipLaunchKernelGGL((k_peer_allreduce_small<0, true>), dim3(1), dim3(256), 0, c->stream, parts, 1, n, G, ++p->seq_red);
+  p->allreduces++;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -407,7 +583,7 @@ int peer_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n) {
     const int have = (p->rank - k + p->nranks) % p->nranks, get = (p->rank - k - 1 + p->nranks) % p->nranks;
     const void *src = recv + (size_t)have * n;
     void *dst = recv + (size_t)get * n;
-    CHK(peer_exchange(c, c->stream, 0, nullptr, 1, &src, nullptr, &dst, n * sizeof(double)));
+    CHK(peer_exchange(c, c->stream, 0, nullptr, 1, &src, nullptr, &dst, n * sizeof(double), 0.0));
   }
   return 0;
 }
@@ -436,6 +612,7 @@ void peer_destroy(qexhip_ctx *c) {
   for (char *a : p->retired) (void)hipFree(a);
   if (p->ctrl) (void)hipFree(p->ctrl);
   if (p->done) (void)hipFree(p->done);
+  if (p->ready) (void)hipFree(p->ready);
   if (p->err) (void)hipHostFree(p->err);
   peer_host_close(&p->host);
   delete p;

@@ -100,6 +100,7 @@ struct qexhip_ctx {
                                                      // s4 / Polyakov sums, [56..59] comm_allreduce_max, [60] comm_init's agreement,
                                                      // [62] link-compression test
   CgScal *cg = nullptr;                              // device CG state
+  int cg_r2parts = 0;                                // values the |r|^2 partial buffer holds after the last cg_update (1 once a peer all-reduce has summed them)
   double *hist = nullptr; int histcap = 0;           // device residual history
   void *pinned = nullptr;                            // pinned host scratch (4 KiB)
   // work vectors (lazily allocated, like the {.global.} temp of stagD.nim:437-442)
@@ -120,6 +121,7 @@ struct qexhip_ctx {
   int opt_recon = 2;      // QEXHIP_RECON: 0 keeps the 18-real links always, 1 sign format only, 2 also the U(3) format
   int opt_overlap = -1;  // QEXHIP_OVERLAP / option "overlap": 1 always use the comm stream, 0 never, -1 measured once per operator shape when the
                          // communicator has more than one rank (sweep_autotune), by interior / face size otherwise; -2: measure on one rank too
+  int emu_link_gbs = 0;                            // option emu_link_gbs: > 0 adds bytes / (GB/s of one xGMI direction) to every emulated exchange
   int emu_exchange_us = 0, emu_allreduce_us = 0;   // options of the same names (test / rehearsal hooks): delay posted in front of every face
                                                    // exchange / all-reduce, as long as the transfer would take between distinct GPUs
   int overlap_auto[2]{-1, -1};          // the measured decision for 8- and 16-link operators (-1: not measured)
@@ -192,6 +194,7 @@ inline bool multi_rank(const qexhip_ctx *c) { return c->nranks > 1 || c->opt_mul
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready; the caller records ev_halo behind what it posts next
 int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parity, int overlap);   // n fields, one RCCL group
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
+int comm_allreduce_parts(qexhip_ctx *c, double *parts, int n, int *n_out);   // workgroup partials -> *n_out values whose sum is the rank-global dot product
 int comm_allreduce_max(qexhip_ctx *c, double *host, int n);      // host values -> max over the ranks, back on the host (n <= 4, synchronous)
 int comm_agree_post(qexhip_ctx *c);                               // max-reduce c->cg->agree over the ranks (on stream)
 int comm_agree_check(qexhip_ctx *c, const CgScal &host);          // after the state was read back: all ranks hold the same residual and count
@@ -208,7 +211,11 @@ int peer_init(qexhip_ctx *c, PeerHost &host);          // after the host rendezv
 void peer_destroy(qexhip_ctx *c);
 int peer_check(qexhip_ctx *c);                          // a device-side wait timed out since the last check -> QEXHIP_ERR_COMM
 int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *src_dn, int ns_up, const void *const *src_up,
-                  void *const *dst_from_up, void *const *dst_from_dn, size_t bytes);
+                  void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us = 0.0);
+int peer_stream_signal(qexhip_ctx *c, hipStream_t from);                          // device-side event: record ...
+int peer_stream_join(qexhip_ctx *c, hipStream_t waiter, hipStream_t from);        // ... and wait, without the runtime's cross-queue dependency
+int peer_wait_ready(qexhip_ctx *c, hipStream_t waiter, hipStream_t posted_on);   // device-side join: a one-wave kernel on `waiter`
+int peer_allreduce_parts(qexhip_ctx *c, double *parts, int n);       // parts[0] := sum over ranks of (sum of parts[0..n) in cg_sum_parts order)
 int peer_allreduce(qexhip_ctx *c, double *dptr, int n, int op);      // on the compute stream; op 0 sum, 1 max; rank order
 int peer_host_reduce(qexhip_ctx *c, double *host, int n, int op);    // host operands (op 0 max, 1 min, 2 sum), synchronous
 int peer_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n);
