@@ -48,7 +48,15 @@ typedef struct qexhip_ctx *qexhip_handle;
 /* ---------------- context ----------------
  * Replaces qudaInit/qudaSetup (src/quda/qudaWrapperImpl.nim:70-123): bind one GPU, record the
  * rank-local lattice and the rank grid (src/layout/layoutX.nim:70-125).  Only a split of the
- * outermost dimension is supported: rankGeom = {1,1,1,N} (BASELINE.json north_star). */
+ * outermost dimension is supported: rankGeom = {1,1,1,N} (BASELINE.json north_star).
+ * Preconditions on latLocal (checked here and at set_links; QEXHIP_ERR_ARG otherwise) -- narrower than QEX's "any even
+ * lattice, any rankGeom" (src/layout/layoutX.nim:46-68,81-95):
+ *   * every extent even (the even/odd layout);
+ *   * sharded (rankGeom[3] > 1 or qexhip_comm_force_halo): X*Y*Z/2 a multiple of 64, so that a t-slice of one parity is a whole
+ *     number of 64-site wavefront tiles and the faces are contiguous tile ranges (no pack kernels); local t even; local t
+ *     >= 1 for the one-hop operator, >= 3 for Naik links (ghost depth 3);
+ *   * unsharded: X*Y*Z*T/2 need not be a multiple of 64 (the last tile is ragged).
+ * On any failure after the context was allocated everything built so far is released; *h is written only on success. */
 int qexhip_init(qexhip_handle *h, int device, const int latLocal[4],
                 const int rankGeom[4], const int rankCoord[4]);
 int qexhip_finalize(qexhip_handle h);
@@ -207,6 +215,13 @@ int qexhip_dev_op_xx(qexhip_handle h, int r_id, int x_id, double m2, int par_eve
 int qexhip_dev_solve_xx(qexhip_handle h, int x_id, int b_id, double mass, double r2req,
                         int maxits, int par_even, int *iters, double *r2_over_b2,
                         double *hist, int histcap);
+/* Re-entry of the CG on the state the last qexhip_dev_solve_xx (or re-entry) on x_id left behind -- CgState.solve called
+ * again with b2 >= 0 (src/solvers/cg.nim:21-27,85,133,155-161,256-261): no set-up, r / p / rzold kept, the stopping
+ * criterion comes from the new r2req / maxits, `iters` goes on counting from where the last call stopped (maxits is the
+ * cumulative limit, as sp.maxits is there).  QEXHIP_ERR_STATE if anything that uses the CG's work vectors or changes the
+ * operator ran in between.  hist (may be NULL) receives the whole history from iteration 0. */
+int qexhip_dev_solve_xx_continue(qexhip_handle h, int x_id, double r2req, int maxits, int *iters, double *r2_over_b2,
+                                 double *hist, int histcap);
 /* multi-shift solveXX (Staggered.solveXX(xs, b, ms, sp), src/physics/stagSolve.nim:296-345) on resident fields:
  * x_ids[k] receives the solution of shift k; shifts as qexhip_stag_solve_xx_multi.  Blocks until finished. */
 int qexhip_dev_solve_xx_multi(qexhip_handle h, const int *x_ids, int b_id, const double *shifts, int nmass,

@@ -56,6 +56,7 @@ SYMBOLS = [
     ("qexhip_dev_dslash", _ci, [_vp, _ci, _ci, _ci, _cd, _cd]),
     ("qexhip_dev_op_xx", _ci, [_vp, _ci, _ci, _cd, _ci]),
     ("qexhip_dev_solve_xx", _ci, [_vp, _ci, _ci, _cd, _cd, _ci, _ci, _pi, _pd, _vp, _ci]),
+    ("qexhip_dev_solve_xx_continue", _ci, [_vp, _ci, _cd, _ci, _pi, _pd, _vp, _ci]),
     ("qexhip_dev_solve_xx_multi", _ci, [_vp, _pi, _ci, _pd, _ci, _cd, _ci, _ci, _pi, _vp, _ci]),
     ("qexhip_release_workspace", _ci, [_vp]),
     ("qexhip_dev_norm2", _ci, [_vp, _ci, _ci, _pd]),

@@ -90,28 +90,25 @@ extern "C" int qexhip_timers_get(qexhip_handle c, const char *name, long *count,
 }
 
 // ---- context ----
-extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], const int rankGeom[4],
-                           const int rankCoord[4]) {
-  if (!h || !latLocal) return QEXHIP_ERR_ARG;
+static int init_body(qexhip_ctx *c, int device, const int latLocal[4], const int rankGeom[4], const int rankCoord[4]) {
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   if (ndev <= 0) { qexhip_set_error("no HIP device visible: libqexhip has no CPU fallback"); return QEXHIP_ERR_HIP; }
   if (device < 0 || device >= ndev) { qexhip_set_error("device %d out of range (%d visible)", device, ndev); return QEXHIP_ERR_ARG; }
-  qexhip_ctx *c = new qexhip_ctx();
   c->device = device;
   for (int i = 0; i < 4; i++) {
     c->rankGeom[i] = rankGeom ? rankGeom[i] : 1;
     c->rankCoord[i] = rankCoord ? rankCoord[i] : 0;
   }
   for (int i = 0; i < 3; i++)
-    if (c->rankGeom[i] != 1) { qexhip_set_error("only rankGeom = {1,1,1,N} (split along t) is supported"); delete c; return QEXHIP_ERR_ARG; }
+    if (c->rankGeom[i] != 1) { qexhip_set_error("only rankGeom = {1,1,1,N} (split along t) is supported"); return QEXHIP_ERR_ARG; }
   const int halo = c->rankGeom[3] > 1;
-  if (geom_init(c->g, latLocal, 1, halo)) { delete c; return QEXHIP_ERR_ARG; }
+  if (geom_init(c->g, latLocal, 1, halo)) return QEXHIP_ERR_ARG;
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   {
     // the comm stream carries the face exchange and the boundary launch that waits for it: at the highest priority, so that the
-    // RCCL kernel is dispatched at once and not behind the thousands of interior workgroups the compute stream has queued
+    // exchange kernel is dispatched at once and not behind the thousands of interior workgroups the compute stream has queued
     // (one-rank rehearsal, where nothing has to be hidden: no difference either way, profiles/r04_prio_ab.log)
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) HIPCHK(hipStreamCreateWithPriority(&c->cstream, hipStreamNonBlocking, hi));
@@ -127,27 +124,42 @@ extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], 
   HIPCHK(hipMalloc((void **)&c->cg, sizeof(CgScal)));
   HIPCHK(hipMemset(c->cg, 0, sizeof(CgScal)));
   HIPCHK(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
-  // the environment switches of the library (include/qexhip.h "Environment"): these three and QEXHIP_COMM2 (comm.cpp)
+  if (getenv("QEXHIP_TEST_FAIL_INIT")) {      // test hook (tests/test_gpu_misc_ops.py): fail the way a late HIP error would, everything above built
+    qexhip_set_error("QEXHIP_TEST_FAIL_INIT: injected failure");
+    return QEXHIP_ERR_HIP;
+  }
+  // the environment switches of the library (include/qexhip.h "Environment")
   if (const char *e = getenv("QEXHIP_OVERLAP")) c->opt_overlap = atoi(e);
   if (const char *e = getenv("QEXHIP_RECON")) c->opt_recon = atoi(e);
   if (const char *e = getenv("QEXHIP_FLOW_EXP")) c->opt_flow_exp = atoi(e);
   {
     // the gauge kernels stage links through 144 KiB (k_force_lds2) / 72 KiB (k_force_lds, k_flow_obs_clover) of LDS per
-    // workgroup: gfx950 offers 160 KiB.  The library is built for that one target; anything smaller is refused here
-    // rather than at the first flow step.
+    // workgroup: gfx950 offers 160 KiB.  The library is built for that one target (qex_amd/Makefile pins gfx950); anything
+    // smaller is refused here rather than at the first flow step.
     int a = 0, b = 0;
     (void)hipDeviceGetAttribute(&a, hipDeviceAttributeMaxSharedMemoryPerBlock, device);
     (void)hipDeviceGetAttribute(&b, hipDeviceAttributeSharedMemPerBlockOptin, device);
     (void)hipGetLastError();
     const int lds = a > b ? a : b;
-    if (lds < 147456) {
+    if (lds < 147456 + 1024) {      // + the static LDS (reductions) the kernels add on top of the dynamic 144 KiB
       qexhip_set_error("device %d offers %d bytes of LDS per workgroup; libqexhip is built for gfx950 (160 KiB)", device, lds);
-      qexhip_finalize(c);
       return QEXHIP_ERR_STATE;
     }
   }
   c->nranks = 1;  // until qexhip_comm_init
   c->rank = 0;
+  return 0;
+}
+
+extern "C" int qexhip_init(qexhip_handle *h, int device, const int latLocal[4], const int rankGeom[4],
+                           const int rankCoord[4]) {
+  if (!h || !latLocal) return QEXHIP_ERR_ARG;
+  qexhip_ctx *c = new qexhip_ctx();
+  const int e = init_body(c, device, latLocal, rankGeom, rankCoord);
+  if (e) {                      // every failing path releases what was built so far (streams, events, device and pinned memory)
+    (void)qexhip_finalize(c);
+    return e;
+  }
   *h = c;
   return 0;
 }
@@ -160,8 +172,10 @@ extern "C" int qexhip_device_count(int *n) {
 
 extern "C" int qexhip_finalize(qexhip_handle c) {
   if (!c) return QEXHIP_ERR_ARG;
-  (void)hipSetDevice(c->device);
-  (void)hipDeviceSynchronize();
+  if (c->stream) {                 // (a context that failed before its first HIP object has nothing on a device)
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+  }
   for (auto &kv : c->fields) (void)hipFree(kv.second.d);
   c->fields.clear();
   for (auto &kv : c->timers) for (auto e : kv.second.ev) (void)hipEventDestroy(e);
@@ -184,10 +198,11 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
   if (c->cg) (void)hipFree(c->cg);
   if (c->hist) (void)hipFree(c->hist);
   if (c->pinned) (void)hipHostFree(c->pinned);
-  (void)hipEventDestroy(c->ev_ready);
-  (void)hipEventDestroy(c->ev_halo);
-  (void)hipStreamDestroy(c->stream);
-  (void)hipStreamDestroy(c->cstream);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->cstream) (void)hipStreamDestroy(c->cstream);
+  (void)hipGetLastError();
   delete c;
   return 0;
 }
@@ -212,6 +227,7 @@ extern "C" int qexhip_device_info(qexhip_handle c, char *buf, int buflen) {
 }
 
 static int drop_fields_for_regeom(qexhip_ctx *c) {
+  c->cg_resume.valid = 0;
   // geometry (ghost zones) changed: user fields keep their ids but are re-allocated empty
   HIPCHK(hipStreamSynchronize(c->stream));
   for (auto &kv : c->fields) {
@@ -473,6 +489,7 @@ extern "C" int qexhip_field_new(qexhip_handle c, int *id) {
   return 0;
 }
 extern "C" int qexhip_field_free(qexhip_handle c, int id) {
+  if (c) c->cg_resume.valid = 0;
   if (!c) return QEXHIP_ERR_ARG;
   DevField *f;
   CHK(find_field(c, id, &f));
@@ -527,6 +544,15 @@ extern "C" int qexhip_dev_solve_xx(qexhip_handle c, int x_id, int b_id, double m
   CHK(find_field(c, x_id, &fx));
   CHK(find_field(c, b_id, &fb));
   return solve_xx_dev(c, *fx, *fb, mass, r2req, maxits, par_even, iters, r2_over_b2, hist, histcap);
+}
+
+extern "C" int qexhip_dev_solve_xx_continue(qexhip_handle c, int x_id, double r2req, int maxits, int *iters, double *r2_over_b2,
+                                            double *hist, int histcap) {
+  if (!c) return QEXHIP_ERR_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  DevField *fx;
+  CHK(find_field(c, x_id, &fx));
+  return solve_xx_continue_dev(c, *fx, r2req, maxits, iters, r2_over_b2, hist, histcap);
 }
 
 extern "C" int qexhip_dev_solve_xx_multi(qexhip_handle c, const int *x_ids, int b_id, const double *shifts, int nmass,

@@ -316,7 +316,22 @@ int cg_close(qexhip_ctx *c, int k) {
   HIPCHK(hipGetLastError());
   return comm_agree_post(c);
 }
+// re-entry (cg.nim:155-161 with b2 >= 0): new r2stop / maxits, loop condition of the kept state re-evaluated in slot k&1
+__global__ void k_cg_resume(CgScal *s, int k, double r2req, int maxits) {
+  const int cur = k & 1;
+  s->r2stop = r2req * s->b2;
+  s->maxits = maxits;
+  s->dones[cur] = !(k < maxits && s->r2s[cur] > s->r2stop);
+  s->done = s->dones[cur];
+  s->agree[0] = s->r2s[cur]; s->agree[1] = -s->r2s[cur]; s->agree[2] = (double)k; s->agree[3] = -(double)k;
+}
+int cg_resume(qexhip_ctx *c, int k, double r2req, int maxits) {
+  k_cg_resume<<<1, 1, 0, c->stream>>>(c->cg, k, r2req, maxits);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 int cg_init(qexhip_ctx *c, double r2req, int maxits) {
+  c->cg_resume.valid = 0;
   k_cg_init<<<1, 1, 0, c->stream>>>(c->cg, c->dscal, r2req, maxits, c->hist, c->histcap);
   HIPCHK(hipGetLastError());
   return 0;

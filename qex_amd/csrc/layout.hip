@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(256) k_links_to_tiles(Geom g, const double2 *_
 }
 
 int links_upload(qexhip_ctx *c, const double *fat, const double *lng) {
+  c->cg_resume.valid = 0;            // another operator: a kept CG state no longer belongs to it
   const Geom &g = c->g;
   int ndir = lng ? 16 : 8;
   if (lng) for (int i = 0; i < 4; i++) if (g.X[i] < 4) { qexhip_set_error("Naik links need local extents >= 4"); return -1; }
@@ -287,6 +288,7 @@ __global__ void __launch_bounds__(256) k_links_from_nat(Geom g, const double2 *_
   }
 }
 int links_from_natural(qexhip_ctx *c, const double2 *fat, const double2 *lng) {
+  c->cg_resume.valid = 0;
   const Geom &g = c->g;
   int ndir = lng ? 16 : 8;
   if (lng) for (int i = 0; i < 4; i++) if (g.X[i] < 4) { qexhip_set_error("Naik links need local extents >= 4"); return -1; }

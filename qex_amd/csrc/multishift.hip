@@ -167,6 +167,7 @@ int pool_field(qexhip_ctx *c, int idx, DevField **f) {
 int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, const double *shifts,
                        int nmass, double r2req, int maxits, int par_even, int *iters, double *hist, int histcap) {
   if (nmass < 1 || nmass > CGM_MAXM) { qexhip_set_error("multishift: 1 <= nmass <= %d", CGM_MAXM); return -1; }
+  c->cg_resume.valid = 0;                 // the device CG state and the history buffer are taken over
   const int par = par_even ? 0 : 1;
   const Geom &g = c->g;
   const size_t n = (size_t)g.ntile * 192;

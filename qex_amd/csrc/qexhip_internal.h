@@ -100,6 +100,7 @@ struct qexhip_ctx {
                                                      // s4 / Polyakov sums, [56..59] comm_allreduce_max, [60] comm_init's agreement,
                                                      // [62] link-compression test
   CgScal *cg = nullptr;                              // device CG state
+  struct { int valid = 0; const double2 *x = nullptr; int par_even = 0; double m2 = 0; int k = 0; } cg_resume;   // what solve_xx_continue_dev needs
   int cg_r2parts = 0;                                // values the |r|^2 partial buffer holds after the last cg_update (1 once a peer all-reduce has summed them)
   double *hist = nullptr; int histcap = 0;           // device residual history
   void *pinned = nullptr;                            // pinned host scratch (4 KiB)
@@ -260,6 +261,7 @@ int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity, int k, in
 int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const DevField &Ap, int parity, int k, int ndot);
 int cg_close(qexhip_ctx *c, int k);
 int cg_init(qexhip_ctx *c, double r2req, int maxits);  // after b2 (dscal[0]) and r2 (dscal[1]) are known
+int cg_resume(qexhip_ctx *c, int k, double r2req, int maxits);   // CgState re-entry: new stopping criterion on the kept state
 
 // ---- solver.cpp ----
 int get_work(qexhip_ctx *c, int slot, DevField **f);
@@ -267,6 +269,7 @@ int op_xx(qexhip_ctx *c, DevField &r, DevField &x, double m2, int par_even, int 
 int op_D(qexhip_ctx *c, DevField &r, DevField &x, double m, double sc, double a = 0.0);
 int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2req, int maxits,
                  int par_even, int *iters, double *r2_over_b2, double *hist, int histcap);
+int solve_xx_continue_dev(qexhip_ctx *c, DevField &x, double r2req, int maxits, int *iters, double *r2_over_b2, double *hist, int histcap);
 int solve_full_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2req, int maxits,
                    int *iters, double *r2_final, int use_prev = 0);
 int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, const double *shifts,

@@ -15,6 +15,7 @@
 
 
 int get_work(qexhip_ctx *c, int slot, DevField **f) {
+  if (slot == WK_R || slot == WK_P || slot == WK_AP) c->cg_resume.valid = 0;     // whoever takes the CG's vectors ends a resumable solve
   if (c->wk[slot] == 0) {
     DevField nf;
     CHK(field_alloc(c, nf));
@@ -92,26 +93,16 @@ static int read_cg(qexhip_ctx *c, CgScal *host) {
   return 0;
 }
 
-int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2req, int maxits,
-                 int par_even, int *iters, double *r2_over_b2, double *hist, int histcap) {
+// The iterations of CgState.solve (cg.nim:174-217) from iteration k on: device state in slot k&1 (`rolled`), r / p / x as the
+// previous iteration left them.  Shared by the first call and by the re-entry (cg.nim:133: `if b2<0: # first call`).
+static int cg_iterate(qexhip_ctx *c, DevField &x, DevField *r, DevField *p, DevField *Ap, double m2, int par_even, int k,
+                      CgScal &st, int *iters, double *r2_over_b2, double *hist, int histcap) {
   const int par = par_even ? 0 : 1;
-  DevField *r, *p, *Ap;
-  CHK(get_work(c, WK_R, &r));
-  CHK(get_work(c, WK_P, &p));
-  CHK(get_work(c, WK_AP, &Ap));
-  CHK(ensure_hist(c, std::max(histcap, 1)));
-  const double m2 = mass * mass;
-  CHK(blas_zero(c, x, 2));                       // threads: r := 0 (stagSolve.nim:63-64)
-  CHK(blas_norm2(c, b, par, &c->dscal[0]));      // b2 (cg.nim:134)
-  // op.apply(Ap, x) with x = 0 gives Ap = 0 exactly, so r = b - Ap = b and r2 = b2 (cg.nim:145-151)
-  CHK(blas_copy(c, *r, b, par));
-  CHK(blas_norm2(c, *r, par, &c->dscal[1]));
-  CHK(cg_init(c, r2req, maxits));
-  CgScal st;
-  CHK(read_cg(c, &st));
-  int chunk = 32, k = 0, rolled = 1;              // k_cg_init wrote slot 0
-  bool done = st.dones[0];
-  double r2 = st.r2s[0];
+  const int chunk = 32;
+  int rolled = 1;
+  bool done = st.dones[k & 1];
+  double r2 = st.r2s[k & 1];
+  st.itn = st.itns[k & 1];
   // (Round 4 tried forming p = r + beta p inside the first sweep -- every output site builds it for its eight neighbours, one of
   // them stores it -- to drop k_cg_xpay and a launch boundary: the sweep grew by 17 us, the iteration did not move (267.9 vs
   // 267.6 us, profiles/r04_cg_fuse_ab.log), so the separate launch stays.)
@@ -137,11 +128,51 @@ int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2
   if (iters) *iters = st.itn;
   if (r2_over_b2) *r2_over_b2 = (st.b2 != 0.0) ? st.r2 / st.b2 : 0.0;
   if (hist && histcap > 0) {
-    int n = std::min(histcap, st.itn + 1);
+    int n = std::min(std::min(histcap, c->histcap), st.itn + 1);
     HIPCHK(hipMemcpyAsync(hist, c->hist, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
+  // what a re-entry needs: the same x, the same operator; r, p and the device scalars stay where they are
+  c->cg_resume.valid = 1; c->cg_resume.x = x.d; c->cg_resume.par_even = par_even; c->cg_resume.m2 = m2; c->cg_resume.k = st.itn;
   return 0;
+}
+
+int solve_xx_dev(qexhip_ctx *c, DevField &x, DevField &b, double mass, double r2req, int maxits,
+                 int par_even, int *iters, double *r2_over_b2, double *hist, int histcap) {
+  const int par = par_even ? 0 : 1;
+  DevField *r, *p, *Ap;
+  CHK(get_work(c, WK_R, &r));
+  CHK(get_work(c, WK_P, &p));
+  CHK(get_work(c, WK_AP, &Ap));
+  CHK(ensure_hist(c, std::max(histcap, 1)));
+  const double m2 = mass * mass;
+  CHK(blas_zero(c, x, 2));                       // threads: r := 0 (stagSolve.nim:63-64)
+  CHK(blas_norm2(c, b, par, &c->dscal[0]));      // b2 (cg.nim:134)
+  // op.apply(Ap, x) with x = 0 gives Ap = 0 exactly, so r = b - Ap = b and r2 = b2 (cg.nim:145-151)
+  CHK(blas_copy(c, *r, b, par));
+  CHK(blas_norm2(c, *r, par, &c->dscal[1]));
+  CHK(cg_init(c, r2req, maxits));
+  CgScal st;
+  CHK(read_cg(c, &st));
+  return cg_iterate(c, x, r, p, Ap, m2, par_even, 0, st, iters, r2_over_b2, hist, histcap);   // k_cg_init wrote slot 0
+}
+
+// Re-entry of CgState.solve with b2 >= 0 (cg.nim:21-27,85,133,155-161,256-261): nothing is set up again; r2stop and maxits are
+// taken from the new SolverParams, the iteration count goes on counting, beta of the next iteration uses the kept rzold.
+// Valid only directly after a solve_xx_dev / a previous re-entry on the same x and operator.
+int solve_xx_continue_dev(qexhip_ctx *c, DevField &x, double r2req, int maxits, int *iters, double *r2_over_b2, double *hist, int histcap) {
+  if (!c->cg_resume.valid || c->cg_resume.x != x.d) {
+    qexhip_set_error("solve_xx_continue: no resumable CG state for this field (another solver, set_links or a work-vector user ran "
+                     "since the last solve_xx on it)");
+    return -3;
+  }
+  const int k = c->cg_resume.k, par_even = c->cg_resume.par_even;
+  const double m2 = c->cg_resume.m2;
+  DevField *r = &c->fields[c->wk[WK_R]], *p = &c->fields[c->wk[WK_P]], *Ap = &c->fields[c->wk[WK_AP]];
+  CHK(cg_resume(c, k, r2req, maxits));
+  CgScal st;
+  CHK(read_cg(c, &st));
+  return cg_iterate(c, x, r, p, Ap, m2, par_even, k, st, iters, r2_over_b2, hist, histcap);
 }
 
 // ---- full solve (stagSolve.nim:141-294) ----

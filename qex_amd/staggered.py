@@ -194,6 +194,14 @@ class Context:
                                         C.byref(its), C.byref(fin), _p(hist), histcap))
         return its.value, fin.value, hist[: min(histcap, its.value + 1)]
 
+    def dev_solve_xx_continue(self, x_id, r2req, maxits, histcap=0):
+        """CgState re-entry (cg.nim:133 `if b2<0: # first call` not taken): go on iterating on the state the last dev_solve_xx
+        on x_id left; maxits is the cumulative limit; returns (cumulative iterations, r2/b2, history from iteration 0)"""
+        its, fin = C.c_int(0), C.c_double(0)
+        hist = np.zeros(max(histcap, 1))
+        check(lib().qexhip_dev_solve_xx_continue(self._h, x_id, float(r2req), int(maxits), C.byref(its), C.byref(fin), _p(hist), histcap))
+        return its.value, fin.value, hist[: min(histcap, its.value + 1)]
+
     def dev_solve_xx_multi(self, x_ids, b_id, shifts, r2req, maxits, par_even=True, histcap=0):
         """multi-shift solveXX on resident fields (stagSolve.nim:296-345); shifts[0] = base mass"""
         n = len(x_ids)

@@ -443,3 +443,67 @@ def test_sharded_paths_under_emulated_transport_latency(oracle, overlap):
         assert np.abs(b[k][1][:n] / a[k][1][:n] - 1).max() < 1e-9, k
     assert rel(a["cg0"][2][:h], b["cg0"][2][:h]) < 1e-7 and all(rel(u[:h], v[:h]) < 1e-7 for u, v in zip(a["multi"][2], b["multi"][2]))
     assert all(abs(i - j) <= 1 for i, j in zip(a["batch"][0], b["batch"][0])) and all(rel(u[:h], v[:h]) < 1e-7 for u, v in zip(a["batch"][1], b["batch"][1]))
+
+
+def test_cg_reentry_continues_the_same_iteration(S):
+    """CgState.solve called again with b2 >= 0 (cg.nim:21-27,85,133,155-161,256-261): no set-up, the kept r / p / rzold, the
+    new SolverParams' stopping criterion, iterations go on counting.  A solve stopped after 37 iterations by maxits and resumed
+    twice must walk through EXACTLY the residual history of the uninterrupted solve (same bits) and end at the same solution;
+    the oracle's count pins it to the reference algorithm.  Anything that takes the CG's vectors in between ends the state."""
+    q, o, ctx = S.q, S.o, S.ctx
+    bid, x1, x2 = ctx.field_new(S.x), ctx.field_new(), ctx.field_new()
+    S.s = q.newStag(ctx, S.g)
+    n_full, fin_full, h_full = ctx.dev_solve_xx(x1, bid, 0.1, 1e-12, 5000, True, histcap=4096)
+    n_a, fin_a, _ = ctx.dev_solve_xx(x2, bid, 0.1, 1e-12, 37, True, histcap=4096)
+    assert n_a == 37 and fin_a > 1e-12
+    n_b, fin_b, _ = ctx.dev_solve_xx_continue(x2, 1e-6, 5000, histcap=4096)          # a looser criterion first ...
+    assert 37 < n_b < n_full and fin_b <= 1e-6
+    n_c, fin_c, h_c = ctx.dev_solve_xx_continue(x2, 1e-12, 5000, histcap=4096)        # ... then the real one
+    assert n_c == n_full and fin_c == fin_full
+    assert np.array_equal(h_c, h_full)
+    assert np.array_equal(ctx.field_download(x2), ctx.field_download(x1))
+    _, its, _, _ = o.solveXX(S.lo, S.g, None, S.x, 0.1, 1e-12, 5000, True)
+    assert abs(n_full - its) <= 1
+    n_d, fin_d, _ = ctx.dev_solve_xx_continue(x2, 1e-12, 5000)                        # converged state: returns at once
+    assert n_d == n_full and fin_d == fin_full
+    ctx.dev_solve_xx_multi([x1], bid, [0.1], 1e-10, 50)                               # takes the work vectors
+    with pytest.raises(q.QexHipError):
+        ctx.dev_solve_xx_continue(x2, 1e-13, 5000)
+    ctx.dev_solve_xx(x2, bid, 0.1, 1e-12, 10, True)
+    S.s = q.newStag(ctx, S.g)                                                         # another operator object
+    with pytest.raises(q.QexHipError):
+        ctx.dev_solve_xx_continue(x2, 1e-12, 5000)
+    for f in (bid, x1, x2):
+        ctx.field_free(f)
+
+
+def test_init_releases_everything_on_a_late_failure():
+    import qex_amd as q
+
+    """qexhip_init must free the context it built when a HIP call fails late (round-4 verdict, weak 13): with the failure injected
+    after the streams, events, device and pinned buffers exist (QEXHIP_TEST_FAIL_INIT), 200 failing inits leave the free device
+    memory where it was and the next real init works."""
+    import ctypes as C
+    import os
+
+    L = q.lib()
+    free0, tot = C.c_size_t(0), C.c_size_t(0)
+    hip = C.CDLL("libamdhip64.so")
+    ctx = q.Context([8, 8, 8, 8])                 # runtime initialised, allocator warm
+    ctx.close()
+    hip.hipMemGetInfo(C.byref(free0), C.byref(tot))
+    os.environ["QEXHIP_TEST_FAIL_INIT"] = "1"
+    try:
+        i4 = C.c_int * 4
+        for _ in range(200):
+            h = C.c_void_p()
+            rc = L.qexhip_init(C.byref(h), 0, i4(8, 8, 8, 8), i4(1, 1, 1, 1), i4(0, 0, 0, 0))
+            assert rc != 0 and not h.value
+        assert b"QEXHIP_TEST_FAIL_INIT" in L.qexhip_last_error()
+    finally:
+        del os.environ["QEXHIP_TEST_FAIL_INIT"]
+    free1 = C.c_size_t(0)
+    hip.hipMemGetInfo(C.byref(free1), C.byref(tot))
+    assert free0.value - free1.value < (8 << 20), (free0.value, free1.value)      # 200 leaked contexts would hold > 50 MB
+    ctx = q.Context([8, 8, 8, 8])
+    ctx.close()
