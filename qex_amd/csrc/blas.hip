@@ -321,6 +321,7 @@ __global__ void k_cg_resume(CgScal *s, int k, double r2req, int maxits) {
   const int cur = k & 1;
   s->r2stop = r2req * s->b2;
   s->maxits = maxits;
+  s->r2s[cur] = s->r2; s->r2s[cur ^ 1] = s->rzo; s->itns[cur] = k;      // rz, rzold, iterations as the last live iteration left them
   s->dones[cur] = !(k < maxits && s->r2s[cur] > s->r2stop);
   s->done = s->dones[cur];
   s->agree[0] = s->r2s[cur]; s->agree[1] = -s->r2s[cur]; s->agree[2] = (double)k; s->agree[3] = -(double)k;

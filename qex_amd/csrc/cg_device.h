@@ -11,6 +11,9 @@ __device__ __forceinline__ double cg_sum_parts(const double *parts, int n) {
 }
 __device__ __forceinline__ void cg_roll(CgScal *s, int k, double r2k, double *hist, int histcap) {
   const int cur = k & 1;
+  // the last LIVE bookkeeping is what a re-entry continues from (cg.nim:256-261: state.r2 / rzold / iterations); the carries
+  // that follow a finished solve copy slot to slot and would lose rzold
+  s->rzo = s->r2s[cur ^ 1]; s->r2 = r2k; s->itn = k;
   s->r2s[cur] = r2k;
   s->itns[cur] = k;
   s->dones[cur] = !(k < s->maxits && r2k > s->r2stop);
