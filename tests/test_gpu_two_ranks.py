@@ -32,7 +32,7 @@ def _free_port():
 
 def _launch(nranks, script_args, port=None, timeout=600, extra_env=None):
     port = port or _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=str(max(1, (os.cpu_count() or 8) // nranks)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=str(max(1, min(16, len(os.sched_getaffinity(0))) // nranks)))   # a GPU box leases 16 cores whatever cpu_count() says
     env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + script_args

@@ -33,6 +33,13 @@ def relerr(a, b):
 
 
 def main():
+    import time
+    t_start = time.time()
+
+    def tick(what):
+        if os.environ.get("QEX_WORKER_VERBOSE"):
+            print("[%6.1f s] %s" % (time.time() - t_start, what), file=sys.stderr, flush=True)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("lat", type=int, nargs=4)
     ap.add_argument("--overlap", type=int, default=-1, help="option overlap of the context: -1 by size, 0 never, 1 always")
@@ -60,6 +67,7 @@ def main():
     o.rephase(olo, g3)
     g3 *= 0.3
     x, y = o.vector_gaussian(olo, rf), o.vector_gaussian(olo, rf)
+    tick("imports + oracle inputs done")
     loc, idx = q.Layout(glat).shard_indices(world, rank)
     vh = loc.vol // 2
     dev = 0 if args.share_device else local_rank
@@ -75,6 +83,7 @@ def main():
         ctx.force_halo(True)                                           # ... ghost zones filled through a one-rank communicator,
         ctx.set_option("multi_reduce", 1)                              # reductions through real (one-rank) all-reduces
         ctx.set_option("batch_multi", 1)                               # ... in the lock-step batched CG too
+    tick("context + comm_init done")
     info = ctx.comm_info()
     assert info[0] == world and info[1] == rank, info                  # RCCL's own count and rank
     transport = ctx.comm_transport()[0]
@@ -105,6 +114,7 @@ def main():
         print("rank %d sweep %s" % (rank, json.dumps(res["sweep"])), file=sys.stderr, flush=True)
     assert worst < 1e-13, worst
 
+    tick("operator done")
     # ---- CG (solveEE): history, count, solution ----
     sp = q.SolverParams(r2req=1e-12, maxits=5000, verbosity=0)
     xs = np.zeros_like(sl(x))
@@ -131,6 +141,7 @@ def main():
     res["batch"] = {"its": list(bits), "x": worst}
     assert worst < 1e-6, res["batch"]
 
+    tick("CG + batched CG done")
     # ---- Naik: stagD2 and the 3-mass multi-shift CG (ghost depth 3) ----
     if loc.lat[3] >= 4:
         s3 = q.newStag3(ctx, sl(g), sl(g3))
@@ -188,6 +199,7 @@ def main():
         sf.release()
         assert res["nhyp_smear"] < 1e-12 and res["nhyp_gforce"] < 1e-11, res
 
+    tick("Naik + gauge sector done")
     res["transport_stats"] = ctx.comm_transport()[1]
     ctx.close()
     dist.barrier()
