@@ -114,6 +114,26 @@ int qexhip_stag_sweep_info(qexhip_handle h, int out[8]);
  * (pack -> RCCL self send/recv -> boundary sweep) instead of the periodic wrap. */
 int qexhip_comm_force_halo(qexhip_handle h, int on);
 
+/* ---------------- QEX's SIMD field memory <-> the host format of this header ----------------
+ * A QEX Field[V,T] is double[outer][...T...][re|im][V lanes] with site i = outer*V + lane (src/field/fieldET.nim:18-22,123-128);
+ * which lattice site that is follows LayoutQ (src/layout/qlayout.nim:10-66 set-up, :110-131 index, :133-185 coordinates).
+ * Everything below takes the RANK-LOCAL geometry and the inner (SIMD) geometry of the Layout[V] (l.localGeom, l.innerGeom) and
+ * the field's own memory, and produces / consumes the V = 1 even-odd site-major arrays every other entry point of this header
+ * takes ([site][3][2], [site][4][3][3][2]) -- the per-site copy loops of the QUDA bridge (src/quda/qudaWrapperImpl.nim:198-260:
+ * r.l.coord -> lo1.rankIndex) as one call.  Pure host code, no GPU needed. */
+/* the inner geometry newLayoutX picks for V lanes when none is given (src/layout/layoutX.nim:19-42,98-111); {1,2,2,2} for V = 8
+ * on lattices whose y, z, t extents are multiples of 4; QEXHIP_ERR_ARG where QEX itself gives up ("can't lay out inner geom") */
+int qexhip_layout_default_inner(const int localGeom[4], int V, int innerGeom[4]);
+/* v1_of_simd[outer*V + lane] = index of that site in the V = 1 even-odd order (Layout[1].rankIndex(Layout[V].coord(i))) */
+int qexhip_layout_simd_map(const int localGeom[4], const int innerGeom[4], int *v1_of_simd);
+/* colour vector: simd = double[outer][3][2][V] */
+int qexhip_layout_vec_simd_to_v1(const int localGeom[4], const int innerGeom[4], const double *simd, double *v1);
+int qexhip_layout_vec_v1_to_simd(const int localGeom[4], const int innerGeom[4], const double *v1, double *simd);
+/* gauge field: g[mu] = double[outer][3][3][2][V], one QEX field per direction (s.g[mu]; s.g[2 mu] / s.g[2 mu + 1] for the fat /
+ * long links of a Naik operator, stagD.nim:552-564: the caller picks the four pointers) */
+int qexhip_layout_gauge_simd_to_v1(const int localGeom[4], const int innerGeom[4], const double *const g[4], double *v1);
+int qexhip_layout_gauge_v1_to_simd(const int localGeom[4], const int innerGeom[4], const double *v1, double *const g[4]);
+
 /* ---------------- staggered operator ----------------
  * Staggered.g  (src/physics/stagD.nim:19-22; newStag :522-541, newStag3 :543-564).
  * fat: 4 links per site; lng: NULL (plain) or 4 three-hop links per site (Naik). */

@@ -50,6 +50,7 @@ def lib():
         L.qcs_new.restype = vp
         L.qcs_new.argtypes = [C.POINTER(ci), vp]
         L.qcs_free.argtypes = [vp]
+        L.qcs_site_map.argtypes = [vp, vp]
         L.qcs_stagD2.argtypes = [vp, vp, vp, ci, cd]
         L.qcs_solveXX.restype = ci
         L.qcs_solveXX.argtypes = [vp, vp, vp, cd, cd, ci, ci, vp, ci, C.POINTER(cd)]
@@ -88,6 +89,12 @@ class Lattice:
                 lib().qcs_free(self._h)
         except Exception:
             pass
+
+    def site_map(self):
+        """simd_of_v1[V=1 even-odd index] = outer * 8 + lane, the map this baseline stores its fields by"""
+        m = np.zeros(int(np.prod(self.lat)), dtype=np.int32)
+        lib().qcs_site_map(self._h, m.ctypes.data_as(C.c_void_p))
+        return m
 
     def stagD2(self, r, x, parity, b=0.0):
         lib().qcs_stagD2(self._h, r.ctypes.data_as(C.c_void_p), np.ascontiguousarray(x).ctypes.data_as(C.c_void_p), int(parity), float(b))

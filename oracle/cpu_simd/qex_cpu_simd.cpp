@@ -210,6 +210,11 @@ qcs_handle *qcs_new(const int lat[4], const double *g) {
   return h;
 }
 void qcs_free(qcs_handle *h) { delete h; }
+// the site map this baseline lays its fields out by, per V=1 even-odd index: SIMD site = outer * 8 + lane
+// (tests/test_simd_layout.py holds the product's restatement of LayoutQ against it: two independent implementations)
+void qcs_site_map(const qcs_handle *h, int *simd_of_v1) {
+  for (int idx = 0; idx < h->vol; idx++) simd_of_v1[idx] = h->M.outer[idx] * V + h->M.lane[idx];
+}
 
 static void to_simd(const qcs_handle *h, const double *v, std::vector<CVec> &x) {
   x.assign(h->C.L.nOuter, CVec());

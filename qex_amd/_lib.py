@@ -21,6 +21,12 @@ SYMBOLS = [
     ("qexhip_last_error", C.c_char_p, []),
     ("qexhip_sync", _ci, [_vp]),
     ("qexhip_device_info", _ci, [_vp, C.c_char_p, _ci]),
+    ("qexhip_layout_default_inner", _ci, [_pi, _ci, _pi]),
+    ("qexhip_layout_simd_map", _ci, [_pi, _pi, _pi]),
+    ("qexhip_layout_vec_simd_to_v1", _ci, [_pi, _pi, _vp, _vp]),
+    ("qexhip_layout_vec_v1_to_simd", _ci, [_pi, _pi, _vp, _vp]),
+    ("qexhip_layout_gauge_simd_to_v1", _ci, [_pi, _pi, C.POINTER(C.c_void_p), _vp]),
+    ("qexhip_layout_gauge_v1_to_simd", _ci, [_pi, _pi, _vp, C.POINTER(C.c_void_p)]),
     ("qexhip_comm_unique_id", _ci, [C.c_char_p]),
     ("qexhip_comm_init", _ci, [_vp, C.c_char_p, _ci, _ci]),
     ("qexhip_comm_force_halo", _ci, [_vp, _ci]),

@@ -4,8 +4,8 @@
 ##   -d:qexhipDir=/path/to/repo
 ## and wire the procs below into the call sites named beside each of them (INTEGRATION.md has the
 ## one-line patches).  It mirrors src/quda/qudaWrapperImpl.nim:165-261 (qudaSolveXX): build a V=1 twin
-## layout once, copy the SIMD fields site by site into site-major host arrays, make the C call(s),
-## copy the result back.
+## layout once, turn the SIMD fields into site-major host arrays (one qexhip_layout_* call per field: the library
+## restates QEX's index map in C), make the C call(s), turn the result back.
 ##
 ##   call site in QEX                                                    proc here
 ##   src/physics/stagSolve.nim:65-128  `case sp.backend` (solveEE/OO)    hipSolveEE / hipSolveOO
@@ -51,6 +51,10 @@ proc qexhip_comm_info(h: QexhipHandle; nranks, rank, device: ptr cint; busid: cs
 proc qexhip_last_error(): cstring {.qh.}
 proc qexhip_comm_unique_id(id: ptr char): cint {.qh.}
 proc qexhip_comm_init(h: QexhipHandle; id: ptr char; nranks, rank: cint): cint {.qh.}
+proc qexhip_layout_vec_simd_to_v1(localGeom, innerGeom: ptr cint; simd, v1: ptr cdouble): cint {.qh.}
+proc qexhip_layout_vec_v1_to_simd(localGeom, innerGeom: ptr cint; v1, simd: ptr cdouble): cint {.qh.}
+proc qexhip_layout_gauge_simd_to_v1(localGeom, innerGeom: ptr cint; g: ptr ptr cdouble; v1: ptr cdouble): cint {.qh.}
+proc qexhip_layout_gauge_v1_to_simd(localGeom, innerGeom: ptr cint; v1: ptr cdouble; g: ptr ptr cdouble): cint {.qh.}
 proc qexhip_stag_set_links(h: QexhipHandle; fat, lng: ptr cdouble): cint {.qh.}
 proc qexhip_stag_dslash(h: QexhipHandle; r, x: ptr cdouble; parity: cint; a, b: cdouble): cint {.qh.}
 proc qexhip_stag_D(h: QexhipHandle; r, x: ptr cdouble; m, sc: cdouble): cint {.qh.}
@@ -166,30 +170,29 @@ proc hipSetup*(l: Layout): Layout[1] =
 type HostBuf* = seq[cdouble]
 proc p(b: var HostBuf): ptr cdouble = cast[ptr cdouble](b[0].addr)
 
+# The per-site copy loops of qudaWrapperImpl.nim:198-260 (l.coord -> lo1.rankIndex, element by element) are ONE call into
+# the library each: qexhip_layout_* restate layoutIndexQ / layoutCoordQ (qlayout.nim:110-185) in C, take the field's own
+# memory ([outer][...][re|im][V lanes], fieldET.nim:18-22) and the layout's local / inner geometry, and are tested on the CPU
+# against an independent V = 8 map and the closed form (tests/test_simd_layout.py).  Double-precision fields only.
+type Geom4 = array[4, cint]
+proc geoms(l: Layout): tuple[lg, ig: Geom4] =
+  for i in 0..3:
+    result.lg[i] = l.localGeom[i].cint
+    result.ig[i] = l.innerGeom[i].cint
+template raw(f: Field): ptr cdouble = cast[ptr cdouble](f.dataPtr)     # qudaWrapperImpl.nim:190-191 uses the same accessor
+
 proc toHost*(v: Field; b: var HostBuf) =
-  ## colour vector field -> host buffer (the copy loop of qudaWrapperImpl.nim:198-207)
+  ## colour vector field -> host buffer (replaces the copy loop of qudaWrapperImpl.nim:198-207)
   let lo1 = v.l.hipSetup
   b.setLen(lo1.nSites * 6)
-  threads:
-    for i in v.sites:
-      var cv: array[4, cint]
-      v.l.coord(cv, (v.l.myRank, i))
-      let j = lo1.rankIndex(cv).index
-      forO a, 0, 2:
-        b[6*j + 2*a] = v{i}[a].re
-        b[6*j + 2*a + 1] = v{i}[a].im
+  var (lg, ig) = v.l.geoms
+  chk qexhip_layout_vec_simd_to_v1(lg[0].addr, ig[0].addr, v.raw, b.p)
 
 proc fromHost*(v: Field; b: HostBuf) =
   ## host buffer -> colour vector field (qudaWrapperImpl.nim:252-260)
-  let lo1 = v.l.hipSetup
-  threads:
-    for i in v.sites:
-      var cv: array[4, cint]
-      v.l.coord(cv, (v.l.myRank, i))
-      let j = lo1.rankIndex(cv).index
-      forO a, 0, 2:
-        v{i}[a].re = b[6*j + 2*a]
-        v{i}[a].im = b[6*j + 2*a + 1]
+  discard v.l.hipSetup
+  var (lg, ig) = v.l.geoms
+  chk qexhip_layout_vec_v1_to_simd(lg[0].addr, ig[0].addr, cast[ptr cdouble](b[0].unsafeAddr), v.raw)
 
 proc toHostG*(g: openArray[Field]; b: var HostBuf; first = 0; stride = 1) =
   ## gauge field g[first], g[first+stride], .. (4 directions) -> host buffer (qudaWrapperImpl.nim:216-240;
@@ -197,30 +200,18 @@ proc toHostG*(g: openArray[Field]; b: var HostBuf; first = 0; stride = 1) =
   let l = g[first].l
   let lo1 = l.hipSetup
   b.setLen(lo1.nSites * 72)
-  threads:
-    for i in g[first].sites:
-      var cv: array[4, cint]
-      l.coord(cv, (l.myRank, i))
-      let j = lo1.rankIndex(cv).index
-      forO mu, 0, 3:
-        forO a, 0, 2:
-          forO c, 0, 2:
-            b[72*j + 18*mu + 6*a + 2*c] = g[first + stride*mu]{i}[a,c].re
-            b[72*j + 18*mu + 6*a + 2*c + 1] = g[first + stride*mu]{i}[a,c].im
+  var (lg, ig) = l.geoms
+  var ptrs: array[4, ptr cdouble]
+  for mu in 0..3: ptrs[mu] = g[first + stride*mu].raw
+  chk qexhip_layout_gauge_simd_to_v1(lg[0].addr, ig[0].addr, ptrs[0].addr, b.p)
 
 proc fromHostG*(g: openArray[Field]; b: HostBuf) =
   let l = g[0].l
-  let lo1 = l.hipSetup
-  threads:
-    for i in g[0].sites:
-      var cv: array[4, cint]
-      l.coord(cv, (l.myRank, i))
-      let j = lo1.rankIndex(cv).index
-      forO mu, 0, 3:
-        forO a, 0, 2:
-          forO c, 0, 2:
-            g[mu]{i}[a,c].re = b[72*j + 18*mu + 6*a + 2*c]
-            g[mu]{i}[a,c].im = b[72*j + 18*mu + 6*a + 2*c + 1]
+  discard l.hipSetup
+  var (lg, ig) = l.geoms
+  var ptrs: array[4, ptr cdouble]
+  for mu in 0..3: ptrs[mu] = g[mu].raw
+  chk qexhip_layout_gauge_v1_to_simd(lg[0].addr, ig[0].addr, cast[ptr cdouble](b[0].unsafeAddr), ptrs[0].addr)
 
 # ---------------------------------------------------------------------------------------------------------------
 # the operator: Staggered.g -> device (once per link update; QUDA re-uploads per solve, qudaWrapperImpl.nim:216-240)

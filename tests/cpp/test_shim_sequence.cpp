@@ -179,6 +179,56 @@ int main() {
     qo_eoReconstruct(lo, g.data(), nullptr, eref.data(), x.data(), 0.1);
     CHECK(relerr(e, eref) < 1e-13, "hipEoReconstruct: %g", relerr(e, eref));
   }
+  // ---- through the seam from QEX's OWN memory: SIMD fields in, SIMD field out (toHostG / toHost / fromHost of qexhip.nim) ----
+  // The SIMD arrays are filled here by the closed form of layoutIndexQ for an inner geometry without checkerboard shift
+  // (qlayout.nim:110-131: lane = lex of c / outer, outer index = lex(c % outer) / 2 (+ half for odd sites)) -- written out
+  // independently of the library's restatement, which then has to undo it.
+  {
+    int ig[4];
+    CHK(qexhip_layout_default_inner(lat, 8, ig));                    // newLayoutX's choice for V = 8 on 4x6x8x4: {2,1,2,2}
+    CHECK(ig[0] == 2 && ig[1] == 1 && ig[2] == 2 && ig[3] == 2, "default inner geometry %d %d %d %d", ig[0], ig[1], ig[2], ig[3]);
+    const int V = 8, og[4] = {lat[0] / ig[0], lat[1] / ig[1], lat[2] / ig[2], lat[3] / ig[3]};
+    const size_t nouter = vol / V;
+    std::vector<size_t> simd_of_v1(vol);
+    for (size_t lex = 0; lex < vol; lex++) {
+      int c[4], par = 0; size_t r = lex;
+      for (int i = 0; i < 4; i++) { c[i] = (int)(r % lat[i]); r /= lat[i]; par += c[i]; }
+      const size_t j = lex / 2 + ((par & 1) ? vh : 0);
+      int lane = 0, lmul = 1; size_t olex = 0, omul = 1;
+      for (int i = 0; i < 4; i++) { lane += (c[i] / og[i]) * lmul; lmul *= ig[i]; olex += (size_t)(c[i] % og[i]) * omul; omul *= og[i]; }
+      simd_of_v1[j] = (olex / 2 + ((par & 1) ? nouter / 2 : 0)) * V + lane;
+    }
+    auto vec_to_simd = [&](const Buf &v1, Buf &sv) {
+      sv.assign(vol * 6, 0.0);
+      for (size_t j = 0; j < vol; j++) for (int k = 0; k < 6; k++) sv[((simd_of_v1[j] / V) * 6 + k) * V + simd_of_v1[j] % V] = v1[j * 6 + k];
+    };
+    std::vector<Buf> gq(4, Buf(nouter * 18 * V));                    // s.g[mu]: four QEX fields
+    for (size_t j = 0; j < vol; j++) for (int mu = 0; mu < 4; mu++) for (int k = 0; k < 18; k++)
+      gq[mu][((simd_of_v1[j] / V) * 18 + k) * V + simd_of_v1[j] % V] = g[j * 72 + mu * 18 + k];
+    Buf xq, rq(vol * 6, 0.0);
+    vec_to_simd(x, xq);
+    // hipSetLinks(s): toHostG(s.g, g1) -> qexhip_stag_set_links
+    Buf g1(vol * 72), xb(vol * 6), rb(vol * 6);
+    const double *gp[4] = {gq[0].data(), gq[1].data(), gq[2].data(), gq[3].data()};
+    CHK(qexhip_layout_gauge_simd_to_v1(lat, ig, gp, g1.data()));
+    CHECK(relerr(g1, g) == 0.0, "toHostG: %g", relerr(g1, g));
+    hipSetLinks(g1, nullptr);
+    // hipSolveEE(s, r, t, m, sp): toHost(t) -> solve -> fromHost(r)
+    CHK(qexhip_layout_vec_simd_to_v1(lat, ig, xq.data(), xb.data()));
+    double r2 = 0, fin = 0;
+    const int its = hipSolveXX(rb, xb, 0.1, 1e-12, 5000, true, &r2);
+    CHK(qexhip_layout_vec_v1_to_simd(lat, ig, rb.data(), rq.data()));
+    Buf ref(vol * 6), refq;
+    const int oits = qo_solveXX(lo, g.data(), nullptr, ref.data(), x.data(), 0.1, 1e-12, 5000, 1, nullptr, 0, &fin);
+    for (size_t k = vh * 6; k < vol * 6; k++) ref[k] = rb[k];       // the odd half is not part of solveEE's answer
+    vec_to_simd(ref, refq);
+    CHECK(std::abs(its - oits) <= 1 && relerr(rq, refq) < 1e-6, "hipSolveEE on SIMD-layout fields: its %d / %d, %g", its, oits, relerr(rq, refq));
+    // gauge field back into QEX's memory (hipGaugeFlow's last step): fromHostG
+    std::vector<Buf> gback(4, Buf(nouter * 18 * V));
+    double *gbp[4] = {gback[0].data(), gback[1].data(), gback[2].data(), gback[3].data()};
+    CHK(qexhip_layout_gauge_v1_to_simd(lat, ig, g1.data(), gbp));
+    for (int mu = 0; mu < 4; mu++) CHECK(relerr(gback[mu], gq[mu]) == 0.0, "fromHostG mu %d", mu);
+  }
   // ---- hipSolveEE / hipSolveOO / hipSolve ----
   for (int pe = 1; pe >= 0; pe--) {
     Buf r(vol * 6), ref(vol * 6);
