@@ -335,6 +335,27 @@ def solveXX(lo, fat, lng, b, m, r2req, maxits, par_even=True, histcap=0):
     return x, its, fin.value, hist[: min(histcap, its + 1)]
 
 
+def solveXX_ext(lo, fat, lng, b, m, r2req, maxits, par_even=True, histcap=0):
+    """the same CG in binary128 arithmetic throughout (oracle/qex_oracle_ext.inc): (iterations, residual history) -- the yardstick"""
+    hist = np.zeros(max(histcap, 1))
+    fin = C.c_double(0)
+    L = lib()
+    L.qo_solveXX_ext.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    its = L.qo_solveXX_ext(lo._h, _p(fat), _p(lng), None, _p(b), m, r2req, maxits, 1 if par_even else 0, _p(hist), histcap, C.byref(fin))
+    return its, hist[: min(histcap, its + 1)]
+
+
+def solveXX_multi_ext(lo, fat, lng, b, shifts, r2req, maxits, par_even=True, histcap=0):
+    sh = np.array(shifts, dtype=np.float64)
+    hist = np.zeros(max(histcap, 1))
+    L = lib()
+    L.qo_solveXX_multi_ext.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_int]
+    its = L.qo_solveXX_multi_ext(lo._h, _p(fat), _p(lng), _p(b), _p(sh), len(sh), r2req, maxits, 1 if par_even else 0, _p(hist), histcap)
+    return its, hist[: min(histcap, its + 1)]
+
+
 def solve(lo, fat, lng, b, m, r2req, maxits):
     x = np.zeros_like(b)
     fin = C.c_double(0)

@@ -1889,3 +1889,6 @@ void qo_hisq_force(const qo_layout *lo, const double *g, const double *dsdsu, co
   fat7_deriv(lo, f, g, t, c_first, NULL, 0.0);                          /* first fat7 */
   free(v); free(w); free(t);
 }
+
+/* extended-precision twins of the two CGs: the yardstick of tests/parity_log.py (a file of its own: it restates no fp64 path of QEX) */
+#include "qex_oracle_ext.inc"

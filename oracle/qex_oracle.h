@@ -153,6 +153,14 @@ int qo_solve_multi(const qo_layout *lo, const double *fat, const double *lng,
 int qo_num_threads(void);
 void qo_set_num_threads(int n);
 
+/* extended-precision (IEEE binary128) twins of qo_solveXX / qo_solveXX_multi: the same algorithms with every vector, operator
+ * application, accumulation and scalar in binary128 arithmetic; the yardstick tests/parity_log.py measures both the HIP path and
+ * the fp64 oracle against along the chaotic tail of hard systems.  x may be NULL. */
+int qo_solveXX_ext(const qo_layout *lo, const double *fat, const double *lng, double *x, const double *b, double m, double r2req,
+                   int maxits, int par_even, double *r2hist, int histcap, double *final_r2_over_b2);
+int qo_solveXX_multi_ext(const qo_layout *lo, const double *fat, const double *lng, const double *b, const double *shifts, int nmass,
+                         double r2req, int maxits, int par_even, double *r2hist, int histcap);
+
 #ifdef __cplusplus
 }
 #endif

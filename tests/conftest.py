@@ -27,7 +27,7 @@ def oracle():
 
 
 def pytest_sessionfinish(session, exitstatus):
-    # what the history-parity tests measured (tests/parity_log.py) -> gpurun_out/r04_parity_devs.json
+    # what the history-parity tests measured (tests/parity_log.py) -> gpurun_out/r05_parity_devs.json
     try:
         import parity_log
         parity_log.flush()

@@ -211,17 +211,14 @@ def test_solveXX_history(request, fix, par_even):
     S.s.solveXX(x, S.x, 0.1, sp, parEven=par_even, histcap=4096)
     xr, its, fin, hist = S.o.solveXX(S.lo, S.g, S.g3, S.x, 0.1, 1e-12, 2000, par_even, histcap=4096)
     assert abs(sp.iterations - its) <= 1
-    n = min(len(hist), len(sp.r2hist))
-    assert n > 100
-    dev = np.abs(sp.r2hist[:n] / hist[:n] - 1)
-    assert dev[:100].max() < 1e-10                      # before amplification sets in
-    tol, spread, per = history_tolerance(S.o, S.lo, S.g, S.g3, S.x, 0.1, 1e-12, 2000, par_even, hist)
+    assert min(len(hist), len(sp.r2hist)) > 100
+    # first 100 iterations 1e-10 against the oracle, 1e-6 over the whole history on BASELINE configs[0], and the tail against the
+    # binary128 truth with the fp64 reference algorithm's own deviation from it as the yardstick (tests/parity_log.py)
     import parity_log
-    parity_log.record("test_solveXX_history[%s-%s]" % (par_even, fix), dev, spread, per, (sp.iterations, its), tol,
-                      solution_relerr=relerr(x, xr))
-    assert dev.max() < tol, (dev.max(), spread)
-    if fix == "s8":
-        assert dev.max() < 1e-6                         # BASELINE.json configs[0], north star
+    parity_log.judge("test_solveXX_history[%s-%s]" % (par_even, fix), sp.r2hist, S.o,
+                     lambda: S.o.solveXX(S.lo, S.g, S.g3, S.x, 0.1, 1e-12, 2000, par_even, histcap=4096)[3],
+                     lambda: S.o.solveXX_ext(S.lo, S.g, S.g3, S.x, 0.1, 1e-12, 2000, par_even, histcap=4096)[1],
+                     its=(sp.iterations, its), baseline=(fix == "s8"), solution_relerr=relerr(x, xr))
     assert relerr(x, xr) < 1e-6
     assert sp.r2 <= 1e-12
 
@@ -334,12 +331,13 @@ def test_forced_halo_equals_periodic(oracle, naik, warm):
     n = min(len(spa.r2hist), len(spb.r2hist))
     dev = np.abs(spb.r2hist[:n] / spa.r2hist[:n] - 1)
     assert dev[:100].max() < 1e-12          # same kernels; only the partial-sum grouping differs
-    xr, its, fin, hist = oracle.solveXX(A.lo, A.g, A.g3, A.x, 0.1, 1e-12, 2000, True, histcap=4096)
-    tol, spread, per = history_tolerance(oracle, A.lo, A.g, A.g3, A.x, 0.1, 1e-12, 2000, True, hist)
+    # both forms against the oracle and the binary128 truth, each on its own
     import parity_log
-    parity_log.record("test_forced_halo_equals_periodic[naik=%s-warm=%s] (halo vs periodic, both HIP)" % (naik, warm), dev, spread, per,
-                      (spb.iterations, spa.iterations), tol)
-    assert dev.max() < tol, (dev.max(), spread)
+    for tag, spx in (("periodic", spa), ("halo", spb)):
+        parity_log.judge("test_forced_halo_equals_periodic[naik=%s-warm=%s] %s" % (naik, warm, tag), spx.r2hist, oracle,
+                         lambda: oracle.solveXX(A.lo, A.g, A.g3, A.x, 0.1, 1e-12, 2000, True, histcap=4096)[3],
+                         lambda: oracle.solveXX_ext(A.lo, A.g, A.g3, A.x, 0.1, 1e-12, 2000, True, histcap=4096)[1],
+                         its=(spx.iterations, spa.iterations), counts=[2], cache_key=("halo_vs_periodic", naik, warm))
     assert relerr(xb, xa) < 1e-6
     assert abs(spc.iterations - spa.iterations) <= 1 and relerr(xc, xa) < 1e-6
 
