@@ -3,6 +3,8 @@
 // the average launch time measured with hipEvents (interleave variants in ONE process:
 // cdna_hip_programming.md 5.4 rule 24).  The winner is folded back into dslash.hip by hand.
 #include "qexhip_internal.h"
+#include <algorithm>
+#include <vector>
 #include "site_index.h"
 #include "../../include/qexhip.h"
 
@@ -463,6 +465,151 @@ extern "C" int qexhip_tune_gather(qexhip_handle c, int nw, int wgpc, int depth, 
   *avg_us = 1e3 * ms / nrep;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- round 5: the same 48-operand gather stream with the links interpreted in a BRICK tile shape (round-4 verdict, Next 3) ----
+// A tile position = an 8(x) x 4(y) x 4(z) x 1(t) brick = 128 sites, 64 per parity; lane = (xi >> 1) + 4 * (yi + 4 * zi).  In-tile hop
+// fraction 7/8 + 3/4 + 3/4 + 0 = 2.375 of 4 against 1.75 for the product's 128 consecutive sites (4 x-rows).  The buffer is the
+// product's link field read as [parity][brick][mu][9][64] (same size when 8 | X, 4 | Y, 4 | Z: only the address pattern matters to a
+// gather-rate measurement).  Same operand kinds, same persistent-workgroup walk, visiting order built the same way (one contiguous
+// (t, z) region per XCD, walked in 8y x 4z x 4t blocks, parities adjacent).
+struct BrickGeom { int X[4], nb[3], nbrick; };
+struct BrickSite { int b[3], i[3], t, par; };      // brick coordinates, in-brick coordinates
+__device__ __forceinline__ void brick_site(const BrickGeom &g, int brick, int par, int lane, BrickSite &s) {
+  unsigned r = (unsigned)brick;
+  s.b[0] = r % g.nb[0]; r /= g.nb[0];
+  s.b[1] = r % g.nb[1]; r /= g.nb[1];
+  s.b[2] = r % g.nb[2]; s.t = r / g.nb[2];
+  const int xh = lane & 3, yi = (lane >> 2) & 3, zi = lane >> 4;
+  s.i[1] = yi; s.i[2] = zi;
+  s.i[0] = 2 * xh + ((yi + zi + s.t + par) & 1);           // brick origins are even in every coordinate
+  s.par = par;
+}
+// one hop of +-1 in direction d (wavefront-uniform) -> (brick, lane, parity) of the neighbour
+__device__ __forceinline__ void brick_hop(const BrickGeom &g, BrickSite &s, int d, int sgn) {
+  s.par ^= 1;
+  if (d == 3) { s.t += sgn; s.t = s.t >= g.X[3] ? 0 : (s.t < 0 ? g.X[3] - 1 : s.t); return; }
+  const int ext = d == 0 ? 8 : 4;
+  int v = (d == 0 ? s.i[0] : (d == 1 ? s.i[1] : s.i[2])) + sgn;
+  int b = d == 0 ? s.b[0] : (d == 1 ? s.b[1] : s.b[2]);
+  const int nb = d == 0 ? g.nb[0] : (d == 1 ? g.nb[1] : g.nb[2]);
+  if (v >= ext) { v = 0; b = b + 1 >= nb ? 0 : b + 1; }
+  if (v < 0) { v = ext - 1; b = b == 0 ? nb - 1 : b - 1; }
+  if (d == 0) { s.i[0] = v; s.b[0] = b; } else if (d == 1) { s.i[1] = v; s.b[1] = b; } else { s.i[2] = v; s.b[2] = b; }
+}
+__device__ __forceinline__ unsigned brick_link_off(const BrickGeom &g, const BrickSite &s, int mu) {
+  const unsigned brick = s.b[0] + g.nb[0] * (s.b[1] + g.nb[1] * (s.b[2] + g.nb[2] * (unsigned)s.t));
+  const unsigned lane = (s.i[0] >> 1) + 4 * (s.i[1] + 4 * s.i[2]);
+  return ((unsigned)(s.par * g.nbrick + brick) * 4u + (unsigned)mu) * 576u + lane;
+}
+template <int D>
+__global__ void __launch_bounds__(512) k_gather_brick(BrickGeom g, const double2 *__restrict__ U, const int *__restrict__ order, int chunk,
+                                                        unsigned long long *out) {
+  const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, jstride = gridDim.x >> 3;
+  const int *ord = order + (size_t)xcd * chunk;
+  M3 st[D];
+  unsigned long long acc = 0;
+  const int npw = 48 / nw;
+  int ntile = 0;
+  for (int j = j0; j < chunk; j += jstride) { if (ord[j] < 0) break; ntile++; }
+  const int nunit = ntile * npw;
+  BrickSite s0;
+  int cur = -1;
+  auto src = [&](int u) -> const double2 * {
+    const int uc = u < nunit ? u : nunit - 1;
+    const int ti = uc / npw, k = wave + nw * (uc - ti * npw);
+    if (ti != cur) {
+      const int e = ord[j0 + ti * jstride];
+      brick_site(g, e >> 1, e & 1, lane, s0);
+      cur = ti;
+    }
+    const int gi = k >> 2, w = k & 3;
+    BrickSite s = s0;
+    int mu = w;
+    if (gi == 1) brick_hop(g, s, w, -1);
+    else if (gi >= 2 && gi <= 10) {
+      const int r = (gi - 2) / 3 + 1, kk = (gi - 2) % 3, q = w ^ r;
+      if (kk == 0) brick_hop(g, s, q, 1);
+      else if (kk == 1) { brick_hop(g, s, w, -1); mu = q; }
+      else { brick_hop(g, s, w, -1); brick_hop(g, s, q, 1); }
+    }
+    return U + brick_link_off(g, s, mu);
+  };
+  if (nunit == 0) return;
+#pragma unroll
+  for (int d = 0; d < D; d++) { st[d] = m3_load(src(d), 64); __builtin_amdgcn_sched_barrier(0); }
+  for (int u0 = 0; u0 < nunit; u0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) acc ^= (unsigned long long)__double_as_longlong(st[d].e[k].x) + (unsigned long long)__double_as_longlong(st[d].e[k].y);
+      st[d] = m3_load(src(u0 + d + D), 64);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (acc == 0x123456789abcdefull) out[0] = acc;
+}
+// as qexhip_tune_gather, brick tile shape; lattices with 8 | X, 4 | Y, 4 | Z only
+extern "C" int qexhip_tune_gather_brick(qexhip_handle c, int nw, int wgpc, int depth, int nrep, double *avg_us) {
+  if (!c || !avg_us || nw < 1 || nw > 8 || 48 % nw || wgpc < 1) return -1;
+  const double2 *U = gauge_links_dev(c);
+  if (!U) { qexhip_set_error("tune_gather_brick: qexhip_gauge_set first"); return -3; }
+  const Geom &gg = c->g;
+  if (gg.X[0] % 8 || gg.X[1] % 4 || gg.X[2] % 4 || gg.halo) { qexhip_set_error("tune_gather_brick: needs 8 | X, 4 | Y, 4 | Z, no halo"); return -1; }
+  BrickGeom g;
+  for (int i = 0; i < 4; i++) g.X[i] = gg.X[i];
+  g.nb[0] = gg.X[0] / 8; g.nb[1] = gg.X[1] / 4; g.nb[2] = gg.X[2] / 4;
+  g.nbrick = g.nb[0] * g.nb[1] * g.nb[2] * gg.X[3];
+  if (g.nbrick != gg.ntile) { qexhip_set_error("tune_gather_brick: brick count != tile count"); return -1; }
+  // visiting order: 8 XCD regions contiguous in (t, z), each walked in blocks of 8 y x 4 z x 4 t (2 x 1 x 4 bricks, all of x), parities adjacent
+  const int n = 2 * g.nbrick, chunk = (n + 7) / 8;
+  struct Ent { unsigned long long key0, key1; int e; };
+  std::vector<Ent> v(n);
+  for (int p = 0; p < 2; p++)
+    for (int b = 0; b < g.nbrick; b++) {
+      unsigned r = (unsigned)b;
+      const int bx = r % g.nb[0]; r /= g.nb[0];
+      const int by = r % g.nb[1]; r /= g.nb[1];
+      const int bz = r % g.nb[2], t = r / g.nb[2];
+      Ent &a = v[(size_t)p * g.nbrick + b];
+      a.e = 2 * b + p;
+      a.key0 = ((((unsigned long long)t * 1024u + bz) * 1024u + by) * 1024u + bx) * 2 + p;
+      a.key1 = (((((((unsigned long long)(t / 4) * 1024u + bz) * 1024u + by / 2) * 1024u + t % 4) * 1024u + by % 2) * 1024u + bx)) * 2 + p;
+    }
+  std::sort(v.begin(), v.end(), [](const Ent &a, const Ent &b) { return a.key0 < b.key0; });
+  std::vector<int> h((size_t)8 * chunk, -1);
+  for (int k = 0; k < 8; k++) {
+    const int lo = std::min(n, k * chunk), hi = std::min(n, (k + 1) * chunk);
+    std::sort(v.begin() + lo, v.begin() + hi, [](const Ent &a, const Ent &b) { return a.key1 < b.key1; });
+    for (int j = lo; j < hi; j++) h[(size_t)k * chunk + (j - lo)] = v[j].e;
+  }
+  int *order;
+  HIPCHK(hipMalloc((void **)&order, h.size() * sizeof(int)));
+  HIPCHK(hipMemcpy(order, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+  unsigned long long *out;
+  HIPCHK(hipMalloc((void **)&out, 8));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  const int nblk = 256 * wgpc;
+  auto run = [&]() {
+    if (depth == 2) k_gather_brick<2><<<nblk, 64 * nw, 0, c->stream>>>(g, U, order, chunk, out);
+    else if (depth == 4) k_gather_brick<4><<<nblk, 64 * nw, 0, c->stream>>>(g, U, order, chunk, out);
+    else k_gather_brick<1><<<nblk, 64 * nw, 0, c->stream>>>(g, U, order, chunk, out);
+  };
+  run();
+  HIPCHK(hipEventRecord(e0, c->stream));
+  for (int i = 0; i < nrep; i++) run();
+  HIPCHK(hipEventRecord(e1, c->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  *avg_us = 1e3 * ms / nrep;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(out); (void)hipFree(order);
   HIPCHK(hipGetLastError());
   return 0;
 }
