@@ -75,9 +75,14 @@ static int smear_order(qexhip_ctx *c, const Geom &g, const int **order, int *chu
 // (the `l.proj lx` that follows the last staple of a level).
 template <bool HALO>
 __global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, int swz,
-                                                    MView init, double cinit, MViewW proj, const int *order, int chunk, int nt) {
+                                                    MView init, double cinit, MViewW proj, const int *order, int chunk, int nt,
+                                                    int gc0 = 0, int gc1 = 0) {
   int p, c;
-  if (order) {   // blocked visiting order (tile_order_table): wavefront w takes slot 4*(b>>3)+w of XCD b&7
+  if (gc1 > gc0) {   // t-sharded, communication-avoiding levels: the positions [gc0, gc1) of both parities -- ghost slices
+    const int n = gc1 - gc0, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * n) return;
+    p = i >= n; c = gc0 + i - p * n;
+  } else if (order) {   // blocked visiting order (tile_order_table): wavefront w takes slot 4*(b>>3)+w of XCD b&7
     const int slot = 4 * (blockIdx.x >> 3) + (threadIdx.x >> 6);
     const int e = slot < chunk ? order[(blockIdx.x & 7) * chunk + slot] : -1;
     if (e < 0) return;
@@ -92,6 +97,7 @@ __global__ void __launch_bounds__(256) k_gen_staple(Geom g, MView A, MView B, in
   }
   int x[4], xpn[4], xpm[4], xmn[4], xmnpm[4];
   coords_sm(g, c, p, x);
+  if (HALO && x[3] >= g.X[3] + 3) x[3] -= g.X[3] + 6;     // a position in ghost_lo: virtual slice -3..-1 (Xt + 6 is even: same parity)
   shift_sm_t<HALO>(g, x, nu, 1, xpn);
   shift_sm_t<HALO>(g, x, mu, 1, xpm);
   shift_sm_t<HALO>(g, x, nu, -1, xmn);
@@ -691,8 +697,10 @@ struct Smear {
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
   }
+  // ext > 0 (t-sharded only): also on the `ext` ghost slices either side of the slab -- the operands must be valid `ext + 1`
+  // slices out (communication-avoiding smearing levels: nhyp() below)
   int staple(MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, MView init = MView{nullptr, 0}, double cinit = 0.0,
-             MViewW proj = MViewW{nullptr, 0}) {
+             MViewW proj = MViewW{nullptr, 0}, int ext = 0) {
     ScopedTimer tm(c, "smear", c->stream);
     constexpr int swz = 1;     // XCD-aware block remap of the gather kernels (measured winner, profiles/r02_pmc_staple_kernels_order.log)
     const int *order; int chunk, nblk;
@@ -705,6 +713,13 @@ struct Smear {
     constexpr int gnt = 1;     // non-temporal stores of the staple / accumulator (written once, read by a later kernel)
     if (g.halo) k_gen_staple<true><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk, gnt);
     else k_gen_staple<false><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk, gnt);
+    if (g.halo && ext > 0) {
+      // ghost_hi holds the virtual slices Xt .. Xt+2 at [Vh, Vh + 3F), ghost_lo the slices -3 .. -1 at [Vh + 3F, Vh + 6F)
+      const int F = g.F, hi0 = g.Vh, lo1 = g.Vh + 6 * F;
+      const int nb = (2 * ext * F + 255) / 256;
+      k_gen_staple<true><<<nb, 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, 0, init, cinit, proj, nullptr, 0, gnt, hi0, hi0 + ext * F);
+      k_gen_staple<true><<<nb, 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, 0, init, cinit, proj, nullptr, 0, gnt, lo1 - ext * F, lo1);
+    }
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -872,16 +887,22 @@ struct Smear {
     const double alp1 = a1 / 2.0, alp2 = a2 / 4.0, alp3 = a3 / 6.0;
     const MViewW none{nullptr, 0};
     const MView noinit{nullptr, 0};
-    // every level: first staple starts the sum from ma * U_mu, last staple projects it (fused, see k_gen_staple);
-    // t-sharded: the projected links of a level get their ghost slices before the next level reads them shifted
-    CHK(ghosts_g(G));
+    // every level: first staple starts the sum from ma * U_mu, last staple projects it (fused, see k_gen_staple).
+    // t-sharded, communication-avoiding (round 5): ONE exchange -- the thin links three slices deep -- and then level 1 is
+    // computed on the slab plus two ghost slices either side, level 2 on the slab plus one, level 3 on the slab: the ghost
+    // slices of the projected level-1/2 fields are computed here, redundantly with the neighbour that owns them, instead of
+    // being fetched (rounds 1-4: 12 + 12 matrix-field refreshes of 16 MB per direction at 48^3 x 12 against 3 x 64 MB once,
+    // i.e. 382 -> 191 MB per direction, and no exchange left inside the levels; profiles/r05_notes.md).  Extra arithmetic:
+    // 4 / T of level 1 and 2 / T of level 2.
+    const bool ca = g.halo && c->opt_smear_ca;      // option "smear_ca" = 0: the per-field refreshes of rounds 1-4 (A/B, test hook)
+    CHK(ghosts_g(G, ca ? 3 : 1));
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
-        CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(K.l1x[mu][nu]), alp1, gv(G, mu), 1 - a1, fvw(K.l1[mu][nu])));
-        CHK(ghosts_f_async(K.l1[mu][nu]));                  // travels while the next (mu, nu) is computed
+        CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(K.l1x[mu][nu]), alp1, gv(G, mu), 1 - a1, fvw(K.l1[mu][nu]), ca ? 2 : 0));
+        if (g.halo && !ca) CHK(ghosts_f_async(K.l1[mu][nu]));                  // travels while the next (mu, nu) is computed
       }
-    CHK(ghosts_join());
+    if (g.halo && !ca) CHK(ghosts_join());
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;
@@ -891,12 +912,12 @@ struct Smear {
           const int b = 6 - mu - nu - a;
           const bool first = cnt == 0, last = cnt == 1;
           CHK(staple(fv(K.l1[a][b]), fv(K.l1[mu][b]), mu, a, none, fvw(K.l2x[mu][nu]), alp2, first ? gv(G, mu) : noinit, 1 - a2,
-                     last ? fvw(K.l2[mu][nu]) : none));
+                     last ? fvw(K.l2[mu][nu]) : none, ca ? 1 : 0));
           cnt++;
         }
-        CHK(ghosts_f_async(K.l2[mu][nu]));
+        if (g.halo && !ca) CHK(ghosts_f_async(K.l2[mu][nu]));
       }
-    CHK(ghosts_join());
+    if (g.halo && !ca) CHK(ghosts_join());
     for (int mu = 0; mu < 4; mu++) {
       const MViewW x3 = keep ? gvw(K.flx, mu) : fvw(tmp);
       int cnt = 0;
