@@ -383,6 +383,8 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *   "batch_multi"  1: the same for the lock-step multi-system CG
  *   "smear_ca"     0: the nHYP levels of a t-sharded field refresh the ghost slices of every projected level field (rounds 1-4) instead of
  *                  computing them on shrinking ghost slices from one depth-3 thin-link exchange (default 1)
+ *   "chain_overlap" 0: the nHYP force chain of a t-sharded field exchanges a level's chain fields first and runs the next staple
+ *                  derivative in one pass, instead of running its ghost-free slices beside the exchange (default 1; bit-identical)
  *   "force_pair"   0: k_force_lds (one tile and parity per workgroup), what shapes without paired tile positions run
  *   "obs_clover"   0: the generic path walker, what fmunu loops 3-5 run, for the clover loop as well
  *   "emu_exchange_us", "emu_allreduce_us"   transport emulation for one-GPU rehearsals: every face exchange / all-reduce is preceded,

@@ -658,6 +658,7 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "multi_reduce") c->opt_multi_reduce = value;
   else if (n == "flow_exp") c->opt_flow_exp = value;
   else if (n == "smear_ca") c->opt_smear_ca = value;
+  else if (n == "chain_overlap") c->opt_chain_overlap = value;
   else if (n == "emu_exchange_us") c->emu_exchange_us = value;
   else if (n == "emu_allreduce_us") c->emu_allreduce_us = value;
   else if (n == "emu_link_gbs") c->emu_link_gbs = value;

@@ -116,6 +116,8 @@ struct qexhip_ctx {
                             // (with a one-rank RCCL communicator the all-reduces are real collectives)
   int opt_force_pair = 1; // option "force_pair" (test hook): 0 takes k_force_lds, the form lattice shapes without paired tile positions get, on any shape
   int opt_obs_clover = 1; // option "obs_clover" (test hook): 0 takes the generic path walker, the form fmunu loops 3-5 get, for loop 1 as well
+  int opt_chain_overlap = 1; // option "chain_overlap" (A/B, test hook): 1 = the nHYP force chain's staple derivatives of a t-sharded field run in two passes,
+                          // the ghost-free slices beside the exchange of the level's chain fields, the boundary slices behind it
   int opt_smear_ca = 1;   // option "smear_ca" (A/B, test hook): 1 = the nHYP levels of a t-sharded field are computed on shrinking ghost slices from
                           // ONE depth-3 thin-link exchange; 0 = every projected level field refreshes its ghost slices (rounds 1-4)
   int opt_flow_exp = 1;   // QEXHIP_FLOW_EXP / option "flow_exp": 1 = closed-form exp(v) in the fused Wilson-flow stage (same function,

@@ -476,13 +476,20 @@ __global__ void __launch_bounds__(256, WPE) k_staple_deriv(Geom g, MViewW f1, MV
 // for each other at the hand-off, which costs more than the smaller working set saves.)
 template <bool HALO>
 __global__ void __launch_bounds__(256) k_staple_deriv_pair(Geom g, MViewW F1, MViewW F2, MView g1, MView g2, MView cA, MView cB, int mu, int nu,
-                                                          int z1, int z2, const int *order, int chunk, int nt) {
+                                                          int z1, int z2, const int *order, int chunk, int nt, int tsel = 0) {
   const int wv = threadIdx.x >> 6;
   const int slot = 2 * (blockIdx.x >> 3) + (wv >> 1);
   const int e = slot < chunk ? order[(blockIdx.x & 7) * chunk + slot] : -1;
   if (e < 0) return;
   const int p = e & 1, c = (e >> 1) * 64 + (threadIdx.x & 63);
   if (c >= g.Vh) return;
+  if (HALO && tsel) {
+    // t-sharded: a tile lies in ONE t-slice (64 | F), so whole wavefronts take part or leave.  tsel 1: the slices that read
+    // no ghost data (0 < t < Xt-1: they run while the chain fields' ghost slices travel), 2: the two boundary slices
+    const int t = (e >> 1) * 64 / g.F;
+    const bool bnd = t == 0 || t == g.X[3] - 1;
+    if (bnd != (tsel == 2)) return;
+  }
   const bool second = __builtin_amdgcn_readfirstlane(wv & 1) != 0;      // wavefront-uniform role
   const MViewW Fo = second ? F2 : F1;
   const MView ga = second ? g2 : g1, gb = second ? g1 : g2, ca = second ? cB : cA, cb = second ? cA : cB;
@@ -981,12 +988,12 @@ int nhyp_prepare(qexhip_ctx *c, const double *g_host, double a1, double a2, doub
 // smearedForce(f, chain) on the device field st->F (in: chain, out: f)   (hypsmear.nim:146-245)
 // the (mu, nu) and (nu, mu) symStapleDerivs of a level in one pass (k_staple_deriv_pair)
 static int staple_deriv_pair(qexhip_ctx *c, const Geom &g, MViewW F1, MViewW F2, MView g1, MView g2, MView cA, MView cB, int mu, int nu,
-                             int z1, int z2) {
+                             int z1, int z2, int tsel = 0) {
   const int *order; int chunk, nblk;
   CHK(smear_order(c, g, &order, &chunk, &nblk, mu, nu));
   const int nb2 = 8 * ((chunk + 1) / 2);         // two wavefronts per tile: 2 table slots per 256-thread workgroup
   constexpr int nt = 1;
-  if (g.halo) k_staple_deriv_pair<true><<<nb2, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk, nt);
+  if (g.halo) k_staple_deriv_pair<true><<<nb2, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk, nt, tsel);
   else k_staple_deriv_pair<false><<<nb2, 256, 0, c->stream>>>(g, F1, F2, g1, g2, cA, cB, mu, nu, z1, z2, order, chunk, nt);
   HIPCHK(hipGetLastError());
   return 0;
@@ -998,8 +1005,6 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
   const double alp1 = st->a1 / 2.0, alp2 = st->a2 / 4.0, alp3 = st->a3 / 6.0;
   const double ma1 = 1 - st->a1, ma2 = 1 - st->a2, ma3 = 1 - st->a3;
   ScopedTimer tm(c, "nhyp_force", c->stream);
-  // fl1 / fl2 are sums of several staple derivatives: the first contribution to each writes, the rest accumulate
-  bool t1[4][4] = {}, t2[4][4] = {};
   if (!(c->lds_attr_done & 16)) {
     HIPCHK(hipFuncSetAttribute((const void *)k_projUderiv_batch, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
     c->lds_attr_done |= 16;
@@ -1016,13 +1021,36 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
     QX_PB_LAUNCH;
   }
   HIPCHK(hipGetLastError());
-  CHK(S.ghosts_g(st->fc));          // t-sharded: a chain field is read at shifted sites by the staple derivative
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = mu + 1; nu < 4; nu++) {       // (mu, nu) and (nu, mu) together
-      CHK(staple_deriv_pair(c, g, S.fvw(st->fl2[nu][mu]), S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[nu][mu]), S.fv(st->K.l2[mu][nu]),
-                            S.gv(st->fc, mu), S.gv(st->fc, nu), mu, nu, !t2[nu][mu], !t2[mu][nu]));
-      t2[nu][mu] = t2[mu][nu] = true;
-    }
+  // t-sharded: the chain fields of a level are read at shifted sites by the next staple derivative, so their ghost slices have
+  // to arrive first -- 4 / 12 / 12 matrix fields per level, 64 / 191 / 191 MB per direction at 48^3 x 12.  Round 5: the exchange is
+  // posted on the comm stream and the derivative runs in two passes, first the slices that read no ghost data (0 < t < Xt-1)
+  // beside it, then, after the join, the two boundary slices.  Every site still receives its contributions in the same call
+  // order, so the result is bit-identical to the one-pass form (option "chain_overlap" = 0).
+  const bool split = g.halo && c->opt_chain_overlap && g.X[3] >= 4;
+  auto refresh = [&](const double2 *const *fs, int nf, int tstride) -> int {
+    if (!g.halo) return 0;
+    return S.ghosts_many(fs, nf, tstride, 1, split ? 1 : 0);
+  };
+  auto passes = [&](auto &&level) -> int {       // level(tsel): all staple-derivative launches of one level
+    if (!split) return level(0);
+    CHK(level(1));
+    CHK(S.ghosts_join());
+    return level(2);
+  };
+  {
+    const double2 *fs[1] = {st->fc};
+    CHK(refresh(fs, 1, 4 * 576));
+  }
+  CHK(passes([&](int tsel) -> int {
+    bool w[4][4] = {};          // fl2 is a sum of several staple derivatives: the first contribution of a PASS to each field writes, the rest accumulate
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = mu + 1; nu < 4; nu++) {       // (mu, nu) and (nu, mu) together
+        CHK(staple_deriv_pair(c, g, S.fvw(st->fl2[nu][mu]), S.fvw(st->fl2[mu][nu]), S.fv(st->K.l2[nu][mu]), S.fv(st->K.l2[mu][nu]),
+                              S.gv(st->fc, mu), S.gv(st->fc, nu), mu, nu, !w[nu][mu], !w[mu][nu], tsel));
+        w[nu][mu] = w[mu][nu] = true;
+      }
+    return 0;
+  }));
   HIPCHK(hipGetLastError());
   {
     for (int mu = 0; mu < 4; mu++) {
@@ -1042,20 +1070,24 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
       for (int mu = 0; mu < 4; mu++)
         for (int nu = 0; nu < 4; nu++)
           if (nu != mu) fs[nf++] = st->fl2[mu][nu];
-      CHK(S.ghosts_many(fs, nf, 576, 1, 0));      // the twelve chain fields of the level in ONE group
+      CHK(refresh(fs, nf, 576));                  // the twelve chain fields of the level in ONE group
     }
   }
   HIPCHK(hipGetLastError());
   // the call (mu, nu, a) and its partner (a, nu, mu) share b = 6 - mu - nu - a and exchange the roles of their fields
-  for (int mu = 0; mu < 4; mu++)
-    for (int a = mu + 1; a < 4; a++)
-      for (int nu = 0; nu < 4; nu++) {
-        if (nu == mu || nu == a) continue;
-        const int b = 6 - mu - nu - a;
-        CHK(staple_deriv_pair(c, g, S.fvw(st->fl1[a][b]), S.fvw(st->fl1[mu][b]), S.fv(st->K.l1[a][b]), S.fv(st->K.l1[mu][b]),
-                              S.fv(st->fl2[mu][nu]), S.fv(st->fl2[a][nu]), mu, a, !t1[a][b], !t1[mu][b]));
-        t1[a][b] = t1[mu][b] = true;
-      }
+  CHK(passes([&](int tsel) -> int {
+    bool w[4][4] = {};
+    for (int mu = 0; mu < 4; mu++)
+      for (int a = mu + 1; a < 4; a++)
+        for (int nu = 0; nu < 4; nu++) {
+          if (nu == mu || nu == a) continue;
+          const int b = 6 - mu - nu - a;
+          CHK(staple_deriv_pair(c, g, S.fvw(st->fl1[a][b]), S.fvw(st->fl1[mu][b]), S.fv(st->K.l1[a][b]), S.fv(st->K.l1[mu][b]),
+                                S.fv(st->fl2[mu][nu]), S.fv(st->fl2[a][nu]), mu, a, !w[a][b], !w[mu][b], tsel));
+          w[a][b] = w[mu][b] = true;
+        }
+    return 0;
+  }));
   HIPCHK(hipGetLastError());
   {
     for (int mu = 0; mu < 4; mu++) {
@@ -1075,14 +1107,17 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
       for (int mu = 0; mu < 4; mu++)
         for (int nu = 0; nu < 4; nu++)
           if (nu != mu) fs[nf++] = st->fl1[mu][nu];
-      CHK(S.ghosts_many(fs, nf, 576, 1, 0));
+      CHK(refresh(fs, nf, 576));
     }
   }
   HIPCHK(hipGetLastError());
-  for (int mu = 0; mu < 4; mu++)
-    for (int nu = mu + 1; nu < 4; nu++)
-      CHK(staple_deriv_pair(c, g, S.gvw(st->F, nu), S.gvw(st->F, mu), S.gv(st->G, nu), S.gv(st->G, mu),
-                            S.fv(st->fl1[mu][nu]), S.fv(st->fl1[nu][mu]), mu, nu, 0, 0));
+  CHK(passes([&](int tsel) -> int {
+    for (int mu = 0; mu < 4; mu++)
+      for (int nu = mu + 1; nu < 4; nu++)
+        CHK(staple_deriv_pair(c, g, S.gvw(st->F, nu), S.gvw(st->F, mu), S.gv(st->G, nu), S.gv(st->G, mu),
+                              S.fv(st->fl1[mu][nu]), S.fv(st->fl1[nu][mu]), mu, nu, 0, 0, tsel));
+    return 0;
+  }));
   HIPCHK(hipGetLastError());
   return 0;
 }

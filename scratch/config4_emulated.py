@@ -15,11 +15,15 @@ hc, hq = q.HypCoefs(0.4, 0.5, 0.5), q.HisqCoefs()
 
 def timed(fn, ctx, n=3):
     fn(); ctx.sync()
-    t = time.perf_counter()
+    ts = []
     for _ in range(n):
+        t = time.perf_counter()
         fn()
-    ctx.sync()
-    return 1e3 * (time.perf_counter() - t) / n
+        ctx.sync()
+        ts.append(1e3 * (time.perf_counter() - t))
+    if max(ts) > 3 * min(ts):
+        print("   (uneven calls: %s ms)" % ", ".join("%.1f" % v for v in ts), flush=True)
+    return sorted(ts)[len(ts) // 2]
 
 
 rows = []

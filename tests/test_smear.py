@@ -368,6 +368,7 @@ def test_gpu_smearing_and_forces_on_the_sharded_path(oracle):
     B.force_halo(True)                 # nHYP levels communication-avoiding (one depth-3 thin-link exchange, levels on shrinking ghost slices)
     Cc.force_halo(True)
     Cc.set_option("smear_ca", 0)       # ... and with the per-field ghost refreshes of rounds 1-4
+    Cc.set_option("chain_overlap", 0)  # ... and the force chain's levels in one pass behind their exchange (B: ghost-free slices beside it)
     eq = lambda a, b: np.linalg.norm(a - b) <= 1e-15 * np.linalg.norm(a)
     coef = (0.9, -0.11, 0.021, -0.0043, -0.07)
     out = {}
