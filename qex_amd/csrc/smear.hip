@@ -706,8 +706,9 @@ struct Smear {
   }
   // ext > 0 (t-sharded only): also on the `ext` ghost slices either side of the slab -- the operands must be valid `ext + 1`
   // slices out (communication-avoiding smearing levels: nhyp() below)
+  // ext_acc = false: on the ghost slices only the staple field `st` is wanted (fat7: the accumulator is read on the slab only)
   int staple(MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, MView init = MView{nullptr, 0}, double cinit = 0.0,
-             MViewW proj = MViewW{nullptr, 0}, int ext = 0) {
+             MViewW proj = MViewW{nullptr, 0}, int ext = 0, bool ext_acc = true) {
     ScopedTimer tm(c, "smear", c->stream);
     constexpr int swz = 1;     // XCD-aware block remap of the gather kernels (measured winner, profiles/r02_pmc_staple_kernels_order.log)
     const int *order; int chunk, nblk;
@@ -724,8 +725,9 @@ struct Smear {
       // ghost_hi holds the virtual slices Xt .. Xt+2 at [Vh, Vh + 3F), ghost_lo the slices -3 .. -1 at [Vh + 3F, Vh + 6F)
       const int F = g.F, hi0 = g.Vh, lo1 = g.Vh + 6 * F;
       const int nb = (2 * ext * F + 255) / 256;
-      k_gen_staple<true><<<nb, 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, 0, init, cinit, proj, nullptr, 0, gnt, hi0, hi0 + ext * F);
-      k_gen_staple<true><<<nb, 256, 0, c->stream>>>(g, A, B, mu, nu, st, acc, coef, 0, init, cinit, proj, nullptr, 0, gnt, lo1 - ext * F, lo1);
+      const MViewW ga = ext_acc ? acc : MViewW{nullptr, 0}, gp = ext_acc ? proj : MViewW{nullptr, 0};
+      k_gen_staple<true><<<nb, 256, 0, c->stream>>>(g, A, B, mu, nu, st, ga, coef, 0, init, cinit, gp, nullptr, 0, gnt, hi0, hi0 + ext * F);
+      k_gen_staple<true><<<nb, 256, 0, c->stream>>>(g, A, B, mu, nu, st, ga, coef, 0, init, cinit, gp, nullptr, 0, gnt, lo1 - ext * F, lo1);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -740,20 +742,26 @@ struct Smear {
     CHK(alloc(&stp, fsz));
     CHK(alloc(&tmp, fsz));
     const MViewW none{nullptr, 0};
+    // t-sharded, communication-avoiding (round 5, as the nHYP levels): the thin links arrive three slices deep ONCE; the
+    // 3-staple field is computed on the slab plus two ghost slices either side (one without 7-staples), the 5-staple field on the
+    // slab plus one -- 36 single-field refreshes per pass (12 + 24 x 16 MB per direction at 48^3 x 12) become none.
+    const bool ca = g.halo && c->opt_smear_ca;
+    const int ext5 = ca ? (c7 != 0.0 ? 1 : 0) : 0, ext3 = ca ? (have5 ? ext5 + 1 : 0) : 0;
+    if (ca) CHK(ghosts_g(gf, 3));
     for (int dir = 0; dir < 4; dir++) {
       k_mscale<<<nb(), 256, 0, c->stream>>>(g, gvw(fl, dir), c1, gv(gf, dir));
       HIPCHK(hipGetLastError());
       if (!have3) continue;
       for (int nu = 0; nu < 4; nu++) {
         if (nu == dir) continue;
-        CHK(staple(gv(gf, nu), gv(gf, dir), dir, nu, fvw(stp), gvw(fl, dir), c3));
-        if (have5) CHK(ghosts_f(stp));                      // the staple is the middle link of the next level
+        CHK(staple(gv(gf, nu), gv(gf, dir), dir, nu, fvw(stp), gvw(fl, dir), c3, MView{nullptr, 0}, 0.0, none, ext3, false));
+        if (have5 && !ca) CHK(ghosts_f(stp));               // the staple is the middle link of the next level
         if (cL != 0.0) CHK(staple(gv(gf, nu), fv(stp), dir, nu, none, gvw(fl, dir), cL));
         if (c5 != 0.0 || c7 != 0.0)
           for (int rho = 0; rho < 4; rho++) {
             if (rho == dir || rho == nu) continue;
-            CHK(staple(gv(gf, rho), fv(stp), dir, rho, fvw(tmp), gvw(fl, dir), c5));
-            if (c7 != 0.0) CHK(ghosts_f(tmp));
+            CHK(staple(gv(gf, rho), fv(stp), dir, rho, fvw(tmp), gvw(fl, dir), c5, MView{nullptr, 0}, 0.0, none, ext5, false));
+            if (c7 != 0.0 && !ca) CHK(ghosts_f(tmp));
             if (c7 != 0.0)
               for (int sig = 0; sig < 4; sig++) {
                 if (sig == dir || sig == nu || sig == rho) continue;
@@ -838,7 +846,7 @@ struct Smear {
   int hisq_first(const double2 *G, double2 *V, double2 *W) {
     const double f7lf = 0.0;
     const double c_first[5] = {(1.0 + 3.0 * f7lf + 0.0) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f7lf / 16.0};
-    CHK(ghosts_g(G));
+    if (!(g.halo && c->opt_smear_ca)) CHK(ghosts_g(G));    // (communication-avoiding: fat7 fetches its input three slices deep itself)
     CHK(fat7(V, G, c_first, nullptr, G, 0.0));
     for (int mu = 0; mu < 4; mu++) k_projectU<<<nb(), 256, 0, c->stream>>>(g, gvw(W, mu), gv(V, mu));
     HIPCHK(hipGetLastError());
@@ -866,13 +874,13 @@ struct Smear {
     const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
     double2 *T1, *T2;
     CHK(alloc(&T1, gsz)); CHK(alloc(&T2, gsz));
-    CHK(ghosts_g(G));
+    if (!(g.halo && c->opt_smear_ca)) CHK(ghosts_g(G));
     CHK(fat7(T1, G, c_first, nullptr, G, 0.0));
     for (int mu = 0; mu < 4; mu++) {
       k_projectU<<<nb(), 256, 0, c->stream>>>(g, gvw(T2, mu), gv(T1, mu));
       HIPCHK(hipGetLastError());
     }
-    CHK(ghosts_g(T2, 2));                                   // Naik: x+d, x+2d
+    if (!(g.halo && c->opt_smear_ca)) CHK(ghosts_g(T2, 2)); // Naik: x+d, x+2d
     return fat7(FL, T2, c_second, LL, T2, -naik / 24.0);
   }
   // nHYP forward smearing (hypsmear.nim:49-144) on device fields; with `keep` the unprojected and
