@@ -63,6 +63,19 @@ def test_ranks_sharing_one_device_against_the_global_oracle(nranks, lat, overlap
     assert all(r["transport_stats"]["exchanges"] > 100 and r["transport_stats"]["allreduces"] > 100 for r in res), res[0]["transport_stats"]
 
 
+@pytest.mark.parametrize("scenario", ["absent", "vanish", "mismatch"])
+def test_peer_transport_failures_are_errors_not_hangs(scenario):
+    """A neighbour that never exchanges, or ranks that disagree about the transport, must end in QEXHIP_ERR_COMM with a message,
+    within the configured bounds -- every device-side wait of the peer transport has an exit (tests/peer_failure_worker.py)."""
+    p = _launch(2, [os.path.join(ROOT, "tests", "peer_failure_worker.py"), scenario], timeout=240,
+                extra_env={"QEXHIP_PEER_TIMEOUT": "3", "QEXHIP_RENDEZVOUS_TIMEOUT": "4"})
+    ok = [ln for ln in p.stdout.splitlines() if ln.startswith("PEER_FAILURE_OK")]
+    if len(ok) != 1:
+        print(p.stdout[-3000:])
+        print(p.stderr[-6000:])
+    assert len(ok) == 1, (p.returncode, len(ok))
+
+
 @needs2
 @pytest.mark.parametrize("lat,overlap", [([8, 8, 8, 8], -1), ([8, 8, 8, 8], 1), ([16, 16, 16, 32], -1), ([16, 16, 16, 32], 1)])
 def test_two_ranks_against_the_global_oracle(lat, overlap):
