@@ -85,7 +85,7 @@ def test_naik_multishift_solveXX_vs_oracle(links, mode, ladder):
     parity_log.judge("test_naik_multishift_solveXX_vs_oracle[%s-%s]" % (ladder, mode), sp.r2hist, o,
                      lambda: o.solveXX_multi(L.lo, L.fat, L.lng, L.b, sh, rq, 5000, True, histcap=8192)[2],
                      lambda: o.solveXX_multi_ext(L.lo, L.fat, L.lng, L.b, sh, rq, 5000, True, histcap=8192)[1],
-                     its=(sp.iterations, its))
+                     its=(sp.iterations, its), cache_key=("config4 naik multishift", ladder))
     h = L.lo.vol // 2
     for k, (a, r) in enumerate(zip(xs, xr)):
         assert relerr(a[:h], r[:h]) < 1e-6, (k, relerr(a[:h], r[:h]))
