@@ -15,3 +15,13 @@ run QEXHIP_TRANSPORT=rccl --halo --lat 48 48 48 12 --emulate-transport 6 30 --se
 run QEXHIP_TRANSPORT=peer --halo --lat 48 48 48 12 --emulate-transport 6 6 --set-option emu_link_gbs=22 --set-option overlap=-2
 run QEXHIP_TRANSPORT=peer --halo --lat 48 48 48 12 --set-option overlap=-2
 run QEXHIP_TRANSPORT=rccl --halo --lat 48 48 48 12 --set-option overlap=-2
+# 32^4 (latency-dominated, SURVEY 8e: reported, not tuned for): a 32^3 face is 0.79 MB = 20 us at 45 GB/s
+run QEXHIP_TRANSPORT=rccl --lat 32 32 32 32
+for lt in 16 8 4; do
+  run QEXHIP_TRANSPORT=rccl --halo --lat 32 32 32 $lt --emulate-transport 3 15 --set-option emu_link_gbs=45 --set-option overlap=-2
+  run QEXHIP_TRANSPORT=peer --halo --lat 32 32 32 $lt --emulate-transport 3 3 --set-option emu_link_gbs=45 --set-option overlap=-2
+done
+# configs[4]'s solver: HISQ Naik links, one rank's slab
+run QEXHIP_TRANSPORT=rccl --naik --lat 48 48 48 96
+run QEXHIP_TRANSPORT=rccl --naik --halo --lat 48 48 48 12 --emulate-transport 3 15 --set-option emu_link_gbs=45 --set-option overlap=-2
+run QEXHIP_TRANSPORT=peer --naik --halo --lat 48 48 48 12 --emulate-transport 3 3 --set-option emu_link_gbs=45 --set-option overlap=-2
