@@ -497,6 +497,11 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
     // (162 workgroups for two 2.65 MB faces cost 30 us per iteration at 48^3 x 12, profiles/r05_emulated_scaling.log).
     // One workgroup per 64 KiB chunk of either phase, 2..128.
     const size_t tot = (size_t)(nd + nu) * bytes;
+    // Residency: a workgroup that has pushed spins in its unpack phase until the neighbour's LAST pushing workgroup is through, so the
+    // workgroups of one exchange kernel must all be able to become resident while their siblings spin.  128 of the chip's ~2000
+    // slots for this kernel's register budget, on streams that own the whole chip (other kernels' workgroups retire on their own):
+    // never put this kernel on a CU-masked stream with fewer slots than its grid -- the round-5 experiment that gave the comm
+    // stream 8 CUs of its own deadlocked until the grid was capped (and lost anyway: profiles/r05_comm_cus_experiment.log).
     const int grid = (int)std::min<size_t>(nch, std::max<size_t>(2, std::min<size_t>(128, tot >> 16)));
     hipLaunchKernelGGL(k_peer_exchange, dim3(grid), dim3(256), 0, st, X);
     HIPCHK(hipGetLastError());
