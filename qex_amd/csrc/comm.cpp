@@ -52,9 +52,16 @@ static int choose_transport(qexhip_ctx *c, const char *id, int nranks, int rank,
   *use_peer = 0;
   const int wish = transport_wish(c);
   if (wish == 1 || nranks > PEER_MAXR) return 0;
+  if (wish == 0 && nranks == 1) return 0;          // one rank, no preference: nobody to meet (the one-rank RCCL communicator of the rehearsals)
   double tmo = 120.0;
   if (const char *e = getenv("QEXHIP_RENDEZVOUS_TIMEOUT")) { const double v = atof(e); if (v > 0) tmo = v; }
-  CHK(peer_host_open(host, (const unsigned char *)id, nranks, rank, tmo));
+  if (int e = peer_host_open(host, (const unsigned char *)id, nranks, rank, tmo)) {
+    if (wish == 2) return e;
+    // auto: no shared-memory segment to meet in (no /dev/shm, a sandbox): RCCL is the only transport left, and says so itself if the
+    // ranks turn out to share a device
+    fprintf(stderr, "libqexhip: rank %d: no rendezvous segment (%s): taking the RCCL transport\n", rank, qexhip_last_error());
+    return 0;
+  }
   PeerShmSlot &me = host->shm->s[rank];
   me.device = c->device;
   me.wish = wish;
