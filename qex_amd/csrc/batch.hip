@@ -293,7 +293,8 @@ static int sweep_mrhs(qexhip_ctx *c, MrhsArgs &A, bool second, int *ndot, DevFie
   if (g.halo) sweep_plan(c, &lo_end, &hi_beg, &overlap);
   // the decision of sweep_plan is for ONE system's faces; a batch moves nrhs times as much per exchange, and between distinct
   // GPUs that transfer is what the overlap is for: with a real communicator, overlap from 1 MiB of faces per direction on
-  if (g.halo && !overlap && c->opt_overlap < 0 && c->nranks > 1 && hi_beg > lo_end &&
+  // -- unless the single-system form was MEASURED at set_links and lost: a measurement outranks the rule (round-4 advice)
+  if (g.halo && !overlap && c->opt_overlap < 0 && c->nranks > 1 && hi_beg > lo_end && c->overlap_auto[c->ndir == 16] < 0 &&
       (size_t)A.nrhs * g.depth * g.F * 48 >= ((size_t)1 << 20)) overlap = 1;
   if (g.halo && overlap) HIPCHK(hipEventRecord(c->ev_ready, c->stream));
   if (g.halo) CHK(comm_halo_exchange_multi(c, A.nrhs, infield, inpar, overlap));
