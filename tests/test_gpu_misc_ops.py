@@ -183,7 +183,7 @@ def test_bench_two_ranks_share_one_gpu():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", QEX_BENCH_FORCE_CANARY="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-48x96"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=root, env=env)
@@ -198,6 +198,9 @@ def test_bench_two_ranks_share_one_gpu():
     assert ln["shard_check"]["ok"] is True and ln["repeats"]["n"] >= 1, ln["shard_check"]
     for k in ("interior_us", "boundary_us", "exchange_us", "allreduce_us", "comm_count", "overlap", "per_rank"):
         assert k in ln["multi_gpu"], k
+    # the peer-transport canary that precedes the RCCL measurement on a multi-GPU node (forced here): verified like every sharded leg
+    can = ln["cg_32x4_peer_transport"]
+    assert "error" not in can and can["transport"] == "peer" and can["shard_check"]["ok"] is True and can["value"] > 0, can
 
 
 @pytest.mark.parametrize("comm2", ["1", "0"])
