@@ -369,7 +369,11 @@ int peer_init(qexhip_ctx *c, PeerHost &host) {
   if (khz <= 0) khz = 100000;
   p->ticks = (long long)(tmo * 1000.0 * khz);
   p->timeout_s = tmo;
-  HIPCHK(hipMalloc((void **)&p->ctrl, CTRL_BYTES));
+  // Everything a PEER writes lives in fine-grained device memory: between distinct GPUs the writes arrive over xGMI behind the
+  // local L2's back, and only fine-grained (MTYPE NC) lines are guaranteed to be dropped by a system-scope acquire -- coarse-grained
+  // hipMalloc memory is kept coherent for the owning agent only.  (Between processes on ONE device both kinds pass every check of
+  // scratch/ipc_probe.cpp; what RCCL allocates for its own receive buffers is the precedent.)
+  HIPCHK(hipExtMallocWithFlags((void **)&p->ctrl, CTRL_BYTES, hipDeviceMallocFinegrained));
   HIPCHK(hipMemset(p->ctrl, 0, CTRL_BYTES));
   HIPCHK(hipMalloc((void **)&p->done, 64));
   HIPCHK(hipMemset(p->done, 0, 64));
@@ -421,7 +425,7 @@ static int peer_ensure_arena(qexhip_ctx *c, int s, size_t bytes) {
   p->arena[s] = nullptr;
   size_t cap = std::max<size_t>(std::max<size_t>(bytes + bytes / 4, 2 * p->cap[s]), (size_t)1 << 20);
   cap = (cap + 4095) & ~(size_t)4095;
-  HIPCHK(hipMalloc((void **)&p->arena[s], 2 * cap));
+  HIPCHK(hipExtMallocWithFlags((void **)&p->arena[s], 2 * cap, hipDeviceMallocFinegrained));    // written by the neighbours: see peer_init
   PeerShmSlot &me = p->host.shm->s[p->rank];
   if (p->nranks > 1) {
     hipIpcMemHandle_t h;
