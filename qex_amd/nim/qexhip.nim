@@ -51,6 +51,7 @@ proc qexhip_comm_info(h: QexhipHandle; nranks, rank, device: ptr cint; busid: cs
 proc qexhip_last_error(): cstring {.qh.}
 proc qexhip_comm_unique_id(id: ptr char): cint {.qh.}
 proc qexhip_comm_init(h: QexhipHandle; id: ptr char; nranks, rank: cint): cint {.qh.}
+proc qexhip_comm_transport(h: QexhipHandle; name: cstring; len: cint; stats: ptr clong): cint {.qh.}
 proc qexhip_layout_vec_simd_to_v1(localGeom, innerGeom: ptr cint; simd, v1: ptr cdouble): cint {.qh.}
 proc qexhip_layout_vec_v1_to_simd(localGeom, innerGeom: ptr cint; v1, simd: ptr cdouble): cint {.qh.}
 proc qexhip_layout_gauge_simd_to_v1(localGeom, innerGeom: ptr cint; g: ptr ptr cdouble; v1: ptr cdouble): cint {.qh.}
@@ -157,7 +158,9 @@ proc hipSetup*(l: Layout): Layout[1] =
       var nr, rk, dv: cint
       var bus = newString(64)
       chk qexhip_comm_info(hipParam.h, nr.addr, rk.addr, dv.addr, bus.cstring, 64)
-      echoAll "libqexhip: rank ", l.myRank, " = RCCL rank ", rk, " of ", nr, " on device ", dv, " (", $bus.cstring, ")"
+      var tr = newString(16)
+      chk qexhip_comm_transport(hipParam.h, tr.cstring, 16, nil)      # "rccl" between distinct GPUs, "peer" when ranks share one
+      echoAll "libqexhip: rank ", l.myRank, " = rank ", rk, " of ", nr, " on device ", dv, " (", $bus.cstring, "), transport ", $tr.cstring
     hipParam.layout1 = l.physGeom.newLayout 1
     hipParam.initialized = true
   hipParam.layout1
