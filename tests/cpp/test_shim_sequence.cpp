@@ -23,6 +23,7 @@ extern "C" {
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 typedef std::vector<double> Buf;
@@ -50,6 +51,9 @@ static void hipSetup(const int lat[4]) {
   CHK(qexhip_device_count(&ndev));
   const int rg[4] = {1, 1, 1, 1}, rc[4] = {0, 0, 0, 0};
   CHK(qexhip_init(&h, 0 % (ndev > 0 ? ndev : 1), lat, rg, rc));      // one rank: no unique id / comm_init
+  char tr[16];
+  CHK(qexhip_comm_transport(h, tr, 16, nullptr));                    // the line hipSetup prints: "none" without a communicator
+  CHECK(std::string(tr) == "none", "transport before comm_init: %s", tr);
 }
 static void hipSetLinks(const Buf &fat, const Buf *lng) { CHK(qexhip_stag_set_links(h, fat.data(), lng ? lng->data() : nullptr)); }
 static void hipStagD2(Buf &r, const Buf &x, double a, double b, int subset) { CHK(qexhip_stag_dslash(h, r.data(), x.data(), subset, a, b)); }
