@@ -10,7 +10,7 @@ against the global oracle result:
                                             both reductions end in a rank sum, commsUtils.nim:195-204)
   lock-step batched CG (3 systems)          iteration counts +-1, solutions 1e-6 (all faces in one RCCL group)
   Naik 3-mass multi-shift CG                the same bars, ghost depth 3
-  plaquettes, one Wilson-flow step          1e-13 / 1e-12 (ghost links refreshed per stage)
+  plaquettes, Polyakov loops, one flow step 1e-13 / 1e-13 / 1e-12 (ghost links refreshed per stage; the t-line through every rank's slab)
   nHYP smearing + smeared gauge force       1e-11
 
 usage (by the test): python -m torch.distributed.run --nproc-per-node N two_rank_worker.py LX LY LZ LT [--overlap K]
@@ -168,6 +168,12 @@ def main():
         pl = q.plaq(ctx, sl(g0))
         res["plaq"] = float(np.abs(pl - o.plaq(olo, g0)).max())
         assert res["plaq"] < 1e-13, res["plaq"]
+        # the four Polyakov loops: the t-line runs through EVERY rank's slab (one segment product per rank, rank-ordered
+        # all-gather, gauge.hip k_tline_segment / k_tline_trace), the spatial lines stay inside a slab and are rank-summed
+        pls = q.ploops(ctx)
+        ref_pl = [o.wline(olo, g0, [d + 1] * glat[d]) for d in range(4)]
+        res["ploops"] = float(max(abs(a - b) for a, b in zip(pls, ref_pl)))
+        assert res["ploops"] < 1e-13, (pls, ref_pl)
         gf = sl(g0)
         q.gaugeFlow(ctx, gf, 1, 0.01)
         gr = g0.copy()
