@@ -3,6 +3,7 @@
 optional gauge action on the smeared links -- with every field operation in libqexhip.
 
     python examples/staghmc_spv.py [-lat 8 8 8 16] [-trajs 2] [-host-fields] [-halo] [-time]
+    python -m torch.distributed.run --nproc-per-node N examples/staghmc_spv.py ...     # t-sharded over N ranks (one GPU each, or sharing one)
 
 The driver below follows the reference's procs one to one (file:line in the docstrings); the parameters are those of
 src/stagg_pv_hmc/input_hmc.xml.  By default the MD loop keeps links, momenta and forces on the device (qexhip_md_*);
@@ -48,18 +49,32 @@ def coefs(act, beta, adj, c1):
 
 
 class Spv:
-    def __init__(self, lat, resident=True, halo=False, **kw):
+    def __init__(self, lat, resident=True, halo=False, ranks=None, **kw):
+        """ranks = (world, rank, dist): the lattice split along t over `world` processes (QEX: -rankgeom:1,1,1,N); every rank holds
+        its slab of every field, the per-site random streams are seeded by GLOBAL site index (so the fields do not depend on
+        the partition), the library exchanges faces and rank-sums its own reductions, and the two sums this driver forms on
+        the host (kinetic energy, pseudofermion actions) go through `dist` (torch.distributed, gloo)."""
         self.prm = dict(DEFAULTS)
         self.prm.update(kw)
         P = self.prm
-        self.lat, self.resident = list(lat), resident
+        self.glat, self.resident = list(lat), resident
+        self.world, self.rank, self.dist = ranks if ranks else (1, 0, None)
+        lt = self.glat[3] // self.world
+        self.lat = self.glat[:3] + [lt]
         self.lo = q.Layout(self.lat)
-        self.ctx = q.Context(self.lat)
+        if self.world > 1:
+            self.ctx = q.Context(self.lat, device=self.rank % q.device_count(), rank_geom=(1, 1, 1, self.world), rank_coord=(0, 0, 0, self.rank))
+            uid = [q.Context.unique_id() if self.rank == 0 else None]
+            self.dist.broadcast_object_list(uid, src=0)
+            self.ctx.comm_init(uid[0], self.world, self.rank)
+        else:
+            self.ctx = q.Context(self.lat)
         if halo:
             self.ctx.force_halo(True)
         self.md = q.ResidentMD(self.ctx)
         self.hc = q.HypCoefs(*P["alpha"])
-        self.rng = q.RngField(self.lat, q.RngMilc6, P["seed"])
+        self.rng = q.RngField(self.lat, q.RngMilc6, P["seed"], glat=self.glat, t_offset=self.rank * lt) if self.world > 1 \
+            else q.RngField(self.lat, q.RngMilc6, P["seed"])
         self.gact = coefs(P["gauge_act"], P["beta"], P["adj_fac"], P["c1"])
         self.sgact = coefs(P["smeared_gauge_act"], P["sm_beta"], P["sm_adj_fac"], P["sm_c1"])
         self.g = q.unit(self.lo) if P["start"] == "cold" else self.rng.warm(float(P["start"]))
@@ -76,6 +91,15 @@ class Spv:
 
     def _sp(self, tol):
         return q.SolverParams(r2req=tol, maxits=self.prm["maxits"], verbosity=0)
+
+    def _gsum(self, v):
+        """rank sum of a host-side scalar (QEX: the threadRankSum at the end of norm2, commsUtils.nim:195-204)"""
+        if self.world == 1:
+            return float(v)
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self.dist.all_reduce(t)
+        return float(t[0])
 
     # ---- generate_momenta / generate_pseudoferms (:493-557) ----
     def refresh(self):
@@ -99,7 +123,7 @@ class Spv:
     # ---- calc_action (:559-695) ----
     def action(self):
         P = self.prm
-        T = 0.5 * (self.p * self.p).sum() - 16.0 * self.lo.vol
+        T = 0.5 * self._gsum((self.p * self.p).sum()) - 16.0 * self.lo.vol * self.world
         ga = q.gaugeAction(self.ctx, self.g, **self.gact)
         sg = np.zeros_like(self.g) if P["sg_opt"] else None
         self.smear(self.g, sg)
@@ -112,7 +136,7 @@ class Spv:
                 self.iters["action"] += sp.iterations
             else:
                 self.s.D(psi, ph, P["mass_pv"])                       # s.D(psi, phi, masses[1])
-            f2.append(0.5 * (psi * psi).sum())
+            f2.append(0.5 * self._gsum((psi * psi).sum()))
         sga = q.gaugeAction(self.ctx, sg, **self.sgact) if P["sg_opt"] else 0.0    # sg_act.gaction(sgf), unphased links
         return dict(H=ga + sga + sum(f2) + T, ga=ga, sga=sga, fa=sum(f2), f2=f2, T=T)
 
@@ -218,8 +242,17 @@ def main():
     ap.add_argument("-time", action="store_true")
     ap.add_argument("-start", default="cold", help="cold, or the spread of a warm start (e.g. 0.3)")
     a = ap.parse_args()
-    hmc = Spv(a.lat, resident=not a.host_fields, halo=a.halo, start=a.start)
-    print(hmc.ctx.info())
+    ranks = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        ranks = (dist.get_world_size(), dist.get_rank(), dist)
+    hmc = Spv(a.lat, resident=not a.host_fields, halo=a.halo, start=a.start, ranks=ranks)
+    if hmc.rank != 0:
+        sys.stdout = open(os.devnull, "w")            # one log, rank 0's (QEX: echo prints on rank 0)
+    print(hmc.ctx.info(), "transport", hmc.ctx.comm_transport()[0])
     for n in range(1, a.trajs + 1):
         t0 = time.time()
         g0 = hmc.g.copy()

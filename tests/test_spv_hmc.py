@@ -59,3 +59,38 @@ def test_gpu_spv_trajectory_is_reversible_and_second_order():
     dH2 = e2["H"] - b2["H"]
     assert abs(b2["H"] - b["H"]) <= 1e-12 * abs(b["H"])                 # same start (same seed)
     assert abs(dH1) > 1e-6 and abs(dH2) < abs(dH1) / 2.8, (dH1, dH2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2])
+def test_gpu_spv_trajectory_over_real_ranks(nranks):
+    """BASELINE configs[4]'s program with REAL neighbours: the same trajectory (nHYP closure, smeared gauge force, fermion and
+    Pauli-Villars forces with their solves, 2MN schedule, resident MD) with the lattice split along t over processes that share
+    the one GPU (peer transport) -- per-site random streams seeded by global index, so the fields are those of the single-rank
+    run -- must give the single-rank energies, sector by sector, and the same end links on every slab."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hr, br, er = _traj(resident=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", QEXHIP_PEER_TIMEOUT="60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(root, "tests", "spv_rank_worker.py")] + [str(v) for v in LAT] + [json.dumps(PRM)]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=root, env=env)
+    rows = [json.loads(ln.split(" ", 1)[1]) for ln in p.stdout.splitlines() if ln.startswith("SPV_RANK ")]
+    if p.returncode != 0 or len(rows) != nranks:
+        print(p.stdout[-3000:])
+        print(p.stderr[-6000:])
+    assert p.returncode == 0 and len(rows) == nranks
+    lt = LAT[3] // nranks
+    for r in rows:
+        for k in ("H", "ga", "sga", "fa", "T"):
+            assert abs(r["begin"][k] - br[k]) <= 1e-12 * abs(br["H"]), (k, r["begin"][k], br[k])
+            assert abs(r["end"][k] - er[k]) <= 1e-10 * abs(er["H"]), (k, r["end"][k], er[k])
+        # this rank's slab of the end links: the single-rank field cut along t (V=1 even-odd order: select by coordinates)
+        import qex_amd as q
+        _, idx = q.Layout(LAT).shard_indices(nranks, r["rank"])
+        slab = hr.g[idx]
+        assert abs(r["g_sum"] - float((slab * slab).sum())) <= 1e-9 * abs(r["g_sum"])
+        assert np.abs(np.array(r["g_first"]) - slab.reshape(-1)[:6]).max() < 1e-10
+    assert rows[0]["begin"]["H"] == rows[1]["begin"]["H"]                 # every rank holds the same rank-summed numbers
