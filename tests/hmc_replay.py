@@ -147,17 +147,31 @@ class Replay:
          be.plaq(g) -> 6 plaquettes;  be.exp_update(g, p, t): g := exp(t p) g;  be.reunit(g);  be.wline(g, path)
        The random numbers (momenta, pseudofermion and pbp sources) come from `rng` (see __init__)."""
 
-    def __init__(self, o, be, cfg=None, rng=None):
+    def __init__(self, o, be, cfg=None, rng=None, ranks=None):
         """rng: object with randomTAH() / gaussian_vector() / u1_vector() drawing from newRNGField(RngMilc6, SEED);
-        default = the oracle's; the GPU replay passes the product's own (qex_amd.RngField)."""
+        default = the oracle's; the GPU replay passes the product's own (qex_amd.RngField).
+        ranks = (world, rank, dist): the lattice split along t over `world` processes; every field below is this rank's slab
+        (the backend's context carries the rank geometry, the rng is seeded by GLOBAL site index), and the three sums the driver
+        forms on the host -- kinetic energy, pseudofermion actions, pbp -- are rank-summed through `dist` (gloo)."""
         self.o, self.be = o, be
         self.cfg = cfg or CONFIGS[0]
-        self.lo = o.Layout(LAT)
+        self.world, self.rank, self.dist = ranks if ranks else (1, 0, None)
+        self.lo = o.Layout(LAT[:3] + [LAT[3] // self.world])
+        self.gvol = LAT[0] * LAT[1] * LAT[2] * LAT[3]
         self.rng = rng or OracleRng(o, self.lo)
         self.g = o.gauge_unit(self.lo)
         self.p = None
         self.phi = None                              # phi[j] for the flattened fields
         self.stats = {"force_iters": [[] for _ in self.cfg.fields], "action_iters": [[] for _ in self.cfg.fields]}
+
+    def gsum(self, v):
+        """rank sum of a host-side scalar (the threadRankSum behind QEX's norm2, commsUtils.nim:195-204)"""
+        if self.world == 1:
+            return v
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self.dist.all_reduce(t)
+        return float(t[0])
 
     def _m(self, j):
         """mass the field j is solved with: light mass at level 0, else the previous Hasenbusch mass"""
@@ -190,14 +204,14 @@ class Replay:
         fa = []
         for j, (x, its) in enumerate(be.solve_many(h, srcs, ms)):     # the chain's solves share the links
             self.stats["action_iters"][j].append(its)
-            fa.append((x * x).sum())
+            fa.append(self.gsum((x * x).sum()))
         return fa
 
     def energies(self, h, g):
         fa = self.faction(h)
         Sg = self.be.gauge_action(g)
         Sf = [0.5 * v for v in fa]
-        T = 0.5 * (self.p * self.p).sum() - 16.0 * self.lo.vol
+        T = 0.5 * self.gsum((self.p * self.p).sum()) - 16.0 * self.gvol
         return dict(H=Sg + sum(Sf) + T, Sg=Sg, Sf=Sf, T=T)
 
     def refresh(self):
@@ -366,7 +380,7 @@ class Replay:
         pbp, iters = [], []
         srcs = [self.rng.u1_vector() for _ in range(2)]                    # pbpreps = 2
         for x, its in be.solve_many(h, srcs, [PBPMASS, PBPMASS]):
-            pbp.append(PBPMASS * (x * x).sum() / lo.vol)
+            pbp.append(PBPMASS * self.gsum((x * x).sum()) / self.gvol)
             iters.append(its)
         pl = be.plaq(self.g)
         ps, pt = 2.0 * sum(pl[:3]), 2.0 * sum(pl[3:])
@@ -443,11 +457,20 @@ class OracleBackend:
 class HipBackend:
     """Every operator on the hot path runs through libqexhip (C ABI)."""
 
-    def __init__(self, q, lat, halo=False, resident=False):
+    def __init__(self, q, lat, halo=False, resident=False, ranks=None):
         """halo=True: every kernel runs in its t-sharded form (ghost zones, face exchanges, rank reductions) on one GPU.
-        resident=True: the MD evolution keeps links and momenta on the device (qexhip_md_*, Replay.evolve)"""
+        resident=True: the MD evolution keeps links and momenta on the device (qexhip_md_*, Replay.evolve).
+        ranks = (world, rank, dist): this process holds one t-slab of `lat` (GLOBAL extents) among `world` ranks"""
         self.q = q
-        self.ctx = q.Context(lat)
+        if ranks:
+            world, rank, dist = ranks
+            loc = list(lat[:3]) + [lat[3] // world]
+            self.ctx = q.Context(loc, device=rank % q.device_count(), rank_geom=(1, 1, 1, world), rank_coord=(0, 0, 0, rank))
+            uid = [q.Context.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            self.ctx.comm_init(uid[0], world, rank)
+        else:
+            self.ctx = q.Context(lat)
         if halo:
             self.ctx.force_halo(True)
         self.hc = q.HypCoefs(*ALPHA)

@@ -8,6 +8,8 @@ psi_i = D(m_i)^-1 D(h_i) phi_i and Sf_i = |psi_i|^2 / 2.  It pins RngMilc6 gauss
 Staggered.D (phases, boundary, normalisation, mass sign) and Staggered.solve (even-odd CG +
 reconstruction, r2req = 1e-24) to numbers printed by the reference itself.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -154,6 +156,30 @@ def test_gpu_replays_reference_trajectory(oracle, run, halo, resident):
     # resident: the MD evolution through qexhip_md_* (links, momenta and forces never leave the device)
     _check_trajectory(R.Replay(oracle, R.HipBackend(q, R.LAT, halo=halo, resident=resident), R.CONFIGS[run], rng=rng),
                       second=(run == 0 and not halo and not resident))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("run,resident", [(0, False), (1, True)])
+def test_gpu_replays_reference_trajectory_over_real_ranks(run, resident):
+    """G7 with REAL neighbours: the reference's golden HMC log -- Begin / End H sector by sector, pbp, plaquettes, Polyakov loops,
+    the reversibility check and the second trajectory (run 0), the solver iteration statistics -- reproduced at the reference
+    harness's own 2e-11 by TWO processes that each hold half of the 8^4 lattice and share the one GPU (peer-memory transport):
+    nHYP closure and force chain, fermion forces with their Hasenbusch solves, adjoint-plaquette gauge force, force-gradient
+    updates (run 1, MD loop resident on the device), all t-sharded with faces and sums crossing between processes
+    (tests/golden_rank_worker.py)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", QEXHIP_PEER_TIMEOUT="60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29581 + run), os.path.join(root, "tests", "golden_rank_worker.py"), str(run), str(int(resident))]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=root, env=env)
+    ok = [ln for ln in p.stdout.splitlines() if ln.startswith("GOLDEN_RANK_OK")]
+    if p.returncode != 0 or len(ok) != 2:
+        print(p.stdout[-3000:])
+        print(p.stderr[-8000:])
+    assert p.returncode == 0 and len(ok) == 2
 
 
 @pytest.mark.gpu
