@@ -22,9 +22,13 @@
 //             destination: nothing has to be registered), then credit := n in the sender's control block.
 //     The push of exchange n needs only the peer's unpack n-1, which needs only my push n-1 (an earlier kernel on the same
 //     stream): no cycle, whatever the residency of the workgroups.
-//   all-reduce k (k_peer_allreduce, one workgroup): copy my operand into slot k&3 of EVERY rank's mailbox, flag := k; wait
-//     for the N flags of my own mailbox; sum the N operands in rank order -- the same bits on every rank, whatever the
-//     arrival order.  A rank can be at most one all-reduce ahead of the slowest one, so four slots never collide.
+//   all-reduce k, ONE single-workgroup kernel per rank: my operand goes into slot k&3 of EVERY rank's mailbox, then I wait for the
+//     N operands in my own mailbox and sum them in rank order -- the same bits on every rank, whatever the arrival order.  A
+//     rank can be at most one all-reduce ahead of the slowest one, so four slots never collide.  Up to 32 doubles (the CG's
+//     scalars: k_peer_allreduce_small) travel INSIDE sequence-tagged 8-byte words, no fence and no separate flag; longer
+//     vectors (k_peer_allreduce) as payload + release + flag.
+//   stream join: a one-lane kernel raises a device counter behind what a stream has posted, a one-wave kernel makes another
+//     stream wait for it -- instead of the runtime's cross-queue event dependency (~20 us of dead time per sweep here).
 // Every device-side wait is bounded (timeout -> error word in pinned host memory -> QEXHIP_ERR_COMM at the next host
 // sync): both processes may share the CUs, and a wave that never exits would take the box down.
 #include "qexhip_internal.h"
@@ -58,9 +62,8 @@ struct PeerComm {
   unsigned int *done = nullptr;          // device: [class][push | unpack] completion counters
   u64 *err = nullptr;                    // pinned host word the kernels write on a timeout
   u64 seq_out[2][2]{}, seq_in[2][2]{}, seq_red = 0;
-  u64 *ready = nullptr;                  // device, local: ready[class] = number of exchanges of that class whose unpack has completed
-  u64 ready_seq[2]{};                    // exchanges posted per class
-  u64 join_seq[2]{};                     // peer_stream_signal / _join counters (ready + 32 + k*16)
+  u64 *ready = nullptr;                  // device, local: the two stream-join counters (word k*16 for joins FROM stream k)
+  u64 join_seq[2]{};                     // peer_stream_signal / _join sequence numbers
   long long ticks = 0;                   // timeout in wall_clock64 ticks
   double timeout_s = 30.0;
   long exchanges = 0, allreduces = 0, grows = 0;
@@ -99,8 +102,6 @@ struct PeerXfer {
   u64 seq_out[2], seq_in[2];
   u64 *err;
   unsigned int *done;                 // [0] push, [1] unpack
-  u64 *ready;                         // own, device-local: := ready_val once every workgroup has unpacked (peer_wait_ready)
-  u64 ready_val;
   long long ticks;
   long long emu_ticks;                // transport emulation: the inbound data counts as arrived no earlier than this long after the kernel started
   unsigned n16;                       // 16-byte units per piece (< 2^32: pieces below 64 GiB)
@@ -196,15 +197,13 @@ __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
       __hip_atomic_store(&X.done[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int d = 0; d < 2; d++)
         if (X.nr[d] > 0) __hip_atomic_store(X.credit_out[d], X.seq_in[d], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      // every workgroup's acq_rel add above released its ghost stores: a kernel of ANOTHER stream that sees this value may read them
-      __hip_atomic_store(X.ready, X.ready_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
-// One wave on the consumer's stream: returns once the exchange number `want` of a stream class has been unpacked.  Replaces
-// the cross-stream event join (record on the comm stream, wait on the compute stream: ~20 us of dead time per sweep on this
-// runtime, profiles/r05_timeline_*.txt) by a device-side flag; the kernel boundary behind it is the consumer's acquire.
+// One wave on the consumer's stream: returns once a device counter has reached `want` (peer_stream_join).  Replaces the
+// cross-stream event join (record on the comm stream, wait on the compute stream: ~20 us of dead time per sweep on this
+// runtime, profiles/r05_timeline_*.txt); the kernel boundary behind it is the consumer's acquire.
 __global__ void k_peer_wait(const u64 *ready, u64 want, u64 *err, long long ticks) {
   if (threadIdx.x == 0) (void)peer_poll_ge(ready, want, err, ticks, 0x400);
 }
@@ -333,7 +332,8 @@ static u64 *ctrl_word(char *ctrl, int w) { return (u64 *)ctrl + w; }
 static int peer_check_err(PeerComm *p) {
   const u64 e = __atomic_load_n(p->err, __ATOMIC_ACQUIRE);
   if (e) {
-    const char *what = (e & 0xF00) == 0x100 ? "credit of an outbound channel" : (e & 0xF00) == 0x200 ? "data of an inbound channel" : "all-reduce contribution";
+    const char *what = (e & 0xF00) == 0x100 ? "credit of an outbound channel" : (e & 0xF00) == 0x200 ? "data of an inbound channel"
+                       : (e & 0xF00) == 0x400 ? "boundary launch on the comm stream (stream join)" : "all-reduce contribution";
     qexhip_set_error("peer transport: rank %d timed out waiting for the %s (code 0x%llx): a neighbour is gone, or the ranks "
                      "did not issue the same sequence of exchanges", p->rank, what, e);
     peer_host_fail(&p->host);
@@ -493,7 +493,6 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
     }
     X.err = p->err; X.done = p->done + s * 2; X.ticks = p->ticks;
     X.emu_ticks = (long long)(emu_us * 1e-6 * (double)p->ticks / p->timeout_s);
-    X.ready = p->ready + s * 16; X.ready_val = ++p->ready_seq[s];
     const size_t cpp = ((size_t)X.n16 + PEER_CHUNK - 1) / PEER_CHUNK;
     const size_t nch = (size_t)(nd + nu) * cpp;
     // Few, fat workgroups: between distinct GPUs the push is bound by one xGMI direction (~45 GB/s: a couple of workgroups
@@ -523,23 +522,14 @@ __global__ void k_peer_set(u64 *flag, u64 val) {
 int peer_stream_signal(qexhip_ctx *c, hipStream_t from) {
   PeerComm *p = c->peer;
   const int k = (from == c->cstream) ? 1 : 0;
-  hipLaunchKernelGGL(k_peer_set, dim3(1), dim3(64), 0, from, p->ready + 32 + k * 16, ++p->join_seq[k]);
+  hipLaunchKernelGGL(k_peer_set, dim3(1), dim3(64), 0, from, p->ready + k * 16, ++p->join_seq[k]);
   HIPCHK(hipGetLastError());
   return 0;
 }
 int peer_stream_join(qexhip_ctx *c, hipStream_t waiter, hipStream_t from) {
   PeerComm *p = c->peer;
   const int k = (from == c->cstream) ? 1 : 0;
-  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, waiter, p->ready + 32 + k * 16, p->join_seq[k], p->err, p->ticks);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-// on stream `waiter`: everything posted so far on the stream class of `posted_on` has arrived in the ghost zones
-int peer_wait_ready(qexhip_ctx *c, hipStream_t waiter, hipStream_t posted_on) {
-  PeerComm *p = c->peer;
-  const int s = (posted_on == c->cstream) ? 1 : 0;
-  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, waiter, p->ready + s * 16, p->ready_seq[s], p->err, p->ticks);
+  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, waiter, p->ready + k * 16, p->join_seq[k], p->err, p->ticks);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -219,7 +219,6 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
                   void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us = 0.0);
 int peer_stream_signal(qexhip_ctx *c, hipStream_t from);                          // device-side event: record ...
 int peer_stream_join(qexhip_ctx *c, hipStream_t waiter, hipStream_t from);        // ... and wait, without the runtime's cross-queue dependency
-int peer_wait_ready(qexhip_ctx *c, hipStream_t waiter, hipStream_t posted_on);   // device-side join: a one-wave kernel on `waiter`
 int peer_allreduce_parts(qexhip_ctx *c, double *parts, int n);       // parts[0] := sum over ranks of (sum of parts[0..n) in cg_sum_parts order)
 int peer_allreduce(qexhip_ctx *c, double *dptr, int n, int op);      // on the compute stream; op 0 sum, 1 max; rank order
 int peer_host_reduce(qexhip_ctx *c, double *host, int n, int op);    // host operands (op 0 max, 1 min, 2 sum), synchronous
