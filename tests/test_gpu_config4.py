@@ -31,7 +31,7 @@ class Links:
     scaled by 0.3), 'hisq' = HisqCoefs.smear of a rephased g.warm(0.5) (testStagProp.nim:18-40)."""
 
     def __init__(self, o, kind, lat=(8, 8, 8, 8)):
-        self.o, self.lat = o, list(lat)
+        self.o, self.lat, self.kind = o, list(lat), kind
         self.lo = o.Layout(self.lat)
         rf = o.RngField(self.lo, o.RNG_MILC6, SEED)
         if kind == "naik":
@@ -85,7 +85,7 @@ def test_naik_multishift_solveXX_vs_oracle(links, mode, ladder):
     parity_log.judge("test_naik_multishift_solveXX_vs_oracle[%s-%s]" % (ladder, mode), sp.r2hist, o,
                      lambda: o.solveXX_multi(L.lo, L.fat, L.lng, L.b, sh, rq, 5000, True, histcap=8192)[2],
                      lambda: o.solveXX_multi_ext(L.lo, L.fat, L.lng, L.b, sh, rq, 5000, True, histcap=8192)[1],
-                     its=(sp.iterations, its), cache_key=("config4 naik multishift", ladder))
+                     its=(sp.iterations, its), cache_key=("config4 multishift", L.kind, ladder))
     h = L.lo.vol // 2
     for k, (a, r) in enumerate(zip(xs, xr)):
         assert relerr(a[:h], r[:h]) < 1e-6, (k, relerr(a[:h], r[:h]))
