@@ -110,6 +110,14 @@ int qexhip_comm_count(qexhip_handle h, int *ncomms);
  * at -1, the rule of the one-rank rehearsals (overlap when the interior is >= 131072 sites and a face >= 1 MiB);
  * out[7] = the option's value.  bench.py prints it so that a scaling run explains its own launch structure. */
 int qexhip_stag_sweep_info(qexhip_handle h, int out[8]);
+/* ... and how a PAIR of sweeps -- the normal operator D_eo D_oe of stagD.nim:434-456, every CG iteration -- runs when the sweeps
+ * overlap on the peer transport: out[0] = 1 if the pair is CHAINED (no join between the two sweeps: the second one's interior
+ * launch is narrowed by the stencil depth so that it reads nothing the first one's boundary launch wrote, its boundary launch
+ * widened by as much on the second stream, its faces sent the moment the first boundary launch has written them), out[1] = 1 if
+ * that was measured by set_links beside out[5], out[6] above, out[2] = microseconds per sweep it saw chained, out[3] = option
+ * "sweep_chain".  Chaining regroups the dot-product partials (as overlap does), nothing else: results are the unchained ones to
+ * summation order. */
+int qexhip_stag_sweep_chain_info(qexhip_handle h, int out[4]);
 /* test hook: with one rank, route the t-direction hops through the halo path
  * (pack -> RCCL self send/recv -> boundary sweep) instead of the periodic wrap. */
 int qexhip_comm_force_halo(qexhip_handle h, int on);
@@ -383,6 +391,11 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *   "batch_multi"  1: the same for the lock-step multi-system CG
  *   "smear_ca"     0: the nHYP levels of a t-sharded field refresh the ghost slices of every projected level field (rounds 1-4) instead of
  *                  computing them on shrinking ghost slices from one depth-3 thin-link exchange (default 1)
+ *   "peer_zc"      0: peer transport, overlapped sweep: the neighbours' faces are copied from the receive arena into the field's ghost
+ *                  tiles before the boundary launch, instead of being read from the arena by it (default 1)
+ *   "sweep_chain"  1 / 0: the two overlapped sweeps of the normal operator always / never run chained (qexhip_stag_sweep_chain_info); -1
+ *                  (default): chained where set_links measured it > 3 % faster than the overlapped pair (it wins while the interior
+ *                  launch is longer than the exchange, loses when the exchange is: a narrower interior hides less of it)
  *   "chain_overlap" 0: the nHYP force chain of a t-sharded field exchanges a level's chain fields first and runs the next staple
  *                  derivative in one pass, instead of running its ghost-free slices beside the exchange (default 1; bit-identical)
  *   "force_pair"   0: k_force_lds (one tile and parity per workgroup), what shapes without paired tile positions run

@@ -209,6 +209,7 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
 
 extern "C" int qexhip_sync(qexhip_handle c) {
   if (!c) return QEXHIP_ERR_ARG;
+  CHK(peer_flush_join(c));
   HIPCHK(hipStreamSynchronize(c->cstream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return peer_check(c);
@@ -334,6 +335,18 @@ extern "C" int qexhip_stag_sweep_info(qexhip_handle c, int out[8]) {
   out[5] = (int)(c->overlap_tune_us[slot][0] + 0.5);
   out[6] = (int)(c->overlap_tune_us[slot][1] + 0.5);
   out[7] = c->opt_overlap;
+  return 0;
+}
+
+extern "C" int qexhip_stag_sweep_chain_info(qexhip_handle c, int out[4]) {
+  if (!c || !out) return QEXHIP_ERR_ARG;
+  int lo_end = 0, hi_beg = 0, overlap = 0;
+  sweep_plan(c, &lo_end, &hi_beg, &overlap);
+  const int slot = c->ndir == 16;
+  out[0] = overlap && sweep_chain_on(c);
+  out[1] = c->chain_auto[slot] >= 0 && c->overlap_tune_us[slot][2] > 0.0;
+  out[2] = (int)(c->overlap_tune_us[slot][2] + 0.5);
+  out[3] = c->opt_sweep_chain;
   return 0;
 }
 
@@ -659,6 +672,8 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "flow_exp") c->opt_flow_exp = value;
   else if (n == "smear_ca") c->opt_smear_ca = value;
   else if (n == "chain_overlap") c->opt_chain_overlap = value;
+  else if (n == "peer_zc") c->opt_peer_zc = value;
+  else if (n == "sweep_chain") c->opt_sweep_chain = value;
   else if (n == "emu_exchange_us") c->emu_exchange_us = value;
   else if (n == "emu_allreduce_us") c->emu_allreduce_us = value;
   else if (n == "emu_link_gbs") c->emu_link_gbs = value;

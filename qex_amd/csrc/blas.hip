@@ -302,6 +302,7 @@ int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const 
   int nb = grid_for(n);
   double *r2p = c->partials + c->part2_off;
   if (ndot > 0) CHK(comm_allreduce_parts(c, c->partials, ndot, &ndot));
+  CHK(peer_flush_join(c));              // (no-op when the all-reduce has taken the second sweep's join with it)
   {
     ScopedTimer tm(c, "blas", c->stream);
     k_cg_update<<<nb, 256, 0, c->stream>>>(x.par(parity), r.par(parity), p.par(parity), Ap.par(parity), n, c->cg, k, r2p,

@@ -32,13 +32,25 @@ struct DslashArgs {
   const int *done;
   int swz;               // number of workgroups if XCD swizzle is on, else 0
   int ntstore;           // 1: non-temporal stores of the output
+  const double2 *gh_hi, *gh_lo;   // GX kernels: where ghost POSITIONS are read from instead of `in` (pre-offset: gh[vec_off(pos, k)])
 };
 
 #include "dslash_core.h"
 
-template <int NDIR, bool HALO, bool INIT, bool DOT, int RECON>
+// GX (t-sharded boundary launches of the peer transport): hops that leave the slab read the neighbours' faces where the exchange
+// kernel's neighbours WROTE them -- the transport's receive arena -- instead of the field's ghost tiles.  A tile lies in one
+// t-slice, so which base a t-hop reads from is wavefront-uniform: four scalar selects per wavefront, nothing per lane.
+template <int NDIR, bool HALO, bool INIT, bool DOT, int RECON, bool GX = false>
 __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
   if (A.done && *A.done) return;
+  if (GX) {
+    // the arena was written by other processes / devices: system-scope acquire on every CU that reads it
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
   int bid = blockIdx.x;
   if (A.swz) {
     // XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs; give every XCD a
@@ -81,6 +93,14 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
     constexpr int LROW = NLOAD * 64;             // double2 per (tile, direction)
     const double2 *w = A.W + (size_t)(c >> 6) * (NDIR * LROW) + (c & 63);
     const unsigned long long *sm = RECON == 1 ? A.S + (size_t)(c >> 6) * NDIR : nullptr;
+    const double2 *in_f1 = A.in, *in_b1 = A.in, *in_f3 = A.in, *in_b3 = A.in;
+    if (GX) {
+      const int tu = __builtin_amdgcn_readfirstlane(s.t);
+      in_f1 = tu + 1 >= g.X[3] ? A.gh_hi : A.in;
+      in_b1 = tu - 1 < 0 ? A.gh_lo : A.in;
+      in_f3 = tu + 3 >= g.X[3] ? A.gh_hi : A.in;
+      in_b3 = tu - 3 < 0 ? A.gh_lo : A.in;
+    }
     // One loop iteration = the forward and the backward hop of one direction (fat links: pairs
     // 0..3, 3-hop links: pairs 4..7).  How far the loop is unrolled decides how many link loads a
     // wave keeps in flight.  Measured inside CG on 32^4 (scratch A/B builds, 2 rounds):
@@ -119,10 +139,12 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
         recon_row2<2>(U, false);
         recon_row2<2>(W, false);
       }
+      const double2 *srcf = (GX && mu == 3) ? (hop == 3 ? in_f3 : in_f1) : A.in;
+      const double2 *srcb = (GX && mu == 3) ? (hop == 3 ? in_b3 : in_b1) : A.in;
 #pragma unroll
-      for (int k = 0; k < 3; k++) vf[k] = A.in[vec_off(pf, k)];
+      for (int k = 0; k < 3; k++) vf[k] = srcf[vec_off(pf, k)];
 #pragma unroll
-      for (int k = 0; k < 3; k++) vb[k] = A.in[vec_off(pb, k)];
+      for (int k = 0; k < 3; k++) vb[k] = srcb[vec_off(pb, k)];
       // forward hops add, backward hops subtract (compile-time sign: no per-direction multiply).
       // stagDM's overall minus sign is carried by the initial value and the final scale: negation is
       // exact, so init - sum == -((-init) + sum) bit for bit.
@@ -162,7 +184,7 @@ static void launch_timed(qexhip_ctx *c, const char *tname, K kernel, dim3 grid, 
 
 template <int NDIR, bool HALO>
 static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool dot, int part_off,
-                  int d0 = 0, int d1 = 0, const char *tname = "dslash", hipStream_t st = nullptr) {
+                  int d0 = 0, int d1 = 0, const char *tname = "dslash", hipStream_t st = nullptr, bool gx = false) {
   if (!st) st = c->stream;
   if (c1 <= c0 && d1 <= d0) return 0;
   if (c1 <= c0) { c0 = d0; c1 = d1; d0 = d1 = 0; }
@@ -178,7 +200,12 @@ static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool 
   dim3 grid(nb), block(256);
 #define QX_LAUNCH(R) \
   do { \
-    if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true, R>, grid, block, A, st); \
+    if (HALO && gx) { \
+      if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true, R, HALO>, grid, block, A, st); \
+      else if (init) launch_timed(c, tname, k_dslash<NDIR, HALO, true, false, R, HALO>, grid, block, A, st); \
+      else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true, R, HALO>, grid, block, A, st); \
+      else launch_timed(c, tname, k_dslash<NDIR, HALO, false, false, R, HALO>, grid, block, A, st); \
+    } else if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true, R>, grid, block, A, st); \
     else if (init) launch_timed(c, tname, k_dslash<NDIR, HALO, true, false, R>, grid, block, A, st); \
     else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true, R>, grid, block, A, st); \
     else launch_timed(c, tname, k_dslash<NDIR, HALO, false, false, R>, grid, block, A, st); \
@@ -216,6 +243,19 @@ void sweep_plan(const qexhip_ctx *c, int *lo_end_out, int *hi_beg_out, int *over
 // sweeps in either mode on scratch fields, the slower rank's time decides (max-all-reduce, so every rank takes the same
 // branch).  Collective over the communicator, like set_links itself (ghost links).  Option "overlap" = 0 / 1 switches the
 // measurement off, -2 asks for it on one rank too (test hook).
+// whether a chained pair of sweeps (dslash_sweep) is possible at all on this context: zero-copy receive on the peer transport and a
+// slab deep enough for a narrowed interior
+static bool chain_possible(const qexhip_ctx *c) {
+  const Geom &g = c->g;
+  return g.halo && c->peer && c->opt_peer_zc && g.Vh - 4 * g.depth * g.F > 0;
+}
+// ... and whether an overlapped pair runs chained: option "sweep_chain" 1 / 0, or at -1 what sweep_autotune measured (off until then)
+static bool chain_on(const qexhip_ctx *c) {
+  if (!chain_possible(c)) return false;
+  return c->opt_sweep_chain >= 0 ? c->opt_sweep_chain != 0 : c->chain_auto[c->ndir == 16] == 1;
+}
+bool sweep_chain_on(const qexhip_ctx *c) { return chain_on(c); }
+
 int sweep_autotune(qexhip_ctx *c) {
   const Geom &g = c->g;
   const int slot = c->ndir == 16;
@@ -224,10 +264,13 @@ int sweep_autotune(qexhip_ctx *c) {
   if (multi) {
     // The overlap decision selects the stream (and, on RCCL, the communicator) an exchange is posted on: ranks that disagreed
     // would never match.  set_links is collective, so this is the place to find out (QEXHIP_OVERLAP / option "overlap").
-    double v[2] = {(double)c->opt_overlap, -(double)c->opt_overlap};
+    // The forms of the overlapped sweep (peer_zc, sweep_chain) ride along: they regroup the dot partials, not the messages.
+    const double code = 64.0 * c->opt_overlap + 8.0 * (c->opt_sweep_chain + 1) + c->opt_peer_zc;
+    double v[2] = {code, -code};
     CHK(comm_allreduce_max(c, v, 2));
     if (v[0] != -v[1]) {
-      qexhip_set_error("option overlap / QEXHIP_OVERLAP differs between the ranks (%g .. %g): it must be the same everywhere", -v[1], v[0]);
+      qexhip_set_error("options overlap (QEXHIP_OVERLAP) / sweep_chain / peer_zc differ between the ranks (64 overlap + 8 (sweep_chain + 1) + peer_zc = %g .. %g): "
+                       "they must be the same everywhere", -v[1], v[0]);
       return -3;
     }
   }
@@ -235,40 +278,50 @@ int sweep_autotune(qexhip_ctx *c) {
   if (!(c->opt_overlap == -2 || (c->opt_overlap == -1 && multi))) return 0;
   int lo_end, hi_beg, dummy;
   sweep_plan(c, &lo_end, &hi_beg, &dummy);
-  if (hi_beg <= lo_end) { c->overlap_auto[slot] = 0; return 0; }        // no interior to overlap with
-  DevField a, b;
-  int rc = field_alloc(c, a);
-  if (!rc) rc = field_alloc(c, b);
-  const int saved = c->opt_overlap, saved_timers = c->timers_on;
+  if (hi_beg <= lo_end) { c->overlap_auto[slot] = 0; c->chain_auto[slot] = 0; return 0; }        // no interior to overlap with
+  // three forms of a PAIR of sweeps a -> b -> c (what the normal operator runs): exchange first, overlapped, overlapped + chained
+  const bool try_chain = chain_possible(c) && c->opt_sweep_chain < 0;
+  DevField f[3];
+  int rc = 0;
+  for (int k = 0; k < 3 && !rc; k++) rc = field_alloc(c, f[k]);
+  const int saved = c->opt_overlap, saved_chain = c->opt_sweep_chain, saved_timers = c->timers_on;
   c->timers_on = 0;
-  double t[2] = {0, 0};
-  for (int mode = 0; mode < 2 && !rc; mode++) {
-    c->opt_overlap = mode;
-    for (int k = 0; k < 12 && !rc; k++) {
-      if (k == 2) { rc = hipStreamSynchronize(c->stream) != hipSuccess ? -2 : 0; t[mode] = -now_us(); }
-      DslashOpts o;
-      if (!rc) rc = dslash_sweep(c, (k & 1) ? a : b, (k & 1) ? b : a, k & 1, o);
+  double t[3] = {0, 0, 0};
+  for (int mode = 0; mode < (try_chain ? 3 : 2) && !rc; mode++) {
+    c->opt_overlap = mode ? 1 : 0;
+    c->opt_sweep_chain = mode == 2 ? 1 : 0;
+    for (int k = 0; k < 6 && !rc; k++) {
+      if (k == 1) { rc = hipStreamSynchronize(c->stream) != hipSuccess ? -2 : 0; t[mode] = -now_us(); }
+      DslashOpts o1, o2;
+      o1.chain = 1; o2.chain = 2;
+      DevField &in0 = f[(k & 1) ? 2 : 0], &out2 = f[(k & 1) ? 0 : 2];
+      if (!rc) rc = dslash_sweep(c, f[1], in0, 1, o1);
+      if (!rc) rc = dslash_sweep(c, out2, f[1], 0, o2);
     }
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = -2;
     t[mode] += now_us();
   }
   c->opt_overlap = saved;
+  c->opt_sweep_chain = saved_chain;
   c->timers_on = saved_timers;
-  if (a.d) (void)hipFree(a.d);
-  if (b.d) (void)hipFree(b.d);
+  for (int k = 0; k < 3; k++) if (f[k].d) (void)hipFree(f[k].d);
   // every rank reaches the collective, a failed one with a sentinel, so that all fail together instead of one hanging the others
-  double v[3] = {t[0], t[1], rc ? 1.0 : 0.0};
+  double v[4] = {t[0], t[1], t[2], rc ? 1.0 : 0.0};
   if (multi) {
-    const int e = comm_allreduce_max(c, v, 3);
+    const int e = comm_allreduce_max(c, v, 4);
     if (e && !rc) rc = e;
   }
   if (rc) return rc;
-  if (v[2] != 0.0) { qexhip_set_error("sweep_autotune: another rank failed while measuring"); return -4; }
-  // Overlap only on a clear win (> 5 %): the two forms group the deferred dot partials differently, so a decision that flips
-  // between runs on timing noise would cost run-to-run bit-reproducibility of the residual history for nothing.
-  // Option overlap = 0 / 1 pins the form (and the bits) outright.
-  c->overlap_auto[slot] = v[1] < 0.95 * v[0] ? 1 : 0;
-  c->overlap_tune_us[slot][0] = v[0] / 10.0; c->overlap_tune_us[slot][1] = v[1] / 10.0;
+  if (v[3] != 0.0) { qexhip_set_error("sweep_autotune: another rank failed while measuring"); return -4; }
+  // Overlap only on a clear win (> 5 %), chain on top of it only on its own clear win (> 3 % of an overlapped sweep: it narrows the
+  // interior that hides the exchange, a loss when the exchange is the longer of the two): the forms group the deferred dot partials
+  // differently, so a decision that flips between runs on timing noise would cost run-to-run bit-reproducibility of the residual
+  // history for nothing.  Options overlap / sweep_chain = 0 / 1 pin the form (and the bits) outright.
+  const int chain = try_chain && v[2] < 0.97 * v[1];
+  const double best = chain ? v[2] : v[1];
+  c->overlap_auto[slot] = best < 0.95 * v[0] ? 1 : 0;
+  c->chain_auto[slot] = chain && c->overlap_auto[slot];
+  c->overlap_tune_us[slot][0] = v[0] / 10.0; c->overlap_tune_us[slot][1] = v[1] / 10.0; c->overlap_tune_us[slot][2] = try_chain ? v[2] / 10.0 : 0.0;
   return 0;
 }
 
@@ -294,6 +347,7 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
   A.parity = parity;
   A.partials = c->partials;
   A.done = o.done;
+  A.gh_hi = A.gh_lo = nullptr;
   const bool init = (o.ca != 0.0 || o.cb != 0.0);
   if ((init || o.dot) && !A.xs) { qexhip_set_error("dslash_sweep: b-term/dot needs xs"); return -1; }
   if (o.ca != 0.0 && !A.rin) { qexhip_set_error("dslash_sweep: a-term needs rin"); return -1; }
@@ -306,8 +360,27 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
     // halo: exchange faces of `in` on the comm stream, interior sweep meanwhile, then boundary
     int lo_end, hi_beg, overlap;
     sweep_plan(c, &lo_end, &hi_beg, &overlap);
+    const bool zc = overlap && c->peer && c->opt_peer_zc;
+    // Chained pair (o.chain 1 then 2: out2 = D (D in), three distinct fields, nothing else on the compute stream between the two):
+    // no join between the sweeps.  Sweep 1's boundary launch stays unjoined on the comm stream; sweep 2's interior launch is
+    // NARROWED by the stencil depth on either side -- it then reads nothing sweep 1's boundary launch wrote -- and its boundary
+    // launch widened by as much, on the comm stream behind sweep 1's (in order) and behind ev_ready (sweep 1's interior).  The faces
+    // sweep 2 sends are sweep 1's boundary output, the comm stream's own work: its exchange starts without waiting for anything.
+    // One join per operator instead of two, and the second exchange is posted ~30 us earlier.
+    const bool chain_ok = zc && chain_on(c);
+    if (c->chain_pending && !(o.chain == 2 && chain_ok)) {       // a broken pair: join first, then an ordinary sweep
+      c->chain_pending = 0;
+      CHK(peer_stream_join(c, c->stream, c->cstream));
+    }
+    const bool chain2 = o.chain == 2 && chain_ok && c->chain_pending;
+    c->chain_pending = 0;
+    if (!chain2) CHK(peer_flush_join(c));
+    if (chain2) { lo_end *= 2; hi_beg = g.Vh - lo_end; }
     if (overlap) HIPCHK(hipEventRecord(c->ev_ready, c->stream));
-    CHK(comm_halo_exchange(c, in, 1 - parity, overlap));
+    if (zc) {
+      CHK(comm_halo_exchange_zc(c, in, 1 - parity, &A.gh_hi, &A.gh_lo, !chain2));
+      if (chain2) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+    } else CHK(comm_halo_exchange(c, in, 1 - parity, overlap));
     if (!overlap) {
       // the exchange is already ordered before us on the compute stream: one launch over all sites
       // (small local volumes are launch-latency-bound; this drops two launches per CG iteration)
@@ -323,10 +396,15 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
         // interior's tail -- but the join back to the compute stream is a device-side counter (a one-lane signal kernel behind
         // the boundary launch, a one-wave wait kernel on the compute stream) instead of an event: the runtime's cross-queue
         // dependency alone was ~20 us of dead time per sweep (profiles/r05_timeline_*.txt).
-        if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream)));
-        else CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream)));
-        CHK(peer_stream_signal(c, c->cstream));
-        CHK(peer_stream_join(c, c->stream, c->cstream));
+        // Zero-copy receive (option peer_zc): the boundary launch reads the neighbours' faces from the receive arena itself; the
+        // credits go back behind it together with the join signal.  Otherwise the exchange kernel has unpacked into the ghost tiles.
+        if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream, zc)));
+        else CHK((launch<16, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream, zc)));
+        if (zc) CHK(peer_release_zc(c, c->cstream));
+        else CHK(peer_stream_signal(c, c->cstream));
+        if (o.chain == 1 && chain_ok) c->chain_pending = 1;                       // the chain-2 sweep (or whatever comes instead) joins
+        else if (chain2 && o.defer_join) CHK(peer_stream_join_defer(c));          // rides in the <p,Ap> all-reduce's prologue
+        else CHK(peer_stream_join(c, c->stream, c->cstream));
       } else {
       // Both t-faces in ONE launch, posted on the COMM stream right behind the exchange: it needs the ghost zones and nothing
       // of the interior launch, so it starts the moment the faces have arrived and runs beside the interior's tail instead of
@@ -347,6 +425,7 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
     if (o.dot == 2 && o.nparts_out && nparts <= 4096) *o.nparts_out = nparts;
     else {
       if (o.nparts_out) *o.nparts_out = 0;
+      CHK(peer_flush_join(c));                 // (the reduction reads the boundary launch's partials)
       CHK(reduce_partials(c, nparts, o.dot_out));
     }
   }

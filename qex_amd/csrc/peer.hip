@@ -64,6 +64,9 @@ struct PeerComm {
   u64 seq_out[2][2]{}, seq_in[2][2]{}, seq_red = 0;
   u64 *ready = nullptr;                  // device, local: the two stream-join counters (word k*16 for joins FROM stream k)
   u64 join_seq[2]{};                     // peer_stream_signal / _join sequence numbers
+  int join_deferred = 0;                 // the compute stream still owes a wait for join_seq[1] (peer_stream_join_defer): the next granule all-reduce of
+                                         // workgroup partials polls for it in its prologue, anything else flushes it first (peer_flush_join)
+  struct { int live = 0; u64 *credit_out[2]; u64 seq_in[2]; } zc[2];   // per stream class: the zero-copy exchange whose credits are still owed
   long long ticks = 0;                   // timeout in wall_clock64 ticks
   double timeout_s = 30.0;
   long exchanges = 0, allreduces = 0, grows = 0;
@@ -106,6 +109,7 @@ struct PeerXfer {
   long long emu_ticks;                // transport emulation: the inbound data counts as arrived no earlier than this long after the kernel started
   unsigned n16;                       // 16-byte units per piece (< 2^32: pieces below 64 GiB)
   int ns[2], nr[2];
+  int zc;                             // zero-copy receive: what arrives stays in the arena for the consumer (peer_exchange_zc); no unpack, no credit here
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -167,6 +171,7 @@ __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
     }
   }
   // ---- unpack ----
+  if (X.zc && blockIdx.x != 0) return;             // zero-copy: ONE workgroup keeps the kernel alive until the faces have arrived
   const unsigned nin = (unsigned)(X.nr[0] + X.nr[1]) * cpp;
   if (threadIdx.x == 0) {
     int good = 1;
@@ -180,7 +185,7 @@ __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
     ok = good;
   }
   __syncthreads();
-  if (!ok) return;
+  if (!ok || X.zc) return;                         // (zero-copy: the consumer reads the arena; peer_release_zc returns the credits behind it)
   for (unsigned ch = blockIdx.x; ch < nin; ch += gridDim.x) {
     const unsigned q = ch / cpp, j = ch - q * cpp;
     const int d = q >= (unsigned)X.nr[0];
@@ -287,16 +292,27 @@ struct PeerGran {
 
 // x[0..n) := reduction over the ranks (OP 0 sum, 1 max), n <= PEER_GRAN_N.  PARTS: x[0..nparts) are workgroup partials whose sum
 // (in cg_sum_parts order, the order in which the consumers would have summed the vector themselves) is this rank's ONE operand.
+// join != nullptr: the stream this kernel is on has not waited yet for what the other stream posted (a deferred peer_stream_join:
+// the partials of the boundary launch come from there) -- one lane polls the join counter first, bounded like every wait here.
 template <int OP, bool PARTS>
-__global__ void __launch_bounds__(256) k_peer_allreduce_small(double *x, int n, int nparts, const PeerGran G, u64 seq) {
+__global__ void __launch_bounds__(256) k_peer_allreduce_small(double *x, int n, int nparts, const PeerGran G, u64 seq, const u64 *join, u64 joinval) {
   __shared__ double val[PEER_MAXR * PEER_GRAN_N];
   __shared__ int ok;
+  if (threadIdx.x == 0) ok = 1;
+  if (join) {
+    if (threadIdx.x == 0) {
+      if (!peer_poll_ge(join, joinval, G.err, G.ticks, 0x400)) ok = 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!ok) return;
+  }
   const long long t_start = G.emu_ticks > 0 ? wall_clock64() : 0;
   double local = 0;
   if (PARTS) { local = cg_sum_parts(x, nparts); n = 1; }
   const int slot = (int)(seq & (PEER_NSLOT - 1));
   const unsigned tag = (unsigned)seq;
-  if (threadIdx.x == 0) ok = 1;
   __syncthreads();
   const int r = threadIdx.x / PEER_GRAN_N, i = threadIdx.x % PEER_GRAN_N;      // 256 lanes >= 8 ranks x 32 values; more ranks loop
   for (int rr = r; rr < G.nranks; rr += 256 / PEER_GRAN_N) {
@@ -457,9 +473,14 @@ static int peer_ensure_arena(qexhip_ctx *c, int s, size_t bytes) {
 // One exchange on stream st: ns_dn pieces to the lower neighbour (they arrive in ITS from-upper half), ns_up pieces to the upper
 // one; by symmetry ns_up pieces arrive from the lower neighbour (-> dst_from_dn) and ns_dn from the upper one (-> dst_from_up).
 // Every piece is `bytes` long (a multiple of 16).
+// zc_from_up / zc_from_dn non-null (one piece per direction): zero-copy receive -- nothing is unpacked, the two pointers return
+// where the faces from the upper / lower neighbour lie in the receive arena, and the credits stay owed until peer_release_zc.
 int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *src_dn, int ns_up, const void *const *src_up,
-                  void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us) {
+                  void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us, const void **zc_from_up,
+                  const void **zc_from_dn) {
   PeerComm *p = c->peer;
+  const bool zc = zc_from_up && zc_from_dn;
+  if (zc && (ns_dn != 1 || ns_up != 1)) { qexhip_set_error("peer transport: zero-copy receive takes one piece per direction"); return QEXHIP_ERR_ARG; }
   if (bytes % 16 != 0) { qexhip_set_error("peer transport: message of %zu bytes is not a multiple of 16", bytes); return QEXHIP_ERR_ARG; }
   if (ns_dn < 0 || ns_up < 0 || (ns_dn == 0 && ns_up == 0) || bytes == 0) return 0;
   const int s = (st == c->cstream) ? 1 : 0;
@@ -470,8 +491,10 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
     PeerXfer X;
     memset(&X, 0, sizeof X);
     const int lo = lower(p), up = upper(p);
-    for (int k = 0; k < nd; k++) { X.src[0][k] = (const uint4 *)src_dn[k0 + k]; X.dst[1][k] = (uint4 *)dst_from_up[k0 + k]; }
-    for (int k = 0; k < nu; k++) { X.src[1][k] = (const uint4 *)src_up[k0 + k]; X.dst[0][k] = (uint4 *)dst_from_dn[k0 + k]; }
+    if (p->zc[s].live) { qexhip_set_error("peer transport: an exchange was posted while the credits of a zero-copy receive are still owed"); return QEXHIP_ERR_STATE; }
+    for (int k = 0; k < nd; k++) { X.src[0][k] = (const uint4 *)src_dn[k0 + k]; X.dst[1][k] = zc ? nullptr : (uint4 *)dst_from_up[k0 + k]; }
+    for (int k = 0; k < nu; k++) { X.src[1][k] = (const uint4 *)src_up[k0 + k]; X.dst[0][k] = zc ? nullptr : (uint4 *)dst_from_dn[k0 + k]; }
+    X.zc = zc ? 1 : 0;
     X.ns[0] = nd; X.ns[1] = nu; X.nr[0] = nu; X.nr[1] = nd;
     if (bytes / 16 >= ((size_t)1 << 32) - PEER_CHUNK) { qexhip_set_error("peer transport: a piece of %zu bytes is too large", bytes); return QEXHIP_ERR_ARG; }
     X.n16 = (unsigned)(bytes / 16);
@@ -509,7 +532,36 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
     hipLaunchKernelGGL(k_peer_exchange, dim3(grid), dim3(256), 0, st, X);
     HIPCHK(hipGetLastError());
     p->exchanges++;
+    if (zc) {
+      p->zc[s].live = 1;
+      for (int d = 0; d < 2; d++) { p->zc[s].credit_out[d] = X.credit_out[d]; p->zc[s].seq_in[d] = X.seq_in[d]; }
+      *zc_from_dn = X.in_arena[0];
+      *zc_from_up = X.in_arena[1];
+    }
   }
+  return 0;
+}
+
+// behind the consumer of a zero-copy exchange: the arena halves are free again (credits to the two senders, system scope), and the
+// stream that waits for the consumer may go on (join counter, agent scope)
+__global__ void k_peer_release(u64 *credit0, u64 seq0, u64 *credit1, u64 seq1, u64 *join, u64 joinval) {
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(credit0, seq0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(credit1, seq1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(join, joinval, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// behind the kernel that consumed a zero-copy receive on `st`: the senders get their credits, and the stream join counter FROM `st`
+// is raised (peer_stream_join on the waiting stream comes next, as after peer_stream_signal)
+int peer_release_zc(qexhip_ctx *c, hipStream_t st) {
+  PeerComm *p = c->peer;
+  const int s = (st == c->cstream) ? 1 : 0;
+  if (!p->zc[s].live) { qexhip_set_error("peer transport: no zero-copy receive to release"); return QEXHIP_ERR_STATE; }
+  hipLaunchKernelGGL(k_peer_release, dim3(1), dim3(64), 0, st, p->zc[s].credit_out[0], p->zc[s].seq_in[0], p->zc[s].credit_out[1], p->zc[s].seq_in[1],
+                     p->ready + s * 16, ++p->join_seq[s]);
+  HIPCHK(hipGetLastError());
+  p->zc[s].live = 0;
   return 0;
 }
 
@@ -526,9 +578,19 @@ int peer_stream_signal(qexhip_ctx *c, hipStream_t from) {
   HIPCHK(hipGetLastError());
   return 0;
 }
+// the compute stream's wait for what the comm stream has signalled so far is postponed into the next peer_allreduce_parts
+// (the CG's <p,Ap> right behind the second sweep); peer_flush_join posts it as a kernel of its own if something else comes first
+int peer_stream_join_defer(qexhip_ctx *c) { c->peer->join_deferred = 1; return 0; }
+int peer_flush_join(qexhip_ctx *c) {
+  PeerComm *p = c->peer;
+  if (!p || !p->join_deferred) return 0;
+  p->join_deferred = 0;
+  return peer_stream_join(c, c->stream, c->cstream);
+}
 int peer_stream_join(qexhip_ctx *c, hipStream_t waiter, hipStream_t from) {
   PeerComm *p = c->peer;
   const int k = (from == c->cstream) ? 1 : 0;
+  if (waiter == c->stream && k == 1) p->join_deferred = 0;
   hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, waiter, p->ready + k * 16, p->join_seq[k], p->err, p->ticks);
   HIPCHK(hipGetLastError());
   return 0;
@@ -537,12 +599,13 @@ int peer_stream_join(qexhip_ctx *c, hipStream_t waiter, hipStream_t from) {
 int peer_allreduce(qexhip_ctx *c, double *dptr, int n, int op) {
   PeerComm *p = c->peer;
   CHK(peer_check_err(p));
+  CHK(peer_flush_join(c));
   if (n <= PEER_GRAN_N) {
     PeerGran G;
     fill_gran(p, G);
     G.emu_ticks = (long long)(c->emu_allreduce_us * 1e-6 * (double)p->ticks / p->timeout_s);
-    if (op == 0) hipLaunchKernelGGL((k_peer_allreduce_small<0, false>), dim3(1), dim3(256), 0, c->stream, dptr, n, 0, G, ++p->seq_red);
-    else hipLaunchKernelGGL((k_peer_allreduce_small<1, false>), dim3(1), dim3(256), 0, c->stream, dptr, n, 0, G, ++p->seq_red);
+    if (op == 0) hipLaunchKernelGGL((k_peer_allreduce_small<0, false>), dim3(1), dim3(256), 0, c->stream, dptr, n, 0, G, ++p->seq_red, (const u64 *)nullptr, (u64)0);
+    else hipLaunchKernelGGL((k_peer_allreduce_small<1, false>), dim3(1), dim3(256), 0, c->stream, dptr, n, 0, G, ++p->seq_red, (const u64 *)nullptr, (u64)0);
     p->allreduces++;
     HIPCHK(hipGetLastError());
     return 0;
@@ -566,7 +629,9 @@ int peer_allreduce_parts(qexhip_ctx *c, double *parts, int n) {
   PeerGran G;
   fill_gran(p, G);
   G.emu_ticks = (long long)(c->emu_allreduce_us * 1e-6 * (double)p->ticks / p->timeout_s);
-  hipLaunchKernelGGL((k_peer_allreduce_small<0, true>), dim3(1), dim3(256), 0, c->stream, parts, 1, n, G, ++p->seq_red);
+  const u64 *join = p->join_deferred ? p->ready + 16 : nullptr;      // the deferred join from the comm stream rides in this kernel's prologue
+  p->join_deferred = 0;
+  hipLaunchKernelGGL((k_peer_allreduce_small<0, true>), dim3(1), dim3(256), 0, c->stream, parts, 1, n, G, ++p->seq_red, join, p->join_seq[1]);
   p->allreduces++;
   HIPCHK(hipGetLastError());
   return 0;

@@ -116,6 +116,12 @@ struct qexhip_ctx {
                             // (with a one-rank RCCL communicator the all-reduces are real collectives)
   int opt_force_pair = 1; // option "force_pair" (test hook): 0 takes k_force_lds, the form lattice shapes without paired tile positions get, on any shape
   int opt_obs_clover = 1; // option "obs_clover" (test hook): 0 takes the generic path walker, the form fmunu loops 3-5 get, for loop 1 as well
+  int opt_peer_zc = 1;    // option "peer_zc" (A/B, test hook): 1 = the boundary launch of an overlapped sweep reads the neighbours' faces straight from the
+                          // peer transport's receive arena (no unpack kernel phase), 0 = they are copied into the field's ghost tiles first
+  int opt_sweep_chain = -1;  // option "sweep_chain": 1 = the two sweeps of the normal operator run without a join between them (dslash_sweep), 0 = never,
+                             // -1 = where sweep_autotune measured it faster (off until measured)
+  int chain_auto[2]{-1, -1}; // that measurement's decision for 8- and 16-link operators
+  int chain_pending = 0;     // a chain-1 sweep has left its boundary launch unjoined: only its chain-2 successor may follow on the compute stream
   int opt_chain_overlap = 1; // option "chain_overlap" (A/B, test hook): 1 = the nHYP force chain's staple derivatives of a t-sharded field run in two passes,
                           // the ghost-free slices beside the exchange of the level's chain fields, the boundary slices behind it
   int opt_smear_ca = 1;   // option "smear_ca" (A/B, test hook): 1 = the nHYP levels of a t-sharded field are computed on shrinking ghost slices from
@@ -130,7 +136,7 @@ struct qexhip_ctx {
   int emu_exchange_us = 0, emu_allreduce_us = 0;   // options of the same names (test / rehearsal hooks): delay posted in front of every face
                                                    // exchange / all-reduce, as long as the transfer would take between distinct GPUs
   int overlap_auto[2]{-1, -1};          // the measured decision for 8- and 16-link operators (-1: not measured)
-  double overlap_tune_us[2][2]{};       // us per sweep the measurement saw: [8 | 16 links][exchange first | overlapped], max over ranks
+  double overlap_tune_us[2][3]{};       // us per sweep the measurement saw: [8 | 16 links][exchange first | overlapped | overlapped + chained], max over ranks
   // natural gauge (flow)
   GaugeNat *gn = nullptr;
   void *nhyp = nullptr;   // NhypState (smear.hip): the smearGetForce closure
@@ -196,6 +202,7 @@ int solve_batch_host(qexhip_ctx *c, int n, double *const *x, const double *const
 inline bool multi_rank(const qexhip_ctx *c) { return c->nranks > 1 || c->opt_multi_reduce; }
 
 // ---- comm.cpp ----
+int comm_halo_exchange_zc(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, bool wait_ready = true);   // peer transport, comm stream: see dslash_sweep
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready; the caller records ev_halo behind what it posts next
 int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parity, int overlap);   // n fields, one RCCL group
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
@@ -216,9 +223,13 @@ int peer_init(qexhip_ctx *c, PeerHost &host);          // after the host rendezv
 void peer_destroy(qexhip_ctx *c);
 int peer_check(qexhip_ctx *c);                          // a device-side wait timed out since the last check -> QEXHIP_ERR_COMM
 int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *src_dn, int ns_up, const void *const *src_up,
-                  void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us = 0.0);
+                  void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us = 0.0, const void **zc_from_up = nullptr,
+                  const void **zc_from_dn = nullptr);                  // zc_*: zero-copy receive (the faces stay in the arena, credits owed)
+int peer_release_zc(qexhip_ctx *c, hipStream_t st);                   // behind the consumer of a zero-copy receive: credits + join signal
 int peer_stream_signal(qexhip_ctx *c, hipStream_t from);                          // device-side event: record ...
 int peer_stream_join(qexhip_ctx *c, hipStream_t waiter, hipStream_t from);        // ... and wait, without the runtime's cross-queue dependency
+int peer_stream_join_defer(qexhip_ctx *c);                                        // the compute stream's wait rides in the next peer_allreduce_parts ...
+int peer_flush_join(qexhip_ctx *c);                                               // ... or is posted now (no-op when nothing is deferred / no peer transport)
 int peer_allreduce_parts(qexhip_ctx *c, double *parts, int n);       // parts[0] := sum over ranks of (sum of parts[0..n) in cg_sum_parts order)
 int peer_allreduce(qexhip_ctx *c, double *dptr, int n, int op);      // on the compute stream; op 0 sum, 1 max; rank order
 int peer_host_reduce(qexhip_ctx *c, double *host, int n, int op);    // host operands (op 0 max, 1 min, 2 sum), synchronous
@@ -238,8 +249,11 @@ struct DslashOpts {
   int *nparts_out = nullptr;
   double *dot_out = nullptr;       // device scalar
   const int *done = nullptr;       // device flag: skip when set
+  int chain = 0;                   // 1 / 2: first / second sweep of a back-to-back pair out2 = D (D in) with three distinct fields (op_xx); see dslash_sweep
+  int defer_join = 0;              // chain == 2: the caller's next operation on the compute stream is comm_allreduce_parts (or peer_flush_join)
 };
 int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const DslashOpts &o);
+bool sweep_chain_on(const qexhip_ctx *c); // an overlapped pair of sweeps runs chained (dslash_sweep)
 int sweep_autotune(qexhip_ctx *c);      // measure exchange-first against overlapped once per operator shape (collective)
 void sweep_plan(const qexhip_ctx *c, int *lo_end, int *hi_beg, int *overlap);   // boundary / interior ranges and the overlap decision
 

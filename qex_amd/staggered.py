@@ -138,6 +138,12 @@ class Context:
              "option_overlap": int(o[7])}
         if o[4]:
             r["measured_us_per_sweep"] = {"exchange_first": int(o[5]), "overlapped": int(o[6])}
+        k = (C.c_int * 4)()
+        check(lib().qexhip_stag_sweep_chain_info(self._h, k))
+        r["chained"] = bool(k[0])
+        r["option_sweep_chain"] = int(k[3])
+        if o[4] and k[1]:
+            r["measured_us_per_sweep"]["overlapped_chained"] = int(k[2])
         return r
 
     def force_halo(self, on=True):

@@ -343,6 +343,52 @@ def test_forced_halo_equals_periodic(oracle, naik, warm):
     assert abs(spc.iterations - spa.iterations) <= 1 and relerr(xc, xa) < 1e-6
 
 
+@pytest.mark.parametrize("naik", [False, True])
+def test_peer_transport_sweep_forms_equal_periodic(oracle, naik):
+    """One rank on the peer-memory transport (its own neighbour through the receive arena), every form of the overlapped sweep
+    against the periodic-wrap kernel: unpacking exchange, zero-copy receive (the boundary launch reads the arena), zero-copy +
+    chained pair (narrowed second interior, no join between the sweeps, the join of the pair inside the <p,Ap> all-reduce),
+    and the form set_links measures for itself (option overlap = -2)."""
+    import qex_amd as q
+
+    lat = [8, 8, 8, 16]                       # depth 3 (Naik): a chained pair needs more than 12 slices
+    A = Setup(oracle, lat, naik=naik, warm=True)
+    forms = {"unpack": dict(overlap=1, peer_zc=0, sweep_chain=0), "zero_copy": dict(overlap=1, peer_zc=1, sweep_chain=0),
+             "chained": dict(overlap=1, peer_zc=1, sweep_chain=1), "measured": dict(overlap=-2)}
+    xa = np.zeros_like(A.x)
+    spa = q.SolverParams(r2req=1e-12, maxits=2000, verbosity=0)
+    A.s.solveEE(xa, A.x, 0.1, spa, histcap=4096)
+    ra = np.zeros_like(A.x)
+    A.s.stagD2ee(ra, A.x, 0.01)
+    for name, opts in forms.items():
+        ctx = q.Context(lat)
+        ctx.set_option("transport", 2)
+        ctx.comm_init(q.Context.unique_id(), 1, 0)
+        assert ctx.comm_transport()[0] == "peer"
+        ctx.force_halo(True)
+        ctx.set_option("multi_reduce", 1)       # the multi-rank reduction branches: the all-reduce kernel that takes the deferred join
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        s = q.newStag3(ctx, A.g, A.g3) if naik else q.newStag(ctx, A.g)
+        si = ctx.sweep_info()
+        if name == "measured":
+            assert si["overlap_measured"] and "overlapped_chained" in si["measured_us_per_sweep"], si
+        else:
+            assert si["overlap"] and si["chained"] == (name == "chained"), si
+        r = np.zeros_like(A.x)
+        s.stagD2ee(r, A.x, 0.01)                 # the pair without a dot product: joined by a kernel of its own
+        assert relerr(r, ra) < 1e-15, name
+        x = np.zeros_like(A.x)
+        sp = q.SolverParams(r2req=1e-12, maxits=2000, verbosity=0)
+        s.solveEE(x, A.x, 0.1, sp, histcap=4096)
+        assert abs(sp.iterations - spa.iterations) <= 1, (name, sp.iterations, spa.iterations)
+        n = min(len(sp.r2hist), len(spa.r2hist), 100)
+        assert np.abs(sp.r2hist[:n] / spa.r2hist[:n] - 1).max() < 1e-12, name     # same kernels; only the partial-sum grouping differs
+        assert relerr(x, xa) < 1e-6, name
+        ctx.sync()
+        del s, ctx
+
+
 @pytest.mark.parametrize("warm", [False, True])
 def test_forced_halo_rccl_self(oracle, warm):
     """Same as above but through a one-rank RCCL communicator (ncclSend/ncclRecv to self)."""

@@ -43,15 +43,18 @@ needs2 = pytest.mark.skipif("_ngpu() < 2", reason="needs two GPUs: real RCCL tra
 
 
 # ---- real neighbours on ONE device: the peer-memory transport (csrc/peer.hip) between processes that share GPU 0 ----
-@pytest.mark.parametrize("nranks,lat,overlap", [(2, [8, 8, 8, 8], -1), (2, [8, 8, 8, 8], 1), (2, [16, 16, 16, 32], -1), (2, [16, 16, 16, 32], 1),
-                                                (4, [8, 8, 8, 16], -1), (4, [8, 8, 8, 16], 1), (4, [16, 16, 16, 32], 1)])
-def test_ranks_sharing_one_device_against_the_global_oracle(nranks, lat, overlap):
+@pytest.mark.parametrize("nranks,lat,overlap,chain", [(2, [8, 8, 8, 8], -1, -1), (2, [8, 8, 8, 8], 1, -1), (2, [16, 16, 16, 32], -1, -1),
+                                                      (2, [16, 16, 16, 32], 1, 0), (2, [16, 16, 16, 32], 1, 1), (4, [8, 8, 8, 16], -1, -1),
+                                                      (4, [8, 8, 8, 16], 1, -1), (4, [16, 16, 16, 32], 1, 0), (4, [16, 16, 16, 32], 1, 1)])
+def test_ranks_sharing_one_device_against_the_global_oracle(nranks, lat, overlap, chain):
     """Every rank is its own process with its own slab, neighbours are OTHER processes: rank > 0 kernels, backward t-links
     fetched from the lower rank, the last-rank-only boundary condition of k_rephase, collective set_links, chunk agreement --
     everything a one-rank rehearsal cannot reach -- checked slab by slab against the global oracle (tests/two_rank_worker.py).
     Faces and reductions go through hipIpc-mapped peer memory (qshifts.nim:51-131, shifts.nim:67-94,254-285,
-    commsUtils.nim:195-204 are what that replaces)."""
-    p = _launch(nranks, [os.path.join(ROOT, "tests", "two_rank_worker.py")] + [str(v) for v in lat] + ["--overlap", str(overlap), "--share-device"],
+    commsUtils.nim:195-204 are what that replaces).  chain = 1: the overlapped sweeps of the normal operator as a chained pair
+    (16 local slices hold it for the Naik operator too, 8 for the one-link operator only)."""
+    p = _launch(nranks, [os.path.join(ROOT, "tests", "two_rank_worker.py")] + [str(v) for v in lat] +
+                ["--overlap", str(overlap), "--sweep-chain", str(chain), "--share-device"],
                 extra_env={"QEXHIP_PEER_TIMEOUT": "60"})
     ok = [ln for ln in p.stdout.splitlines() if ln.startswith("TWO_RANK_OK")]
     if p.returncode != 0 or len(ok) != nranks:
@@ -61,6 +64,8 @@ def test_ranks_sharing_one_device_against_the_global_oracle(nranks, lat, overlap
     res = [json.loads(ln.split(" ", 3)[3]) for ln in ok]
     assert {r["transport"] for r in res} == {"peer"} and len({r["pci_bus"] for r in res}) == 1
     assert all(r["transport_stats"]["exchanges"] > 100 and r["transport_stats"]["allreduces"] > 100 for r in res), res[0]["transport_stats"]
+    if chain >= 0:
+        assert all(r["sweep"]["chained"] == bool(chain) for r in res), res[0]["sweep"]
 
 
 @pytest.mark.parametrize("scenario", ["absent", "vanish", "mismatch"])

@@ -43,6 +43,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("lat", type=int, nargs=4)
     ap.add_argument("--overlap", type=int, default=-1, help="option overlap of the context: -1 by size, 0 never, 1 always")
+    ap.add_argument("--sweep-chain", type=int, default=-1, help="option sweep_chain: 1 = the overlapped sweeps of the normal operator run chained, "
+                                                                "0 never, -1 where set_links measured it faster")
     ap.add_argument("--skip-gauge", action="store_true", help="operator and solvers only")
     ap.add_argument("--share-device", action="store_true", help="every rank binds device 0: the peer-memory transport between processes "
                     "that share one GPU (RCCL refuses that), i.e. real neighbours on a one-GPU box")
@@ -90,6 +92,8 @@ def main():
     assert transport == ("peer" if (args.share_device and world > 1) or os.environ.get("QEXHIP_TRANSPORT") == "peer" else "rccl"), transport
     if args.overlap >= 0:
         ctx.set_option("overlap", args.overlap)
+    if args.sweep_chain >= 0:
+        ctx.set_option("sweep_chain", args.sweep_chain)
     res = {"rank": rank, "device": info[2], "pci_bus": info[3], "comms": ctx.comm_count(), "transport": transport}
 
     def sl(a):
