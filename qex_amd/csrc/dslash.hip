@@ -403,7 +403,7 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
         if (zc) CHK(peer_release_zc(c, c->cstream));
         else CHK(peer_stream_signal(c, c->cstream));
         if (o.chain == 1 && chain_ok) c->chain_pending = 1;                       // the chain-2 sweep (or whatever comes instead) joins
-        else if (chain2 && o.defer_join) CHK(peer_stream_join_defer(c));          // rides in the <p,Ap> all-reduce's prologue
+        else if (o.defer_join) CHK(peer_stream_join_defer(c));                    // rides in the <p,Ap> all-reduce's prologue
         else CHK(peer_stream_join(c, c->stream, c->cstream));
       } else {
       // Both t-faces in ONE launch, posted on the COMM stream right behind the exchange: it needs the ghost zones and nothing

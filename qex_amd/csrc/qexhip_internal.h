@@ -250,7 +250,8 @@ struct DslashOpts {
   double *dot_out = nullptr;       // device scalar
   const int *done = nullptr;       // device flag: skip when set
   int chain = 0;                   // 1 / 2: first / second sweep of a back-to-back pair out2 = D (D in) with three distinct fields (op_xx); see dslash_sweep
-  int defer_join = 0;              // chain == 2: the caller's next operation on the compute stream is comm_allreduce_parts (or peer_flush_join)
+  int defer_join = 0;              // the caller's next operation on the compute stream is comm_allreduce_parts (or peer_flush_join): an overlapped
+                                   // sweep on the peer transport leaves its join from the comm stream to that kernel's prologue
 };
 int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const DslashOpts &o);
 bool sweep_chain_on(const qexhip_ctx *c); // an overlapped pair of sweeps runs chained (dslash_sweep)
