@@ -393,6 +393,8 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *                  computing them on shrinking ghost slices from one depth-3 thin-link exchange (default 1)
  *   "peer_zc"      0: peer transport, overlapped sweep: the neighbours' faces are copied from the receive arena into the field's ghost
  *                  tiles before the boundary launch, instead of being read from the arena by it (default 1)
+ *   "peer_fold"    1: peer transport: the |r|^2 all-reduce of a sharded CG iteration is the work of k_cg_update's last-arriving workgroup
+ *                  instead of a launch of its own behind it (default 0: measured slower; the same bits either way)
  *   "sweep_chain"  1 / 0: the two overlapped sweeps of the normal operator always / never run chained (qexhip_stag_sweep_chain_info); -1
  *                  (default): chained where set_links measured it > 3 % faster than the overlapped pair (it wins while the interior
  *                  launch is longer than the exchange, loses when the exchange is: a narrower interior hides less of it)

@@ -674,6 +674,7 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "chain_overlap") c->opt_chain_overlap = value;
   else if (n == "peer_zc") c->opt_peer_zc = value;
   else if (n == "sweep_chain") c->opt_sweep_chain = value;
+  else if (n == "peer_fold") c->opt_peer_fold = value;
   else if (n == "emu_exchange_us") c->emu_exchange_us = value;
   else if (n == "emu_allreduce_us") c->emu_allreduce_us = value;
   else if (n == "emu_link_gbs") c->emu_link_gbs = value;

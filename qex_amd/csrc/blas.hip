@@ -9,6 +9,8 @@
 #include "qexhip_internal.h"
 #include "reduce.h"
 #include "cg_device.h"
+#include <cstring>
+#include "peer_device.h"
 
 static inline int grid_for(size_t n2) {
   size_t nb = (n2 + 255) / 256;
@@ -246,9 +248,14 @@ __global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, s
 }
 // alpha = rz/qLAp; x += alpha*p; r -= alpha*Ap; partial |r|^2   (cg.nim:208-213)
 // With ndot > 0 every workgroup first sums the <p,Ap> workgroup partials of the preceding Dslash sweep itself.
+// T.on (sharded, peer transport): the all-reduce of |r|^2 (cg.nim:213 `r2 = r.norm2` is a rank sum) happens in this kernel's tail.
+// Every workgroup publishes its partial write-through (sc1 store, drained) and takes an arrival ticket (agent-scope add); the one
+// whose ticket is last reads all partials back with sc1 loads (MI355X_MICROARCH "valid forms": no release / acquire fence
+// needed for sc1 bytes behind a drained store and a ticket), sums them in cg_sum_parts order -- the order the next k_cg_xpay
+// would have used -- and exchanges the sum with the other ranks; partials[0] = the total, which the consumer reads as ONE part.
 __global__ void __launch_bounds__(256) k_cg_update(double2 *x, double2 *r, const double2 *p, const double2 *Ap,
                                                   size_t n, const CgScal *s, int k, double *partials,
-                                                  const double *dotp, int ndot) {
+                                                  const double *dotp, int ndot, const PeerTail T) {
   if (s->dones[k & 1]) return;
   const double pAp = (ndot > 0) ? cg_sum_parts(dotp, ndot) : s->pAp;
   const double alpha = s->r2s[k & 1] / pAp;
@@ -261,7 +268,26 @@ __global__ void __launch_bounds__(256) k_cg_update(double2 *x, double2 *r, const
     acc = fma(rv.x, rv.x, fma(rv.y, rv.y, acc));
   }
   double t = block_sum_256(acc);
-  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+  if (!T.on) {
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+    return;
+  }
+  __shared__ int last;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned a = __hip_atomic_fetch_add(T.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (a == gridDim.x - 1);
+    if (last) __hip_atomic_store(T.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch (kernel boundary in between)
+  }
+  __syncthreads();
+  if (!last) return;
+  double a = 0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double local = block_sum_256_all(a);
+  double tot = 0;
+  if (!gran_allreduce_block(local, T.G, T.seq, &tot)) return;
+  if (threadIdx.x == 0) partials[0] = tot;
 }
 // r2stop = r2req*b2; loop condition `itn<maxits and r2>r2stop` (cg.nim:155,174)
 __global__ void k_cg_init(CgScal *s, const double *dscal, double r2req, int maxits, double *hist, int histcap) {
@@ -303,13 +329,19 @@ int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const 
   double *r2p = c->partials + c->part2_off;
   if (ndot > 0) CHK(comm_allreduce_parts(c, c->partials, ndot, &ndot));
   CHK(peer_flush_join(c));              // (no-op when the all-reduce has taken the second sweep's join with it)
+  // option "peer_fold" (sharded on the peer transport): the |r|^2 all-reduce rides in the kernel's tail instead of being a launch of its own
+  PeerTail T;
+  memset(&T, 0, sizeof T);
+  const bool tail = c->peer && c->opt_peer_fold && multi_rank(c) && comm_ready(c);
+  if (tail) CHK(peer_tail_args(c, &T));
   {
     ScopedTimer tm(c, "blas", c->stream);
     k_cg_update<<<nb, 256, 0, c->stream>>>(x.par(parity), r.par(parity), p.par(parity), Ap.par(parity), n, c->cg, k, r2p,
-                                           c->partials, ndot);
+                                           c->partials, ndot, T);
     HIPCHK(hipGetLastError());
   }
-  CHK(comm_allreduce_parts(c, r2p, nb, &c->cg_r2parts));     // how many values the next k_cg_xpay / k_cg_close has to sum
+  if (tail) c->cg_r2parts = 1;                                    // r2p[0] is the all-reduced |r|^2 already
+  else CHK(comm_allreduce_parts(c, r2p, nb, &c->cg_r2parts));     // how many values the next k_cg_xpay / k_cg_close has to sum
   return 0;
 }
 int cg_close(qexhip_ctx *c, int k) {

@@ -34,6 +34,7 @@
 #include "qexhip_internal.h"
 #include "peer_shm.h"
 #include "cg_device.h"
+#include "peer_device.h"
 #include "../../include/qexhip.h"
 #include <cstring>
 #include <cstdlib>
@@ -42,11 +43,9 @@
 
 static_assert(sizeof(hipIpcMemHandle_t) <= PEER_HANDLE_BYTES, "ipc handle size");
 
-typedef unsigned long long u64;
-enum { PEER_MAXSEG = 32, PEER_CHUNK = 4096, PEER_NSLOT = 4, PEER_MBOX_N = 4096 };
+enum { PEER_MAXSEG = 32, PEER_CHUNK = 4096, PEER_MBOX_N = 4096 };
 // control block, in 8-byte words: every polled word on a 128-byte line of its own
 enum { CW_DATA = 0 /* + (s*2+d)*16 */, CW_CREDIT = 64 /* + (s*2+dir)*16 */, CW_MFLAG = 256 /* + slot*PEER_MAXR + src */,
-       PEER_GRAN_N = 32,                          // doubles per small all-reduce: 2 tagged 8-byte granules each
        CW_GRAN = 1024 /* + ((slot*PEER_MAXR + src)*PEER_GRAN_N + i)*2 */,
        CTRL_MBOX_BYTE = 65536, CTRL_BYTES = CTRL_MBOX_BYTE + PEER_NSLOT * PEER_MAXR * PEER_MBOX_N * 8 };
 static_assert((CW_GRAN + PEER_NSLOT * PEER_MAXR * PEER_GRAN_N * 2) * 8 <= CTRL_MBOX_BYTE, "control block layout");
@@ -63,6 +62,7 @@ struct PeerComm {
   u64 *err = nullptr;                    // pinned host word the kernels write on a timeout
   u64 seq_out[2][2]{}, seq_in[2][2]{}, seq_red = 0;
   u64 *ready = nullptr;                  // device, local: the two stream-join counters (word k*16 for joins FROM stream k)
+  unsigned int *tail_count = nullptr;    // device, local: arrival tickets of the all-reduce in k_cg_update's tail (peer_device.h)
   u64 join_seq[2]{};                     // peer_stream_signal / _join sequence numbers
   int join_deferred = 0;                 // the compute stream still owes a wait for join_seq[1] (peer_stream_join_defer): the next granule all-reduce of
                                          // workgroup partials polls for it in its prologue, anything else flushes it first (peer_flush_join)
@@ -256,40 +256,8 @@ __global__ void __launch_bounds__(512) k_peer_allreduce(double *x, int n, const 
   }
 }
 
-// Small all-reduces (the CG's scalars): the payload travels INSIDE the flags.  A double is cut into two 8-byte granules
-// {32 data bits, 32-bit tag = low half of the sequence number}; an aligned 8-byte store is one transaction, so a granule is
-// either the old one (tag of all-reduce k-4 in this slot) or the new one, never a mixture -- no release before, no acquire
-// after, no separate flag (MI355X_MICROARCH "handoff-1to1": data-tagged granules).  Lane (r, i) sends value i to rank r and
+// Small all-reduces (the CG's scalars): tagged 8-byte granules, peer_device.h.  Lane (r, i) sends value i to rank r and
 // collects value i of rank r; the sums run over the ranks in rank order.
-__device__ inline void gran_send(u64 *dst, double v, unsigned tag) {
-  const u64 b = (u64)__double_as_longlong(v);
-  __hip_atomic_store(dst, (b & 0xffffffff00000000ULL) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(dst + 1, (b << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ inline bool gran_recv(const u64 *src, unsigned tag, double *v, u64 *err, long long ticks, u64 code) {
-  u64 hi = 0, lo = 0;
-  const long long t0 = wall_clock64();
-  for (unsigned it = 1;; it++) {
-    hi = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    lo = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if ((unsigned)hi == tag && (unsigned)lo == tag) break;
-    __builtin_amdgcn_s_sleep(2);
-    if ((it & 255) == 0) {
-      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
-      if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
-    }
-  }
-  *v = __longlong_as_double((long long)((hi & 0xffffffff00000000ULL) | (lo >> 32)));
-  return true;
-}
-
-struct PeerGran {
-  u64 *gran[PEER_MAXR];       // granule area of every rank as mapped here: [slot][src][PEER_GRAN_N][2]
-  u64 *err;
-  long long ticks, emu_ticks;
-  int nranks, me;
-};
-
 // x[0..n) := reduction over the ranks (OP 0 sum, 1 max), n <= PEER_GRAN_N.  PARTS: x[0..nparts) are workgroup partials whose sum
 // (in cg_sum_parts order, the order in which the consumers would have summed the vector themselves) is this rank's ONE operand.
 // join != nullptr: the stream this kernel is on has not waited yet for what the other stream posted (a deferred peer_stream_join:
@@ -395,6 +363,7 @@ int peer_init(qexhip_ctx *c, PeerHost &host) {
   HIPCHK(hipMemset(p->done, 0, 64));
   HIPCHK(hipMalloc((void **)&p->ready, 512));
   HIPCHK(hipMemset(p->ready, 0, 512));
+  p->tail_count = (unsigned int *)(p->ready + 32);          // a 128-byte line of its own in the same allocation
   HIPCHK(hipHostMalloc((void **)&p->err, 64, hipHostMallocDefault));
   *p->err = 0;
   HIPCHK(hipDeviceSynchronize());
@@ -634,6 +603,18 @@ int peer_allreduce_parts(qexhip_ctx *c, double *parts, int n) {
   hipLaunchKernelGGL((k_peer_allreduce_small<0, true>), dim3(1), dim3(256), 0, c->stream, parts, 1, n, G, ++p->seq_red, join, p->join_seq[1]);
   p->allreduces++;
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int peer_tail_args(qexhip_ctx *c, PeerTail *T) {
+  PeerComm *p = c->peer;
+  CHK(peer_check_err(p));
+  T->on = 1;
+  T->count = p->tail_count;
+  fill_gran(p, T->G);
+  T->G.emu_ticks = (long long)(c->emu_allreduce_us * 1e-6 * (double)p->ticks / p->timeout_s);
+  T->seq = ++p->seq_red;
+  p->allreduces++;
   return 0;
 }
 

@@ -118,6 +118,10 @@ struct qexhip_ctx {
   int opt_obs_clover = 1; // option "obs_clover" (test hook): 0 takes the generic path walker, the form fmunu loops 3-5 get, for loop 1 as well
   int opt_peer_zc = 1;    // option "peer_zc" (A/B, test hook): 1 = the boundary launch of an overlapped sweep reads the neighbours' faces straight from the
                           // peer transport's receive arena (no unpack kernel phase), 0 = they are copied into the field's ghost tiles first
+  int opt_peer_fold = 0;     // option "peer_fold" (A/B, test hook): 1 = the |r|^2 all-reduce of a sharded CG iteration on the peer transport runs in the tail of
+                             // k_cg_update (last-arriver workgroup), 0 = as a launch of its own behind it.  Measured 8-10 us per iteration SLOWER
+                             // folded (profiles/r05_fold_compare.log: write-through partials + 2600 arrival tickets + a serial tail cost more
+                             // than the launch boundary they save), so off
   int opt_sweep_chain = -1;  // option "sweep_chain": 1 = the two sweeps of the normal operator run without a join between them (dslash_sweep), 0 = never,
                              // -1 = where sweep_autotune measured it faster (off until measured)
   int chain_auto[2]{-1, -1}; // that measurement's decision for 8- and 16-link operators

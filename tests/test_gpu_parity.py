@@ -348,13 +348,14 @@ def test_peer_transport_sweep_forms_equal_periodic(oracle, naik):
     """One rank on the peer-memory transport (its own neighbour through the receive arena), every form of the overlapped sweep
     against the periodic-wrap kernel: unpacking exchange, zero-copy receive (the boundary launch reads the arena), zero-copy +
     chained pair (narrowed second interior, no join between the sweeps, the join of the pair inside the <p,Ap> all-reduce),
-    and the form set_links measures for itself (option overlap = -2)."""
+    the form set_links measures for itself (option overlap = -2), and the |r|^2 all-reduce folded into k_cg_update."""
     import qex_amd as q
 
     lat = [8, 8, 8, 16]                       # depth 3 (Naik): a chained pair needs more than 12 slices
     A = Setup(oracle, lat, naik=naik, warm=True)
     forms = {"unpack": dict(overlap=1, peer_zc=0, sweep_chain=0), "zero_copy": dict(overlap=1, peer_zc=1, sweep_chain=0),
-             "chained": dict(overlap=1, peer_zc=1, sweep_chain=1), "measured": dict(overlap=-2)}
+             "chained": dict(overlap=1, peer_zc=1, sweep_chain=1), "measured": dict(overlap=-2),
+             "folded": dict(overlap=1, sweep_chain=0, peer_fold=1)}        # |r|^2 all-reduce in k_cg_update's tail
     xa = np.zeros_like(A.x)
     spa = q.SolverParams(r2req=1e-12, maxits=2000, verbosity=0)
     A.s.solveEE(xa, A.x, 0.1, spa, histcap=4096)
