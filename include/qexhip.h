@@ -393,6 +393,12 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *                  computing them on shrinking ghost slices from one depth-3 thin-link exchange (default 1)
  *   "peer_zc"      0: peer transport, overlapped sweep: the neighbours' faces are copied from the receive arena into the field's ghost
  *                  tiles before the boundary launch, instead of being read from the arena by it (default 1)
+ *   "hop_split"    how an overlapped sweep of a t-sharded field is split.  2: by HOPS in one launch -- interior workgroups, and boundary
+ *                  workgroups that take the hops inside the slab, wait (bounded) on the device for the faces, then take the hops that
+ *                  leave it; on the peer transport with zero-copy receive the launch's first workgroups also PUSH the faces: the whole
+ *                  sweep is one kernel on one stream.  1: by hops in two launches (A/B).  0: by SITES (interior launch beside the
+ *                  exchange, boundary launch on the second stream behind it, a join; rounds 1-4).  -1 (default): 2 on the peer transport
+ *                  with zero-copy receive, else 0.  Boundary sites sum their local hops first under 1 / 2: equal to 0 to rounding.
  *   "peer_fold"    1: peer transport: the |r|^2 all-reduce of a sharded CG iteration is the work of k_cg_update's last-arriving workgroup
  *                  instead of a launch of its own behind it (default 0: measured slower; the same bits either way)
  *   "sweep_chain"  1 / 0: the two overlapped sweeps of the normal operator always / never run chained (qexhip_stag_sweep_chain_info); -1

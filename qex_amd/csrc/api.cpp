@@ -31,7 +31,7 @@ static bool timer_class_on(const qexhip_ctx *c, const char *name) {
   return true;
 }
 ScopedTimer::ScopedTimer(qexhip_ctx *c_, const char *name, hipStream_t st_) : c(c_), st(st_) {
-  if (!c->timers_on) return;
+  if (!c->timers_on || !name) return;
   if (!timer_class_on(c, name)) return;
   s = &c->timers[name];
   if (s->used + 2 > s->ev.size()) {
@@ -198,6 +198,8 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
   if (c->cg) (void)hipFree(c->cg);
   if (c->hist) (void)hipFree(c->hist);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->sj_ctr) (void)hipFree(c->sj_ctr);
+  if (c->sj_err) (void)hipHostFree(c->sj_err);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -212,6 +214,10 @@ extern "C" int qexhip_sync(qexhip_handle c) {
   CHK(peer_flush_join(c));
   HIPCHK(hipStreamSynchronize(c->cstream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->sj_err && __atomic_load_n(c->sj_err, __ATOMIC_ACQUIRE)) {
+    qexhip_set_error("sharded sweep: the boundary workgroups gave up waiting for the face exchange (QEXHIP_PEER_TIMEOUT)");
+    return QEXHIP_ERR_COMM;
+  }
   return peer_check(c);
 }
 
@@ -329,7 +335,8 @@ extern "C" int qexhip_stag_sweep_info(qexhip_handle c, int out[8]) {
   const int slot = c->ndir == 16;
   out[0] = c->g.halo;
   out[1] = overlap;
-  out[2] = c->g.halo ? hi_beg - lo_end : c->g.Vh;
+  const int hs = c->opt_hop_split >= 0 ? c->opt_hop_split : ((c->peer && c->opt_peer_zc) ? 2 : 0);
+  out[2] = (c->g.halo && !(overlap && hs)) ? hi_beg - lo_end : c->g.Vh;     // (hop split: the main launch covers the slab)
   out[3] = c->g.halo ? c->g.depth * c->g.F * 48 : 0;
   out[4] = c->overlap_auto[slot] >= 0;
   out[5] = (int)(c->overlap_tune_us[slot][0] + 0.5);
@@ -675,6 +682,7 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "peer_zc") c->opt_peer_zc = value;
   else if (n == "sweep_chain") c->opt_sweep_chain = value;
   else if (n == "peer_fold") c->opt_peer_fold = value;
+  else if (n == "hop_split") c->opt_hop_split = value;
   else if (n == "emu_exchange_us") c->emu_exchange_us = value;
   else if (n == "emu_allreduce_us") c->emu_allreduce_us = value;
   else if (n == "emu_link_gbs") c->emu_link_gbs = value;

@@ -276,7 +276,8 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
 // receive arena.  gh_hi / gh_lo come back pre-offset so that gh[vec_off(pos, colour)] addresses the ghost POSITION pos of the field
 // (ghost_hi: pos in [Vh, Vh + depth F), ghost_lo: the depth F positions behind it) -- the boundary launch reads them instead of the
 // field's ghost tiles, and peer_release_zc behind it returns the credits.  On the comm stream after ev_ready.
-int comm_halo_exchange_zc(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, bool wait_ready) {
+int comm_halo_exchange_zc(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, bool wait_ready, bool linger,
+                          PeerPush *push_only) {
   CHK(need_comm(c));
   if (!c->peer) { qexhip_set_error("internal: zero-copy halo exchange without the peer transport"); return QEXHIP_ERR_STATE; }
   const Geom &g = c->g;
@@ -284,10 +285,10 @@ int comm_halo_exchange_zc(qexhip_ctx *c, DevField &f, int parity, const double2 
   const size_t nd = face2 * 2;
   double2 *base = f.par(parity);
   const void *dn = base, *up = base + (size_t)(g.ntile) * 192 - face2;
-  if (wait_ready) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));      // (not when the comm stream produced the faces itself)
-  ScopedTimer tm(c, "exchange", c->cstream);
+  if (wait_ready && !push_only) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));      // (not when the comm stream produced the faces itself)
+  ScopedTimer tm(c, push_only ? nullptr : "exchange", c->cstream);
   const void *from_up = nullptr, *from_dn = nullptr;
-  CHK(peer_exchange(c, c->cstream, 1, &dn, 1, &up, nullptr, nullptr, nd * sizeof(double), emu_exchange_time(c, nd * sizeof(double)), &from_up, &from_dn));
+  CHK(peer_exchange(c, c->cstream, 1, &dn, 1, &up, nullptr, nullptr, nd * sizeof(double), emu_exchange_time(c, nd * sizeof(double)), &from_up, &from_dn, linger, push_only));
   // tile-aligned zones (64 | F): vec_off(pos, k) - vec_off(zone start, 0) = vec_off(pos - zone start, k)
   *gh_hi = (const double2 *)from_up - (size_t)(g.Vh >> 6) * 192;
   *gh_lo = (const double2 *)from_dn - (size_t)((g.Vh + g.depth * g.F) >> 6) * 192;

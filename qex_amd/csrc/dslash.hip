@@ -10,7 +10,9 @@
 #include "qexhip_internal.h"
 #include "site_index.h"
 #include "reduce.h"
+#include "peer_device.h"
 #include <hip/hip_ext.h>
+#include <cstring>
 #include <chrono>
 
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -28,11 +30,17 @@ struct DslashArgs {
   double post;           // final scale, the `r := (0.5*sc)*r` of stagD (stagD.nim:409)
   int parity, c0, c1;    // first site range [c0,c1)
   int d0, d1, nb1;       // optional second range [d0,d1) handled by workgroups >= nb1 (both t-faces in one launch)
+  int e0, e1, nb2;       // PART 3: third range [e0,e1) handled by workgroups >= nb2 (interior | low face | high face)
+  int nbA;               // PART 3: position of the boundary workgroups in the dispatch order (interior workgroups before and behind them)
   double *partials;
   const int *done;
   int swz;               // number of workgroups if XCD swizzle is on, else 0
   int ntstore;           // 1: non-temporal stores of the output
   const double2 *gh_hi, *gh_lo;   // GX kernels: where ghost POSITIONS are read from instead of `in` (pre-offset: gh[vec_off(pos, k)])
+  // PART == 2 on the peer transport: the launch waits in its prologue for the comm stream's arrival signal and, with a zero-copy
+  // receive, returns the two senders' credits from its last workgroup (peer_device.h: PeerGhost)
+  PeerGhost pg;
+  PeerPush push;         // PART 3 on the peer transport with a zero-copy receive: the launch's FIRST push.nblocks workgroups send the faces themselves
 };
 
 #include "dslash_core.h"
@@ -40,10 +48,35 @@ struct DslashArgs {
 // GX (t-sharded boundary launches of the peer transport): hops that leave the slab read the neighbours' faces where the exchange
 // kernel's neighbours WROTE them -- the transport's receive arena -- instead of the field's ghost tiles.  A tile lies in one
 // t-slice, so which base a t-hop reads from is wavefront-uniform: four scalar selects per wavefront, nothing per lane.
-template <int NDIR, bool HALO, bool INIT, bool DOT, int RECON, bool GX = false>
+// PART (t-sharded, overlapped sweeps split BY HOPS instead of by sites; shifts.nim's own order: local terms while the faces
+// travel, boundary terms when they are in):
+//   1  every site of the slab, every hop that stays inside it; sites with a hop that leaves it (the `depth` outermost slices
+//      either side) keep their RAW accumulator in `out` -- no final scale, no dot product;
+//   2  those sites only, the hops that leave the slab only (1 or 2 of 8 / 16 per site), on top of the raw accumulator; then the
+//      final scale, the store and the dot partial.  ~1/4 of a site's bytes, on 1/6 of the sites of a 48^3 x 12 slab: the only
+//      work left behind the exchange.  Its prologue waits for the comm stream's arrival signal;
+//   3  both in ONE launch: workgroups < nb1 take the interior tiles (the one-launch loop), the workgroups behind them -- dispatched
+//      last -- the boundary tiles: hops that stay inside the slab, then a bounded wait for the arrival signal (long raised by
+//      then unless the exchange is the longer of the two), then the hops that leave it, accumulator in registers throughout.
+// The sum of a boundary site runs local hops first, then the others: results agree with the one-launch kernel to rounding.
+template <int NDIR, bool HALO, bool INIT, bool DOT, int RECON, bool GX = false, int PART = 0>
 __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
-  if (A.done && *A.done) return;
-  if (GX) {
+  // a finished solve turns the rest of its chunk into no-ops -- except that a launch which owes credits still returns them
+  // (the exchanges on the comm stream go on, and their pushes wait for these credits)
+  const bool skip = A.done && *A.done;
+  if (skip && !(PART >= 2 && A.pg.ticket)) return;
+  __shared__ int arrived;
+  if (PART == 2 && A.pg.join) {
+    if (threadIdx.x == 0) arrived = peer_poll_ge(A.pg.join, A.pg.joinval, A.pg.err, A.pg.ticks, 0x500) ? 1 : 0;
+    __syncthreads();
+    if (!arrived) return;
+    if (!GX && threadIdx.x == 0) {        // (GX: the system-scope acquire below covers it)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (!GX) __syncthreads();
+  }
+  if (GX && PART != 3) {
     // the arena was written by other processes / devices: system-scope acquire on every CU that reads it
     if (threadIdx.x == 0) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -52,7 +85,23 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
     __syncthreads();
   }
   int bid = blockIdx.x;
-  if (A.swz) {
+  if (PART == 3 && GX) {
+    // the exchange inside the sweep: the workgroups dispatched first push this rank's faces into the neighbours' arenas -- no second
+    // stream, no event, no exchange launch (peer_device.h)
+    if (bid < A.push.nblocks) {
+      if (!skip) peer_push_block(A.push, (unsigned)bid);
+      return;
+    }
+    bid -= A.push.nblocks;
+  }
+  const int ngrid = (int)gridDim.x - ((PART == 3 && GX) ? A.push.nblocks : 0);
+  // PART 3: the boundary workgroups sit at position nbA of the dispatch order, interior workgroups before AND behind them: late
+  // enough for the faces to be in when they start (unless the exchange is the longer of the two), early enough for their slower
+  // rolled loops not to be the tail of the launch
+  const int nbnd = PART == 3 ? ngrid - A.nb1 : 0;
+  const bool bnd = PART == 3 && bid >= A.nbA && bid < A.nbA + nbnd;        // workgroup-uniform
+  if (PART == 3) bid = bnd ? A.nb1 + (bid - A.nbA) : (bid < A.nbA ? bid : bid - nbnd);
+  if (A.swz && !bnd) {
     // XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs; give every XCD a
     // contiguous run of tiles (= a contiguous t-range) so that y/z/t neighbours share its L2.
     int per = A.swz >> 3;
@@ -60,18 +109,104 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
   }
   int c = A.c0 + bid * 256 + threadIdx.x;
   int clim = A.c1;
-  if (bid >= A.nb1) { c = A.d0 + (bid - A.nb1) * 256 + threadIdx.x; clim = A.d1; }
+  if (bnd || (PART != 3 && bid >= A.nb1)) {
+    c = A.d0 + (bid - A.nb1) * 256 + threadIdx.x; clim = A.d1;
+    if (PART == 3 && bid >= A.nb2) { c = A.e0 + (bid - A.nb2) * 256 + threadIdx.x; clim = A.e1; }
+  }
   double dotv = 0;
-  if (c < clim) {
-    const Geom &g = A.g;
-    SiteXYZT s = site_coord(g, c, A.parity);
-    double2 acc[3];
-    double2 xsv[3];
-    if (INIT || DOT) {
+  const bool active = c < clim && !skip;
+  const Geom &g = A.g;
+  const SiteXYZT s = site_coord(g, c, A.parity);     // (arithmetic only: harmless beyond clim)
+  // a tile lies in one t-slice (64 | F on sharded handles): t is wavefront-uniform
+  const int tu = (GX || PART != 0) ? __builtin_amdgcn_readfirstlane(s.t) : 0;
+  const bool ghostdep = PART != 0 && (tu < g.depth || tu >= g.X[3] - g.depth);
+  double2 acc[3];
+  double2 xsv[3];
+  constexpr int NLOAD = RECON == 1 ? 6 : (RECON == 2 ? 7 : 9);
+  constexpr int LROW = NLOAD * 64;             // double2 per (tile, direction)
+  const double2 *w = A.W + (size_t)(c >> 6) * (NDIR * LROW) + (c & 63);
+  const unsigned long long *sm = RECON == 1 ? A.S + (size_t)(c >> 6) * NDIR : nullptr;
+  const double2 *in_f1 = A.in, *in_b1 = A.in, *in_f3 = A.in, *in_b3 = A.in;
+  if (GX) {
+    in_f1 = tu + 1 >= g.X[3] ? A.gh_hi : A.in;
+    in_b1 = tu - 1 < 0 ? A.gh_lo : A.in;
+    in_f3 = tu + 3 >= g.X[3] ? A.gh_hi : A.in;
+    in_b3 = tu - 3 < 0 ? A.gh_lo : A.in;
+  }
+  // One pair = the forward and the backward hop of one direction (fat links: pairs 0..3, 3-hop links: pairs 4..7);
+  // do_f / do_b: which of the two this call takes (literally true on the fast path).
+  auto pair = [&](const int pr, const bool do_f, const bool do_b) __attribute__((always_inline)) {
+    const int mu = pr & 3;
+    const int hop = pr >= 4 ? 3 : 1;
+    const int pf = nbr_pos<HALO>(g, c, s, mu, hop);
+    const int pb = nbr_pos<HALO>(g, c, s, mu, -hop);
+    const double2 *wp = w + (size_t)pr * (2 * LROW);
+    double2 U[9], W[9], vf[3], vb[3];
+    // links are read exactly once per sweep: stream them past the caches (non-temporal), which
+    // leaves L2 / Infinity Cache to the 8x re-read neighbour vectors.  Measured on MI355X,
+    // 32^4: 120 us -> 108 us per sweep (scratch/tune_dslash.py, profiles/r01_tune_dslash.log).
+    if (do_f) {
+#pragma unroll
+      for (int k = 0; k < NLOAD; k++) {
+        d2v t = __builtin_nontemporal_load((const d2v *)&wp[k * 64]);
+        U[k] = make_double2(t.x, t.y);
+      }
+    }
+    if (do_b) {
+#pragma unroll
+      for (int k = 0; k < NLOAD; k++) {
+        d2v t = __builtin_nontemporal_load((const d2v *)&wp[LROW + k * 64]);
+        W[k] = make_double2(t.x, t.y);
+      }
+    }
+    if (RECON == 1) {
+      const int lane = c & 63;
+      if (do_f) recon_row2<1>(U, (sm[2 * pr] >> lane) & 1ull);
+      if (do_b) recon_row2<1>(W, (sm[2 * pr + 1] >> lane) & 1ull);
+    } else if (RECON == 2) {
+      if (do_f) recon_row2<2>(U, false);
+      if (do_b) recon_row2<2>(W, false);
+    }
+    const double2 *srcf = (GX && mu == 3) ? (hop == 3 ? in_f3 : in_f1) : A.in;
+    const double2 *srcb = (GX && mu == 3) ? (hop == 3 ? in_b3 : in_b1) : A.in;
+    if (do_f) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) vf[k] = srcf[vec_off(pf, k)];
+    }
+    if (do_b) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) vb[k] = srcb[vec_off(pb, k)];
+    }
+    // forward hops add, backward hops subtract (compile-time sign: no per-direction multiply).
+    // stagDM's overall minus sign is carried by the initial value and the final scale: negation is
+    // exact, so init - sum == -((-init) + sum) bit for bit.
+    if (do_f) mv3<false>(acc, U, vf);
+    if (do_b) mv3<true>(acc, W, vb);
+  };
+  // the outermost slices of a hop-split sweep (wavefront-uniform branch): `crossing` false takes every hop but the t-hops that
+  // leave the slab, true exactly those.  Rolled: these few tiles must not cost the fast path registers.
+  auto edge_pairs = [&](const bool crossing) __attribute__((always_inline)) {
+#pragma unroll 1
+    for (int pr = (crossing ? 3 : 0); pr < NDIR / 2; pr += (crossing ? 4 : 1)) {
+      bool do_f = true, do_b = true;
+      if ((pr & 3) == 3) {
+        const int hop = pr >= 4 ? 3 : 1;
+        const bool xf = tu + hop >= g.X[3], xb = tu - hop < 0;
+        do_f = crossing ? xf : !xf;
+        do_b = crossing ? xb : !xb;
+      }
+      pair(pr, do_f, do_b);
+    }
+  };
+  if (active) {
+    if ((INIT && PART != 2) || DOT) {
 #pragma unroll
       for (int k = 0; k < 3; k++) xsv[k] = A.xs[vec_off(c, k)];
     }
-    if (INIT) {
+    if (PART == 2) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) acc[k] = A.out[vec_off(c, k)];          // the raw accumulator PART 1 left here
+    } else if (INIT) {
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         acc[k].x = (A.sgn * A.cb) * xsv[k].x;
@@ -89,86 +224,73 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
 #pragma unroll
       for (int k = 0; k < 3; k++) acc[k] = make_double2(0.0, 0.0);
     }
-    constexpr int NLOAD = RECON == 1 ? 6 : (RECON == 2 ? 7 : 9);
-    constexpr int LROW = NLOAD * 64;             // double2 per (tile, direction)
-    const double2 *w = A.W + (size_t)(c >> 6) * (NDIR * LROW) + (c & 63);
-    const unsigned long long *sm = RECON == 1 ? A.S + (size_t)(c >> 6) * NDIR : nullptr;
-    const double2 *in_f1 = A.in, *in_b1 = A.in, *in_f3 = A.in, *in_b3 = A.in;
-    if (GX) {
-      const int tu = __builtin_amdgcn_readfirstlane(s.t);
-      in_f1 = tu + 1 >= g.X[3] ? A.gh_hi : A.in;
-      in_b1 = tu - 1 < 0 ? A.gh_lo : A.in;
-      in_f3 = tu + 3 >= g.X[3] ? A.gh_hi : A.in;
-      in_b3 = tu - 3 < 0 ? A.gh_lo : A.in;
-    }
-    // One loop iteration = the forward and the backward hop of one direction (fat links: pairs
-    // 0..3, 3-hop links: pairs 4..7).  How far the loop is unrolled decides how many link loads a
-    // wave keeps in flight.  Measured inside CG on 32^4 (scratch A/B builds, 2 rounds):
+    // How far the loop is unrolled decides how many link loads a wave keeps in flight.  Measured inside CG on 32^4
+    // (scratch A/B builds, 2 rounds):
     //   1-hop: rolled 117 us, x2 120 us, fully unrolled 113.6 us (all 96 loads in flight, 256 VGPRs)
     //   Naik : rolled 215 us, x2 210 us, x4 222 us; FULLY unrolled hipcc hoists all 192 loads and
     //          spills to scratch (290-330 us) -- never unroll the 16-link loop completely.
     // mu/hop are wave-uniform, so the neighbour arithmetic of the rolled loop branches on scalars.
     // compressed 8-link kernel (rows 0,1 + sign, 864 B/site): rolled 80.2 us, x2 81.9, x4 83.5 (32^4, in CG)
     constexpr int UNR = (NDIR == 8) ? (RECON ? 1 : 4) : 2;
+    if (PART == 0 || (PART != 2 && !ghostdep)) {
+      // every hop of the site: the loop of the one-launch kernel
 #pragma unroll UNR
-    for (int pr = 0; pr < NDIR / 2; pr++) {
-      const int mu = pr & 3;
-      const int hop = pr >= 4 ? 3 : 1;
-      const int pf = nbr_pos<HALO>(g, c, s, mu, hop);
-      const int pb = nbr_pos<HALO>(g, c, s, mu, -hop);
-      const double2 *wp = w + (size_t)pr * (2 * LROW);
-      double2 U[9], W[9], vf[3], vb[3];
-      // links are read exactly once per sweep: stream them past the caches (non-temporal), which
-      // leaves L2 / Infinity Cache to the 8x re-read neighbour vectors.  Measured on MI355X,
-      // 32^4: 120 us -> 108 us per sweep (scratch/tune_dslash.py, profiles/r01_tune_dslash.log).
-#pragma unroll
-      for (int k = 0; k < NLOAD; k++) {
-        d2v t = __builtin_nontemporal_load((const d2v *)&wp[k * 64]);
-        U[k] = make_double2(t.x, t.y);
-      }
-#pragma unroll
-      for (int k = 0; k < NLOAD; k++) {
-        d2v t = __builtin_nontemporal_load((const d2v *)&wp[LROW + k * 64]);
-        W[k] = make_double2(t.x, t.y);
-      }
-      if (RECON == 1) {
-        const int lane = c & 63;
-        recon_row2<1>(U, (sm[2 * pr] >> lane) & 1ull);
-        recon_row2<1>(W, (sm[2 * pr + 1] >> lane) & 1ull);
-      } else if (RECON == 2) {
-        recon_row2<2>(U, false);
-        recon_row2<2>(W, false);
-      }
-      const double2 *srcf = (GX && mu == 3) ? (hop == 3 ? in_f3 : in_f1) : A.in;
-      const double2 *srcb = (GX && mu == 3) ? (hop == 3 ? in_b3 : in_b1) : A.in;
-#pragma unroll
-      for (int k = 0; k < 3; k++) vf[k] = srcf[vec_off(pf, k)];
-#pragma unroll
-      for (int k = 0; k < 3; k++) vb[k] = srcb[vec_off(pb, k)];
-      // forward hops add, backward hops subtract (compile-time sign: no per-direction multiply).
-      // stagDM's overall minus sign is carried by the initial value and the final scale: negation is
-      // exact, so init - sum == -((-init) + sum) bit for bit.
-      mv3<false>(acc, U, vf);
-      mv3<true>(acc, W, vb);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      acc[k].x *= (A.sgn * A.post); acc[k].y *= (A.sgn * A.post);
-      if (A.ntstore) {
-        d2v t; t.x = acc[k].x; t.y = acc[k].y;
-        __builtin_nontemporal_store(t, (d2v *)&A.out[vec_off(c, k)]);
-      } else {
-        A.out[vec_off(c, k)] = acc[k];
-      }
-    }
-    if (DOT) {
-#pragma unroll
-      for (int k = 0; k < 3; k++) dotv = fma(xsv[k].x, acc[k].x, fma(xsv[k].y, acc[k].y, dotv));
+      for (int pr = 0; pr < NDIR / 2; pr++) pair(pr, true, true);
+    } else {
+      edge_pairs(PART == 2);
     }
   }
-  if (DOT) {
+  const int pidx = (PART == 3 && GX) ? (int)blockIdx.x - A.push.nblocks : (int)blockIdx.x;      // (partials: the pushing workgroups have none)
+  if (PART == 3 && bnd && !skip) {
+    // the faces: a bounded wait (one lane), then the acquire for what other devices / the comm stream wrote
+    if (threadIdx.x == 0) {
+      arrived = peer_ghost_wait(A.pg) ? 1 : 0;
+      if (GX) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (active && arrived) edge_pairs(true);
+  }
+  if (active) {
+    if (PART == 1 && ghostdep) {
+      // a hop of this site leaves the slab: the raw accumulator waits in `out` for the PART 2 launch (which re-reads it soon: plain stores)
+#pragma unroll
+      for (int k = 0; k < 3; k++) A.out[vec_off(c, k)] = acc[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        acc[k].x *= (A.sgn * A.post); acc[k].y *= (A.sgn * A.post);
+        if (A.ntstore) {
+          d2v t; t.x = acc[k].x; t.y = acc[k].y;
+          __builtin_nontemporal_store(t, (d2v *)&A.out[vec_off(c, k)]);
+        } else {
+          A.out[vec_off(c, k)] = acc[k];
+        }
+      }
+      if (DOT) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dotv = fma(xsv[k].x, acc[k].x, fma(xsv[k].y, acc[k].y, dotv));
+      }
+    }
+  }
+  if (DOT && !skip) {
     double r = block_sum_256(dotv);
-    if (threadIdx.x == 0) A.partials[blockIdx.x] = r;
+    if (threadIdx.x == 0) A.partials[pidx] = r;
+  }
+  if ((PART == 2 || (PART == 3 && bnd)) && A.pg.ticket) {
+    // zero-copy receive: the workgroup whose ticket comes last returns the arena halves to the two senders (every wave's loads of
+    // the arena have returned before its workgroup takes the ticket)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned a = __hip_atomic_fetch_add(A.pg.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a == (unsigned)(PART == 3 ? nbnd : (int)gridDim.x) - 1) {
+        __hip_atomic_store(A.pg.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(A.pg.credit[0], A.pg.credit_val[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(A.pg.credit[1], A.pg.credit_val[1], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 
@@ -184,23 +306,50 @@ static void launch_timed(qexhip_ctx *c, const char *tname, K kernel, dim3 grid, 
 
 template <int NDIR, bool HALO>
 static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool dot, int part_off,
-                  int d0 = 0, int d1 = 0, const char *tname = "dslash", hipStream_t st = nullptr, bool gx = false) {
+                  int d0 = 0, int d1 = 0, const char *tname = "dslash", hipStream_t st = nullptr, bool gx = false, int part = 0,
+                  int e0 = 0, int e1 = 0) {
   if (!st) st = c->stream;
   if (c1 <= c0 && d1 <= d0) return 0;
   if (c1 <= c0) { c0 = d0; c1 = d1; d0 = d1 = 0; }
-  A.c0 = c0; A.c1 = c1; A.d0 = d0; A.d1 = d1;
+  A.c0 = c0; A.c1 = c1; A.d0 = d0; A.d1 = d1; A.e0 = e0; A.e1 = e1;
   A.nb1 = (c1 - c0 + 255) / 256;
-  int nb = A.nb1 + (d1 > d0 ? (d1 - d0 + 255) / 256 : 0);
+  A.nb2 = A.nb1 + (d1 > d0 ? (d1 - d0 + 255) / 256 : 0);
+  int nb = A.nb2 + (e1 > e0 ? (e1 - e0 + 255) / 256 : 0);
   // XCD swizzle: measured on for compressed links, off for 18-real links (profiles/r01_tune_dslash.log); output stores are
   // non-temporal (the result is read by the NEXT kernel, after 0.6 GB of links went through the caches)
-  A.swz = (c->recon != 0 && nb >= 64 && (nb & 7) == 0) ? nb : 0;
+  const int nsw = part == 3 ? A.nb1 : nb;          // (the fused launch remaps its interior workgroups only)
+  A.nbA = part == 3 ? (int)(0.65 * A.nb1) : 0;
+  A.swz = (c->recon != 0 && nsw >= 64 && (nsw & 7) == 0) ? nsw : 0;
   A.ntstore = 1;
   double *psave = A.partials;
   A.partials = psave ? psave + part_off : nullptr;
-  dim3 grid(nb), block(256);
+  if (!(part == 3 && gx)) A.push.nblocks = 0;
+  dim3 grid(nb + A.push.nblocks), block(256);
 #define QX_LAUNCH(R) \
   do { \
-    if (HALO && gx) { \
+    if (HALO && part == 3) { \
+      if (gx) { \
+        if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true, R, HALO, HALO ? 3 : 0>, grid, block, A, st); \
+        else if (init) launch_timed(c, tname, k_dslash<NDIR, HALO, true, false, R, HALO, HALO ? 3 : 0>, grid, block, A, st); \
+        else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true, R, HALO, HALO ? 3 : 0>, grid, block, A, st); \
+        else launch_timed(c, tname, k_dslash<NDIR, HALO, false, false, R, HALO, HALO ? 3 : 0>, grid, block, A, st); \
+      } else { \
+        if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true, R, false, HALO ? 3 : 0>, grid, block, A, st); \
+        else if (init) launch_timed(c, tname, k_dslash<NDIR, HALO, true, false, R, false, HALO ? 3 : 0>, grid, block, A, st); \
+        else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true, R, false, HALO ? 3 : 0>, grid, block, A, st); \
+        else launch_timed(c, tname, k_dslash<NDIR, HALO, false, false, R, false, HALO ? 3 : 0>, grid, block, A, st); \
+      } \
+    } else if (HALO && part == 2) { \
+      if (gx && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true, R, HALO, HALO ? 2 : 0>, grid, block, A, st); \
+      else if (gx) launch_timed(c, tname, k_dslash<NDIR, HALO, false, false, R, HALO, HALO ? 2 : 0>, grid, block, A, st); \
+      else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true, R, false, HALO ? 2 : 0>, grid, block, A, st); \
+      else launch_timed(c, tname, k_dslash<NDIR, HALO, false, false, R, false, HALO ? 2 : 0>, grid, block, A, st); \
+    } else if (HALO && part == 1) { \
+      if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true, R, false, HALO ? 1 : 0>, grid, block, A, st); \
+      else if (init) launch_timed(c, tname, k_dslash<NDIR, HALO, true, false, R, false, HALO ? 1 : 0>, grid, block, A, st); \
+      else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true, R, false, HALO ? 1 : 0>, grid, block, A, st); \
+      else launch_timed(c, tname, k_dslash<NDIR, HALO, false, false, R, false, HALO ? 1 : 0>, grid, block, A, st); \
+    } else if (HALO && gx) { \
       if (init && dot) launch_timed(c, tname, k_dslash<NDIR, HALO, true, true, R, HALO>, grid, block, A, st); \
       else if (init) launch_timed(c, tname, k_dslash<NDIR, HALO, true, false, R, HALO>, grid, block, A, st); \
       else if (dot) launch_timed(c, tname, k_dslash<NDIR, HALO, false, true, R, HALO>, grid, block, A, st); \
@@ -216,6 +365,33 @@ static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool 
 #undef QX_LAUNCH
   A.partials = psave;
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// The fused hop-split launch waits on the device for "the faces are in".  The peer transport has its join counters; the RCCL arm (and
+// the communicator-less rehearsal) gets the same from the context: a counter a one-lane kernel raises on the comm stream behind the
+// exchange, an error word in pinned memory, the timeout of every other device-side wait (QEXHIP_PEER_TIMEOUT).
+__global__ void k_sweep_signal(unsigned long long *ctr, unsigned long long val) {
+  if (threadIdx.x == 0) __hip_atomic_store(ctr, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+static int sweep_join_args(qexhip_ctx *c, PeerGhost *G) {
+  if (!c->sj_ctr) {
+    HIPCHK(hipMalloc((void **)&c->sj_ctr, 128));
+    HIPCHK(hipMemset(c->sj_ctr, 0, 128));
+    HIPCHK(hipHostMalloc((void **)&c->sj_err, 64, hipHostMallocDefault));
+    *c->sj_err = 0;
+    double tmo = 30.0;
+    if (const char *e = getenv("QEXHIP_PEER_TIMEOUT")) { const double v = atof(e); if (v > 0) tmo = v; }
+    int khz = 0;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device);
+    if (khz <= 0) khz = 100000;
+    c->sj_ticks = (long long)(tmo * 1000.0 * khz);
+  }
+  k_sweep_signal<<<1, 64, 0, c->cstream>>>(c->sj_ctr, ++c->sj_seq);
+  HIPCHK(hipGetLastError());
+  memset(G, 0, sizeof *G);
+  G->join = c->sj_ctr; G->joinval = c->sj_seq;
+  G->err = c->sj_err; G->ticks = c->sj_ticks;
   return 0;
 }
 
@@ -247,7 +423,7 @@ void sweep_plan(const qexhip_ctx *c, int *lo_end_out, int *hi_beg_out, int *over
 // slab deep enough for a narrowed interior
 static bool chain_possible(const qexhip_ctx *c) {
   const Geom &g = c->g;
-  return g.halo && c->peer && c->opt_peer_zc && g.Vh - 4 * g.depth * g.F > 0;
+  return g.halo && c->peer && c->opt_peer_zc && c->opt_hop_split == 0 && g.Vh - 4 * g.depth * g.F > 0;
 }
 // ... and whether an overlapped pair runs chained: option "sweep_chain" 1 / 0, or at -1 what sweep_autotune measured (off until then)
 static bool chain_on(const qexhip_ctx *c) {
@@ -265,11 +441,11 @@ int sweep_autotune(qexhip_ctx *c) {
     // The overlap decision selects the stream (and, on RCCL, the communicator) an exchange is posted on: ranks that disagreed
     // would never match.  set_links is collective, so this is the place to find out (QEXHIP_OVERLAP / option "overlap").
     // The forms of the overlapped sweep (peer_zc, sweep_chain) ride along: they regroup the dot partials, not the messages.
-    const double code = 64.0 * c->opt_overlap + 8.0 * (c->opt_sweep_chain + 1) + c->opt_peer_zc;
+    const double code = 64.0 * c->opt_overlap + 8.0 * (c->opt_sweep_chain + 1) + c->opt_peer_zc + 1024.0 * (c->opt_hop_split + 1);
     double v[2] = {code, -code};
     CHK(comm_allreduce_max(c, v, 2));
     if (v[0] != -v[1]) {
-      qexhip_set_error("options overlap (QEXHIP_OVERLAP) / sweep_chain / peer_zc differ between the ranks (64 overlap + 8 (sweep_chain + 1) + peer_zc = %g .. %g): "
+      qexhip_set_error("options overlap (QEXHIP_OVERLAP) / sweep_chain / peer_zc / hop_split differ between the ranks (1024 (hop_split + 1) + 64 overlap + 8 (sweep_chain + 1) + peer_zc = %g .. %g): "
                        "they must be the same everywhere", -v[1], v[0]);
       return -3;
     }
@@ -348,6 +524,8 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
   A.partials = c->partials;
   A.done = o.done;
   A.gh_hi = A.gh_lo = nullptr;
+  memset(&A.pg, 0, sizeof A.pg);
+  memset(&A.push, 0, sizeof A.push);
   const bool init = (o.ca != 0.0 || o.cb != 0.0);
   if ((init || o.dot) && !A.xs) { qexhip_set_error("dslash_sweep: b-term/dot needs xs"); return -1; }
   if (o.ca != 0.0 && !A.rin) { qexhip_set_error("dslash_sweep: a-term needs rin"); return -1; }
@@ -367,6 +545,49 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
     // launch widened by as much, on the comm stream behind sweep 1's (in order) and behind ev_ready (sweep 1's interior).  The faces
     // sweep 2 sends are sweep 1's boundary output, the comm stream's own work: its exchange starts without waiting for anything.
     // One join per operator instead of two, and the second exchange is posted ~30 us earlier.
+    const int hop_split = !overlap ? 0 : (c->opt_hop_split >= 0 ? c->opt_hop_split : (zc ? 2 : 0));
+    if (hop_split) {
+      // Overlapped sweep split BY HOPS (option hop_split): the hops that stay inside the slab are taken while the faces travel, the
+      // 1-2 hops per boundary site that leave it once they are in -- ~1/4 of the bytes of 2 * depth slices is all that is left behind
+      // the exchange.  2 (default): ONE launch on the compute stream, interior workgroups first, the boundary workgroups behind
+      // them wait on the device for the signal the comm stream raises behind the exchange (long raised by then unless the exchange
+      // is the longer of the two); no second launch, no join, nothing on the comm stream but the exchange.  1: two launches (whole
+      // slab; boundary sites on top of their raw accumulators), for the A/B.  Zero-copy receive on the peer transport either way:
+      // the last boundary workgroup returns the credits.
+      if (c->chain_pending) { c->chain_pending = 0; CHK(peer_stream_join(c, c->stream, c->cstream)); }
+      CHK(peer_flush_join(c));
+      // fused + zero-copy (peer transport): the exchange is INSIDE the launch -- its first workgroups push the faces, its boundary
+      // workgroups poll the inbound data words -- and the comm stream is not involved at all
+      const bool direct = zc && hop_split == 2;
+      if (!direct) HIPCHK(hipEventRecord(c->ev_ready, c->stream));
+      if (direct) CHK(comm_halo_exchange_zc(c, in, 1 - parity, &A.gh_hi, &A.gh_lo, false, false, &A.push));
+      else if (zc) CHK(comm_halo_exchange_zc(c, in, 1 - parity, &A.gh_hi, &A.gh_lo));
+      else CHK(comm_halo_exchange(c, in, 1 - parity, 1));
+      const int nb_lo = (lo_end + 255) / 256, nb_hi = (g.Vh - hi_beg + 255) / 256;
+      if (c->peer) {
+        if (!direct) CHK(peer_stream_signal(c, c->cstream));
+        CHK(peer_ghost_args(c, &A.pg, zc, direct));
+      } else if (hop_split == 2) CHK(sweep_join_args(c, &A.pg));
+      else HIPCHK(hipEventRecord(c->ev_halo, c->cstream));
+      if (hop_split == 2) {
+        if (c->ndir == 8) CHK((launch<8, true>(c, A, lo_end, hi_beg, init, o.dot, 0, 0, lo_end, "dslash", nullptr, zc, 3, hi_beg, g.Vh)));
+        else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0, 0, lo_end, "dslash", nullptr, zc, 3, hi_beg, g.Vh)));
+        nparts = (hi_beg - lo_end + 255) / 256 + nb_lo + nb_hi;
+      } else {
+        const int nb_main = (g.Vh + 255) / 256;
+        PeerGhost pg = A.pg;
+        memset(&A.pg, 0, sizeof A.pg);
+        if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, g.Vh, init, o.dot, 0, 0, 0, "dslash", nullptr, false, 1)));
+        else CHK((launch<16, true>(c, A, 0, g.Vh, init, o.dot, 0, 0, 0, "dslash", nullptr, false, 1)));
+        A.pg = pg;
+        if (!c->peer) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+        if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, false, o.dot, nb_main, hi_beg, g.Vh, "dslash_bnd", nullptr, zc, 2)));
+        else CHK((launch<16, true>(c, A, 0, lo_end, false, o.dot, nb_main, hi_beg, g.Vh, "dslash_bnd", nullptr, zc, 2)));
+        nparts = nb_main + nb_lo + nb_hi;
+      }
+      memset(&A.pg, 0, sizeof A.pg);
+      memset(&A.push, 0, sizeof A.push);
+    } else {
     const bool chain_ok = zc && chain_on(c);
     if (c->chain_pending && !(o.chain == 2 && chain_ok)) {       // a broken pair: join first, then an ordinary sweep
       c->chain_pending = 0;
@@ -416,6 +637,7 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
       HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
       }
       nparts = nb_int + nb_lo + (g.Vh - hi_beg + 255) / 256;
+    }
     }
   }
   if (o.dot) {

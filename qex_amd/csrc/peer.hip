@@ -43,7 +43,7 @@
 
 static_assert(sizeof(hipIpcMemHandle_t) <= PEER_HANDLE_BYTES, "ipc handle size");
 
-enum { PEER_MAXSEG = 32, PEER_CHUNK = 4096, PEER_MBOX_N = 4096 };
+enum { PEER_MAXSEG = 32, PEER_MBOX_N = 4096 };
 // control block, in 8-byte words: every polled word on a 128-byte line of its own
 enum { CW_DATA = 0 /* + (s*2+d)*16 */, CW_CREDIT = 64 /* + (s*2+dir)*16 */, CW_MFLAG = 256 /* + slot*PEER_MAXR + src */,
        CW_GRAN = 1024 /* + ((slot*PEER_MAXR + src)*PEER_GRAN_N + i)*2 */,
@@ -66,7 +66,7 @@ struct PeerComm {
   u64 join_seq[2]{};                     // peer_stream_signal / _join sequence numbers
   int join_deferred = 0;                 // the compute stream still owes a wait for join_seq[1] (peer_stream_join_defer): the next granule all-reduce of
                                          // workgroup partials polls for it in its prologue, anything else flushes it first (peer_flush_join)
-  struct { int live = 0; u64 *credit_out[2]; u64 seq_in[2]; } zc[2];   // per stream class: the zero-copy exchange whose credits are still owed
+  struct { int live = 0; u64 *credit_out[2]; u64 seq_in[2]; const u64 *in_flag[2]; long long emu_ticks; } zc[2];   // per stream class: the zero-copy exchange whose credits are still owed
   long long ticks = 0;                   // timeout in wall_clock64 ticks
   double timeout_s = 30.0;
   long exchanges = 0, allreduces = 0, grows = 0;
@@ -77,22 +77,6 @@ static inline int upper(const PeerComm *p) { return (p->rank + 1) % p->nranks; }
 static inline int lower(const PeerComm *p) { return (p->rank - 1 + p->nranks) % p->nranks; }
 
 // ---------------- device side ----------------
-__device__ inline bool peer_poll_ge(const u64 *p, u64 want, u64 *err, long long ticks, u64 code) {
-  if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
-  const long long t0 = wall_clock64();
-  for (unsigned it = 1;; it++) {
-    __builtin_amdgcn_s_sleep(4);
-    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want) return true;
-    if ((it & 255) == 0) {
-      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;    // somebody gave up already
-      if (wall_clock64() - t0 > ticks) {
-        __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return false;
-      }
-    }
-  }
-}
-
 struct PeerXfer {
   const uint4 *src[2][PEER_MAXSEG];   // pieces to [lower | upper]
   uint4 *dst[2][PEER_MAXSEG];         // destinations of the pieces from [lower | upper]
@@ -109,33 +93,16 @@ struct PeerXfer {
   long long emu_ticks;                // transport emulation: the inbound data counts as arrived no earlier than this long after the kernel started
   unsigned n16;                       // 16-byte units per piece (< 2^32: pieces below 64 GiB)
   int ns[2], nr[2];
-  int zc;                             // zero-copy receive: what arrives stays in the arena for the consumer (peer_exchange_zc); no unpack, no credit here
+  int zc;                             // zero-copy receive: what arrives stays in the arena for the consumer; no unpack, no credit here.
+                                      // 1: one workgroup stays until the faces are in (the stream order behind this kernel means "arrived");
+                                      // 2: nobody stays -- the consumer polls the data words itself (fused hop-split sweep)
+  long long *t_start_out;             // zc == 2 under emulation: when this kernel started (the consumer counts the transport time from here)
 };
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ inline void peer_copy_chunk(uint4 *__restrict__ d4, const uint4 *__restrict__ s4, unsigned n) {
-  // n <= PEER_CHUNK units, 256 lanes.  Whole chunks: 16 loads (256 B) in flight per lane before the first store -- beside an
-  // HBM-saturating sweep a copy gets bandwidth in proportion to the requests it keeps outstanding
-  u32x4 *__restrict__ d = (u32x4 *)d4;
-  const u32x4 *__restrict__ s = (const u32x4 *)s4;
-  if (n == PEER_CHUNK) {
-    u32x4 v[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) v[j] = s[threadIdx.x + 256 * j];
-    // all 16 loads issued before the first store: hipcc otherwise sinks every load to its store (one 16-byte request in flight
-    // per lane; seen in the ISA).  An empty asm that "modifies" the values pins them in registers at this point.
-#pragma unroll
-    for (int j = 0; j < 16; j++) asm volatile("" : "+v"(v[j]));
-#pragma unroll
-    for (int j = 0; j < 16; j++) d[threadIdx.x + 256 * j] = v[j];
-  } else {
-    for (unsigned i = threadIdx.x; i < n; i += 256) d[i] = s[i];
-  }
-}
 
 __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
   __shared__ int ok;
   const long long t_start = X.emu_ticks > 0 ? wall_clock64() : 0;
+  if (X.t_start_out && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(X.t_start_out, t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // NOTE all chunk arithmetic is 32-bit on purpose: with a 64-bit `n16 - off < PEER_CHUNK ? n16 - off : PEER_CHUNK` hipcc
   // (ROCm 7.2, gfx950) selected the tail length on a stale SCC (s_cselect_b32 behind a VALU v_cmp_lt_u64): piece 0 of a
   // multi-piece message copied a whole chunk and ran over its neighbour in the arena (profiles/r05_notes.md)
@@ -171,7 +138,7 @@ __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
     }
   }
   // ---- unpack ----
-  if (X.zc && blockIdx.x != 0) return;             // zero-copy: ONE workgroup keeps the kernel alive until the faces have arrived
+  if (X.zc == 2 || (X.zc && blockIdx.x != 0)) return;   // zero-copy: ONE workgroup keeps the kernel alive until the faces have arrived, or (2) none
   const unsigned nin = (unsigned)(X.nr[0] + X.nr[1]) * cpp;
   if (threadIdx.x == 0) {
     int good = 1;
@@ -446,7 +413,7 @@ static int peer_ensure_arena(qexhip_ctx *c, int s, size_t bytes) {
 // where the faces from the upper / lower neighbour lie in the receive arena, and the credits stay owed until peer_release_zc.
 int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *src_dn, int ns_up, const void *const *src_up,
                   void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us, const void **zc_from_up,
-                  const void **zc_from_dn) {
+                  const void **zc_from_dn, bool zc_linger, PeerPush *push_only) {
   PeerComm *p = c->peer;
   const bool zc = zc_from_up && zc_from_dn;
   if (zc && (ns_dn != 1 || ns_up != 1)) { qexhip_set_error("peer transport: zero-copy receive takes one piece per direction"); return QEXHIP_ERR_ARG; }
@@ -463,7 +430,8 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
     if (p->zc[s].live) { qexhip_set_error("peer transport: an exchange was posted while the credits of a zero-copy receive are still owed"); return QEXHIP_ERR_STATE; }
     for (int k = 0; k < nd; k++) { X.src[0][k] = (const uint4 *)src_dn[k0 + k]; X.dst[1][k] = zc ? nullptr : (uint4 *)dst_from_up[k0 + k]; }
     for (int k = 0; k < nu; k++) { X.src[1][k] = (const uint4 *)src_up[k0 + k]; X.dst[0][k] = zc ? nullptr : (uint4 *)dst_from_dn[k0 + k]; }
-    X.zc = zc ? 1 : 0;
+    X.zc = zc ? (zc_linger ? 1 : 2) : 0;
+    X.t_start_out = (zc && !zc_linger) ? (long long *)(p->ready + 56) : nullptr;
     X.ns[0] = nd; X.ns[1] = nu; X.nr[0] = nu; X.nr[1] = nd;
     if (bytes / 16 >= ((size_t)1 << 32) - PEER_CHUNK) { qexhip_set_error("peer transport: a piece of %zu bytes is too large", bytes); return QEXHIP_ERR_ARG; }
     X.n16 = (unsigned)(bytes / 16);
@@ -498,12 +466,23 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
     // never put this kernel on a CU-masked stream with fewer slots than its grid -- the round-5 experiment that gave the comm
     // stream 8 CUs of its own deadlocked until the grid was capped (and lost anyway: profiles/r05_comm_cus_experiment.log).
     const int grid = (int)std::min<size_t>(nch, std::max<size_t>(2, std::min<size_t>(128, tot >> 16)));
-    hipLaunchKernelGGL(k_peer_exchange, dim3(grid), dim3(256), 0, st, X);
-    HIPCHK(hipGetLastError());
+    if (push_only) {
+      // the caller's own kernel pushes (its first `nblocks` workgroups run peer_push_block): nothing is launched here
+      if (!zc || zc_linger) { qexhip_set_error("internal: push-only exchange without a direct zero-copy receive"); return QEXHIP_ERR_STATE; }
+      PeerPush &P = *push_only;
+      for (int d = 0; d < 2; d++) {
+        P.src[d] = X.src[d][0]; P.out_arena[d] = X.out_arena[d]; P.out_flag[d] = X.out_flag[d]; P.credit[d] = X.credit[d]; P.seq_out[d] = X.seq_out[d];
+      }
+      P.n16 = X.n16; P.done = X.done; P.t_start_out = X.t_start_out; P.err = X.err; P.ticks = X.ticks; P.nblocks = grid;
+    } else {
+      hipLaunchKernelGGL(k_peer_exchange, dim3(grid), dim3(256), 0, st, X);
+      HIPCHK(hipGetLastError());
+    }
     p->exchanges++;
     if (zc) {
       p->zc[s].live = 1;
-      for (int d = 0; d < 2; d++) { p->zc[s].credit_out[d] = X.credit_out[d]; p->zc[s].seq_in[d] = X.seq_in[d]; }
+      for (int d = 0; d < 2; d++) { p->zc[s].credit_out[d] = X.credit_out[d]; p->zc[s].seq_in[d] = X.seq_in[d]; p->zc[s].in_flag[d] = X.in_flag[d]; }
+      p->zc[s].emu_ticks = X.emu_ticks;
       *zc_from_dn = X.in_arena[0];
       *zc_from_up = X.in_arena[1];
     }
@@ -603,6 +582,28 @@ int peer_allreduce_parts(qexhip_ctx *c, double *parts, int n) {
   hipLaunchKernelGGL((k_peer_allreduce_small<0, true>), dim3(1), dim3(256), 0, c->stream, parts, 1, n, G, ++p->seq_red, join, p->join_seq[1]);
   p->allreduces++;
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int peer_ghost_args(qexhip_ctx *c, PeerGhost *G, bool zc, bool direct) {
+  PeerComm *p = c->peer;
+  memset(G, 0, sizeof *G);
+  G->err = p->err; G->ticks = p->ticks;
+  if (direct && zc) {
+    // the consumer polls the two data words itself: nothing was posted behind the exchange kernel, which did not stay either
+    for (int d = 0; d < 2; d++) { G->flag[d] = p->zc[1].in_flag[d]; G->flagval[d] = p->zc[1].seq_in[d]; }
+    G->t_start = (const long long *)(p->ready + 56);
+    G->emu_ticks = p->zc[1].emu_ticks;
+  } else {
+    G->join = p->ready + 16;               // joins FROM the comm stream
+    G->joinval = p->join_seq[1];
+  }
+  if (zc) {
+    if (!p->zc[1].live) { qexhip_set_error("peer transport: no zero-copy receive to release"); return QEXHIP_ERR_STATE; }
+    G->ticket = p->tail_count + 32;      // a line of its own (p->ready + 48)
+    for (int d = 0; d < 2; d++) { G->credit[d] = p->zc[1].credit_out[d]; G->credit_val[d] = p->zc[1].seq_in[d]; }
+    p->zc[1].live = 0;
+  }
   return 0;
 }
 

@@ -118,6 +118,13 @@ struct qexhip_ctx {
   int opt_obs_clover = 1; // option "obs_clover" (test hook): 0 takes the generic path walker, the form fmunu loops 3-5 get, for loop 1 as well
   int opt_peer_zc = 1;    // option "peer_zc" (A/B, test hook): 1 = the boundary launch of an overlapped sweep reads the neighbours' faces straight from the
                           // peer transport's receive arena (no unpack kernel phase), 0 = they are copied into the field's ghost tiles first
+  int opt_hop_split = -1;    // option "hop_split": how an overlapped sweep is split.  2 = by hops in ONE launch (interior workgroups, and boundary workgroups
+                             // that wait on the device for the faces between their local and their remote hops; on the peer transport with a
+                             // zero-copy receive the launch also pushes the faces itself: no second stream at all), 1 = by hops in two launches
+                             // (A/B), 0 = by sites (interior launch | boundary launch on the comm stream; rounds 1-5a), -1 = 2 on the peer
+                             // transport with zero-copy receive, else 0 (measured: profiles/r05_hop_split.log)
+  unsigned long long *sj_ctr = nullptr, *sj_err = nullptr, sj_seq = 0;   // the fused launch's arrival signal without the peer transport (dslash.hip)
+  long long sj_ticks = 0;
   int opt_peer_fold = 0;     // option "peer_fold" (A/B, test hook): 1 = the |r|^2 all-reduce of a sharded CG iteration on the peer transport runs in the tail of
                              // k_cg_update (last-arriver workgroup), 0 = as a launch of its own behind it.  Measured 8-10 us per iteration SLOWER
                              // folded (profiles/r05_fold_compare.log: write-through partials + 2600 arrival tickets + a serial tail cost more
@@ -206,7 +213,8 @@ int solve_batch_host(qexhip_ctx *c, int n, double *const *x, const double *const
 inline bool multi_rank(const qexhip_ctx *c) { return c->nranks > 1 || c->opt_multi_reduce; }
 
 // ---- comm.cpp ----
-int comm_halo_exchange_zc(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, bool wait_ready = true);   // peer transport, comm stream: see dslash_sweep
+int comm_halo_exchange_zc(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, bool wait_ready = true, bool linger = true,
+                          struct PeerPush *push_only = nullptr);   // push_only: nothing is launched, the caller's kernel pushes (peer_device.h)   // peer transport, comm stream: see dslash_sweep
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready; the caller records ev_halo behind what it posts next
 int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parity, int overlap);   // n fields, one RCCL group
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
@@ -228,7 +236,7 @@ void peer_destroy(qexhip_ctx *c);
 int peer_check(qexhip_ctx *c);                          // a device-side wait timed out since the last check -> QEXHIP_ERR_COMM
 int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *src_dn, int ns_up, const void *const *src_up,
                   void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us = 0.0, const void **zc_from_up = nullptr,
-                  const void **zc_from_dn = nullptr);                  // zc_*: zero-copy receive (the faces stay in the arena, credits owed)
+                  const void **zc_from_dn = nullptr, bool zc_linger = true, struct PeerPush *push_only = nullptr);                  // zc_*: zero-copy receive (the faces stay in the arena, credits owed)
 int peer_release_zc(qexhip_ctx *c, hipStream_t st);                   // behind the consumer of a zero-copy receive: credits + join signal
 int peer_stream_signal(qexhip_ctx *c, hipStream_t from);                          // device-side event: record ...
 int peer_stream_join(qexhip_ctx *c, hipStream_t waiter, hipStream_t from);        // ... and wait, without the runtime's cross-queue dependency

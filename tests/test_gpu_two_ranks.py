@@ -44,17 +44,19 @@ needs2 = pytest.mark.skipif("_ngpu() < 2", reason="needs two GPUs: real RCCL tra
 
 # ---- real neighbours on ONE device: the peer-memory transport (csrc/peer.hip) between processes that share GPU 0 ----
 @pytest.mark.parametrize("nranks,lat,overlap,chain", [(2, [8, 8, 8, 8], -1, -1), (2, [8, 8, 8, 8], 1, -1), (2, [16, 16, 16, 32], -1, -1),
-                                                      (2, [16, 16, 16, 32], 1, 0), (2, [16, 16, 16, 32], 1, 1), (4, [8, 8, 8, 16], -1, -1),
-                                                      (4, [8, 8, 8, 16], 1, -1), (4, [16, 16, 16, 32], 1, 0), (4, [16, 16, 16, 32], 1, 1)])
+                                                      (2, [16, 16, 16, 32], 1, -1), (2, [16, 16, 16, 32], 1, 0), (2, [16, 16, 16, 32], 1, 1),
+                                                      (4, [8, 8, 8, 16], -1, -1), (4, [8, 8, 8, 16], 1, -1), (4, [16, 16, 16, 32], 1, -1),
+                                                      (4, [16, 16, 16, 32], 1, 0), (4, [16, 16, 16, 32], 1, 1)])
 def test_ranks_sharing_one_device_against_the_global_oracle(nranks, lat, overlap, chain):
     """Every rank is its own process with its own slab, neighbours are OTHER processes: rank > 0 kernels, backward t-links
     fetched from the lower rank, the last-rank-only boundary condition of k_rephase, collective set_links, chunk agreement --
     everything a one-rank rehearsal cannot reach -- checked slab by slab against the global oracle (tests/two_rank_worker.py).
     Faces and reductions go through hipIpc-mapped peer memory (qshifts.nim:51-131, shifts.nim:67-94,254-285,
-    commsUtils.nim:195-204 are what that replaces).  chain = 1: the overlapped sweeps of the normal operator as a chained pair
-    (16 local slices hold it for the Naik operator too, 8 for the one-link operator only)."""
+    commsUtils.nim:195-204 are what that replaces).  Overlapped sweeps are split by hops (the default: chain = -1); chain = 0 / 1: split
+    by sites, without / with the two sweeps of the normal operator as a chained pair (16 local slices hold it for the Naik operator
+    too, 8 for the one-link operator only)."""
     p = _launch(nranks, [os.path.join(ROOT, "tests", "two_rank_worker.py")] + [str(v) for v in lat] +
-                ["--overlap", str(overlap), "--sweep-chain", str(chain), "--share-device"],
+                ["--overlap", str(overlap), "--sweep-chain", str(chain), "--hop-split", str(-1 if chain < 0 else 0), "--share-device"],
                 extra_env={"QEXHIP_PEER_TIMEOUT": "60"})
     ok = [ln for ln in p.stdout.splitlines() if ln.startswith("TWO_RANK_OK")]
     if p.returncode != 0 or len(ok) != nranks:
