@@ -43,7 +43,9 @@ __device__ __forceinline__ void recon_row2(double2 U[9], bool neg) {
     ry -= U[a].x * U[3 + b].y;
     ry -= U[a].y * U[3 + b].x;
     if (FMT == 1) r2[k] = make_double2(neg ? -rx : rx, neg ? -ry : ry);
-    else r2[k] = make_double2(ph.x * rx - ph.y * ry, ph.x * ry + ph.y * rx);
+    // explicit fma: "a*b - c*d" leaves the compiler two ways to contract, and it chose differently in different kernels -- the
+    // single-system and the lock-step batched sweep must reconstruct the same bits (tests/test_gpu_batch.py)
+    else r2[k] = make_double2(fma(ph.x, rx, -(ph.y * ry)), fma(ph.x, ry, ph.y * rx));
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) U[6 + k] = r2[k];
