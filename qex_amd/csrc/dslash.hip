@@ -184,18 +184,19 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
     if (do_b) mv3<true>(acc, W, vb);
   };
   // the outermost slices of a hop-split sweep (wavefront-uniform branch): `crossing` false takes every hop but the t-hops that
-  // leave the slab, true exactly those.  Rolled: these few tiles must not cost the fast path registers.
+  // leave the slab -- the spatial pairs in the fast loop's form, then the t pairs hop by hop --, true exactly those t-hops.
   auto edge_pairs = [&](const bool crossing) __attribute__((always_inline)) {
+    if (!crossing) {
+      constexpr int NSP = NDIR / 2 - NDIR / 8;       // spatial pairs: 0,1,2 (and 4,5,6)
+      constexpr int UNS = NDIR == 8 ? (RECON ? 1 : 3) : 2;      // (the fast loop's policy: compressed links stay rolled)
+#pragma unroll UNS
+      for (int q = 0; q < NSP; q++) pair(q + q / 3, true, true);
+    }
 #pragma unroll 1
-    for (int pr = (crossing ? 3 : 0); pr < NDIR / 2; pr += (crossing ? 4 : 1)) {
-      bool do_f = true, do_b = true;
-      if ((pr & 3) == 3) {
-        const int hop = pr >= 4 ? 3 : 1;
-        const bool xf = tu + hop >= g.X[3], xb = tu - hop < 0;
-        do_f = crossing ? xf : !xf;
-        do_b = crossing ? xb : !xb;
-      }
-      pair(pr, do_f, do_b);
+    for (int pr = 3; pr < NDIR / 2; pr += 4) {
+      const int hop = pr >= 4 ? 3 : 1;
+      const bool xf = tu + hop >= g.X[3], xb = tu - hop < 0;
+      pair(pr, crossing ? xf : !xf, crossing ? xb : !xb);
     }
   };
   if (active) {
