@@ -13,6 +13,7 @@
 #include "peer_device.h"
 #include <hip/hip_ext.h>
 #include <cstring>
+#include <algorithm>
 #include <chrono>
 
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -319,7 +320,22 @@ static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool 
   // XCD swizzle: measured on for compressed links, off for 18-real links (profiles/r01_tune_dslash.log); output stores are
   // non-temporal (the result is read by the NEXT kernel, after 0.6 GB of links went through the caches)
   const int nsw = part == 3 ? A.nb1 : nb;          // (the fused launch remaps its interior workgroups only)
-  A.nbA = part == 3 ? (int)(0.65 * A.nb1) : 0;
+  A.nbA = 0;
+  if (part == 3) {
+    // Where the boundary workgroups go in the dispatch order.  Once started they hold their slots until the faces are in -- and the
+    // 18-real 8-link instantiation runs one workgroup per SIMD pair (255 VGPRs: 512 slots on the chip, 432 boundary workgroups on a
+    // 48^3 slab) -- so they should start about when the faces arrive: estimated transfer time (3 us + face bytes at the link rate:
+    // 45 GB/s per xGMI direction unless option emu_link_gbs says otherwise) over estimated interior time (its bytes at 5.5 TB/s);
+    // never before 65 % (their edge loops should not be the tail either), last of all when the exchange is the longer of the two.
+    // Measured on the 48^3 x 12 slab (profiles/r05_emulated_scaling_v4..v6.log): at a fixed 65 % the rehearsal with 126 us of
+    // transport ran 446 us per iteration, placed by this estimate 378; with 62 us of transport both 369-371.
+    const double link = (c->emu_link_gbs > 0 ? c->emu_link_gbs : 45.0) * 1e9;
+    const double t_x = 3e-6 + (double)c->g.depth * c->g.F * 48.0 / link;
+    const double bsite = NDIR * (c->recon == 1 ? 96.0 : (c->recon == 2 ? 112.0 : 144.0)) + 120.0;
+    const double t_int = (double)(c1 - c0) * bsite / 5.5e12;
+    const double f = t_int > 0 ? std::min(1.0, std::max(0.65, t_x / t_int)) : 1.0;
+    A.nbA = (int)(f * A.nb1);
+  }
   A.swz = (c->recon != 0 && nsw >= 64 && (nsw & 7) == 0) ? nsw : 0;
   A.ntstore = 1;
   double *psave = A.partials;

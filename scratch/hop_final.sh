@@ -9,3 +9,5 @@ for rep in 1 2; do
     run QEXHIP_TRANSPORT=peer QEX_BENCH_TIMERS=0 --halo --lat 48 48 48 24 --emulate-transport 3 3 --set-option emu_link_gbs=45 --set-option overlap=1
     run QEXHIP_TRANSPORT=peer QEX_BENCH_TIMERS=0 --halo --lat 32 32 32 4 --emulate-transport 3 3 --set-option emu_link_gbs=45 --set-option overlap=1
 done
+run QEXHIP_TRANSPORT=peer QEX_BENCH_TIMERS=0 --halo --lat 48 48 48 12 --emulate-transport 6 6 --set-option emu_link_gbs=22 --set-option overlap=1
+run QEXHIP_TRANSPORT=peer QEX_BENCH_TIMERS=0 --halo --lat 32 32 32 8 --emulate-transport 3 3 --set-option emu_link_gbs=45 --set-option overlap=1
