@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) k_dslash(DslashArgs A) {
   auto edge_pairs = [&](const bool crossing) __attribute__((always_inline)) {
     if (!crossing) {
       constexpr int NSP = NDIR / 2 - NDIR / 8;       // spatial pairs: 0,1,2 (and 4,5,6)
-      constexpr int UNS = NDIR == 8 ? (RECON ? 1 : 3) : 2;      // (the fast loop's policy: compressed links stay rolled)
+      constexpr int UNS = NDIR == 8 ? 1 : 2;      // (8 links: rolled -- unrolled x3 the function takes 255 VGPRs, one workgroup per SIMD pair, and waiting boundary workgroups then hold most of the chip's slots)
 #pragma unroll UNS
       for (int q = 0; q < NSP; q++) pair(q + q / 3, true, true);
     }
@@ -322,13 +322,13 @@ static int launch(qexhip_ctx *c, DslashArgs &A, int c0, int c1, bool init, bool 
   const int nsw = part == 3 ? A.nb1 : nb;          // (the fused launch remaps its interior workgroups only)
   A.nbA = 0;
   if (part == 3) {
-    // Where the boundary workgroups go in the dispatch order.  Once started they hold their slots until the faces are in -- and the
-    // 18-real 8-link instantiation runs one workgroup per SIMD pair (255 VGPRs: 512 slots on the chip, 432 boundary workgroups on a
-    // 48^3 slab) -- so they should start about when the faces arrive: estimated transfer time (3 us + face bytes at the link rate:
-    // 45 GB/s per xGMI direction unless option emu_link_gbs says otherwise) over estimated interior time (its bytes at 5.5 TB/s);
-    // never before 65 % (their edge loops should not be the tail either), last of all when the exchange is the longer of the two.
-    // Measured on the 48^3 x 12 slab (profiles/r05_emulated_scaling_v4..v6.log): at a fixed 65 % the rehearsal with 126 us of
-    // transport ran 446 us per iteration, placed by this estimate 378; with 62 us of transport both 369-371.
+    // Where the boundary workgroups go in the dispatch order.  Once started they hold their slots until the faces are in, so they
+    // should start about when the faces arrive: estimated transfer time (3 us + face bytes at the link rate: 45 GB/s per xGMI
+    // direction unless option emu_link_gbs says otherwise) over estimated interior time (its bytes at 5.5 TB/s); never before 65 %
+    // (their edge loops should not be the tail either), last of all when the exchange is the longer of the two.  How much a
+    // wrong guess costs depends on the slots left: with the edge loop unrolled the 18-real 8-link function took 255 VGPRs (512
+    // slots; 432 boundary workgroups on a 48^3 slab) and a fixed 65 % cost 446 instead of 378 us per iteration under 126 us of
+    // transport (profiles/r05_emulated_scaling_v6.log against v5); rolled it takes 141 (1536 slots).
     const double link = (c->emu_link_gbs > 0 ? c->emu_link_gbs : 45.0) * 1e9;
     const double t_x = 3e-6 + (double)c->g.depth * c->g.F * 48.0 / link;
     const double bsite = NDIR * (c->recon == 1 ? 96.0 : (c->recon == 2 ? 112.0 : 144.0)) + 120.0;
