@@ -73,8 +73,19 @@ if kernels:
 
 
 def matches(full, fn, targs):
+    """exact function name; template arguments equal, or -- a kernel that has GROWN template parameters since the pattern was written --
+    equal up to trailing defaults (false / 0): `<8,false,true,true,0>` also names `<8,false,true,true,0,false,0>`"""
     f, t = split_name(full)
-    return f == fn and (targs is None or t == targs.replace(" ", ""))
+    if f != fn:
+        return False
+    if targs is None:
+        return True
+    want = targs.replace(" ", "")
+    if t == want:
+        return True
+    if t.startswith(want[:-1] + ","):
+        return all(x in ("false", "0") for x in t[len(want):-1].split(","))
+    return False
 
 
 def mean(fn, targs, counter):
