@@ -399,8 +399,11 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *                  sweep is one kernel on one stream.  1: by hops in two launches (A/B).  0: by SITES (interior launch beside the
  *                  exchange, boundary launch on the second stream behind it, a join; rounds 1-4).  -1 (default): 2 on the peer transport
  *                  with zero-copy receive, else 0.  Boundary sites sum their local hops first under 1 / 2: equal to 0 to rounding.
- *   "peer_fold"    1: peer transport: the |r|^2 all-reduce of a sharded CG iteration is the work of k_cg_update's last-arriving workgroup
- *                  instead of a launch of its own behind it (default 0: measured slower; the same bits either way)
+ *   "peer_fold"    peer transport, the two rank sums of a sharded CG iteration (cg.nim:206-214).  0 (default): one-workgroup launches of
+ *                  their own; 2: inside the prologues of the kernels that consume them (k_cg_update for <p,Ap>, k_cg_xpay / k_cg_close
+ *                  for |r|^2: two launches and launch boundaries less per iteration) -- every workgroup of those launches then spins
+ *                  until the slowest rank has sent, so it is taken only where the ranks have a GPU each or the launch is <= 256
+ *                  workgroups; 1: |r|^2 in k_cg_update's tail (measured slower).  The same bits in every form.
  *   "sweep_chain"  1 / 0: the two overlapped sweeps of the normal operator always / never run chained (qexhip_stag_sweep_chain_info); -1
  *                  (default): chained where set_links measured it > 3 % faster than the overlapped pair (it wins while the interior
  *                  launch is longer than the exchange, loses when the exchange is: a narrower interior hides less of it)

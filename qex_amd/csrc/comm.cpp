@@ -78,6 +78,7 @@ static int choose_transport(qexhip_ctx *c, const char *id, int nranks, int rank,
     }
   }
   *use_peer = (any_peer || shared) ? 1 : 0;
+  c->ranks_share_device = shared;
   if (!*use_peer) {
     // every rank has read the table (it decided the same): a second barrier keeps rank 0 from unmapping under a slow reader
     int e = peer_host_barrier(host);

@@ -607,6 +607,18 @@ int peer_ghost_args(qexhip_ctx *c, PeerGhost *G, bool zc, bool direct) {
   return 0;
 }
 
+int peer_fold_args(qexhip_ctx *c, PeerFold *F) {
+  PeerComm *p = c->peer;
+  CHK(peer_check_err(p));
+  F->on = 1;
+  fill_gran(p, F->G);
+  F->G.emu_ticks = (long long)(c->emu_allreduce_us * 1e-6 * (double)p->ticks / p->timeout_s);
+  F->t_send = (long long *)(p->ready + 60);
+  F->seq = ++p->seq_red;
+  p->allreduces++;
+  return 0;
+}
+
 int peer_tail_args(qexhip_ctx *c, PeerTail *T) {
   PeerComm *p = c->peer;
   CHK(peer_check_err(p));

@@ -155,6 +155,46 @@ __device__ inline void peer_push_block(const PeerPush &P, const unsigned blk) {
   }
 }
 
+// The same reduction in the PROLOGUE of a many-workgroup consumer (k_cg_update for <p,Ap>, k_cg_xpay / k_cg_close for |r|^2): every
+// workgroup holds the same `local` (it summed the same partials in the same order); workgroup 0 sends it, every workgroup collects
+// the N operands from the own mailbox and sums them in rank order -- no all-reduce launch, no launch boundary.  Every workgroup of
+// the launch spins until the slowest rank has sent: only where the ranks have a GPU each, or the launch is small (blas.hip decides).
+struct PeerFold {
+  int on;
+  u64 seq;
+  long long *t_send;          // under emulation: when workgroup 0 sent (the transport time counts from there)
+  PeerGran G;
+};
+__device__ inline bool gran_allreduce_grid(double local, const PeerFold &F, double *out) {
+  __shared__ double gf_val[PEER_MAXR];
+  __shared__ int gf_ok;
+  const int slot = (int)(F.seq & (PEER_NSLOT - 1));
+  const unsigned tag = (unsigned)F.seq;
+  const int r = threadIdx.x;
+  if (threadIdx.x == 0) gf_ok = 1;
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (r == 0 && F.G.emu_ticks > 0) __hip_atomic_store(F.t_send, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (r < F.G.nranks) gran_send(F.G.gran[r] + ((size_t)(slot * PEER_MAXR + F.G.me) * PEER_GRAN_N) * 2, local, tag);
+  }
+  if (r < F.G.nranks) {
+    double v = 0;
+    if (!gran_recv(F.G.gran[F.G.me] + ((size_t)(slot * PEER_MAXR + r) * PEER_GRAN_N) * 2, tag, &v, F.G.err, F.G.ticks, 0x300 + r)) gf_ok = 0;
+    gf_val[r] = v;
+  }
+  if (F.G.emu_ticks > 0 && r == 0) {       // rehearsal: the peers' granules cross xGMI (all operands are in: workgroup 0 has sent)
+    const long long t0 = __hip_atomic_load(F.t_send, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (wall_clock64() - t0 < F.G.emu_ticks) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  if (!gf_ok) return false;
+  double acc = gf_val[0];
+  for (int q = 1; q < F.G.nranks; q++) acc += gf_val[q];
+  *out = acc;
+  return true;
+}
+int peer_fold_args(qexhip_ctx *c, PeerFold *F);     // fills F for ONE all-reduce (sequence number taken); peer.hip
+
 // The |r|^2 all-reduce of a sharded CG iteration inside the tail of k_cg_update (blas.hip): the workgroup whose arrival ticket comes
 // last sums the partials and runs gran_allreduce_block -- one launch and one launch boundary less per iteration, and still only
 // ONE spinning workgroup per rank (ranks may share a device).  on == 0: the kernel leaves its partials for comm_allreduce_parts.

@@ -125,6 +125,8 @@ struct qexhip_ctx {
                              // transport with zero-copy receive, else 0 (measured: profiles/r05_hop_split.log)
   unsigned long long *sj_ctr = nullptr, *sj_err = nullptr, sj_seq = 0;   // the fused launch's arrival signal without the peer transport (dslash.hip)
   long long sj_ticks = 0;
+  int ranks_share_device = 0;   // comm_init's rendezvous saw two ranks of this job on one GPU (kernels that spin for a PEER must then stay small)
+  int cg_r2_fold = 0;           // the |r|^2 partials of the last k_cg_update still want their rank sum: the next k_cg_xpay / k_cg_close takes it (peer_fold 2)
   int opt_peer_fold = 0;     // option "peer_fold" (A/B, test hook): 1 = the |r|^2 all-reduce of a sharded CG iteration on the peer transport runs in the tail of
                              // k_cg_update (last-arriver workgroup), 0 = as a launch of its own behind it.  Measured 8-10 us per iteration SLOWER
                              // folded (profiles/r05_fold_compare.log: write-through partials + 2600 arrival tickets + a serial tail cost more

@@ -105,6 +105,7 @@ static int cg_iterate(qexhip_ctx *c, DevField &x, DevField *r, DevField *p, DevF
   const int par = par_even ? 0 : 1;
   const int chunk = 32;
   int rolled = 1;
+  c->cg_r2_fold = 0;                 // (a rank sum left pending by an aborted solve is not this solve's)
   bool done = st.dones[k & 1];
   double r2 = st.r2s[k & 1];
   st.itn = st.itns[k & 1];

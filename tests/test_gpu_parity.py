@@ -369,7 +369,8 @@ def test_peer_transport_sweep_forms_equal_periodic(oracle, naik):
              "two_launch": dict(overlap=1, hop_split=1), "two_launch_unpack": dict(overlap=1, hop_split=1, peer_zc=0),
              "unpack": dict(overlap=1, hop_split=0, peer_zc=0, sweep_chain=0), "zero_copy": dict(overlap=1, hop_split=0, peer_zc=1, sweep_chain=0),
              "chained": dict(overlap=1, hop_split=0, peer_zc=1, sweep_chain=1), "measured": dict(overlap=-2),
-             "folded": dict(overlap=1, hop_split=0, sweep_chain=0, peer_fold=1)}        # |r|^2 all-reduce in k_cg_update's tail
+             "folded": dict(overlap=1, hop_split=0, sweep_chain=0, peer_fold=1),        # |r|^2 all-reduce in k_cg_update's tail
+             "prologue_fold": dict(overlap=1, peer_fold=2)}                              # both rank sums inside the kernels that consume them
     xa = np.zeros_like(A.x)
     spa = q.SolverParams(r2req=1e-12, maxits=2000, verbosity=0)
     A.s.solveEE(xa, A.x, 0.1, spa, histcap=4096)

@@ -70,6 +70,20 @@ def test_ranks_sharing_one_device_against_the_global_oracle(nranks, lat, overlap
         assert all(r["sweep"]["chained"] == bool(chain) for r in res), res[0]["sweep"]
 
 
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_ranks_sharing_one_device_rank_sums_inside_the_consumers(nranks):
+    """Option peer_fold = 2 with real neighbours: <p,Ap> summed over the ranks in k_cg_update's prologue, |r|^2 in k_cg_xpay's /
+    k_cg_close's, every workgroup collecting the N operands itself (8^3 x 8 / 16 slabs: launches small enough for ranks that share a GPU)."""
+    lat = [8, 8, 8, 8 * nranks // 2]
+    p = _launch(nranks, [os.path.join(ROOT, "tests", "two_rank_worker.py")] + [str(v) for v in lat] +
+                ["--overlap", "1", "--peer-fold", "2", "--share-device", "--skip-gauge"], extra_env={"QEXHIP_PEER_TIMEOUT": "60"})
+    ok = [ln for ln in p.stdout.splitlines() if ln.startswith("TWO_RANK_OK")]
+    if p.returncode != 0 or len(ok) != nranks:
+        print(p.stdout[-4000:])
+        print(p.stderr[-8000:])
+    assert p.returncode == 0 and len(ok) == nranks, (p.returncode, len(ok))
+
+
 @pytest.mark.parametrize("scenario", ["absent", "vanish", "mismatch"])
 def test_peer_transport_failures_are_errors_not_hangs(scenario):
     """A neighbour that never exchanges, or ranks that disagree about the transport, must end in QEXHIP_ERR_COMM with a message,
