@@ -398,7 +398,8 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *                  leave it; on the peer transport with zero-copy receive the launch's first workgroups also PUSH the faces: the whole
  *                  sweep is one kernel on one stream.  1: by hops in two launches (A/B).  0: by SITES (interior launch beside the
  *                  exchange, boundary launch on the second stream behind it, a join; rounds 1-4).  -1 (default): 2 on the peer transport
- *                  with zero-copy receive, else 0.  Boundary sites sum their local hops first under 1 / 2: equal to 0 to rounding.
+ *                  with zero-copy receive where every rank has a GPU of its own (ranks sharing one keep 0: two processes' waiting
+ *                  boundary workgroups on one chip ran a 48^3 x 96 solve into the wait bound), else 0.  Boundary sites sum their local hops first under 1 / 2: equal to 0 to rounding.
  *   "peer_fold"    peer transport, the two rank sums of a sharded CG iteration (cg.nim:206-214).  0 (default): one-workgroup launches of
  *                  their own; 2: inside the prologues of the kernels that consume them (k_cg_update for <p,Ap>, k_cg_xpay / k_cg_close
  *                  for |r|^2: two launches and launch boundaries less per iteration) -- every workgroup of those launches then spins
@@ -417,7 +418,7 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *                  times under it are what bench.py --halo --emulate-transport reports
  *
  * Environment (read once, at qexhip_init / qexhip_comm_init) -- the complete list:
- *   QEXHIP_RECON, QEXHIP_OVERLAP, QEXHIP_FLOW_EXP   initial values of the options of the same (lower-case) name
+ *   QEXHIP_RECON, QEXHIP_OVERLAP, QEXHIP_HOP_SPLIT, QEXHIP_FLOW_EXP   initial values of the options of the same (lower-case) name
  *   QEXHIP_TRANSPORT=auto|rccl|peer, QEXHIP_RENDEZVOUS_TIMEOUT, QEXHIP_PEER_TIMEOUT   see "communicator"
  *   QEXHIP_COMM2=0   keep ONE RCCL communicator for both streams (default: the overlapped face exchange gets a communicator
  *                    of its own); the ranks agree on this by a min-all-reduce, any rank's 0 wins

@@ -130,6 +130,7 @@ static int init_body(qexhip_ctx *c, int device, const int latLocal[4], const int
   }
   // the environment switches of the library (include/qexhip.h "Environment")
   if (const char *e = getenv("QEXHIP_OVERLAP")) c->opt_overlap = atoi(e);
+  if (const char *e = getenv("QEXHIP_HOP_SPLIT")) c->opt_hop_split = atoi(e);
   if (const char *e = getenv("QEXHIP_RECON")) c->opt_recon = atoi(e);
   if (const char *e = getenv("QEXHIP_FLOW_EXP")) c->opt_flow_exp = atoi(e);
   {
@@ -335,7 +336,7 @@ extern "C" int qexhip_stag_sweep_info(qexhip_handle c, int out[8]) {
   const int slot = c->ndir == 16;
   out[0] = c->g.halo;
   out[1] = overlap;
-  const int hs = c->opt_hop_split >= 0 ? c->opt_hop_split : ((c->peer && c->opt_peer_zc) ? 2 : 0);
+  const int hs = c->opt_hop_split >= 0 ? c->opt_hop_split : ((c->peer && c->opt_peer_zc && !c->ranks_share_device) ? 2 : 0);
   out[2] = (c->g.halo && !(overlap && hs)) ? hi_beg - lo_end : c->g.Vh;     // (hop split: the main launch covers the slab)
   out[3] = c->g.halo ? c->g.depth * c->g.F * 48 : 0;
   out[4] = c->overlap_auto[slot] >= 0;

@@ -562,7 +562,11 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
     // launch widened by as much, on the comm stream behind sweep 1's (in order) and behind ev_ready (sweep 1's interior).  The faces
     // sweep 2 sends are sweep 1's boundary output, the comm stream's own work: its exchange starts without waiting for anything.
     // One join per operator instead of two, and the second exchange is posted ~30 us earlier.
-    const int hop_split = !overlap ? 0 : (c->opt_hop_split >= 0 ? c->opt_hop_split : (zc ? 2 : 0));
+    // -1: the fused form where it is proven AND safe: peer transport with zero-copy receive, every rank on a GPU of its own.  Ranks
+    // that SHARE a GPU keep the split by sites: with two processes' 10 000-workgroup sweeps on one chip, each holding 432 waiting
+    // boundary workgroups, a 48^3 x 96 solve over 2 ranks ran into the 30 s wait bound (bench.py --gpus 2 on one device;
+    // 8^4 ... 16^3 x 32 with 2 and 4 ranks are green and stay in the test suite with hop_split = 2 forced)
+    const int hop_split = !overlap ? 0 : (c->opt_hop_split >= 0 ? c->opt_hop_split : ((zc && !c->ranks_share_device) ? 2 : 0));
     if (hop_split) {
       // Overlapped sweep split BY HOPS (option hop_split): the hops that stay inside the slab are taken while the faces travel, the
       // 1-2 hops per boundary site that leave it once they are in -- ~1/4 of the bytes of 2 * depth slices is all that is left behind

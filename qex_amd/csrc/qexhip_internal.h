@@ -122,7 +122,7 @@ struct qexhip_ctx {
                              // that wait on the device for the faces between their local and their remote hops; on the peer transport with a
                              // zero-copy receive the launch also pushes the faces itself: no second stream at all), 1 = by hops in two launches
                              // (A/B), 0 = by sites (interior launch | boundary launch on the comm stream; rounds 1-5a), -1 = 2 on the peer
-                             // transport with zero-copy receive, else 0 (measured: profiles/r05_hop_split.log)
+                             // transport with zero-copy receive when every rank has a GPU of its own, else 0 (measured: profiles/r05_hop_split.log)
   unsigned long long *sj_ctr = nullptr, *sj_err = nullptr, sj_seq = 0;   // the fused launch's arrival signal without the peer transport (dslash.hip)
   long long sj_ticks = 0;
   int ranks_share_device = 0;   // comm_init's rendezvous saw two ranks of this job on one GPU (kernels that spin for a PEER must then stay small)

@@ -52,11 +52,12 @@ def test_ranks_sharing_one_device_against_the_global_oracle(nranks, lat, overlap
     fetched from the lower rank, the last-rank-only boundary condition of k_rephase, collective set_links, chunk agreement --
     everything a one-rank rehearsal cannot reach -- checked slab by slab against the global oracle (tests/two_rank_worker.py).
     Faces and reductions go through hipIpc-mapped peer memory (qshifts.nim:51-131, shifts.nim:67-94,254-285,
-    commsUtils.nim:195-204 are what that replaces).  Overlapped sweeps are split by hops (the default: chain = -1); chain = 0 / 1: split
+    commsUtils.nim:195-204 are what that replaces).  Overlapped sweeps are split by hops in one self-pushing launch (chain = -1: forced
+    here, since ranks that share a GPU default to the split by sites -- see option hop_split); chain = 0 / 1: split
     by sites, without / with the two sweeps of the normal operator as a chained pair (16 local slices hold it for the Naik operator
     too, 8 for the one-link operator only)."""
     p = _launch(nranks, [os.path.join(ROOT, "tests", "two_rank_worker.py")] + [str(v) for v in lat] +
-                ["--overlap", str(overlap), "--sweep-chain", str(chain), "--hop-split", str(-1 if chain < 0 else 0), "--share-device"],
+                ["--overlap", str(overlap), "--sweep-chain", str(chain), "--hop-split", str(2 if chain < 0 else 0), "--share-device"],
                 extra_env={"QEXHIP_PEER_TIMEOUT": "60"})
     ok = [ln for ln in p.stdout.splitlines() if ln.startswith("TWO_RANK_OK")]
     if p.returncode != 0 or len(ok) != nranks:
