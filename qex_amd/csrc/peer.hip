@@ -284,7 +284,8 @@ static int peer_check_err(PeerComm *p) {
   const u64 e = __atomic_load_n(p->err, __ATOMIC_ACQUIRE);
   if (e) {
     const char *what = (e & 0xF00) == 0x100 ? "credit of an outbound channel" : (e & 0xF00) == 0x200 ? "data of an inbound channel"
-                       : (e & 0xF00) == 0x400 ? "boundary launch on the comm stream (stream join)" : "all-reduce contribution";
+                       : (e & 0xF00) == 0x400 ? "boundary launch on the comm stream (stream join)"
+                       : (e & 0xF00) == 0x500 ? "neighbours' faces in a fused sweep (its boundary workgroups)" : "all-reduce contribution";
     qexhip_set_error("peer transport: rank %d timed out waiting for the %s (code 0x%llx): a neighbour is gone, or the ranks "
                      "did not issue the same sequence of exchanges", p->rank, what, e);
     peer_host_fail(&p->host);
