@@ -156,5 +156,9 @@ def run(ctx, lat, nranks, rank, g0, g, b, mass=0.1, naik=True, kick=None):
     got = compute(ctx, g0, g, b, mass, naik=naik and "naik_x2" in want["values"], kick=kick)
     res = compare(got, want)
     res["fixture"] = "tests/golden/shard_checks.json[%s]: %s" % (lat_key(lat), want.get("source", "?"))
+    # the committed numbers are the product's on one GPU, and every one of them was recomputed by the CPU oracle (the restatement
+    # pinned to the reference's golden vectors); the agreement found then is part of the fixture
+    vo = want.get("vs_oracle") or {}
+    res["fixture_pinned_to_oracle"] = {"ok": bool(vo.get("ok")), "max_rel": vo.get("max_rel"), "covers": vo.get("covers"), "how": vo.get("how")}
     res["ranks"] = nranks
     return res

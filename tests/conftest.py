@@ -17,6 +17,17 @@ if os.path.join(ROOT, "tests") not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU test of several minutes and tens of GB (deselected unless -m slow is given)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m "not gpu"` (the driver's CPU run) must stay a few minutes: slow tests run only when the marker expression names them
+    if "slow" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="slow: run with -m slow")
+    for it in items:
+        if "slow" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -339,6 +339,38 @@ def test_shard_check_fixture_against_the_oracle(lat):
     assert r["max_rel"]["operator"] < 1e-13 and r["max_rel"]["history"] < 1e-11 and r["max_rel"]["solution"] < 1e-12, r
 
 
+@pytest.mark.parametrize("key", ["8x8x8x8", "32x32x32x32", "48x48x48x96"])
+def test_shard_check_fixture_records_its_oracle_pin(key):
+    """Every entry of the fixture -- the 48^3 x 96 one that bench.py's cg_48x48x48x96.shard_check and every N > 1 run of configs[3]
+    verify against included -- carries the agreement the CPU oracle found when it recomputed ALL of its quantities (plaquettes,
+    |b|^2, |D b|^2, 20 CG residuals, the converged HISQ Naik 10-shift norms and count): operator 1e-13, history 1e-11.  The
+    recomputation itself: test_shard_check_fixture_against_the_oracle (8^4, 32^4 always; 48^3 x 96 under -m slow, ~5 min, 40 GB)."""
+    import json
+
+    from qex_amd import selfcheck as sc
+
+    e = json.load(open(sc.FIXTURE))["lattices"][key]
+    vo = e["vs_oracle"]
+    assert vo["ok"] and not vo["failed"]
+    assert set(vo["covers"]) == set(e["values"].keys()), (vo["covers"], list(e["values"]))
+    assert vo["max_rel"]["operator"] < 1e-13 and vo["max_rel"]["history"] < 1e-11 and vo["max_rel"]["solution"] < 1e-12, vo
+
+
+@pytest.mark.slow
+def test_shard_check_fixture_against_the_oracle_48x96():
+    """The recomputation of the largest entry (10.6 M sites; ~5 min on 8 cores, ~40 GB): `pytest -m slow`.  Last run in the build
+    container in round 6: operator 1.2e-15, history 2.5e-14, solution 2.8e-15 (292 s)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_shard_checks as gen
+    from qex_amd import selfcheck as sc
+
+    lat = [48, 48, 48, 96]
+    want = sc.load_fixture(lat, 0.1)
+    r = sc.compare(gen.oracle_values(lat), want)
+    assert r["ok"], r
+    assert r["max_rel"]["operator"] < 1e-13 and r["max_rel"]["history"] < 1e-11 and r["max_rel"]["solution"] < 1e-12, r
+
+
 def test_every_entry_point_refuses_a_null_handle():
     """Error behaviour of the boundary (SURVEY 8b "Errors": int return codes, 0 = ok, < 0 = error): every exported function
     that takes the context handle must answer a NULL handle with a negative code before it touches the device -- this
