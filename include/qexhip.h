@@ -75,17 +75,22 @@ int qexhip_device_info(qexhip_handle h, char *buf, int buflen);
  * Rank 0 obtains an id, the host broadcasts it (QMP_broadcast in QEX), every rank calls init (collective; an id serves ONE
  * comm_init).  Two transports sit behind the same entry points (QEXHIP_TRANSPORT / option "transport", one value for the
  * whole job):
- *   rccl   ncclSend/ncclRecv groups and ncclAllReduce between DISTINCT devices -- the default whenever every rank has a GPU
- *          of its own; works across nodes
- *   peer   every rank maps its neighbours' receive arenas and every rank's mailbox through hipIpc; a face exchange is one
- *          kernel that pushes into the neighbour's HBM and unpacks what arrived, an all-reduce one single-workgroup kernel
- *          that sums the ranks' mailboxes in rank order (bit-identical on every rank).  One node only (<= 16 ranks).  It is
- *          the only transport that lets several ranks share ONE device, which RCCL refuses
- *   auto   (default) the ranks of the node meet in a POSIX shared-memory segment named after the id and take `peer` if any
- *          two of them are bound to the same device, `rccl` otherwise.  A job that spans nodes sets QEXHIP_TRANSPORT=rccl
- *          (no rendezvous).  QEXHIP_RENDEZVOUS_TIMEOUT (s, default 120) bounds the wait for the other ranks,
- *          QEXHIP_PEER_TIMEOUT (s, default 30) every device-side wait of the peer transport: a rank that never arrives
- *          becomes QEXHIP_ERR_COMM on the others, never a hang. */
+ *   rccl   ncclSend/ncclRecv groups and ncclAllReduce between DISTINCT devices; no rendezvous; works across nodes
+ *   peer   every rank maps its neighbours' receive arenas and every rank's mailbox through hipIpc; a face exchange is a push into
+ *          the neighbour's HBM (from inside the sweep kernel itself where sweeps overlap: option "hop_split"), an all-reduce one
+ *          single-workgroup kernel that sums the ranks' mailboxes in rank order (bit-identical on every rank).  One node only
+ *          (<= 16 ranks).  It is the only transport that lets several ranks share ONE device, which RCCL refuses
+ *   mbox   RCCL for the faces, the mailboxes of `peer` for the scalar rank sums of the solvers (one single-workgroup kernel of ~4 us
+ *          instead of an ncclAllReduce of 15-20 us, two per CG iteration; cg.nim:206-214); one node; reported as "rccl+mbox"
+ *   auto   (default) the ranks of a ONE-NODE job meet in a POSIX shared-memory segment named after the id and take `peer` if any
+ *          two of them are bound to the same device, else `mbox` -- provided the control blocks map between the devices and a
+ *          self-test of the mailbox all-reduce (known answers, 5 s bound) passes on every rank; if not, all ranks drop to `rccl`
+ *          together.  A job that SPANS NODES takes `rccl`: by what the launcher says (QEXHIP_LOCAL_RANKS, LOCAL_WORLD_SIZE,
+ *          OMPI_COMM_WORLD_LOCAL_SIZE, MPI_LOCALNRANKS, SLURM_NTASKS_PER_NODE: fewer local ranks than nranks -> no rendezvous at
+ *          all) or, with no such variable, when the node-local rendezvous does not complete within QEXHIP_RENDEZVOUS_TIMEOUT
+ *          (s, default 120) -- every node's ranks time out alike, so the decision stays one for the whole job; only an explicit
+ *          `peer` / `mbox` turns that timeout into QEXHIP_ERR_COMM.  QEXHIP_PEER_TIMEOUT (s, default 30) bounds every device-side
+ *          wait: a rank that never arrives becomes QEXHIP_ERR_COMM on the others, never a hang. */
 #define QEXHIP_UNIQUE_ID_BYTES 128
 int qexhip_comm_unique_id(char id[QEXHIP_UNIQUE_ID_BYTES]);
 int qexhip_comm_init(qexhip_handle h, const char id[QEXHIP_UNIQUE_ID_BYTES], int nranks, int rank);
@@ -94,7 +99,7 @@ int qexhip_comm_init(qexhip_handle h, const char id[QEXHIP_UNIQUE_ID_BYTES], int
  * Without a communicator nranks = 0, rank = -1.  Any output pointer may be NULL.
  * A context with rankGeom[3] > 1 refuses every exchange / reduction until qexhip_comm_init has run (QEXHIP_ERR_STATE). */
 int qexhip_comm_info(qexhip_handle h, int *nranks, int *rank, int *device, char *busid, int buslen);
-/* which transport the communicator runs on: name = "none" | "rccl" | "peer"; stats (may be NULL) = peer-transport counters
+/* which transport the communicator runs on: name = "none" | "rccl" | "rccl+mbox" | "peer"; stats (may be NULL) = peer-transport counters
  * {face exchanges posted, all-reduces posted, arena (re)allocations, bytes of receive arena}, zeros otherwise */
 int qexhip_comm_transport(qexhip_handle h, char *name, int len, long stats[4]);
 /* number of RCCL communicators the context holds: 0 before comm_init, 2 afterwards (one for the compute stream's all-reduces
@@ -110,14 +115,16 @@ int qexhip_comm_count(qexhip_handle h, int *ncomms);
  * at -1, the rule of the one-rank rehearsals (overlap when the interior is >= 131072 sites and a face >= 1 MiB);
  * out[7] = the option's value.  bench.py prints it so that a scaling run explains its own launch structure. */
 int qexhip_stag_sweep_info(qexhip_handle h, int out[8]);
-/* ... and how a PAIR of sweeps -- the normal operator D_eo D_oe of stagD.nim:434-456, every CG iteration -- runs when the sweeps
- * overlap on the peer transport: out[0] = 1 if the pair is CHAINED (no join between the two sweeps: the second one's interior
- * launch is narrowed by the stencil depth so that it reads nothing the first one's boundary launch wrote, its boundary launch
- * widened by as much on the second stream, its faces sent the moment the first boundary launch has written them), out[1] = 1 if
- * that was measured by set_links beside out[5], out[6] above, out[2] = microseconds per sweep it saw chained, out[3] = option
- * "sweep_chain".  Chaining regroups the dot-product partials (as overlap does), nothing else: results are the unchained ones to
- * summation order. */
-int qexhip_stag_sweep_chain_info(qexhip_handle h, int out[4]);
+/* ... and what set_links MEASURED for them (collective, max over ranks; qexhip_device_info prints the same):
+ *   out[0] one face exchange of this operator, microseconds (measured where the communicator has more than one rank or option
+ *          "overlap" = -2 asked for it; otherwise the estimate 3 us + face bytes at 45 GB/s per xGMI direction)
+ *   out[1] where in its dispatch order the fused sweep puts its boundary workgroups (0.65 .. 1: out[0] over the estimated interior time)
+ *   out[2..4] microseconds per sweep in the three forms: exchange first | overlapped, split by sites | fused (0: not measured / not available)
+ *   out[5] the form an overlapped sweep takes: 2 fused, 0 split by sites        out[6] the fused sweep's short wait, us (-1: parks always)
+ *   out[7] 1 if sweeps overlap at all
+ * The decisions are timing-dependent and regroup the dot-product partials (the fused form also sums a boundary site's local hops
+ * first): a job that needs its residual history bit-reproducible from run to run pins "overlap" and "hop_split". */
+int qexhip_stag_sweep_tuning(qexhip_handle h, double out[8]);
 /* test hook: with one rank, route the t-direction hops through the halo path
  * (pack -> RCCL self send/recv -> boundary sweep) instead of the periodic wrap. */
 int qexhip_comm_force_halo(qexhip_handle h, int on);
@@ -133,6 +140,7 @@ int qexhip_comm_force_halo(qexhip_handle h, int on);
  * on lattices whose y, z, t extents are multiples of 4; QEXHIP_ERR_ARG where QEX itself gives up ("can't lay out inner geom") */
 int qexhip_layout_default_inner(const int localGeom[4], int V, int innerGeom[4]);
 /* v1_of_simd[outer*V + lane] = index of that site in the V = 1 even-odd order (Layout[1].rankIndex(Layout[V].coord(i))) */
+/* (all of these refuse an ODD local extent: the even/odd split of a QEX field then depends on the rank origin, which they are not given) */
 int qexhip_layout_simd_map(const int localGeom[4], const int innerGeom[4], int *v1_of_simd);
 /* colour vector: simd = double[outer][3][2][V] */
 int qexhip_layout_vec_simd_to_v1(const int localGeom[4], const int innerGeom[4], const double *simd, double *v1);
@@ -383,7 +391,7 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *                  0 / 1 also pin the launch structure, and with it the bits of a sharded residual history, from run to run
  *                  (the measurement takes the overlapped form only on a > 5 % win).  Must be the same on every rank (checked
  *                  at set_links)
- *   "transport"    before qexhip_comm_init: 0 auto, 1 rccl, 2 peer (see "communicator"); the same on every rank
+ *   "transport"    before qexhip_comm_init: 0 auto, 1 rccl, 2 peer, 3 mbox (see "communicator"); the same on every rank
  *   "flow_exp"     1: closed-form exp(v) in the Wilson-flow stage (default; agrees with the reference's to ~1e-15 per element),
  *                  0: the reference's algorithm, order-4 Taylor + 20 squarings (matexp.nim:80-85,634-649)
  *   test hooks -- each selects, on any lattice, the code path that some lattices / ranks take by necessity:
@@ -391,23 +399,19 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *   "batch_multi"  1: the same for the lock-step multi-system CG
  *   "smear_ca"     0: the nHYP levels of a t-sharded field refresh the ghost slices of every projected level field (rounds 1-4) instead of
  *                  computing them on shrinking ghost slices from one depth-3 thin-link exchange (default 1)
- *   "peer_zc"      0: peer transport, overlapped sweep: the neighbours' faces are copied from the receive arena into the field's ghost
- *                  tiles before the boundary launch, instead of being read from the arena by it (default 1)
- *   "hop_split"    how an overlapped sweep of a t-sharded field is split.  2: by HOPS in one launch -- interior workgroups, and boundary
- *                  workgroups that take the hops inside the slab, wait (bounded) on the device for the faces, then take the hops that
- *                  leave it; on the peer transport with zero-copy receive the launch's first workgroups also PUSH the faces: the whole
- *                  sweep is one kernel on one stream.  1: by hops in two launches (A/B).  0: by SITES (interior launch beside the
- *                  exchange, boundary launch on the second stream behind it, a join; rounds 1-4).  -1 (default): 2 on the peer transport
- *                  with zero-copy receive where every rank has a GPU of its own (ranks sharing one keep 0: two processes' waiting
- *                  boundary workgroups on one chip ran a 48^3 x 96 solve into the wait bound), else 0.  Boundary sites sum their local hops first under 1 / 2: equal to 0 to rounding.
- *   "peer_fold"    peer transport, the two rank sums of a sharded CG iteration (cg.nim:206-214).  0 (default): one-workgroup launches of
- *                  their own; 2: inside the prologues of the kernels that consume them (k_cg_update for <p,Ap>, k_cg_xpay / k_cg_close
- *                  for |r|^2: two launches and launch boundaries less per iteration) -- every workgroup of those launches then spins
- *                  until the slowest rank has sent, so it is taken only where the ranks have a GPU each or the launch is <= 256
- *                  workgroups; 1: |r|^2 in k_cg_update's tail (measured slower).  The same bits in every form.
- *   "sweep_chain"  1 / 0: the two overlapped sweeps of the normal operator always / never run chained (qexhip_stag_sweep_chain_info); -1
- *                  (default): chained where set_links measured it > 3 % faster than the overlapped pair (it wins while the interior
- *                  launch is longer than the exchange, loses when the exchange is: a narrower interior hides less of it)
+ *   "hop_split"    how an OVERLAPPED sweep of a t-sharded field is laid out on the peer transport (RCCL always runs 0).
+ *                  2: the FUSED sweep, one kernel on one stream (shifts.nim:67-94,254-285: local terms while the faces travel, boundary
+ *                  terms when they are in): its first workgroups push the faces into the neighbours' receive arenas, the interior
+ *                  workgroups take every hop of their sites, the boundary workgroups take the hops inside the slab, wait SHORTLY (about
+ *                  one measured exchange time) for the inbound data words and then either take the 1-2 hops per site that leave the slab
+ *                  straight from the arena, or -- faces late -- park their raw accumulator and give up their slot; the last <= 64
+ *                  workgroups of the grid finish the parked blocks behind the one LONG bounded wait (QEXHIP_PEER_TIMEOUT: a lost
+ *                  neighbour).  No kernel holds more than those 64 slots hostage to another rank's progress -- ranks may share a chip.
+ *                  0: by SITES (interior launch beside the exchange, boundary launch on the second stream behind it, device-side join).
+ *                  -1 (default): whichever set_links measured faster (qexhip_stag_sweep_tuning), fused until measured.  Boundary sites
+ *                  sum their local hops first under 2, parked or not: equal to 0 to rounding, and to itself to the bit.
+ *   "fused_spin_us" the fused sweep's short wait: -1 (default) max(25 us, one exchange time), >= 0 microseconds, -2 park every boundary
+ *                  block (test hook: the cleanup path everywhere)
  *   "chain_overlap" 0: the nHYP force chain of a t-sharded field exchanges a level's chain fields first and runs the next staple
  *                  derivative in one pass, instead of running its ghost-free slices beside the exchange (default 1; bit-identical)
  *   "force_pair"   0: k_force_lds (one tile and parity per workgroup), what shapes without paired tile positions run
@@ -419,7 +423,7 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *
  * Environment (read once, at qexhip_init / qexhip_comm_init) -- the complete list:
  *   QEXHIP_RECON, QEXHIP_OVERLAP, QEXHIP_HOP_SPLIT, QEXHIP_FLOW_EXP   initial values of the options of the same (lower-case) name
- *   QEXHIP_TRANSPORT=auto|rccl|peer, QEXHIP_RENDEZVOUS_TIMEOUT, QEXHIP_PEER_TIMEOUT   see "communicator"
+ *   QEXHIP_TRANSPORT=auto|rccl|peer|mbox, QEXHIP_RENDEZVOUS_TIMEOUT, QEXHIP_PEER_TIMEOUT, QEXHIP_LOCAL_RANKS   see "communicator"
  *   QEXHIP_COMM2=0   keep ONE RCCL communicator for both streams (default: the overlapped face exchange gets a communicator
  *                    of its own); the ranks agree on this by a min-all-reduce, any rank's 0 wins
  * Every other choice the kernels make (visiting orders, non-temporal accesses, LDS staging, launch shapes) is fixed to the

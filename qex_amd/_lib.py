@@ -34,7 +34,7 @@ SYMBOLS = [
     ("qexhip_comm_count", _ci, [_vp, _pi]),
     ("qexhip_comm_transport", _ci, [_vp, C.c_char_p, _ci, C.POINTER(C.c_long)]),
     ("qexhip_stag_sweep_info", _ci, [_vp, _pi]),
-    ("qexhip_stag_sweep_chain_info", _ci, [_vp, _pi]),
+    ("qexhip_stag_sweep_tuning", _ci, [_vp, _pd]),
     ("qexhip_dot", _ci, [_vp, _vp, _vp, _ci, _pd]),
     ("qexhip_dev_dot", _ci, [_vp, _ci, _ci, _ci, _pd]),
     ("qexhip_stag_set_links", _ci, [_vp, _vp, _vp]),

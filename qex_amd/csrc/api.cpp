@@ -124,13 +124,14 @@ static int init_body(qexhip_ctx *c, int device, const int latLocal[4], const int
   HIPCHK(hipMalloc((void **)&c->cg, sizeof(CgScal)));
   HIPCHK(hipMemset(c->cg, 0, sizeof(CgScal)));
   HIPCHK(hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault));
+  CHK(devjoin_init(c));
   if (getenv("QEXHIP_TEST_FAIL_INIT")) {      // test hook (tests/test_gpu_misc_ops.py): fail the way a late HIP error would, everything above built
     qexhip_set_error("QEXHIP_TEST_FAIL_INIT: injected failure");
     return QEXHIP_ERR_HIP;
   }
   // the environment switches of the library (include/qexhip.h "Environment")
   if (const char *e = getenv("QEXHIP_OVERLAP")) c->opt_overlap = atoi(e);
-  if (const char *e = getenv("QEXHIP_HOP_SPLIT")) c->opt_hop_split = atoi(e);
+  if (const char *e = getenv("QEXHIP_HOP_SPLIT")) { const int v = atoi(e); c->opt_hop_split = v < 0 ? -1 : (v ? 2 : 0); }
   if (const char *e = getenv("QEXHIP_RECON")) c->opt_recon = atoi(e);
   if (const char *e = getenv("QEXHIP_FLOW_EXP")) c->opt_flow_exp = atoi(e);
   {
@@ -199,8 +200,8 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
   if (c->cg) (void)hipFree(c->cg);
   if (c->hist) (void)hipFree(c->hist);
   if (c->pinned) (void)hipHostFree(c->pinned);
-  if (c->sj_ctr) (void)hipFree(c->sj_ctr);
-  if (c->sj_err) (void)hipHostFree(c->sj_err);
+  if (c->fz_buf) (void)hipFree(c->fz_buf);
+  devjoin_destroy(c);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -212,14 +213,10 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
 
 extern "C" int qexhip_sync(qexhip_handle c) {
   if (!c) return QEXHIP_ERR_ARG;
-  CHK(peer_flush_join(c));
+  CHK(devjoin_flush(c));
   HIPCHK(hipStreamSynchronize(c->cstream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (c->sj_err && __atomic_load_n(c->sj_err, __ATOMIC_ACQUIRE)) {
-    qexhip_set_error("sharded sweep: the boundary workgroups gave up waiting for the face exchange (QEXHIP_PEER_TIMEOUT)");
-    return QEXHIP_ERR_COMM;
-  }
-  return peer_check(c);
+  return devjoin_check(c);
 }
 
 extern "C" int qexhip_device_info(qexhip_handle c, char *buf, int buflen) {
@@ -228,9 +225,17 @@ extern "C" int qexhip_device_info(qexhip_handle c, char *buf, int buflen) {
   HIPCHK(hipGetDeviceProperties(&p, c->device));
   // tile_pairs: -1 until a gather kernel has built the visiting order, then whether its slots pair the two parities of a
   // tile position (k_force_lds2 needs that; otherwise the one-tile kernels run)
-  snprintf(buf, buflen, "%s (%s) CUs=%d mem=%.0fGiB local=%dx%dx%dx%d ranks=%d halo=%d tile_pairs=%d", p.name, p.gcnArchName,
-           p.multiProcessorCount, p.totalGlobalMem / 1073741824.0, c->g.X[0], c->g.X[1], c->g.X[2], c->g.X[3],
-           c->rankGeom[3], c->g.halo, c->tile_order ? c->tile_pairs_ok : -1);
+  int n = snprintf(buf, buflen, "%s (%s) CUs=%d mem=%.0fGiB local=%dx%dx%dx%d ranks=%d halo=%d tile_pairs=%d", p.name, p.gcnArchName,
+                   p.multiProcessorCount, p.totalGlobalMem / 1073741824.0, c->g.X[0], c->g.X[1], c->g.X[2], c->g.X[3],
+                   c->rankGeom[3], c->g.halo, c->tile_order ? c->tile_pairs_ok : -1);
+  // what set_links measured and decided for the sweeps of a t-sharded slab (qexhip_stag_sweep_tuning has the numbers as numbers):
+  // timing-dependent decisions change the grouping of the dot partials, i.e. the last bits of a residual history -- keep them visible
+  if (c->g.halo && c->W && n > 0 && n < buflen) {
+    double t[8];
+    if (qexhip_stag_sweep_tuning(c, t) == 0)
+      snprintf(buf + n, buflen - n, "; sweep: overlap=%d form=%s exchange=%.1fus%s boundary_at=%.2f spin=%.0fus tuned[first|sites|fused]=%.0f|%.0f|%.0f us",
+               (int)t[7], t[5] == 2 ? "fused" : "by-sites", t[0], c->xchg_us[c->ndir == 16] > 0 ? "(measured)" : "(estimate)", t[1], t[6], t[2], t[3], t[4]);
+  }
   return 0;
 }
 
@@ -336,25 +341,29 @@ extern "C" int qexhip_stag_sweep_info(qexhip_handle c, int out[8]) {
   const int slot = c->ndir == 16;
   out[0] = c->g.halo;
   out[1] = overlap;
-  const int hs = c->opt_hop_split >= 0 ? c->opt_hop_split : ((c->peer && c->opt_peer_zc && !c->ranks_share_device) ? 2 : 0);
-  out[2] = (c->g.halo && !(overlap && hs)) ? hi_beg - lo_end : c->g.Vh;     // (hop split: the main launch covers the slab)
+  out[2] = c->g.halo ? hi_beg - lo_end : c->g.Vh;
   out[3] = c->g.halo ? c->g.depth * c->g.F * 48 : 0;
   out[4] = c->overlap_auto[slot] >= 0;
   out[5] = (int)(c->overlap_tune_us[slot][0] + 0.5);
-  out[6] = (int)(c->overlap_tune_us[slot][1] + 0.5);
+  out[6] = (int)(std::max(c->overlap_tune_us[slot][1], 0.0) + 0.5);
   out[7] = c->opt_overlap;
   return 0;
 }
 
-extern "C" int qexhip_stag_sweep_chain_info(qexhip_handle c, int out[4]) {
+extern "C" int qexhip_stag_sweep_tuning(qexhip_handle c, double out[8]) {
   if (!c || !out) return QEXHIP_ERR_ARG;
   int lo_end = 0, hi_beg = 0, overlap = 0;
   sweep_plan(c, &lo_end, &hi_beg, &overlap);
   const int slot = c->ndir == 16;
-  out[0] = overlap && sweep_chain_on(c);
-  out[1] = c->chain_auto[slot] >= 0 && c->overlap_tune_us[slot][2] > 0.0;
-  out[2] = (int)(c->overlap_tune_us[slot][2] + 0.5);
-  out[3] = c->opt_sweep_chain;
+  const double meas = c->xchg_us[slot];
+  // (the estimate the placement falls back on where nothing was measured: dslash.hip exchange_estimate_us)
+  const double link = (c->emu_link_gbs > 0 ? c->emu_link_gbs : 45.0) * 1e3;
+  out[0] = meas > 0 ? meas : (c->g.halo ? 3.0 + (double)c->g.depth * c->g.F * 48.0 / link : 0.0);
+  out[1] = c->g.halo && c->ndir ? sweep_push_fraction(c, hi_beg - lo_end) : 0.0;
+  for (int k = 0; k < 3; k++) out[2 + k] = c->overlap_tune_us[slot][k];
+  out[5] = sweep_form(c, overlap);
+  out[6] = c->opt_fused_spin_us == -2 ? -1.0 : (c->opt_fused_spin_us >= 0 ? (double)c->opt_fused_spin_us : std::max(25.0, out[0]));
+  out[7] = overlap;
   return 0;
 }
 
@@ -672,7 +681,7 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "overlap") c->opt_overlap = value;
   else if (n == "transport") {
     if (comm_ready(c)) { qexhip_set_error("option transport must be set before qexhip_comm_init"); return QEXHIP_ERR_STATE; }
-    if (value < 0 || value > 2) { qexhip_set_error("option transport: 0 auto, 1 rccl, 2 peer"); return QEXHIP_ERR_ARG; }
+    if (value < 0 || value > 3) { qexhip_set_error("option transport: 0 auto, 1 rccl, 2 peer, 3 rccl + mailbox sums"); return QEXHIP_ERR_ARG; }
     c->opt_transport = value;
   }
   else if (n == "batch_multi") c->opt_batch_multi = value;
@@ -680,10 +689,11 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
   else if (n == "flow_exp") c->opt_flow_exp = value;
   else if (n == "smear_ca") c->opt_smear_ca = value;
   else if (n == "chain_overlap") c->opt_chain_overlap = value;
-  else if (n == "peer_zc") c->opt_peer_zc = value;
-  else if (n == "sweep_chain") c->opt_sweep_chain = value;
-  else if (n == "peer_fold") c->opt_peer_fold = value;
-  else if (n == "hop_split") c->opt_hop_split = value;
+  else if (n == "hop_split") {
+    if (value != -1 && value != 0 && value != 2) { qexhip_set_error("option hop_split: -1 measured, 0 split by sites, 2 fused (the two-launch form 1 left the library in round 6)"); return QEXHIP_ERR_ARG; }
+    c->opt_hop_split = value;
+  }
+  else if (n == "fused_spin_us") c->opt_fused_spin_us = value;
   else if (n == "emu_exchange_us") c->emu_exchange_us = value;
   else if (n == "emu_allreduce_us") c->emu_allreduce_us = value;
   else if (n == "emu_link_gbs") c->emu_link_gbs = value;

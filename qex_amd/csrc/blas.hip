@@ -219,9 +219,8 @@ int read_scalars(qexhip_ctx *c, const double *dev, int n, double *host) {
 // Sharded, the partial VECTORS are all-reduced (a few KB: the same latency as one double), which keeps the two one-block
 // reduction launches out of the iteration as well.
 // q := z (itn 0) | q := z + beta*q, beta = rz/rzo   (cg.nim:186-193; cpNone: z=r, q=p)
-// F.on (peer transport, option peer_fold 2): the rank sum of |r|^2 happens here, in every workgroup (peer_device.h: gran_allreduce_grid)
 __global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, size_t n, CgScal *s, int k, int rolled,
-                                                const double *r2parts, int nparts, double *hist, int histcap, const PeerFold F) {
+                                                const double *r2parts, int nparts, double *hist, int histcap) {
   const int cur = k & 1, prv = cur ^ 1;
   double r2k;
   if (rolled) {
@@ -233,7 +232,6 @@ __global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, s
       return;
     }
     r2k = cg_sum_parts(r2parts, nparts);
-    if (F.on && !gran_allreduce_grid(r2k, F, &r2k)) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) cg_roll(s, k, r2k, hist, histcap);
     if (!(k < s->maxits && r2k > s->r2stop)) return;
   }
@@ -250,17 +248,11 @@ __global__ void __launch_bounds__(256) k_cg_xpay(double2 *p, const double2 *r, s
 }
 // alpha = rz/qLAp; x += alpha*p; r -= alpha*Ap; partial |r|^2   (cg.nim:208-213)
 // With ndot > 0 every workgroup first sums the <p,Ap> workgroup partials of the preceding Dslash sweep itself.
-// T.on (sharded, peer transport): the all-reduce of |r|^2 (cg.nim:213 `r2 = r.norm2` is a rank sum) happens in this kernel's tail.
-// Every workgroup publishes its partial write-through (sc1 store, drained) and takes an arrival ticket (agent-scope add); the one
-// whose ticket is last reads all partials back with sc1 loads (MI355X_MICROARCH "valid forms": no release / acquire fence
-// needed for sc1 bytes behind a drained store and a ticket), sums them in cg_sum_parts order -- the order the next k_cg_xpay
-// would have used -- and exchanges the sum with the other ranks; partials[0] = the total, which the consumer reads as ONE part.
 __global__ void __launch_bounds__(256) k_cg_update(double2 *x, double2 *r, const double2 *p, const double2 *Ap,
                                                   size_t n, const CgScal *s, int k, double *partials,
-                                                  const double *dotp, int ndot, const PeerTail T, const PeerFold F) {
+                                                  const double *dotp, int ndot) {
   if (s->dones[k & 1]) return;
-  double pAp = (ndot > 0) ? cg_sum_parts(dotp, ndot) : s->pAp;
-  if (F.on && !gran_allreduce_grid(pAp, F, &pAp)) return;        // (peer_fold 2: <p,Ap>'s rank sum in this kernel's prologue)
+  const double pAp = (ndot > 0) ? cg_sum_parts(dotp, ndot) : s->pAp;
   const double alpha = s->r2s[k & 1] / pAp;
   double acc = 0;
   for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -271,26 +263,7 @@ __global__ void __launch_bounds__(256) k_cg_update(double2 *x, double2 *r, const
     acc = fma(rv.x, rv.x, fma(rv.y, rv.y, acc));
   }
   double t = block_sum_256(acc);
-  if (!T.on) {
-    if (threadIdx.x == 0) partials[blockIdx.x] = t;
-    return;
-  }
-  __shared__ int last;
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(&partials[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned a = __hip_atomic_fetch_add(T.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last = (a == gridDim.x - 1);
-    if (last) __hip_atomic_store(T.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch (kernel boundary in between)
-  }
-  __syncthreads();
-  if (!last) return;
-  double a = 0;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const double local = block_sum_256_all(a);
-  double tot = 0;
-  if (!gran_allreduce_block(local, T.G, T.seq, &tot)) return;
-  if (threadIdx.x == 0) partials[0] = tot;
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 // r2stop = r2req*b2; loop condition `itn<maxits and r2>r2stop` (cg.nim:155,174)
 __global__ void k_cg_init(CgScal *s, const double *dscal, double r2req, int maxits, double *hist, int histcap) {
@@ -307,30 +280,24 @@ __global__ void k_cg_init(CgScal *s, const double *dscal, double r2req, int maxi
   if (histcap > 0) hist[0] = (s->b2 != 0.0) ? s->r2 / s->b2 : 0.0;
 }
 // end of a chunk: the bookkeeping of the last iteration, so that the host can read slot k&1
-__global__ void __launch_bounds__(256) k_cg_close(CgScal *s, int k, const double *r2parts, int nparts, double *hist, int histcap, const PeerFold F) {
+__global__ void __launch_bounds__(256) k_cg_close(CgScal *s, int k, const double *r2parts, int nparts, double *hist, int histcap) {
   if (s->dones[(k & 1) ^ 1]) {
     if (threadIdx.x == 0) cg_carry(s, k);
     return;
   }
-  double r2k = cg_sum_parts(r2parts, nparts);
-  if (F.on && !gran_allreduce_grid(r2k, F, &r2k)) return;
+  const double r2k = cg_sum_parts(r2parts, nparts);
   if (threadIdx.x == 0) cg_roll(s, k, r2k, hist, histcap);
 }
 
-// Option peer_fold = 2 (peer transport): the two rank sums of an iteration ride in the prologues of the kernels that consume them
-// instead of being launches of their own.  EVERY workgroup of such a launch spins until the slowest rank has sent: taken only when
-// the ranks have a GPU each (another rank's kernels could otherwise wait for the slots the spinners hold) or the launch is small.
-static bool fold_in_consumers(const qexhip_ctx *c, int grid) {
-  return c->peer && c->opt_peer_fold == 2 && multi_rank(c) && comm_ready(c) && (!c->ranks_share_device || grid <= 256);
-}
+// The two rank sums of a sharded iteration (cg.nim:206-214: <p,Ap> and |r|^2 both end in threadRankSum) are launches of their own
+// behind the kernels that produce the partials: one workgroup per rank, the scalar through the mailboxes (peer.hip), or RCCL's
+// all-reduce of the partial vector.  Folding them into the tail of k_cg_update or the prologues of the consumers was measured twice in
+// round 5 and lost / tied (profiles/r05_fold_compare.log, r05_fold2_compare.log); those forms are in the history, not in the library.
 int cg_xpay(qexhip_ctx *c, DevField &p, const DevField &r, int parity, int k, int rolled) {
   size_t n = body2(c);
-  PeerFold F;
-  memset(&F, 0, sizeof F);
-  if (!rolled && c->cg_r2_fold) { CHK(peer_fold_args(c, &F)); c->cg_r2_fold = 0; }
   ScopedTimer tm(c, "blas", c->stream);
   k_cg_xpay<<<grid_for(n), 256, 0, c->stream>>>(p.par(parity), r.par(parity), n, c->cg, k, rolled,
-                                               c->partials + c->part2_off, rolled ? grid_for(n) : c->cg_r2parts, c->hist, c->histcap, F);
+                                               c->partials + c->part2_off, rolled ? grid_for(n) : c->cg_r2parts, c->hist, c->histcap);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -340,33 +307,19 @@ int cg_update(qexhip_ctx *c, DevField &x, DevField &r, const DevField &p, const 
   size_t n = body2(c);
   int nb = grid_for(n);
   double *r2p = c->partials + c->part2_off;
-  const bool fold = fold_in_consumers(c, nb);
-  PeerFold F;
-  memset(&F, 0, sizeof F);
-  if (fold && ndot > 0) CHK(peer_fold_args(c, &F));             // <p,Ap>: summed over the ranks inside k_cg_update
-  else if (ndot > 0) CHK(comm_allreduce_parts(c, c->partials, ndot, &ndot));
-  CHK(peer_flush_join(c));              // (no-op when the all-reduce has taken the second sweep's join with it)
-  // option "peer_fold" 1 (sharded on the peer transport): the |r|^2 all-reduce rides in the kernel's tail instead of being a launch of its own
-  PeerTail T;
-  memset(&T, 0, sizeof T);
-  const bool tail = !fold && c->peer && c->opt_peer_fold == 1 && multi_rank(c) && comm_ready(c);
-  if (tail) CHK(peer_tail_args(c, &T));
+  if (ndot > 0) CHK(comm_allreduce_parts(c, c->partials, ndot, &ndot));
+  CHK(devjoin_flush(c));              // (no-op when the all-reduce has taken the second sweep's join with it)
   {
     ScopedTimer tm(c, "blas", c->stream);
     k_cg_update<<<nb, 256, 0, c->stream>>>(x.par(parity), r.par(parity), p.par(parity), Ap.par(parity), n, c->cg, k, r2p,
-                                           c->partials, ndot, T, F);
+                                           c->partials, ndot);
     HIPCHK(hipGetLastError());
   }
-  if (tail) c->cg_r2parts = 1;                                    // r2p[0] is the all-reduced |r|^2 already
-  else if (fold) { c->cg_r2parts = nb; c->cg_r2_fold = 1; }        // the next k_cg_xpay / k_cg_close sums the partials AND the ranks
-  else CHK(comm_allreduce_parts(c, r2p, nb, &c->cg_r2parts));     // how many values the next k_cg_xpay / k_cg_close has to sum
+  CHK(comm_allreduce_parts(c, r2p, nb, &c->cg_r2parts));     // how many values the next k_cg_xpay / k_cg_close has to sum
   return 0;
 }
 int cg_close(qexhip_ctx *c, int k) {
-  PeerFold F;
-  memset(&F, 0, sizeof F);
-  if (c->cg_r2_fold) { CHK(peer_fold_args(c, &F)); c->cg_r2_fold = 0; }
-  k_cg_close<<<1, 256, 0, c->stream>>>(c->cg, k, c->partials + c->part2_off, c->cg_r2parts, c->hist, c->histcap, F);
+  k_cg_close<<<1, 256, 0, c->stream>>>(c->cg, k, c->partials + c->part2_off, c->cg_r2parts, c->hist, c->histcap);
   HIPCHK(hipGetLastError());
   return comm_agree_post(c);
 }

@@ -34,59 +34,38 @@ extern "C" int qexhip_comm_unique_id(char id[QEXHIP_UNIQUE_ID_BYTES]) {
 }
 
 // QEXHIP_TRANSPORT / option "transport": which transport a communicator uses.  One decision for the whole job:
-//   rccl (1)  RCCL between distinct devices, the north star's transport; no rendezvous, works across nodes
-//   peer (2)  peer-mapped memory (peer.hip); one node; the only choice when ranks share a device
-//   auto (0, default)  the ranks meet in a shared-memory segment named after the id, compare devices, and take `peer` if
-//             any two of them share one (RCCL refuses that), `rccl` otherwise
+//   rccl (1)  RCCL for everything, the north star's transport; no rendezvous, works across nodes
+//   peer (2)  peer-mapped memory for faces and sums (peer.hip); one node; the only choice when ranks share a device
+//   mbox (3)  RCCL for the faces, the peer control block's mailboxes for the CG's rank sums (4 us instead of 15-20 per sum); one node
+//   auto (0, default)  the ranks of a ONE-NODE job meet in a shared-memory segment named after the id and compare devices: `peer` if
+//             any two of them share one (RCCL refuses that), else `mbox` if the mailboxes pass a self-test between the devices, else
+//             `rccl`.  A job that spans nodes (LOCAL_WORLD_SIZE and friends say so, or the rendezvous times out) takes `rccl`.
 static int transport_wish(const qexhip_ctx *c) {
   if (c->opt_transport >= 0) return c->opt_transport;
   const char *e = getenv("QEXHIP_TRANSPORT");
   if (!e || !*e) return 0;
   if (!strcmp(e, "rccl") || !strcmp(e, "1")) return 1;
   if (!strcmp(e, "peer") || !strcmp(e, "2")) return 2;
+  if (!strcmp(e, "mbox") || !strcmp(e, "rccl+mbox") || !strcmp(e, "3")) return 3;
   return 0;
 }
 
-// Decide the transport (collective over the node's ranks unless the wish is rccl).  *use_peer = 1: `host` stays open for peer_init.
-static int choose_transport(qexhip_ctx *c, const char *id, int nranks, int rank, PeerHost *host, int *use_peer) {
-  *use_peer = 0;
-  const int wish = transport_wish(c);
-  if (wish == 1 || nranks > PEER_MAXR) return 0;
-  if (wish == 0 && nranks == 1) return 0;          // one rank, no preference: nobody to meet (the one-rank RCCL communicator of the rehearsals)
+// Decide the transport (collective over the node's ranks unless the wish is rccl): peer_shm.cpp has the decision itself (pure host code,
+// CPU-tested with forked ranks incl. the multi-node cases).  *mode: 0 rccl, 2 peer, 3 rccl + mailbox sums; for 2 and 3 `host` stays open
+// for peer_init.
+static int choose_transport(qexhip_ctx *c, const char *id, int nranks, int rank, PeerHost *host, int *mode) {
+  char bus[32];
+  bus[0] = 0;
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, c->device) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "dev%d", c->device); }
   double tmo = 120.0;
   if (const char *e = getenv("QEXHIP_RENDEZVOUS_TIMEOUT")) { const double v = atof(e); if (v > 0) tmo = v; }
-  if (int e = peer_host_open(host, (const unsigned char *)id, nranks, rank, tmo)) {
-    if (wish == 2) return e;
-    // auto: no shared-memory segment to meet in (no /dev/shm, a sandbox): RCCL is the only transport left, and says so itself if the
-    // ranks turn out to share a device
-    fprintf(stderr, "libqexhip: rank %d: no rendezvous segment (%s): taking the RCCL transport\n", rank, qexhip_last_error());
-    return 0;
-  }
-  PeerShmSlot &me = host->shm->s[rank];
-  me.device = c->device;
-  me.wish = wish;
-  me.bus[0] = 0;
-  if (hipDeviceGetPCIBusId(me.bus, (int)sizeof me.bus, c->device) != hipSuccess) { (void)hipGetLastError(); snprintf(me.bus, sizeof me.bus, "dev%d", c->device); }
-  if (int e = peer_host_barrier(host)) { peer_host_close(host); return e; }
-  int any_peer = 0, shared = 0;
-  for (int r = 0; r < nranks; r++) {
-    const PeerShmSlot &a = host->shm->s[r];
-    if (a.wish == 2) any_peer = 1;
-    for (int q = 0; q < r; q++) {
-      const PeerShmSlot &b = host->shm->s[q];
-      if (!strncmp(a.bus, b.bus, sizeof a.bus) && !strncmp(a.host, b.host, sizeof a.host)) shared = 1;
-    }
-  }
-  *use_peer = (any_peer || shared) ? 1 : 0;
+  int shared = 0;
+  CHK(peer_host_choose(host, (const unsigned char *)id, nranks, rank, transport_wish(c), c->device, bus, tmo, mode, &shared));
   c->ranks_share_device = shared;
-  if (!*use_peer) {
-    // every rank has read the table (it decided the same): a second barrier keeps rank 0 from unmapping under a slow reader
-    int e = peer_host_barrier(host);
-    peer_host_close(host);
-    return e;
-  }
   return 0;
 }
+
+static int rccl_init(qexhip_ctx *c, const char *id, int nranks, int rank);
 
 extern "C" int qexhip_comm_init(qexhip_handle c, const char id[QEXHIP_UNIQUE_ID_BYTES], int nranks, int rank) {
   if (!c || !id) return QEXHIP_ERR_ARG;
@@ -97,17 +76,47 @@ extern "C" int qexhip_comm_init(qexhip_handle c, const char id[QEXHIP_UNIQUE_ID_
   }
   if (comm_ready(c)) { qexhip_set_error("communicator already initialised"); return QEXHIP_ERR_STATE; }
   HIPCHK(hipSetDevice(c->device));
-  {
-    PeerHost host;
-    int use_peer = 0;
-    CHK(choose_transport(c, id, nranks, rank, &host, &use_peer));
-    if (use_peer) {
-      c->nranks = nranks;
-      c->rank = rank;
-      if (int e = peer_init(c, host)) { peer_destroy(c); c->nranks = 1; c->rank = 0; return e; }
-      return 0;
-    }
+  PeerHost host;
+  int mode = 0;
+  CHK(choose_transport(c, id, nranks, rank, &host, &mode));
+  if (mode == 2) {
+    c->nranks = nranks;
+    c->rank = rank;
+    if (int e = peer_init(c, host)) { peer_destroy(c); c->nranks = 1; c->rank = 0; return e; }
+    return 0;
   }
+  if (mode == 3) {
+    // RCCL for the faces, the mailboxes for the sums.  The control blocks are mapped between DISTINCT devices here, and a granule that
+    // crosses xGMI is what no box of rounds 1-6 could try: the mapping, a self-test of the all-reduce with known answers, and the
+    // agreement on both are all allowed to fail -- every rank then drops the control block together and RCCL carries the sums as
+    // well (QEXHIP_TRANSPORT=mbox insists instead).
+    c->nranks = nranks;
+    c->rank = rank;
+    const bool insist = transport_wish(c) == 3;
+    int e = peer_init(c, host);
+    double bad[1] = {0.0};
+    if (!e) {
+      bad[0] = peer_selftest(c) ? 1.0 : 0.0;
+      e = peer_host_reduce(c, bad, 1, 0);               // max over the ranks, through the segment: one outcome for the whole job
+    }
+    if (e || bad[0] != 0.0) {
+      if (!e) qexhip_set_error("mailbox self-test between the devices failed on some rank");
+      if (insist) { peer_destroy(c); c->nranks = 1; c->rank = 0; return e ? e : QEXHIP_ERR_COMM; }
+      fprintf(stderr, "libqexhip: rank %d: no mailbox sums between the devices (%s): RCCL carries the rank sums too\n", rank, qexhip_last_error());
+      peer_destroy(c);
+      *c->dj.err = 0;                                    // (a self-test wait that ran out is not an error of the job)
+    } else c->hybrid_sums = 1;
+    c->nranks = 1; c->rank = 0;
+  }
+  if (int e = rccl_init(c, id, nranks, rank)) {
+    if (c->peer) peer_destroy(c);
+    c->hybrid_sums = 0;
+    return e;
+  }
+  return 0;
+}
+
+static int rccl_init(qexhip_ctx *c, const char *id, int nranks, int rank) {
   HIPCHK(hipSetDevice(c->device));
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
@@ -169,7 +178,7 @@ void comm_destroy(qexhip_ctx *c) {
 
 extern "C" int qexhip_comm_count(qexhip_handle c, int *ncomms) {
   if (!c || !ncomms) return QEXHIP_ERR_ARG;
-  *ncomms = c->peer ? 2 : (c->comm ? 1 : 0) + (c->comm2 ? 1 : 0);      // peer transport: the two stream classes are independent channels
+  *ncomms = peer_faces(c) ? 2 : (c->comm ? 1 : 0) + (c->comm2 ? 1 : 0);      // peer transport: the two stream classes are independent channels
   return 0;
 }
 
@@ -187,7 +196,8 @@ static int need_comm(const qexhip_ctx *c) {
 
 extern "C" int qexhip_comm_transport(qexhip_handle c, char *name, int len, long stats[4]) {
   if (!c) return QEXHIP_ERR_ARG;
-  if (name && len > 0) snprintf(name, len, "%s", c->peer ? "peer" : (c->comm ? "rccl" : "none"));
+  // "rccl+mbox": RCCL carries the faces, the peer control block's mailboxes the CG's rank sums (one node, distinct devices)
+  if (name && len > 0) snprintf(name, len, "%s", peer_faces(c) ? "peer" : (c->comm ? (c->peer ? "rccl+mbox" : "rccl") : "none"));
   if (stats) peer_info(c, stats);
   return 0;
 }
@@ -196,7 +206,7 @@ extern "C" int qexhip_comm_transport(qexhip_handle c, char *name, int len, long 
 extern "C" int qexhip_comm_info(qexhip_handle c, int *nranks, int *rank, int *device, char *busid, int buslen) {
   if (!c) return QEXHIP_ERR_ARG;
   int n = 0, r = -1, d = c->device;
-  if (c->peer) { n = c->nranks; r = c->rank; }
+  if (peer_faces(c)) { n = c->nranks; r = c->rank; }
   if (c->comm) {
     NCCLCHK(ncclCommCount((ncclComm_t)c->comm, &n));
     NCCLCHK(ncclCommUserRank((ncclComm_t)c->comm, &r));
@@ -223,7 +233,7 @@ static double emu_exchange_time(const qexhip_ctx *c, size_t bytes) {
 // Peer arm: the time goes INTO the exchange kernel (peer.hip): data counts as arrived no earlier than that long after the
 // kernel started, the local copy that stands in for the remote push runs inside the window -- as the real push would.
 static int emu_exchange(qexhip_ctx *c, hipStream_t st, size_t bytes) {
-  if (c->peer) return 0;
+  if (peer_faces(c)) return 0;
   return blas_delay(st, (int)(emu_exchange_time(c, bytes) + 0.5));
 }
 
@@ -251,7 +261,7 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
   if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   ScopedTimer tm(c, "exchange", cs);            // on the stream the group is posted on: transport + waiting for the neighbours
   CHK(emu_exchange(c, cs, nd * sizeof(double)));
-  if (c->peer) {
+  if (peer_faces(c)) {
     const void *dn = bottom, *up = top;
     void *from_up = ghost_hi, *from_dn = ghost_lo;
     CHK(peer_exchange(c, cs, 1, &dn, 1, &up, &from_up, &from_dn, nd * sizeof(double), emu_exchange_time(c, nd * sizeof(double))));
@@ -273,23 +283,20 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
   return 0;
 }
 
-// Peer transport, overlapped sweep: the faces of one parity half of f are pushed to the neighbours and what arrives STAYS in the
-// receive arena.  gh_hi / gh_lo come back pre-offset so that gh[vec_off(pos, colour)] addresses the ghost POSITION pos of the field
-// (ghost_hi: pos in [Vh, Vh + depth F), ghost_lo: the depth F positions behind it) -- the boundary launch reads them instead of the
-// field's ghost tiles, and peer_release_zc behind it returns the credits.  On the comm stream after ev_ready.
-int comm_halo_exchange_zc(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, bool wait_ready, bool linger,
-                          PeerPush *push_only) {
+// Peer transport, the fused sweep: the faces of one parity half of f will be pushed by the caller's OWN kernel (`push` is filled for its
+// first workgroups) and what arrives STAYS in the receive arena.  gh_hi / gh_lo come back pre-offset so that gh[vec_off(pos, colour)]
+// addresses the ghost POSITION pos of the field (ghost_hi: pos in [Vh, Vh + depth F), ghost_lo: the depth F positions behind it) -- the
+// kernel reads them instead of the field's ghost tiles and returns the credits (peer_ghost_args).  Nothing is launched here.
+int comm_halo_push_only(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, PeerPush *push) {
   CHK(need_comm(c));
-  if (!c->peer) { qexhip_set_error("internal: zero-copy halo exchange without the peer transport"); return QEXHIP_ERR_STATE; }
+  if (!peer_faces(c)) { qexhip_set_error("internal: fused sweep without the peer transport's arenas"); return QEXHIP_ERR_STATE; }
   const Geom &g = c->g;
   const size_t face2 = (size_t)g.depth * g.F * 3;
   const size_t nd = face2 * 2;
   double2 *base = f.par(parity);
   const void *dn = base, *up = base + (size_t)(g.ntile) * 192 - face2;
-  if (wait_ready && !push_only) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));      // (not when the comm stream produced the faces itself)
-  ScopedTimer tm(c, push_only ? nullptr : "exchange", c->cstream);
   const void *from_up = nullptr, *from_dn = nullptr;
-  CHK(peer_exchange(c, c->cstream, 1, &dn, 1, &up, nullptr, nullptr, nd * sizeof(double), emu_exchange_time(c, nd * sizeof(double)), &from_up, &from_dn, linger, push_only));
+  CHK(peer_exchange(c, c->cstream, 1, &dn, 1, &up, nullptr, nullptr, nd * sizeof(double), emu_exchange_time(c, nd * sizeof(double)), &from_up, &from_dn, push));
   // tile-aligned zones (64 | F): vec_off(pos, k) - vec_off(zone start, 0) = vec_off(pos - zone start, k)
   *gh_hi = (const double2 *)from_up - (size_t)(g.Vh >> 6) * 192;
   *gh_lo = (const double2 *)from_dn - (size_t)((g.Vh + g.depth * g.F) >> 6) * 192;
@@ -307,7 +314,7 @@ int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parit
   if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   ScopedTimer tm(c, "exchange", cs);
   CHK(emu_exchange(c, cs, (size_t)n * nd * sizeof(double)));
-  if (c->peer) {
+  if (peer_faces(c)) {
     std::vector<const void *> dn(n), up(n);
     std::vector<void *> from_up(n), from_dn(n);
     for (int j = 0; j < n; j++) {
@@ -345,7 +352,7 @@ int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parit
 int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st) {
   CHK(need_comm(c));
   CHK(emu_exchange(c, st, bytes));
-  if (c->peer) {
+  if (peer_faces(c)) {
     CHK(peer_exchange(c, st, 0, nullptr, 1, &send_up, nullptr, &recv_from_down, bytes, emu_exchange_time(c, bytes)));
   } else if (c->comm) {
     ncclComm_t comm = (ncclComm_t)c->comm;
@@ -371,7 +378,7 @@ int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double 
   if (async) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
   ScopedTimer tm(c, "faces", st);               // after the wait for the producer: transport only (the same span as "exchange" above)
   CHK(emu_exchange(c, st, (size_t)nbuf * ndoubles * sizeof(double)));
-  if (c->peer) {
+  if (peer_faces(c)) {
     CHK(peer_exchange(c, st, nbuf, (const void *const *)bottom, nbuf, (const void *const *)top, (void *const *)ghost_hi, (void *const *)ghost_lo,
                       ndoubles * sizeof(double), emu_exchange_time(c, (size_t)nbuf * ndoubles * sizeof(double))));
   } else if (c->comm) {
@@ -398,7 +405,7 @@ int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double 
 // rank-ordered concatenation of `n` doubles per rank (one rank / no communicator: a copy)
 int comm_allgather(qexhip_ctx *c, const double *send, double *recv, size_t n) {
   CHK(need_comm(c));
-  if (c->peer && c->nranks > 1) return peer_allgather(c, send, recv, n);
+  if (peer_faces(c) && c->nranks > 1) return peer_allgather(c, send, recv, n);
   if (c->comm && c->nranks > 1) {
     NCCLCHK(ncclAllGather(send, recv, n, ncclDouble, (ncclComm_t)c->comm, c->stream));
   } else {
@@ -425,8 +432,8 @@ int comm_allreduce(qexhip_ctx *c, double *dptr, int n) {
 int comm_allreduce_parts(qexhip_ctx *c, double *parts, int n, int *n_out) {
   *n_out = n;
   CHK(need_comm(c));
-  if (!multi_rank(c) || !comm_ready(c) || n <= 0) return peer_flush_join(c);     // (a join deferred to this call still has to happen)
-  if (!c->peer) return comm_allreduce(c, parts, n);
+  if (!multi_rank(c) || !comm_ready(c) || n <= 0) return devjoin_flush(c);     // (a join deferred to this call still has to happen)
+  if (!c->peer) { CHK(devjoin_flush(c)); return comm_allreduce(c, parts, n); }
   ScopedTimer tm(c, "allreduce", c->stream);
   *n_out = 1;
   return peer_allreduce_parts(c, parts, n);
@@ -435,7 +442,7 @@ int comm_allreduce_parts(qexhip_ctx *c, double *parts, int n, int *n_out) {
 int comm_allreduce_max(qexhip_ctx *c, double *host, int n) {
   if (n > 4) return QEXHIP_ERR_ARG;
   if (!comm_ready(c) || c->nranks < 2) return 0;
-  if (c->peer) return peer_host_reduce(c, host, n, 0);     // host operands: through the rendezvous segment, no GPU involved
+  if (c->peer) return peer_host_reduce(c, host, n, 0);     // host operands: through the rendezvous segment, no GPU involved (hybrid too)
   double *d = &c->dscal[56];
   HIPCHK(hipMemcpyAsync(d, host, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   NCCLCHK(ncclAllReduce(d, d, n, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));

@@ -217,7 +217,7 @@ int solve_xx_multi_dev(qexhip_ctx *c, std::vector<DevField *> &xs, DevField &b, 
       // sharded: the workgroup partials themselves are all-reduced (a few KB, the latency of one double), so the
       // iteration needs no one-block reduction launches; ndot == 0: big local volume, op_xx has reduced <p,Ap> already
       if (sharded && ndot > 0) CHK(comm_allreduce_parts(c, c->partials, ndot, &ndot));
-      CHK(peer_flush_join(c));              // (no-op when the all-reduce has taken the second sweep's join with it)
+      CHK(devjoin_flush(c));              // (no-op when the all-reduce has taken the second sweep's join with it)
       {
         ScopedTimer tm(c, "blas", c->stream);
         k_cgm_base<<<nb, 256, 0, c->stream>>>(xs[0]->par(par), r->par(par), ps[0]->par(par), Ap->par(par), n, c->cg, r2p,

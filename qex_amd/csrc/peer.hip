@@ -27,8 +27,9 @@
 //     rank can be at most one all-reduce ahead of the slowest one, so four slots never collide.  Up to 32 doubles (the CG's
 //     scalars: k_peer_allreduce_small) travel INSIDE sequence-tagged 8-byte words, no fence and no separate flag; longer
 //     vectors (k_peer_allreduce) as payload + release + flag.
-//   stream join: a one-lane kernel raises a device counter behind what a stream has posted, a one-wave kernel makes another
-//     stream wait for it -- instead of the runtime's cross-queue event dependency (~20 us of dead time per sweep here).
+//   stream join (devjoin_*, used by BOTH transports since round 6): a one-lane kernel raises a device counter behind what a stream has
+//     posted, a one-wave kernel makes another stream wait for it -- instead of the runtime's cross-queue event dependency (~20-28 us of
+//     dead time per sweep here).
 // Every device-side wait is bounded (timeout -> error word in pinned host memory -> QEXHIP_ERR_COMM at the next host
 // sync): both processes may share the CUs, and a wave that never exits would take the box down.
 #include "qexhip_internal.h"
@@ -59,14 +60,9 @@ struct PeerComm {
   char *pctrl[PEER_MAXR]{};              // every rank's control block as mapped here (own pointer at [rank])
   char *parena[2][PEER_MAXR]{};          // arenas of the two neighbours as mapped here
   unsigned int *done = nullptr;          // device: [class][push | unpack] completion counters
-  u64 *err = nullptr;                    // pinned host word the kernels write on a timeout
+  u64 *err = nullptr;                    // = the context's error word (DevJoin): the kernels write it on a timeout
   u64 seq_out[2][2]{}, seq_in[2][2]{}, seq_red = 0;
-  u64 *ready = nullptr;                  // device, local: the two stream-join counters (word k*16 for joins FROM stream k)
-  unsigned int *tail_count = nullptr;    // device, local: arrival tickets of the all-reduce in k_cg_update's tail (peer_device.h)
-  u64 join_seq[2]{};                     // peer_stream_signal / _join sequence numbers
-  int join_deferred = 0;                 // the compute stream still owes a wait for join_seq[1] (peer_stream_join_defer): the next granule all-reduce of
-                                         // workgroup partials polls for it in its prologue, anything else flushes it first (peer_flush_join)
-  struct { int live = 0; u64 *credit_out[2]; u64 seq_in[2]; const u64 *in_flag[2]; long long emu_ticks; } zc[2];   // per stream class: the zero-copy exchange whose credits are still owed
+  struct { int live = 0; u64 *credit_out[2]; u64 seq_in[2]; const u64 *in_flag[2]; long long emu_ticks; } zc;   // the push-only exchange (comm stream class) whose credits are still owed
   long long ticks = 0;                   // timeout in wall_clock64 ticks
   double timeout_s = 30.0;
   long exchanges = 0, allreduces = 0, grows = 0;
@@ -93,16 +89,11 @@ struct PeerXfer {
   long long emu_ticks;                // transport emulation: the inbound data counts as arrived no earlier than this long after the kernel started
   unsigned n16;                       // 16-byte units per piece (< 2^32: pieces below 64 GiB)
   int ns[2], nr[2];
-  int zc;                             // zero-copy receive: what arrives stays in the arena for the consumer; no unpack, no credit here.
-                                      // 1: one workgroup stays until the faces are in (the stream order behind this kernel means "arrived");
-                                      // 2: nobody stays -- the consumer polls the data words itself (fused hop-split sweep)
-  long long *t_start_out;             // zc == 2 under emulation: when this kernel started (the consumer counts the transport time from here)
 };
 
 __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
   __shared__ int ok;
   const long long t_start = X.emu_ticks > 0 ? wall_clock64() : 0;
-  if (X.t_start_out && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(X.t_start_out, t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // NOTE all chunk arithmetic is 32-bit on purpose: with a 64-bit `n16 - off < PEER_CHUNK ? n16 - off : PEER_CHUNK` hipcc
   // (ROCm 7.2, gfx950) selected the tail length on a stale SCC (s_cselect_b32 behind a VALU v_cmp_lt_u64): piece 0 of a
   // multi-piece message copied a whole chunk and ran over its neighbour in the arena (profiles/r05_notes.md)
@@ -138,7 +129,6 @@ __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
     }
   }
   // ---- unpack ----
-  if (X.zc == 2 || (X.zc && blockIdx.x != 0)) return;   // zero-copy: ONE workgroup keeps the kernel alive until the faces have arrived, or (2) none
   const unsigned nin = (unsigned)(X.nr[0] + X.nr[1]) * cpp;
   if (threadIdx.x == 0) {
     int good = 1;
@@ -152,7 +142,7 @@ __global__ void __launch_bounds__(256) k_peer_exchange(const PeerXfer X) {
     ok = good;
   }
   __syncthreads();
-  if (!ok || X.zc) return;                         // (zero-copy: the consumer reads the arena; peer_release_zc returns the credits behind it)
+  if (!ok) return;
   for (unsigned ch = blockIdx.x; ch < nin; ch += gridDim.x) {
     const unsigned q = ch / cpp, j = ch - q * cpp;
     const int d = q >= (unsigned)X.nr[0];
@@ -280,20 +270,43 @@ __global__ void __launch_bounds__(256) k_peer_allreduce_small(double *x, int n, 
 // ---------------- host side ----------------
 static u64 *ctrl_word(char *ctrl, int w) { return (u64 *)ctrl + w; }
 
-static int peer_check_err(PeerComm *p) {
-  const u64 e = __atomic_load_n(p->err, __ATOMIC_ACQUIRE);
+// ---- device-side joins and the error word: context-level, both transports ----
+int devjoin_init(qexhip_ctx *c) {
+  DevJoin &J = c->dj;
+  double tmo = 30.0;
+  if (const char *e = getenv("QEXHIP_PEER_TIMEOUT")) { const double v = atof(e); if (v > 0) tmo = v; }
+  int khz = 0;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device);
+  if (khz <= 0) khz = 100000;
+  J.ticks = (long long)(tmo * 1000.0 * khz);
+  J.timeout_s = tmo;
+  HIPCHK(hipMalloc((void **)&J.ready, 512));
+  HIPCHK(hipMemset(J.ready, 0, 512));
+  HIPCHK(hipHostMalloc((void **)&J.err, 64, hipHostMallocDefault));
+  *J.err = 0;
+  return 0;
+}
+void devjoin_destroy(qexhip_ctx *c) {
+  if (c->dj.ready) (void)hipFree(c->dj.ready);
+  if (c->dj.err) (void)hipHostFree(c->dj.err);
+  c->dj.ready = nullptr; c->dj.err = nullptr;
+}
+int devjoin_check(qexhip_ctx *c) {
+  if (!c->dj.err) return 0;
+  const u64 e = __atomic_load_n(c->dj.err, __ATOMIC_ACQUIRE);
   if (e) {
     const char *what = (e & 0xF00) == 0x100 ? "credit of an outbound channel" : (e & 0xF00) == 0x200 ? "data of an inbound channel"
                        : (e & 0xF00) == 0x400 ? "boundary launch on the comm stream (stream join)"
-                       : (e & 0xF00) == 0x500 ? "neighbours' faces in a fused sweep (its boundary workgroups)" : "all-reduce contribution";
-    qexhip_set_error("peer transport: rank %d timed out waiting for the %s (code 0x%llx): a neighbour is gone, or the ranks "
-                     "did not issue the same sequence of exchanges", p->rank, what, e);
-    peer_host_fail(&p->host);
+                       : (e & 0xFF0) == 0x510 ? "neighbours' faces in a fused sweep (its cleanup workgroups: the LONG wait)"
+                       : (e & 0xFF0) == 0x520 ? "boundary workgroups of a fused sweep to finish or park" : "all-reduce contribution";
+    qexhip_set_error("rank %d timed out on the device waiting for the %s (code 0x%llx): a neighbour is gone, or the ranks "
+                     "did not issue the same sequence of exchanges", c->rank, what, e);
+    if (c->peer) peer_host_fail(&c->peer->host);
     return QEXHIP_ERR_COMM;
   }
   return 0;
 }
-int peer_check(qexhip_ctx *c) { return c->peer ? peer_check_err(c->peer) : 0; }
+static int peer_check_err(qexhip_ctx *c) { return devjoin_check(c); }
 
 static void fill_mbox(const PeerComm *p, PeerMbox &M) {
   for (int r = 0; r < p->nranks; r++) {
@@ -309,18 +322,20 @@ static void fill_gran(const PeerComm *p, PeerGran &G) {
   G.emu_ticks = 0;
 }
 
+static int peer_init_body(qexhip_ctx *c, PeerHost &host);
 int peer_init(qexhip_ctx *c, PeerHost &host) {
+  const int e = peer_init_body(c, host);
+  if (e && c->peer) peer_host_fail(&c->peer->host);      // the other ranks stand in a barrier of the handle exchange: they fail at once instead of timing out
+  return e;
+}
+static int peer_init_body(qexhip_ctx *c, PeerHost &host) {
   PeerComm *p = new PeerComm();
   p->host = host;
   p->nranks = host.nranks; p->rank = host.rank;
   c->peer = p;                                   // from here comm_destroy owns it
-  double tmo = 30.0;
-  if (const char *e = getenv("QEXHIP_PEER_TIMEOUT")) { const double v = atof(e); if (v > 0) tmo = v; }
-  int khz = 0;
-  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device);
-  if (khz <= 0) khz = 100000;
-  p->ticks = (long long)(tmo * 1000.0 * khz);
-  p->timeout_s = tmo;
+  p->ticks = c->dj.ticks;
+  p->timeout_s = c->dj.timeout_s;
+  p->err = c->dj.err;
   // Everything a PEER writes lives in fine-grained device memory: between distinct GPUs the writes arrive over xGMI behind the
   // local L2's back, and only fine-grained (MTYPE NC) lines are guaranteed to be dropped by a system-scope acquire -- coarse-grained
   // hipMalloc memory is kept coherent for the owning agent only.  (Between processes on ONE device both kinds pass every check of
@@ -329,11 +344,6 @@ int peer_init(qexhip_ctx *c, PeerHost &host) {
   HIPCHK(hipMemset(p->ctrl, 0, CTRL_BYTES));
   HIPCHK(hipMalloc((void **)&p->done, 64));
   HIPCHK(hipMemset(p->done, 0, 64));
-  HIPCHK(hipMalloc((void **)&p->ready, 512));
-  HIPCHK(hipMemset(p->ready, 0, 512));
-  p->tail_count = (unsigned int *)(p->ready + 32);          // a 128-byte line of its own in the same allocation
-  HIPCHK(hipHostMalloc((void **)&p->err, 64, hipHostMallocDefault));
-  *p->err = 0;
   HIPCHK(hipDeviceSynchronize());
   PeerShmSlot &me = p->host.shm->s[p->rank];
   if (p->nranks > 1) {
@@ -361,7 +371,7 @@ static int peer_ensure_arena(qexhip_ctx *c, int s, size_t bytes) {
   if (bytes <= p->cap[s]) return 0;
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipStreamSynchronize(c->cstream));
-  CHK(peer_check_err(p));
+  CHK(peer_check_err(c));
   CHK(peer_host_barrier(&p->host));               // nobody is writing into anybody's old arena any more
   const int nb[2] = {lower(p), upper(p)};
   for (int k = 0; k < 2; k++) {
@@ -410,29 +420,28 @@ static int peer_ensure_arena(qexhip_ctx *c, int s, size_t bytes) {
 // One exchange on stream st: ns_dn pieces to the lower neighbour (they arrive in ITS from-upper half), ns_up pieces to the upper
 // one; by symmetry ns_up pieces arrive from the lower neighbour (-> dst_from_dn) and ns_dn from the upper one (-> dst_from_up).
 // Every piece is `bytes` long (a multiple of 16).
-// zc_from_up / zc_from_dn non-null (one piece per direction): zero-copy receive -- nothing is unpacked, the two pointers return
-// where the faces from the upper / lower neighbour lie in the receive arena, and the credits stay owed until peer_release_zc.
+// push_only (one piece per direction, comm stream class): NOTHING is launched -- the caller's own kernel pushes (its first
+// push_only->nblocks workgroups run peer_push_block) and reads what arrives in the receive arena itself: zc_from_up / zc_from_dn return
+// where the faces from the upper / lower neighbour lie there, and the credits stay owed until that kernel returns them (peer_ghost_args).
 int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *src_dn, int ns_up, const void *const *src_up,
                   void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us, const void **zc_from_up,
-                  const void **zc_from_dn, bool zc_linger, PeerPush *push_only) {
+                  const void **zc_from_dn, PeerPush *push_only) {
   PeerComm *p = c->peer;
-  const bool zc = zc_from_up && zc_from_dn;
-  if (zc && (ns_dn != 1 || ns_up != 1)) { qexhip_set_error("peer transport: zero-copy receive takes one piece per direction"); return QEXHIP_ERR_ARG; }
+  const bool zc = push_only != nullptr;
+  if (zc && (ns_dn != 1 || ns_up != 1 || !zc_from_up || !zc_from_dn)) { qexhip_set_error("peer transport: a push-only exchange takes one piece per direction"); return QEXHIP_ERR_ARG; }
   if (bytes % 16 != 0) { qexhip_set_error("peer transport: message of %zu bytes is not a multiple of 16", bytes); return QEXHIP_ERR_ARG; }
   if (ns_dn < 0 || ns_up < 0 || (ns_dn == 0 && ns_up == 0) || bytes == 0) return 0;
   const int s = (st == c->cstream) ? 1 : 0;
-  CHK(peer_check_err(p));
+  CHK(peer_check_err(c));
   for (int k0 = 0; k0 < std::max(ns_dn, ns_up); k0 += (int)PEER_MAXSEG) {
     const int nd = std::max(0, std::min((int)PEER_MAXSEG, ns_dn - k0)), nu = std::max(0, std::min((int)PEER_MAXSEG, ns_up - k0));
     CHK(peer_ensure_arena(c, s, (size_t)std::max(nd, nu) * bytes));
     PeerXfer X;
     memset(&X, 0, sizeof X);
     const int lo = lower(p), up = upper(p);
-    if (p->zc[s].live) { qexhip_set_error("peer transport: an exchange was posted while the credits of a zero-copy receive are still owed"); return QEXHIP_ERR_STATE; }
+    if (s == 1 && p->zc.live) { qexhip_set_error("peer transport: an exchange was posted while the credits of a fused sweep's receive are still owed"); return QEXHIP_ERR_STATE; }
     for (int k = 0; k < nd; k++) { X.src[0][k] = (const uint4 *)src_dn[k0 + k]; X.dst[1][k] = zc ? nullptr : (uint4 *)dst_from_up[k0 + k]; }
     for (int k = 0; k < nu; k++) { X.src[1][k] = (const uint4 *)src_up[k0 + k]; X.dst[0][k] = zc ? nullptr : (uint4 *)dst_from_dn[k0 + k]; }
-    X.zc = zc ? (zc_linger ? 1 : 2) : 0;
-    X.t_start_out = (zc && !zc_linger) ? (long long *)(p->ready + 56) : nullptr;
     X.ns[0] = nd; X.ns[1] = nu; X.nr[0] = nu; X.nr[1] = nd;
     if (bytes / 16 >= ((size_t)1 << 32) - PEER_CHUNK) { qexhip_set_error("peer transport: a piece of %zu bytes is too large", bytes); return QEXHIP_ERR_ARG; }
     X.n16 = (unsigned)(bytes / 16);
@@ -468,49 +477,39 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
     // stream 8 CUs of its own deadlocked until the grid was capped (and lost anyway: profiles/r05_comm_cus_experiment.log).
     const int grid = (int)std::min<size_t>(nch, std::max<size_t>(2, std::min<size_t>(128, tot >> 16)));
     if (push_only) {
-      // the caller's own kernel pushes (its first `nblocks` workgroups run peer_push_block): nothing is launched here
-      if (!zc || zc_linger) { qexhip_set_error("internal: push-only exchange without a direct zero-copy receive"); return QEXHIP_ERR_STATE; }
       PeerPush &P = *push_only;
       for (int d = 0; d < 2; d++) {
         P.src[d] = X.src[d][0]; P.out_arena[d] = X.out_arena[d]; P.out_flag[d] = X.out_flag[d]; P.credit[d] = X.credit[d]; P.seq_out[d] = X.seq_out[d];
       }
-      P.n16 = X.n16; P.done = X.done; P.t_start_out = X.t_start_out; P.err = X.err; P.ticks = X.ticks; P.nblocks = grid;
+      P.n16 = X.n16; P.done = X.done; P.t_start_out = (long long *)(c->dj.ready + 56); P.err = X.err; P.ticks = X.ticks; P.nblocks = grid;
+      p->zc.live = 1;
+      for (int d = 0; d < 2; d++) { p->zc.credit_out[d] = X.credit_out[d]; p->zc.seq_in[d] = X.seq_in[d]; p->zc.in_flag[d] = X.in_flag[d]; }
+      p->zc.emu_ticks = X.emu_ticks;
+      *zc_from_dn = X.in_arena[0];
+      *zc_from_up = X.in_arena[1];
     } else {
       hipLaunchKernelGGL(k_peer_exchange, dim3(grid), dim3(256), 0, st, X);
       HIPCHK(hipGetLastError());
     }
     p->exchanges++;
-    if (zc) {
-      p->zc[s].live = 1;
-      for (int d = 0; d < 2; d++) { p->zc[s].credit_out[d] = X.credit_out[d]; p->zc[s].seq_in[d] = X.seq_in[d]; p->zc[s].in_flag[d] = X.in_flag[d]; }
-      p->zc[s].emu_ticks = X.emu_ticks;
-      *zc_from_dn = X.in_arena[0];
-      *zc_from_up = X.in_arena[1];
-    }
   }
   return 0;
 }
 
-// behind the consumer of a zero-copy exchange: the arena halves are free again (credits to the two senders, system scope), and the
-// stream that waits for the consumer may go on (join counter, agent scope)
-__global__ void k_peer_release(u64 *credit0, u64 seq0, u64 *credit1, u64 seq1, u64 *join, u64 joinval) {
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(credit0, seq0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(credit1, seq1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(join, joinval, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// behind the kernel that consumed a zero-copy receive on `st`: the senders get their credits, and the stream join counter FROM `st`
-// is raised (peer_stream_join on the waiting stream comes next, as after peer_stream_signal)
-int peer_release_zc(qexhip_ctx *c, hipStream_t st) {
+// what the fused sweep's boundary / cleanup workgroups need for the push-only exchange just prepared: the inbound data words, the
+// emulated transport time, the credits they owe
+int peer_ghost_args(qexhip_ctx *c, PeerGhost *G) {
   PeerComm *p = c->peer;
-  const int s = (st == c->cstream) ? 1 : 0;
-  if (!p->zc[s].live) { qexhip_set_error("peer transport: no zero-copy receive to release"); return QEXHIP_ERR_STATE; }
-  hipLaunchKernelGGL(k_peer_release, dim3(1), dim3(64), 0, st, p->zc[s].credit_out[0], p->zc[s].seq_in[0], p->zc[s].credit_out[1], p->zc[s].seq_in[1],
-                     p->ready + s * 16, ++p->join_seq[s]);
-  HIPCHK(hipGetLastError());
-  p->zc[s].live = 0;
+  memset(G, 0, sizeof *G);
+  if (!p || !p->zc.live) { qexhip_set_error("peer transport: no push-only exchange to consume"); return QEXHIP_ERR_STATE; }
+  G->err = p->err; G->ticks = p->ticks;
+  for (int d = 0; d < 2; d++) {
+    G->flag[d] = p->zc.in_flag[d]; G->flagval[d] = p->zc.seq_in[d];
+    G->credit[d] = p->zc.credit_out[d]; G->credit_val[d] = p->zc.seq_in[d];
+  }
+  G->t_start = (const long long *)(c->dj.ready + 56);
+  G->emu_ticks = p->zc.emu_ticks;
+  p->zc.live = 0;
   return 0;
 }
 
@@ -518,37 +517,33 @@ __global__ void k_peer_set(u64 *flag, u64 val) {
   if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Device-side join of two streams of this context without an event: `signal` raises a counter behind everything posted on
-// `from` so far (a one-lane kernel: the kernel boundary in front of it is the release), `join` makes `waiter` wait for the
+// `from` so far (a one-lane kernel: the kernel boundary in front of it is the release), `wait` makes `waiter` wait for the
 // latest value (a one-wave kernel with a bounded poll: the boundary behind it is the acquire).  One counter per direction.
-int peer_stream_signal(qexhip_ctx *c, hipStream_t from) {
-  PeerComm *p = c->peer;
+int devjoin_signal(qexhip_ctx *c, hipStream_t from) {
   const int k = (from == c->cstream) ? 1 : 0;
-  hipLaunchKernelGGL(k_peer_set, dim3(1), dim3(64), 0, from, p->ready + k * 16, ++p->join_seq[k]);
+  hipLaunchKernelGGL(k_peer_set, dim3(1), dim3(64), 0, from, c->dj.ready + k * 16, ++c->dj.seq[k]);
   HIPCHK(hipGetLastError());
   return 0;
 }
 // the compute stream's wait for what the comm stream has signalled so far is postponed into the next peer_allreduce_parts
-// (the CG's <p,Ap> right behind the second sweep); peer_flush_join posts it as a kernel of its own if something else comes first
-int peer_stream_join_defer(qexhip_ctx *c) { c->peer->join_deferred = 1; return 0; }
-int peer_flush_join(qexhip_ctx *c) {
-  PeerComm *p = c->peer;
-  if (!p || !p->join_deferred) return 0;
-  p->join_deferred = 0;
-  return peer_stream_join(c, c->stream, c->cstream);
+// (the CG's <p,Ap> right behind the second sweep); devjoin_flush posts it as a kernel of its own if something else comes first
+int devjoin_defer(qexhip_ctx *c) { c->dj.deferred = 1; return 0; }
+int devjoin_flush(qexhip_ctx *c) {
+  if (!c->dj.deferred) return 0;
+  return devjoin_wait(c, c->stream, c->cstream);
 }
-int peer_stream_join(qexhip_ctx *c, hipStream_t waiter, hipStream_t from) {
-  PeerComm *p = c->peer;
+int devjoin_wait(qexhip_ctx *c, hipStream_t waiter, hipStream_t from) {
   const int k = (from == c->cstream) ? 1 : 0;
-  if (waiter == c->stream && k == 1) p->join_deferred = 0;
-  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, waiter, p->ready + k * 16, p->join_seq[k], p->err, p->ticks);
+  if (waiter == c->stream && k == 1) c->dj.deferred = 0;
+  hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, waiter, c->dj.ready + k * 16, c->dj.seq[k], c->dj.err, c->dj.ticks);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 int peer_allreduce(qexhip_ctx *c, double *dptr, int n, int op) {
   PeerComm *p = c->peer;
-  CHK(peer_check_err(p));
-  CHK(peer_flush_join(c));
+  CHK(peer_check_err(c));
+  CHK(devjoin_flush(c));
   if (n <= PEER_GRAN_N) {
     PeerGran G;
     fill_gran(p, G);
@@ -574,62 +569,40 @@ int peer_allreduce(qexhip_ctx *c, double *dptr, int n, int op) {
 
 int peer_allreduce_parts(qexhip_ctx *c, double *parts, int n) {
   PeerComm *p = c->peer;
-  CHK(peer_check_err(p));
+  CHK(peer_check_err(c));
   PeerGran G;
   fill_gran(p, G);
   G.emu_ticks = (long long)(c->emu_allreduce_us * 1e-6 * (double)p->ticks / p->timeout_s);
-  const u64 *join = p->join_deferred ? p->ready + 16 : nullptr;      // the deferred join from the comm stream rides in this kernel's prologue
-  p->join_deferred = 0;
-  hipLaunchKernelGGL((k_peer_allreduce_small<0, true>), dim3(1), dim3(256), 0, c->stream, parts, 1, n, G, ++p->seq_red, join, p->join_seq[1]);
+  const u64 *join = c->dj.deferred ? c->dj.ready + 16 : nullptr;      // the deferred join from the comm stream rides in this kernel's prologue
+  c->dj.deferred = 0;
+  hipLaunchKernelGGL((k_peer_allreduce_small<0, true>), dim3(1), dim3(256), 0, c->stream, parts, 1, n, G, ++p->seq_red, join, c->dj.seq[1]);
   p->allreduces++;
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-int peer_ghost_args(qexhip_ctx *c, PeerGhost *G, bool zc, bool direct) {
+// A few mailbox all-reduces with known answers, right after the control blocks were mapped (collective): rank r contributes (r + 1) * k,
+// every rank must read N (N + 1) / 2 * k.  Between distinct GPUs this is the first time a granule crosses xGMI: a mapping that "works" but
+// is not coherent shows up here -- as a wrong sum or as a wait that runs out (bounded: 5 s instead of QEXHIP_PEER_TIMEOUT) -- and
+// comm_init then leaves the rank sums to RCCL instead of finding out in the middle of a solve.  Returns 0 when THIS rank saw every
+// sum right; the caller agrees the outcome over the ranks.
+int peer_selftest(qexhip_ctx *c) {
   PeerComm *p = c->peer;
-  memset(G, 0, sizeof *G);
-  G->err = p->err; G->ticks = p->ticks;
-  if (direct && zc) {
-    // the consumer polls the two data words itself: nothing was posted behind the exchange kernel, which did not stay either
-    for (int d = 0; d < 2; d++) { G->flag[d] = p->zc[1].in_flag[d]; G->flagval[d] = p->zc[1].seq_in[d]; }
-    G->t_start = (const long long *)(p->ready + 56);
-    G->emu_ticks = p->zc[1].emu_ticks;
-  } else {
-    G->join = p->ready + 16;               // joins FROM the comm stream
-    G->joinval = p->join_seq[1];
+  double *d = &c->dscal[60];
+  const long long saved = p->ticks;
+  p->ticks = (long long)(5.0 * (double)saved / p->timeout_s);
+  int bad = 0;
+  for (int k = 1; k <= 8 && !bad; k++) {
+    const double mine = (double)(p->rank + 1) * k;
+    if (hipMemcpyAsync(d, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) { bad = 1; break; }
+    if (peer_allreduce(c, d, 1, 0)) { bad = 1; break; }
+    double got = 0;
+    if (hipMemcpyAsync(&got, d, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { bad = 1; break; }
+    if (__atomic_load_n(p->err, __ATOMIC_ACQUIRE) != 0 || got != 0.5 * p->nranks * (p->nranks + 1) * k) bad = 1;
   }
-  if (zc) {
-    if (!p->zc[1].live) { qexhip_set_error("peer transport: no zero-copy receive to release"); return QEXHIP_ERR_STATE; }
-    G->ticket = p->tail_count + 32;      // a line of its own (p->ready + 48)
-    for (int d = 0; d < 2; d++) { G->credit[d] = p->zc[1].credit_out[d]; G->credit_val[d] = p->zc[1].seq_in[d]; }
-    p->zc[1].live = 0;
-  }
-  return 0;
-}
-
-int peer_fold_args(qexhip_ctx *c, PeerFold *F) {
-  PeerComm *p = c->peer;
-  CHK(peer_check_err(p));
-  F->on = 1;
-  fill_gran(p, F->G);
-  F->G.emu_ticks = (long long)(c->emu_allreduce_us * 1e-6 * (double)p->ticks / p->timeout_s);
-  F->t_send = (long long *)(p->ready + 60);
-  F->seq = ++p->seq_red;
-  p->allreduces++;
-  return 0;
-}
-
-int peer_tail_args(qexhip_ctx *c, PeerTail *T) {
-  PeerComm *p = c->peer;
-  CHK(peer_check_err(p));
-  T->on = 1;
-  T->count = p->tail_count;
-  fill_gran(p, T->G);
-  T->G.emu_ticks = (long long)(c->emu_allreduce_us * 1e-6 * (double)p->ticks / p->timeout_s);
-  T->seq = ++p->seq_red;
-  p->allreduces++;
-  return 0;
+  p->ticks = saved;
+  if (bad) (void)hipGetLastError();
+  return bad;
 }
 
 int peer_host_reduce(qexhip_ctx *c, double *host, int n, int op) { return peer_host_allreduce(&c->peer->host, host, n, op); }
@@ -671,8 +644,6 @@ void peer_destroy(qexhip_ctx *c) {
   for (char *a : p->retired) (void)hipFree(a);
   if (p->ctrl) (void)hipFree(p->ctrl);
   if (p->done) (void)hipFree(p->done);
-  if (p->ready) (void)hipFree(p->ready);
-  if (p->err) (void)hipHostFree(p->err);
   peer_host_close(&p->host);
   delete p;
   c->peer = nullptr;

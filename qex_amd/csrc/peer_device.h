@@ -1,5 +1,5 @@
-// peer_device.h -- the device side of the peer transport's granule all-reduce (peer.hip), shared with the CG kernel that carries
-// one in its tail (blas.hip: k_cg_update).
+// peer_device.h -- the device side of the peer transport that OTHER kernels carry (peer.hip has the transport's own kernels): bounded
+// polls, the tagged granules of the small all-reduce, and the push / wait / park pieces of the fused sweep (dslash.hip).
 //
 // Small all-reduces (the CG's scalars): the payload travels INSIDE the flags.  A double is cut into two 8-byte granules
 // {32 data bits, 32-bit tag = low half of the sequence number}; an aligned 8-byte store is one transaction, so a granule is
@@ -60,34 +60,6 @@ struct PeerGran {
   long long ticks, emu_ticks;
   int nranks, me;
 };
-
-// One double, called by all 256 threads of ONE workgroup: `local` (the same value in every thread) goes into slot seq & 3 of every
-// rank's mailbox, the N operands are collected from the own mailbox and summed in RANK ORDER -- the same bits on every rank,
-// whatever the arrival order.  Returns false (and leaves *out alone) after a timeout; the error word is set.
-// emu_ticks > 0 (one-rank rehearsal): the peers' granules count as arrived no earlier than that long after the send.
-__device__ inline bool gran_allreduce_block(double local, const PeerGran &G, u64 seq, double *out) {
-  __shared__ double gr_val[PEER_MAXR];
-  __shared__ int gr_ok;
-  const int slot = (int)(seq & (PEER_NSLOT - 1));
-  const unsigned tag = (unsigned)seq;
-  if (threadIdx.x == 0) gr_ok = 1;
-  __syncthreads();
-  const int r = threadIdx.x;
-  const long long t0 = G.emu_ticks > 0 ? wall_clock64() : 0;
-  if (r < G.nranks) gran_send(G.gran[r] + ((size_t)(slot * PEER_MAXR + G.me) * PEER_GRAN_N) * 2, local, tag);
-  if (G.emu_ticks > 0) while (wall_clock64() - t0 < G.emu_ticks) __builtin_amdgcn_s_sleep(2);
-  if (r < G.nranks) {
-    double v = 0;
-    if (!gran_recv(G.gran[G.me] + ((size_t)(slot * PEER_MAXR + r) * PEER_GRAN_N) * 2, tag, &v, G.err, G.ticks, 0x300 + r)) gr_ok = 0;
-    gr_val[r] = v;
-  }
-  __syncthreads();
-  if (!gr_ok) return false;
-  double acc = gr_val[0];
-  for (int q = 1; q < G.nranks; q++) acc += gr_val[q];
-  *out = acc;
-  return true;
-}
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ inline void peer_copy_chunk(uint4 *__restrict__ d4, const uint4 *__restrict__ s4, unsigned n) {
@@ -155,79 +127,74 @@ __device__ inline void peer_push_block(const PeerPush &P, const unsigned blk) {
   }
 }
 
-// The same reduction in the PROLOGUE of a many-workgroup consumer (k_cg_update for <p,Ap>, k_cg_xpay / k_cg_close for |r|^2): every
-// workgroup holds the same `local` (it summed the same partials in the same order); workgroup 0 sends it, every workgroup collects
-// the N operands from the own mailbox and sums them in rank order -- no all-reduce launch, no launch boundary.  Every workgroup of
-// the launch spins until the slowest rank has sent: only where the ranks have a GPU each, or the launch is small (blas.hip decides).
-struct PeerFold {
-  int on;
-  u64 seq;
-  long long *t_send;          // under emulation: when workgroup 0 sent (the transport time counts from there)
-  PeerGran G;
-};
-__device__ inline bool gran_allreduce_grid(double local, const PeerFold &F, double *out) {
-  __shared__ double gf_val[PEER_MAXR];
-  __shared__ int gf_ok;
-  const int slot = (int)(F.seq & (PEER_NSLOT - 1));
-  const unsigned tag = (unsigned)F.seq;
-  const int r = threadIdx.x;
-  if (threadIdx.x == 0) gf_ok = 1;
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    if (r == 0 && F.G.emu_ticks > 0) __hip_atomic_store(F.t_send, wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (r < F.G.nranks) gran_send(F.G.gran[r] + ((size_t)(slot * PEER_MAXR + F.G.me) * PEER_GRAN_N) * 2, local, tag);
-  }
-  if (r < F.G.nranks) {
-    double v = 0;
-    if (!gran_recv(F.G.gran[F.G.me] + ((size_t)(slot * PEER_MAXR + r) * PEER_GRAN_N) * 2, tag, &v, F.G.err, F.G.ticks, 0x300 + r)) gf_ok = 0;
-    gf_val[r] = v;
-  }
-  if (F.G.emu_ticks > 0 && r == 0) {       // rehearsal: the peers' granules cross xGMI (all operands are in: workgroup 0 has sent)
-    const long long t0 = __hip_atomic_load(F.t_send, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (wall_clock64() - t0 < F.G.emu_ticks) __builtin_amdgcn_s_sleep(2);
-  }
-  __syncthreads();
-  if (!gf_ok) return false;
-  double acc = gf_val[0];
-  for (int q = 1; q < F.G.nranks; q++) acc += gf_val[q];
-  *out = acc;
-  return true;
-}
-int peer_fold_args(qexhip_ctx *c, PeerFold *F);     // fills F for ONE all-reduce (sequence number taken); peer.hip
-
-// The |r|^2 all-reduce of a sharded CG iteration inside the tail of k_cg_update (blas.hip): the workgroup whose arrival ticket comes
-// last sums the partials and runs gran_allreduce_block -- one launch and one launch boundary less per iteration, and still only
-// ONE spinning workgroup per rank (ranks may share a device).  on == 0: the kernel leaves its partials for comm_allreduce_parts.
-struct PeerTail {
-  int on;
-  unsigned int *count;        // arrival tickets (device, zero between launches)
-  u64 seq;
-  PeerGran G;
-};
-int peer_tail_args(qexhip_ctx *c, PeerTail *T);     // fills T for ONE all-reduce on the compute stream (sequence number taken); peer.hip
-
-// What the hop-split boundary launch of an overlapped sweep (dslash.hip: k_dslash<..., PART = 2>) needs from the transport: the
-// counter the comm stream raises behind its exchange kernel (join == nullptr: ordered by an event instead, RCCL arm), and -- zero-copy
-// receive -- the two credit words its last workgroup writes once every workgroup has read the arena (ticket == nullptr: unpacked).
+// What the boundary workgroups of the fused sweep (dslash.hip: k_dslash_fused) need from the transport: the two inbound data words they
+// poll themselves (nothing is posted behind the push, nobody stays for it), under emulation the transport time counted from the
+// push's start, and the two credit words that go back to the senders once every reader of the arena is through.
 struct PeerGhost {
-  const u64 *join; u64 joinval;
-  const u64 *flag[2]; u64 flagval[2];            // instead of join: the two inbound data words of a zero-copy exchange whose kernel did not stay
-  const long long *t_start; long long emu_ticks; // ... and, under emulation, the transport time counted from that kernel's start
+  const u64 *flag[2]; u64 flagval[2];
+  const long long *t_start; long long emu_ticks;
   u64 *err; long long ticks;
-  unsigned int *ticket;
   u64 *credit[2]; u64 credit_val[2];
 };
-int peer_ghost_args(qexhip_ctx *c, PeerGhost *G, bool zc, bool direct = false);   // after peer_stream_signal(c, c->cstream), or direct; zc: takes over the owed credits; peer.hip
+int peer_ghost_args(qexhip_ctx *c, PeerGhost *G);   // for the push-only exchange just prepared on the comm stream class: takes over the owed credits; peer.hip
 
-// the wait of a consumer for "the faces are in", one lane: true when they are
-__device__ inline bool peer_ghost_wait(const PeerGhost &G) {
-  if (G.flag[0]) {
-    if (!peer_poll_ge(G.flag[0], G.flagval[0], G.err, G.ticks, 0x510) || !peer_poll_ge(G.flag[1], G.flagval[1], G.err, G.ticks, 0x511)) return false;
-    if (G.emu_ticks > 0) {
-      const long long t0 = __hip_atomic_load(G.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while (wall_clock64() - t0 < G.emu_ticks) __builtin_amdgcn_s_sleep(8);
-    }
-    return true;
+__device__ inline bool peer_ghost_ready(const PeerGhost &G) {
+  if (__hip_atomic_load(G.flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < G.flagval[0]) return false;
+  if (__hip_atomic_load(G.flag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < G.flagval[1]) return false;
+  if (G.emu_ticks > 0) {       // rehearsal: nothing arrives earlier than the transfer would take between two GPUs
+    const long long t0 = __hip_atomic_load(G.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wall_clock64() - t0 < G.emu_ticks) return false;
   }
-  return !G.join || peer_poll_ge(G.join, G.joinval, G.err, G.ticks, 0x500);
+  return true;
+}
+// The SHORT wait of a boundary workgroup between its local and its slab-leaving hops, one lane: true when the faces are in.  False
+// after `spin_ticks` (about the estimated transfer time), or at once when another workgroup of this launch has already waited that
+// long in vain (`late`): the caller then parks its accumulator and leaves the slot to others -- on a chip shared with the neighbour's
+// process, to the very kernel it is waiting for.  Never an error: a lost peer is found by the cleanup workgroups' long wait.
+__device__ inline bool peer_ghost_try(const PeerGhost &G, long long spin_ticks, unsigned int *late) {
+  if (peer_ghost_ready(G)) return true;
+  if (spin_ticks <= 0 || __hip_atomic_load(late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+  const long long t0 = wall_clock64();
+  for (unsigned it = 1;; it++) {
+    __builtin_amdgcn_s_sleep(4);
+    if (peer_ghost_ready(G)) return true;
+    if ((it & 15) == 0) {
+      if (__hip_atomic_load(late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      if (wall_clock64() - t0 > spin_ticks) {
+        __hip_atomic_store(late, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
+// the LONG wait (cleanup workgroups; bounded by QEXHIP_PEER_TIMEOUT): false = the neighbour is gone, error word set
+__device__ inline bool peer_ghost_wait(const PeerGhost &G) {
+  if (!peer_poll_ge(G.flag[0], G.flagval[0], G.err, G.ticks, 0x510) || !peer_poll_ge(G.flag[1], G.flagval[1], G.err, G.ticks, 0x511)) return false;
+  if (G.emu_ticks > 0) {
+    const long long t0 = __hip_atomic_load(G.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (wall_clock64() - t0 < G.emu_ticks) __builtin_amdgcn_s_sleep(8);
+  }
+  return true;
+}
+
+// Bookkeeping of ONE fused launch in device memory of the context (dslash.hip): every boundary workgroup counts itself in `dec` once
+// it has finished or parked; a parked one appends its block to `list` first.  All words are zero between launches (the last cleanup
+// workgroup resets them; launches of one stream do not overlap).
+struct FusedCtl {
+  unsigned int *dec, *ndef, *cl_done, *late;     // each on a 128-byte line of its own
+  unsigned int *list;                            // parked blocks (logical workgroup numbers), capacity >= boundary workgroups of the launch
+  long long spin_ticks;                          // the short wait's bound; < 0: park unconditionally (test hook: the cleanup path on every block)
+  int ncl;                                       // cleanup workgroups at the end of the grid (>= 1)
+};
+__device__ inline bool peer_poll_u32(const unsigned int *p, unsigned int want, u64 *err, long long ticks, u64 code) {
+  if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+  const long long t0 = wall_clock64();
+  for (unsigned it = 1;; it++) {
+    __builtin_amdgcn_s_sleep(4);
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+    if ((it & 255) == 0) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;
+      if (wall_clock64() - t0 > ticks) { __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return false; }
+    }
+  }
 }

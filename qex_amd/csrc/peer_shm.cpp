@@ -4,6 +4,8 @@
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
+#include <initializer_list>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <fcntl.h>
@@ -49,7 +51,11 @@ int peer_host_open(PeerHost *h, const unsigned char id[128], int nranks, int ran
 }
 
 void peer_host_fail(PeerHost *h) {
-  if (h && h->shm) __atomic_store_n(&h->shm->s[h->rank].failed, 1, __ATOMIC_RELEASE);
+  if (!h || !h->shm) return;
+  __atomic_store_n(&h->shm->s[h->rank].failed, 1, __ATOMIC_RELEASE);
+  // Whoever notices a failure drops the NAME (unlinking while others have the segment mapped is safe): with rank 0 the absent or late
+  // one nobody else would, and a retry of comm_init with the same id would find its slot "already taken".
+  peer_host_unlink(h);
 }
 
 int peer_host_barrier(PeerHost *h) {
@@ -109,4 +115,54 @@ void peer_host_close(PeerHost *h) {
     munmap((void *)h->shm, sizeof(PeerShm));
     h->shm = nullptr;
   }
+}
+
+int peer_host_local_ranks_hint() {
+  for (const char *name : {"QEXHIP_LOCAL_RANKS", "LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "SLURM_NTASKS_PER_NODE"}) {
+    const char *e = getenv(name);
+    if (e && *e) { const int v = atoi(e); if (v > 0) return v; }
+  }
+  return 0;
+}
+
+int peer_host_choose(PeerHost *h, const unsigned char id[128], int nranks, int rank, int wish, int device, const char *bus,
+                     double timeout_s, int *mode, int *shared) {
+  *mode = 0; *shared = 0;
+  if (wish == 1 || nranks > PEER_MAXR) return 0;
+  if (wish == 0 && nranks == 1) return 0;          // one rank, no preference: nobody to meet (the one-rank RCCL communicator of the rehearsals)
+  if (wish == 0) {
+    const int local = peer_host_local_ranks_hint();
+    if (local > 0 && local < nranks) return 0;      // the job spans nodes: RCCL, without waiting for a rendezvous that cannot complete
+  }
+  if (int e = peer_host_open(h, id, nranks, rank, timeout_s)) {
+    if (wish != 0) return e;
+    // auto: no shared-memory segment to meet in (no /dev/shm, a sandbox): RCCL is the only transport left, and says so itself if the
+    // ranks turn out to share a device.  (Ranks that DID open the segment run into the barrier's timeout below and follow.)
+    fprintf(stderr, "libqexhip: rank %d: no rendezvous segment: taking the RCCL transport\n", rank);
+    return 0;
+  }
+  PeerShmSlot &me = h->shm->s[rank];
+  me.device = device;
+  me.wish = wish;
+  snprintf(me.bus, sizeof me.bus, "%s", bus ? bus : "");
+  if (int e = peer_host_barrier(h)) {
+    peer_host_close(h);
+    if (wish != 0) return e;
+    // auto: somebody never arrived.  Ranks on other nodes cannot (and no launcher variable told us): every node's ranks time out alike --
+    // a failed barrier fails for all its participants -- so "RCCL" is still ONE decision for the whole job.  If a rank is really
+    // gone, RCCL's own bootstrap says so next.
+    fprintf(stderr, "libqexhip: rank %d: the node-local rendezvous did not complete within %.0f s: taking the RCCL transport\n", rank, timeout_s);
+    return 0;
+  }
+  int any[4] = {0, 0, 0, 0};
+  for (int r = 0; r < nranks; r++) {
+    const PeerShmSlot &a = h->shm->s[r];
+    if (a.wish >= 0 && a.wish <= 3) any[a.wish] = 1;
+    for (int q = 0; q < r; q++) {
+      const PeerShmSlot &b = h->shm->s[q];
+      if (!strncmp(a.bus, b.bus, sizeof a.bus) && !strncmp(a.host, b.host, sizeof a.host)) *shared = 1;
+    }
+  }
+  *mode = (any[2] || *shared) ? 2 : 3;             // (distinct devices, nobody insists on peer: the mailboxes ride along with RCCL)
+  return 0;
 }

@@ -44,6 +44,17 @@ struct PeerHost {                    // one rank's view
 int peer_host_open(PeerHost *h, const unsigned char id[128], int nranks, int rank, double timeout_s);   // creates / maps the segment (no wait)
 int peer_host_barrier(PeerHost *h);                                                                    // bounded
 int peer_host_allreduce(PeerHost *h, double *v, int n, int op);                                        // op 0 max, 1 min, 2 sum (rank order); n <= 8; two barriers
-void peer_host_fail(PeerHost *h);                                                                      // mark this rank failed
+void peer_host_fail(PeerHost *h);                                                                      // mark this rank failed (and drop the segment's name: whoever
+                                                                                                       // retries with the same id must not find a stale slot)
 void peer_host_close(PeerHost *h);                                                                     // unmaps; rank 0 unlinks the name if still there
 void peer_host_unlink(PeerHost *h);                                                                    // drop the name early (after the first barrier nobody opens it again)
+
+// What the launcher says about how many of the job's ranks run on THIS node (0: it does not say): QEXHIP_LOCAL_RANKS, then
+// torch.distributed.run's LOCAL_WORLD_SIZE, Open MPI, MPICH / Hydra, Slurm.
+int peer_host_local_ranks_hint();
+// The transport decision of comm_init (comm.cpp), ONE for the whole job.  wish: 0 auto, 1 rccl, 2 peer, 3 rccl + mailbox sums.
+// *mode = 0 rccl (nothing left open), 2 peer, 3 rccl + mailbox sums (`h` stays open for the handle exchange).  *shared = two ranks sit on
+// one device.  auto never fails for want of a rendezvous: a job that spans nodes (the hint says so, or nobody else shows up in the
+// segment within timeout_s -- every node's ranks time out alike) takes rccl; wish 2 / 3 return the error instead.
+int peer_host_choose(PeerHost *h, const unsigned char id[128], int nranks, int rank, int wish, int device, const char *bus,
+                     double timeout_s, int *mode, int *shared);

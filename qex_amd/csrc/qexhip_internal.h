@@ -66,6 +66,20 @@ struct TimerSlot {
   double total_ms = 0;
 };
 
+// Device-side stream join and the one error word of every bounded device-side wait (peer.hip).  `signal` raises a counter behind what a
+// stream has posted (a one-lane kernel), `wait` makes another stream wait for it (a one-wave kernel with a bounded poll) -- instead of
+// the runtime's cross-queue event dependency, which costs ~20-28 us of dead time per join here (profiles/r05_timeline_*.txt).  Both
+// transports use it since round 6.
+struct DevJoin {
+  unsigned long long *ready = nullptr;   // device: word k*16 = joins FROM stream k (0 compute, 1 comm); word 56: start time of the fused sweep's push (emulation)
+  unsigned long long *err = nullptr;     // pinned host word: code of the first wait that gave up
+  long long ticks = 0;                   // QEXHIP_PEER_TIMEOUT in wall_clock64 ticks
+  double timeout_s = 30.0;
+  unsigned long long seq[2]{0, 0};
+  int deferred = 0;                      // the compute stream still owes a wait for seq[1]: the next mailbox all-reduce of partials polls for it in its
+                                         // prologue, anything else posts it first (devjoin_flush)
+};
+
 struct GaugeNat;  // natural-layout gauge field for plaquette / flow (gauge.hip)
 struct PeerComm;  // peer-memory transport (peer.hip)
 
@@ -80,7 +94,9 @@ struct qexhip_ctx {
   // communicator
   void *comm = nullptr;  // ncclComm_t: everything posted on the compute stream (all-reduces, ghost refreshes, non-overlapped faces)
   void *comm2 = nullptr; // ncclComm_t split off comm: the face exchanges posted on cstream beside the interior sweep
-  PeerComm *peer = nullptr; // the other transport: faces and reductions through hipIpc-mapped peer memory (peer.hip); never both
+  PeerComm *peer = nullptr; // peer-mapped memory (peer.hip): control block with the mailboxes of the rank sums, and -- when `comm` is null -- the
+                            // receive arenas of the faces too.  comm && peer: RCCL faces + mailbox sums (hybrid_sums)
+  DevJoin dj;               // device-side stream joins + the error word of the bounded waits (allocated by qexhip_init)
   int opt_transport = -1;   // option "transport" (before comm_init): -1 QEXHIP_TRANSPORT decides, 0 auto, 1 rccl, 2 peer
   int nranks = 1, rank = 0;
   int force_halo = 0;
@@ -116,25 +132,20 @@ struct qexhip_ctx {
                             // (with a one-rank RCCL communicator the all-reduces are real collectives)
   int opt_force_pair = 1; // option "force_pair" (test hook): 0 takes k_force_lds, the form lattice shapes without paired tile positions get, on any shape
   int opt_obs_clover = 1; // option "obs_clover" (test hook): 0 takes the generic path walker, the form fmunu loops 3-5 get, for loop 1 as well
-  int opt_peer_zc = 1;    // option "peer_zc" (A/B, test hook): 1 = the boundary launch of an overlapped sweep reads the neighbours' faces straight from the
-                          // peer transport's receive arena (no unpack kernel phase), 0 = they are copied into the field's ghost tiles first
-  int opt_hop_split = -1;    // option "hop_split": how an overlapped sweep is split.  2 = by hops in ONE launch (interior workgroups, and boundary workgroups
-                             // that wait on the device for the faces between their local and their remote hops; on the peer transport with a
-                             // zero-copy receive the launch also pushes the faces itself: no second stream at all), 1 = by hops in two launches
-                             // (A/B), 0 = by sites (interior launch | boundary launch on the comm stream; rounds 1-5a), -1 = 2 on the peer
-                             // transport with zero-copy receive when every rank has a GPU of its own, else 0 (measured: profiles/r05_hop_split.log)
-  unsigned long long *sj_ctr = nullptr, *sj_err = nullptr, sj_seq = 0;   // the fused launch's arrival signal without the peer transport (dslash.hip)
-  long long sj_ticks = 0;
-  int ranks_share_device = 0;   // comm_init's rendezvous saw two ranks of this job on one GPU (kernels that spin for a PEER must then stay small)
-  int cg_r2_fold = 0;           // the |r|^2 partials of the last k_cg_update still want their rank sum: the next k_cg_xpay / k_cg_close takes it (peer_fold 2)
-  int opt_peer_fold = 0;     // option "peer_fold" (A/B, test hook): 1 = the |r|^2 all-reduce of a sharded CG iteration on the peer transport runs in the tail of
-                             // k_cg_update (last-arriver workgroup), 0 = as a launch of its own behind it.  Measured 8-10 us per iteration SLOWER
-                             // folded (profiles/r05_fold_compare.log: write-through partials + 2600 arrival tickets + a serial tail cost more
-                             // than the launch boundary they save), so off
-  int opt_sweep_chain = -1;  // option "sweep_chain": 1 = the two sweeps of the normal operator run without a join between them (dslash_sweep), 0 = never,
-                             // -1 = where sweep_autotune measured it faster (off until measured)
-  int chain_auto[2]{-1, -1}; // that measurement's decision for 8- and 16-link operators
-  int chain_pending = 0;     // a chain-1 sweep has left its boundary launch unjoined: only its chain-2 successor may follow on the compute stream
+  int opt_hop_split = -1;    // option "hop_split" / QEXHIP_HOP_SPLIT: how an OVERLAPPED sweep is laid out on the peer transport.  2 = the fused sweep
+                             // (k_dslash_fused: ONE launch on ONE stream pushes the faces, takes the interior, and its boundary workgroups take
+                             // the hops that stay inside the slab, wait SHORTLY for the faces, and either finish or park their accumulator for
+                             // the cleanup workgroups at the end of the grid), 0 = split by sites (interior launch | exchange + boundary launch
+                             // on the comm stream, device-side join; what the RCCL transport always runs), -1 = whichever set_links measured
+                             // faster (fused until measured; sweep_autotune)
+  int opt_fused_spin_us = -1; // option "fused_spin_us": the short wait of the fused sweep's boundary workgroups; -1 = about the measured (else estimated)
+                              // transfer time, >= 0 that many microseconds, -2 = park every boundary block (test hook: cleanup path everywhere)
+  int ranks_share_device = 0;   // comm_init's rendezvous saw two ranks of this job on one GPU (informational: no kernel holds more than a few
+                                // dozen slots while it waits for another rank any more)
+  int hybrid_sums = 0;          // RCCL carries the faces, the mailboxes of the peer control block the CG's rank sums (comm.cpp: comm_init)
+  unsigned int *fz_buf = nullptr; int fz_cap = 0;   // FusedCtl words + parked-block list of the fused sweep (dslash.hip)
+  double xchg_us[2]{0, 0};      // measured at set_links (collective, max over ranks): one face exchange of the 8- / 16-link operator, us (0: not measured)
+  int form_auto[2]{-1, -1};     // measured at set_links: 2 fused / 0 by sites for 8- and 16-link operators (-1: not measured)
   int opt_chain_overlap = 1; // option "chain_overlap" (A/B, test hook): 1 = the nHYP force chain's staple derivatives of a t-sharded field run in two passes,
                           // the ghost-free slices beside the exchange of the level's chain fields, the boundary slices behind it
   int opt_smear_ca = 1;   // option "smear_ca" (A/B, test hook): 1 = the nHYP levels of a t-sharded field are computed on shrinking ghost slices from
@@ -149,7 +160,7 @@ struct qexhip_ctx {
   int emu_exchange_us = 0, emu_allreduce_us = 0;   // options of the same names (test / rehearsal hooks): delay posted in front of every face
                                                    // exchange / all-reduce, as long as the transfer would take between distinct GPUs
   int overlap_auto[2]{-1, -1};          // the measured decision for 8- and 16-link operators (-1: not measured)
-  double overlap_tune_us[2][3]{};       // us per sweep the measurement saw: [8 | 16 links][exchange first | overlapped | overlapped + chained], max over ranks
+  double overlap_tune_us[2][3]{};       // us per sweep the measurement saw: [8 | 16 links][exchange first | overlapped by sites | fused], max over ranks (0: form not available)
   // natural gauge (flow)
   GaugeNat *gn = nullptr;
   void *nhyp = nullptr;   // NhypState (smear.hip): the smearGetForce closure
@@ -215,9 +226,9 @@ int solve_batch_host(qexhip_ctx *c, int n, double *const *x, const double *const
 inline bool multi_rank(const qexhip_ctx *c) { return c->nranks > 1 || c->opt_multi_reduce; }
 
 // ---- comm.cpp ----
-int comm_halo_exchange_zc(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, bool wait_ready = true, bool linger = true,
-                          struct PeerPush *push_only = nullptr);   // push_only: nothing is launched, the caller's kernel pushes (peer_device.h)   // peer transport, comm stream: see dslash_sweep
-int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready; the caller records ev_halo behind what it posts next
+int comm_halo_push_only(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, struct PeerPush *push);   // peer faces: the fused sweep
+                                                                              // pushes the faces of f itself and reads what arrives in the receive arena
+int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready; the caller joins behind what it posts next
 int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parity, int overlap);   // n fields, one RCCL group
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
 int comm_allreduce_parts(qexhip_ctx *c, double *parts, int n, int *n_out);   // workgroup partials -> *n_out values whose sum is the rank-global dot product
@@ -230,20 +241,25 @@ int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double 
 int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, size_t bytes, hipStream_t st);
 void comm_destroy(qexhip_ctx *c);
 inline bool comm_ready(const qexhip_ctx *c) { return c->comm != nullptr || c->peer != nullptr; }
+inline bool peer_faces(const qexhip_ctx *c) { return c->peer != nullptr && c->comm == nullptr; }    // the faces travel through peer-mapped arenas (else RCCL / copies)
 
-// ---- peer.hip: the peer-memory transport behind the same comm_* entry points ----
+// ---- peer.hip: device-side joins, and the peer-memory transport behind the same comm_* entry points ----
+int devjoin_init(qexhip_ctx *c);                                                  // qexhip_init
+void devjoin_destroy(qexhip_ctx *c);
+int devjoin_check(qexhip_ctx *c);                       // a bounded device-side wait gave up since the last check -> QEXHIP_ERR_COMM
+int devjoin_signal(qexhip_ctx *c, hipStream_t from);                              // device-side event: record ...
+int devjoin_wait(qexhip_ctx *c, hipStream_t waiter, hipStream_t from);            // ... and wait, without the runtime's cross-queue dependency
+int devjoin_defer(qexhip_ctx *c);                                                 // the compute stream's wait rides in the next peer_allreduce_parts ...
+int devjoin_flush(qexhip_ctx *c);                                                 // ... or is posted now (no-op when nothing is deferred)
 struct PeerHost;
-int peer_init(qexhip_ctx *c, PeerHost &host);          // after the host rendezvous chose this transport (collective)
+int peer_init(qexhip_ctx *c, PeerHost &host);          // after the host rendezvous (collective): control block exported, everybody's mapped
+int peer_selftest(qexhip_ctx *c);                       // a few mailbox all-reduces with known answers (collective; bounded): 0 = this rank saw the right sums
 void peer_destroy(qexhip_ctx *c);
-int peer_check(qexhip_ctx *c);                          // a device-side wait timed out since the last check -> QEXHIP_ERR_COMM
+inline int peer_check(qexhip_ctx *c) { return devjoin_check(c); }
 int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *src_dn, int ns_up, const void *const *src_up,
                   void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us = 0.0, const void **zc_from_up = nullptr,
-                  const void **zc_from_dn = nullptr, bool zc_linger = true, struct PeerPush *push_only = nullptr);                  // zc_*: zero-copy receive (the faces stay in the arena, credits owed)
-int peer_release_zc(qexhip_ctx *c, hipStream_t st);                   // behind the consumer of a zero-copy receive: credits + join signal
-int peer_stream_signal(qexhip_ctx *c, hipStream_t from);                          // device-side event: record ...
-int peer_stream_join(qexhip_ctx *c, hipStream_t waiter, hipStream_t from);        // ... and wait, without the runtime's cross-queue dependency
-int peer_stream_join_defer(qexhip_ctx *c);                                        // the compute stream's wait rides in the next peer_allreduce_parts ...
-int peer_flush_join(qexhip_ctx *c);                                               // ... or is posted now (no-op when nothing is deferred / no peer transport)
+                  const void **zc_from_dn = nullptr, struct PeerPush *push_only = nullptr);   // push_only (+ zc_*): nothing is launched, the caller's kernel
+                                                                                              // pushes and reads the arena (credits owed: peer_ghost_args)
 int peer_allreduce_parts(qexhip_ctx *c, double *parts, int n);       // parts[0] := sum over ranks of (sum of parts[0..n) in cg_sum_parts order)
 int peer_allreduce(qexhip_ctx *c, double *dptr, int n, int op);      // on the compute stream; op 0 sum, 1 max; rank order
 int peer_host_reduce(qexhip_ctx *c, double *host, int n, int op);    // host operands (op 0 max, 1 min, 2 sum), synchronous
@@ -263,14 +279,14 @@ struct DslashOpts {
   int *nparts_out = nullptr;
   double *dot_out = nullptr;       // device scalar
   const int *done = nullptr;       // device flag: skip when set
-  int chain = 0;                   // 1 / 2: first / second sweep of a back-to-back pair out2 = D (D in) with three distinct fields (op_xx); see dslash_sweep
-  int defer_join = 0;              // the caller's next operation on the compute stream is comm_allreduce_parts (or peer_flush_join): an overlapped
-                                   // sweep on the peer transport leaves its join from the comm stream to that kernel's prologue
+  int defer_join = 0;              // the caller's next operation on the compute stream is comm_allreduce_parts (or devjoin_flush): a sweep split by
+                                   // sites leaves its join from the comm stream to that kernel's prologue where the mailboxes carry the sum
 };
 int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const DslashOpts &o);
-bool sweep_chain_on(const qexhip_ctx *c); // an overlapped pair of sweeps runs chained (dslash_sweep)
-int sweep_autotune(qexhip_ctx *c);      // measure exchange-first against overlapped once per operator shape (collective)
+int sweep_autotune(qexhip_ctx *c);      // measure the sweep's forms once per operator shape (collective)
 void sweep_plan(const qexhip_ctx *c, int *lo_end, int *hi_beg, int *overlap);   // boundary / interior ranges and the overlap decision
+int sweep_form(const qexhip_ctx *c, int overlap);                              // 2 fused / 0 by sites: what an overlapped sweep runs as
+double sweep_push_fraction(const qexhip_ctx *c, int interior_sites);           // where in the dispatch order the fused sweep's boundary workgroups go
 
 // ---- blas.hip ----
 int blas_zero(qexhip_ctx *c, DevField &f, int parity);

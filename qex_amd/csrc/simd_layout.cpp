@@ -33,6 +33,14 @@ int simd_setup(SimdLay &l, const int local[4], const int inner[4]) {
       qexhip_set_error("simd layout: localGeom[%d] = %d is not a multiple of innerGeom[%d] = %d", i, local[i], i, inner[i]);
       return QEXHIP_ERR_ARG;
     }
+    if (local[i] & 1) {
+      // QEX takes the parity that splits a field into its even and odd halves from GLOBAL coordinates (qlayout.nim:133-185 adds
+      // localGeom * rankCoord before counting): with an odd local extent a rank at an odd coordinate keeps locally-odd sites in its even
+      // half, and a map built from local coordinates alone -- all these entry points are given -- would permute fields to the wrong
+      // sites without any sign of it.  Every handle libqexhip shards has even local extents (qexhip_init), so nothing is lost.
+      qexhip_set_error("simd layout: localGeom[%d] = %d is odd: the even/odd split would depend on the rank's origin, which this map is not given", i, local[i]);
+      return QEXHIP_ERR_ARG;
+    }
     l.local[i] = local[i]; l.inner[i] = inner[i]; l.outer[i] = local[i] / inner[i];
     lvol *= l.local[i]; ovol *= l.outer[i];
     if (l.inner[i] > 1 && (l.outer[i] & 1) == 1) icb++;

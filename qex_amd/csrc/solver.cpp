@@ -32,12 +32,10 @@ int op_xx(qexhip_ctx *c, DevField &r, DevField &x, double m2, int par_even, int 
   DevField *t;
   CHK(get_work(c, WK_T, &t));
   const int px = par_even ? 0 : 1, py = 1 - px;
-  // the two sweeps as a chained pair (dslash_sweep) when the three fields are distinct; with deferred partials (the CG loops) the
-  // caller's next call is comm_allreduce_parts, which takes the join of the second sweep's boundary launch into its kernel
-  const bool pair = t->d != x.d && t->d != r.d && r.d != x.d;
+  // with deferred partials (the CG loops) the caller's next call is comm_allreduce_parts, which takes the join of the second sweep's
+  // boundary launch into its kernel where the sweep is split by sites and the mailboxes carry the sum
   DslashOpts o1, o2;
   o1.done = done;
-  o1.chain = pair ? 1 : 0;
   o2.cb = 4.0 * m2;
   o2.xs = &x;
   o2.neg = 1;
@@ -45,7 +43,6 @@ int op_xx(qexhip_ctx *c, DevField &r, DevField &x, double m2, int par_even, int 
   o2.nparts_out = ndot;
   o2.dot_out = &c->cg->pAp;
   o2.done = done;
-  o2.chain = pair ? 2 : 0;
   o2.defer_join = (dot && ndot) ? 1 : 0;
   if (o2.cb == 0.0 && dot) { qexhip_set_error("op_xx: dot with m2 == 0 unsupported"); return -1; }
   CHK(dslash_sweep(c, *t, x, py, o1));
@@ -105,7 +102,6 @@ static int cg_iterate(qexhip_ctx *c, DevField &x, DevField *r, DevField *p, DevF
   const int par = par_even ? 0 : 1;
   const int chunk = 32;
   int rolled = 1;
-  c->cg_r2_fold = 0;                 // (a rank sum left pending by an aborted solve is not this solve's)
   bool done = st.dones[k & 1];
   double r2 = st.r2s[k & 1];
   st.itn = st.itns[k & 1];

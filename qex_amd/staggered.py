@@ -138,13 +138,17 @@ class Context:
              "option_overlap": int(o[7])}
         if o[4]:
             r["measured_us_per_sweep"] = {"exchange_first": int(o[5]), "overlapped": int(o[6])}
-        k = (C.c_int * 4)()
-        check(lib().qexhip_stag_sweep_chain_info(self._h, k))
-        r["chained"] = bool(k[0])
-        r["option_sweep_chain"] = int(k[3])
-        if o[4] and k[1]:
-            r["measured_us_per_sweep"]["overlapped_chained"] = int(k[2])
+        r.update(self.sweep_tuning())
+        if o[4]:
+            r["measured_us_per_sweep"]["fused"] = int(r["tuned_us_per_sweep"][2] + 0.5)
         return r
+
+    def sweep_tuning(self):
+        """what set_links measured and decided for the sweeps of a t-sharded slab (qexhip_stag_sweep_tuning)"""
+        t = (C.c_double * 8)()
+        check(lib().qexhip_stag_sweep_tuning(self._h, t))
+        return {"exchange_us": float(t[0]), "boundary_at": float(t[1]), "tuned_us_per_sweep": [float(t[2]), float(t[3]), float(t[4])],
+                "form": "fused" if int(t[5]) == 2 else "by_sites", "fused_spin_us": float(t[6])}
 
     def force_halo(self, on=True):
         check(lib().qexhip_comm_force_halo(self._h, 1 if on else 0))

@@ -12,7 +12,7 @@ run_case() {   # lat4 [--naik]
   port=$((port + 1))
   echo "=== case $* ===" | tee -a $LOG
   for r in 0 1; do
-    RANK=$r WORLD_SIZE=2 LOCAL_RANK=$r MASTER_PORT=$port timeout -k 5 150 python3 scratch/shared_bisect_worker.py "$@" >> $LOG.rank$r 2>&1 &
+    RANK=$r WORLD_SIZE=2 LOCAL_RANK=$r MASTER_PORT=$port timeout -k 5 150 python3 tests/shared_device_worker.py "$@" >> $LOG.rank$r 2>&1 &
     pids[$r]=$!
   done
   rc=0

@@ -2,9 +2,12 @@
 // What QMP gives QEX (src/comms/commsQmp.nim:14-33 init, :127-140 barrier / max) restated over a POSIX shm segment:
 // N forked processes must (1) meet, (2) pass 1000 barriers without one rank ever running a generation ahead,
 // (3) agree bit for bit on max / min / rank-ordered sum, (4) get an error -- not a hang -- when a rank never arrives or
-// reports a failure, (5) refuse a slot that is already taken (a unique id serves one comm_init).
+// reports a failure, (5) refuse a slot that is already taken (a unique id serves one comm_init), and (6) take ONE transport
+// decision for the job in comm_init's `auto` mode (peer_host_choose) -- including jobs that span nodes, whose ranks never share
+// a segment: RCCL by the launcher's hint without any wait, RCCL after the rendezvous timeout without one, never an error.
 #include "../../qex_amd/csrc/peer_shm.h"
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -94,8 +97,62 @@ static int t_failed(int n, int rank, const unsigned char *id) {
   return 0;
 }
 
+// ---- the transport decision (peer_host_choose): mode 0 rccl, 2 peer, 3 rccl + mailbox sums ----
+static int g_wish = 0, g_expect_mode = 0, g_expect_err = 0, g_same_bus = 0, g_present = 0;
+static double g_max_s = 0;
+static int t_choose(int n, int rank, const unsigned char *id) {
+  if (g_present && rank >= g_present) return 0;            // "on another node": never opens THIS node's segment
+  PeerHost h;
+  char bus[32];
+  snprintf(bus, sizeof bus, "0000:%02x:00.0", g_same_bus ? 7 : 16 + rank);
+  int mode = -1, shared = -1;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int e = peer_host_choose(&h, id, n, rank, g_wish, rank, bus, 1.5, &mode, &shared);
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (!e && (mode == 2 || mode == 3)) {                    // the segment stays open for the handle exchange: one more barrier, then close
+    if (peer_host_barrier(&h)) return 5;
+    peer_host_close(&h);
+  }
+  if ((e != 0) != (g_expect_err != 0) || (!e && mode != g_expect_mode) || dt > g_max_s || (!e && mode == 2 && shared != g_same_bus)) {
+    fprintf(stderr, "[%d] choose: rc %d mode %d shared %d after %.2f s (want err %d mode %d within %.1f s): %s\n", rank, e, mode, shared, dt,
+            g_expect_err, g_expect_mode, g_max_s, g_err);
+    return 6;
+  }
+  return 0;
+}
+static int choose_case(const char *what, int n, int present, int wish, int same_bus, const char *hint, int expect_mode, int expect_err, double max_s, int salt) {
+  g_wish = wish; g_expect_mode = expect_mode; g_expect_err = expect_err; g_same_bus = same_bus; g_present = present; g_max_s = max_s;
+  if (hint) setenv("QEXHIP_LOCAL_RANKS", hint, 1); else unsetenv("QEXHIP_LOCAL_RANKS");
+  unsetenv("LOCAL_WORLD_SIZE");
+  const int rc = run_ranks(n, t_choose, salt);
+  unsetenv("QEXHIP_LOCAL_RANKS");
+  printf("transport decision, %s: %s\n", what, rc ? "FAILED" : "ok");
+  return rc;
+}
+
 int main() {
   int bad = 0;
+  bad |= choose_case("4 ranks on 4 devices of one node -> rccl + mailbox sums", 4, 0, 0, 0, nullptr, 3, 0, 1.0, 50);
+  bad |= choose_case("4 ranks sharing one device -> peer", 4, 0, 0, 1, nullptr, 2, 0, 1.0, 51);
+  bad |= choose_case("launcher says 2 of 4 ranks are local -> rccl at once, no segment", 4, 2, 0, 0, "2", 0, 0, 0.2, 52);
+  bad |= choose_case("2 of 4 ranks on this node, no hint -> every local rank times out alike -> rccl", 4, 2, 0, 0, nullptr, 0, 0, 4.0, 53);
+  bad |= choose_case("the same with an explicit wish for peer -> an error, not a fallback", 4, 2, 2, 0, nullptr, 0, 1, 4.0, 54);
+  bad |= choose_case("wish rccl -> no rendezvous", 4, 0, 1, 0, nullptr, 0, 0, 0.2, 55);
+  {
+    // after a failed rendezvous no name is left behind for a retry with the same id to trip over (whoever times out unlinks)
+    unsigned char id[128];
+    for (int i = 0; i < 128; i++) id[i] = (unsigned char)(3 * i + 1);
+    const int pid = (int)getpid();
+    memcpy(id + 16, &pid, sizeof pid);
+    PeerHost a;
+    int mode = -1, shared = -1;
+    const int e1 = peer_host_choose(&a, id, 2, 1, 2, 0, "bus", 0.5, &mode, &shared);      // rank 1 alone, insists on peer: times out
+    PeerHost b;
+    const int e2 = peer_host_open(&b, id, 2, 1, 0.5);                                      // the retry finds slot 1 free again
+    if (!e2) { peer_host_unlink(&b); peer_host_close(&b); }
+    printf("a failed rendezvous leaves no stale slot: %s\n", (e1 != 0 && e2 == 0) ? "ok" : "FAILED");
+    bad |= !(e1 != 0 && e2 == 0);
+  }
   for (int n : {1, 2, 4, 8}) {
     const int rc = run_ranks(n, t_collectives, 10 + n);
     printf("collectives, %d ranks: %s\n", n, rc ? "FAILED" : "ok");

@@ -4,7 +4,7 @@ One process per rank, all on device 0, peer-memory transport, overlap forced, a 
 links -- no oracle, so big slabs cost nothing on the CPU.  The same solve is run with hop_split = 0 (split by sites) first:
 its residual history is the reference the fused run must reproduce (to rounding: the hop split sums local hops first).
 
-  python scratch/shared_bisect_worker.py LX LY LZ LT_GLOBAL [--naik] [--its K]     (RANK / WORLD_SIZE / MASTER_* from the env)
+  python tests/shared_device_worker.py LX LY LZ LT_GLOBAL [--naik] [--its K]     (RANK / WORLD_SIZE / MASTER_* from the env)
 
 Prints one line `BISECT rank r {...}` with ok / the library's error text / the number of boundary workgroups per sweep.
 """

@@ -332,6 +332,44 @@ def test_resident_field_entry_points_against_the_oracle(oracle):
     assert ctx.comm_count() in (1, 2)
 
 
+def test_fused_sweep_placement_follows_the_measured_exchange():
+    """Where the fused sweep puts its boundary workgroups -- and how long they wait before they park -- goes by the face exchange
+    set_links MEASURES (ten exchanges on the compute stream, max over ranks), not by an assumed link rate: under emulated transport
+    of 40 and 80 us per exchange the measured figure grows by what was added, the boundary workgroups move back in the dispatch order,
+    the short wait grows with it.  (qshifts.nim:51-131 is the exchange being timed; no oracle: device-side random links.)"""
+    import qex_amd as q
+
+    lat = [32, 32, 32, 16]
+    vol = int(np.prod(lat))
+    rng = np.random.default_rng(3)
+    g = 0.3 * rng.standard_normal((vol, 4, 3, 3, 2))
+    seen = []
+    for emu in (40, 80):
+        ctx = q.Context(lat)
+        ctx.set_option("transport", 2)
+        ctx.comm_init(q.Context.unique_id(), 1, 0)
+        ctx.force_halo(True)
+        ctx.set_option("emu_exchange_us", emu)
+        ctx.set_option("overlap", -2)                 # measure on one rank too
+        t0 = ctx.sweep_tuning()
+        assert t0["tuned_us_per_sweep"] == [0.0, 0.0, 0.0]
+        s = q.newStag(ctx, g)
+        t = ctx.sweep_tuning()
+        assert "(measured)" in ctx.info() and "boundary_at=" in ctx.info(), ctx.info()
+        assert all(v > 0 for v in t["tuned_us_per_sweep"]), t          # exchange first | by sites | fused: all three were timed
+        seen.append(t)
+        del s
+        ctx.close()
+    a, b = seen
+    assert emu_close(b["exchange_us"] - a["exchange_us"], 40.0), (a, b)
+    assert 0.65 <= a["boundary_at"] < b["boundary_at"] <= 1.0, (a, b)
+    assert b["fused_spin_us"] > a["fused_spin_us"] >= 25.0, (a, b)
+
+
+def emu_close(d, want):
+    return abs(d - want) < 0.5 * want
+
+
 def test_overlap_decision_is_measured_when_asked(oracle):
     """With a communicator of more than one rank the library times exchange-first against overlapped sweeps at set_links and
     takes the faster (collective, the slowest rank decides).  Option overlap = -2 asks for the same measurement on one rank:

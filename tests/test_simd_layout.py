@@ -67,6 +67,16 @@ def test_default_inner_geometry_is_newLayoutX():
     assert default_inner([8, 8, 8, 8], 3)[0] != 0
 
 
+def test_odd_local_extents_are_refused():
+    """With an odd local extent the parity that splits a QEX field into halves depends on the rank's origin (qlayout.nim:133-185 counts
+    GLOBAL coordinates): a rank at an odd coordinate would be permuted wrongly by a map built from local coordinates.  The entry
+    points are given no origin, so they refuse instead of guessing (sharded handles have even local extents anyway)."""
+    for lat in ([3, 4, 4, 4], [4, 4, 4, 5], [6, 3, 4, 4]):
+        rc, _ = simd_map(lat, [1, 1, 1, 1])
+        assert rc < 0, lat
+    assert simd_map([6, 4, 4, 2], [1, 1, 1, 1])[0] == 0
+
+
 @pytest.mark.parametrize("lat,inner", [([8, 8, 8, 8], [1, 2, 2, 2]), ([4, 8, 12, 8], [1, 2, 2, 2]), ([16, 8, 8, 4], [2, 2, 2, 1]),
                                        ([8, 4, 6, 4], [2, 2, 1, 1]), ([4, 6, 10, 6], [1, 1, 1, 1]), ([8, 8, 8, 8], [2, 2, 2, 2]),
                                        ([16, 16, 16, 32], [1, 2, 2, 2]), ([12, 4, 4, 4], [1, 2, 2, 2]),

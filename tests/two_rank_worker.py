@@ -43,10 +43,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("lat", type=int, nargs=4)
     ap.add_argument("--overlap", type=int, default=-1, help="option overlap of the context: -1 by size, 0 never, 1 always")
-    ap.add_argument("--sweep-chain", type=int, default=-1, help="option sweep_chain: 1 = the overlapped sweeps of the normal operator run chained, "
-                                                                "0 never, -1 where set_links measured it faster")
-    ap.add_argument("--hop-split", type=int, default=-1, help="option hop_split: 1 = overlapped sweeps split by hops (default), 0 = by sites")
-    ap.add_argument("--peer-fold", type=int, default=-1, help="option peer_fold: 2 = the CG's rank sums inside the consuming kernels")
+    ap.add_argument("--hop-split", type=int, default=-1, help="option hop_split: 2 = the fused self-pushing sweep, 0 = split by sites, -1 = measured")
+    ap.add_argument("--fused-spin-us", type=int, default=-1, help="option fused_spin_us: -2 = every boundary block parked")
     ap.add_argument("--skip-gauge", action="store_true", help="operator and solvers only")
     ap.add_argument("--share-device", action="store_true", help="every rank binds device 0: the peer-memory transport between processes "
                     "that share one GPU (RCCL refuses that), i.e. real neighbours on a one-GPU box")
@@ -94,12 +92,10 @@ def main():
     assert transport == ("peer" if (args.share_device and world > 1) or os.environ.get("QEXHIP_TRANSPORT") == "peer" else "rccl"), transport
     if args.overlap >= 0:
         ctx.set_option("overlap", args.overlap)
-    if args.sweep_chain >= 0:
-        ctx.set_option("sweep_chain", args.sweep_chain)
     if args.hop_split >= 0:
         ctx.set_option("hop_split", args.hop_split)
-    if args.peer_fold >= 0:
-        ctx.set_option("peer_fold", args.peer_fold)
+    if args.fused_spin_us != -1:
+        ctx.set_option("fused_spin_us", args.fused_spin_us)
     res = {"rank": rank, "device": info[2], "pci_bus": info[3], "comms": ctx.comm_count(), "transport": transport}
 
     def sl(a):
