@@ -4,6 +4,8 @@
 //   (2) a mailbox all-reduce in one single-workgroup kernel
 //   (3) hipStreamWriteValue64 / hipStreamWaitValue64 on the same memory (return codes, then timing if accepted)
 // usage: ipc_probe NRANKS ITERS BYTES MEMKIND(0 hipMalloc, 1 fine-grained, 2 uncached)
+// IPC_PROBE_DISTINCT=1: rank r binds device r mod (device count) instead of device 0 -- the first-contact form for a multi-GPU node
+// (scratch/first_contact.sh): the same pushes, flags and mailboxes, every word checked, now across xGMI.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +27,13 @@ struct Shm {
   hipIpcMemHandle_t h[MAXR];
 };
 
+static int probe_device(int rank) {
+  const char *e = getenv("IPC_PROBE_DISTINCT");
+  if (!e || atoi(e) == 0) return 0;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return 0;
+  return rank % n;
+}
 static long g_gen = 0;
 static void hbarrier(Shm *s, int n, int rank, int id) {
   const long my = ++g_gen;
@@ -131,7 +140,7 @@ __global__ void k_allreduce(double *x, int n, int nranks, int me, double *const 
 // arena, allocate a bigger one, export, open the neighbours'
 static int regrow(int rank, int n, int mode, Shm *shm) {
   g_rank = rank;
-  CK(hipSetDevice(0));
+  CK(hipSetDevice(probe_device(rank)));
   char *arena = nullptr, *peer[MAXR] = {nullptr};
   size_t sz = (size_t)1 << 20;
   int rc = 0;
@@ -162,7 +171,7 @@ static int regrow(int rank, int n, int mode, Shm *shm) {
 
 static int child(int rank, int n, int iters, size_t bytes, int memkind, Shm *shm) {
   g_rank = rank;
-  CK(hipSetDevice(0));
+  CK(hipSetDevice(probe_device(rank)));
   const size_t mbox_bytes = 4 * MAXR * 2048 * sizeof(double);
   const size_t arena_bytes = 4096 + mbox_bytes + bytes;
   char *arena = nullptr;

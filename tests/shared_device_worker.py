@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--naik", action="store_true")
     ap.add_argument("--its", type=int, default=40)
     ap.add_argument("--forms", type=int, nargs="+", default=[0, 2], help="hop_split values to run, in order")
+    ap.add_argument("--distinct-devices", action="store_true", help="rank r binds device LOCAL_RANK instead of device 0 (scratch/first_contact.sh)")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -39,7 +40,8 @@ def main():
     loc[3] //= world
     vol = int(np.prod(loc))
     rng = np.random.default_rng(1234 + rank)
-    ctx = q.Context(loc, device=0, rank_geom=(1, 1, 1, world), rank_coord=(0, 0, 0, rank))
+    dev = int(os.environ.get("LOCAL_RANK", rank)) % max(q.device_count(), 1) if args.distinct_devices else 0
+    ctx = q.Context(loc, device=dev, rank_geom=(1, 1, 1, world), rank_coord=(0, 0, 0, rank))
     uid = [q.Context.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, src=0)
     ctx.comm_init(uid[0], world, rank)

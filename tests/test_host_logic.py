@@ -371,6 +371,30 @@ def test_shard_check_fixture_against_the_oracle_48x96():
     assert r["max_rel"]["operator"] < 1e-13 and r["max_rel"]["history"] < 1e-11 and r["max_rel"]["solution"] < 1e-12, r
 
 
+def test_first_contact_ladder_control_flow(tmp_path):
+    """scratch/first_contact.sh -- what to run first on a node with more than one GPU -- rehearsed without one (--dry-run: every rung
+    is logged and replaced by a hook): all rungs in order when everything passes; the FIRST failing rung ends the ladder with exit 1
+    and nothing behind it runs; a rung that had to be killed (exit status 124..137) ends it with exit 3 at once."""
+    sh = os.path.join(ROOT, "scratch", "first_contact.sh")
+
+    def run(hook, out):
+        env = dict(os.environ, FIRST_CONTACT_DRY_HOOK=hook)
+        p = subprocess.run(["bash", sh, "--dry-run", "--gpus", "8", "--out", str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=60)
+        return p.returncode, open(os.path.join(str(out), "summary.txt")).read()
+
+    rc, summ = run("true", tmp_path / "a")
+    rungs = [ln for ln in summ.splitlines() if ln.startswith("--- rung")]
+    assert rc == 0 and len(rungs) == 12 and "every rung passed" in summ, summ
+    assert ["ipc_probe" in r for r in rungs[:4]] == [True] * 4 and "bench_gpus8" in rungs[-1], rungs
+    assert sum("two_rank_worker" in r for r in rungs) == 3 and all(t in summ for t in ("QEXHIP_TRANSPORT=rccl", "QEXHIP_TRANSPORT=mbox", "QEXHIP_TRANSPORT=peer"))
+    rc, summ = run('[ "$nrung" -ne 6 ]', tmp_path / "b")                      # rung 6 fails
+    assert rc == 1 and "rung 6 failed" in summ and "rung 7:" not in summ, summ
+    rc, summ = run('[ "$nrung" -ne 2 ] || (exit 124)', tmp_path / "c")         # rung 2 had to be killed
+    assert rc == 3 and "had to be killed" in summ and "rung 3:" not in summ, summ
+    p = subprocess.run(["bash", sh, "--dry-run", "--gpus", "1", "--out", str(tmp_path / "e")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+    assert p.returncode == 2 and "at least two GPUs" in p.stdout
+
+
 def test_every_entry_point_refuses_a_null_handle():
     """Error behaviour of the boundary (SURVEY 8b "Errors": int return codes, 0 = ok, < 0 = error): every exported function
     that takes the context handle must answer a NULL handle with a negative code before it touches the device -- this

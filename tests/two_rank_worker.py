@@ -89,7 +89,14 @@ def main():
     info = ctx.comm_info()
     assert info[0] == world and info[1] == rank, info                  # RCCL's own count and rank
     transport = ctx.comm_transport()[0]
-    assert transport == ("peer" if (args.share_device and world > 1) or os.environ.get("QEXHIP_TRANSPORT") == "peer" else "rccl"), transport
+    wish = os.environ.get("QEXHIP_TRANSPORT", "auto")
+    if (args.share_device and world > 1) or wish == "peer":
+        assert transport == "peer", transport
+    elif wish in ("mbox", "rccl"):
+        assert transport == {"mbox": "rccl+mbox", "rccl": "rccl"}[wish], transport
+    else:
+        # auto between distinct devices: RCCL for the faces; the mailboxes for the rank sums if they passed comm_init's self-test
+        assert transport in ("rccl+mbox", "rccl"), transport
     if args.overlap >= 0:
         ctx.set_option("overlap", args.overlap)
     if args.hop_split >= 0:
