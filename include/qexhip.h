@@ -404,9 +404,9 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  *                  terms when they are in): its first workgroups push the faces into the neighbours' receive arenas, the interior
  *                  workgroups take every hop of their sites, the boundary workgroups take the hops inside the slab, wait SHORTLY (about
  *                  one measured exchange time) for the inbound data words and then either take the 1-2 hops per site that leave the slab
- *                  straight from the arena, or -- faces late -- park their raw accumulator and give up their slot; the last <= 64
+ *                  straight from the arena, or -- faces late -- park their raw accumulator and give up their slot; the last <= 32
  *                  workgroups of the grid finish the parked blocks behind the one LONG bounded wait (QEXHIP_PEER_TIMEOUT: a lost
- *                  neighbour).  No kernel holds more than those 64 slots hostage to another rank's progress -- ranks may share a chip.
+ *                  neighbour).  No kernel holds more than those 32 slots hostage to another rank's progress -- ranks may share a chip.
  *                  0: by SITES (interior launch beside the exchange, boundary launch on the second stream behind it, device-side join).
  *                  -1 (default): whichever set_links measured faster (qexhip_stag_sweep_tuning), fused until measured.  Boundary sites
  *                  sum their local hops first under 2, parked or not: equal to 0 to rounding, and to itself to the bit.

@@ -22,6 +22,8 @@ int qexhip_tune_fma64(qexhip_handle h, int kind, int chains, int wps, int iters,
 /* the Wilson-flow stage's operand gathers alone (48 matrices per 64-site tile of the resident links, into registers):
  * nw wavefronts per workgroup (divides 48), wgpc workgroups per CU, depth matrices in flight per wavefront (1, 2, 4, 6); us */
 int qexhip_tune_gather(qexhip_handle h, int nw, int wgpc, int depth, int nrep, double *avg_us);
+/* the same stream with rows = 2: only rows 0,1 of every matrix are gathered (6 of 9 sixteen-byte requests per lane; round 6) */
+int qexhip_tune_gather_rows(qexhip_handle h, int nw, int wgpc, int depth, int rows, int nrep, double *avg_us);
 /* the same operand stream with the links read in a brick tile shape (8 x 4 x 4 x 1 sites per tile position): the round-5 tile-shape
  * experiment (profiles/r05_tile_shape.md); lattices with 8 | X, 4 | Y, 4 | Z */
 int qexhip_tune_gather_brick(qexhip_handle h, int nw, int wgpc, int depth, int nrep, double *avg_us);

@@ -193,6 +193,7 @@ def tune_lib():
         T.qexhip_tune_stream.argtypes = [_vp, _ci, C.c_size_t, _ci, _ci, pd]
         T.qexhip_tune_fma64.argtypes = [_vp, _ci, _ci, _ci, _ci, pd]
         T.qexhip_tune_gather.argtypes = [_vp, _ci, _ci, _ci, _ci, pd]
+        T.qexhip_tune_gather_rows.argtypes = [_vp, _ci, _ci, _ci, _ci, _ci, pd]
         _tune = T
     return _tune
 

@@ -115,7 +115,6 @@ static int init_body(qexhip_ctx *c, int device, const int latLocal[4], const int
     else HIPCHK(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
   }
   HIPCHK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
   c->part2_off = std::max(6144, (c->g.Vh + 255) / 256 + 8);   // >= 6*1024 for the plaquette partials
   c->npartials = c->part2_off + 2048 + 64;
   HIPCHK(hipMalloc((void **)&c->partials, sizeof(double) * c->npartials));
@@ -203,7 +202,6 @@ extern "C" int qexhip_finalize(qexhip_handle c) {
   if (c->fz_buf) (void)hipFree(c->fz_buf);
   devjoin_destroy(c);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-  if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->cstream) (void)hipStreamDestroy(c->cstream);
   (void)hipGetLastError();
@@ -694,6 +692,7 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
     c->opt_hop_split = value;
   }
   else if (n == "fused_spin_us") c->opt_fused_spin_us = value;
+  else if (n == "gauge_su3") c->opt_gauge_su3 = value;
   else if (n == "emu_exchange_us") c->emu_exchange_us = value;
   else if (n == "emu_allreduce_us") c->emu_allreduce_us = value;
   else if (n == "emu_link_gbs") c->emu_link_gbs = value;

@@ -304,8 +304,8 @@ static int sweep_mrhs(qexhip_ctx *c, MrhsArgs &A, bool second, int *ndot, DevFie
   } else {
     const int nb_int = launch_range(c, A, second, lo_end, hi_beg, 0, 0, 0, c->stream);
     const int nb_bnd = launch_range(c, A, second, 0, lo_end, hi_beg, g.Vh, nb_int, c->cstream);
-    HIPCHK(hipEventRecord(c->ev_halo, c->cstream));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    CHK(devjoin_signal(c, c->cstream));               // device-side join (as dslash_sweep): ~15 us instead of the ~28 us of an event dependency
+    CHK(devjoin_wait(c, c->stream, c->cstream));
     *ndot = nb_int + nb_bnd;
   }
   HIPCHK(hipGetLastError());

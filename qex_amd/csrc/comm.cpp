@@ -241,7 +241,7 @@ static inline int upper(const qexhip_ctx *c) { return (c->rank + 1) % c->nranks;
 static inline int lower(const qexhip_ctx *c) { return (c->rank - 1 + c->nranks) % c->nranks; }
 
 // Exchange the t-faces of one parity half of f.  Runs on the comm stream after ev_ready (the
-// producer of f on the compute stream); the caller records ev_halo behind whatever it posts after the exchange.  Message order is the same on every
+// producer of f on the compute stream); the caller joins (devjoin_signal / devjoin_wait) behind whatever it posts after the exchange.  Message order is the same on every
 // rank -- sends {bottom->lower, top->upper}, receives {ghost_hi<-upper, ghost_lo<-lower} -- so
 // that with two ranks (upper == lower) or one rank (self) the k-th send pairs with the k-th recv.
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
@@ -279,7 +279,7 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
     HIPCHK(hipMemcpyAsync(ghost_hi, bottom, nd * sizeof(double), hipMemcpyDeviceToDevice, cs));
     HIPCHK(hipMemcpyAsync(ghost_lo, top, nd * sizeof(double), hipMemcpyDeviceToDevice, cs));
   }
-  // overlap: the caller (dslash_sweep) posts its boundary launch behind the group on cstream and records ev_halo after it
+  // overlap: the caller (dslash_sweep) posts its boundary launch behind the group on cstream and the join signal after it
   return 0;
 }
 
@@ -369,7 +369,7 @@ int comm_exchange_raw(qexhip_ctx *c, const void *send_up, void *recv_from_down, 
 // faces of several buffers (the two parity halves of one or more matrix fields) in ONE group, both directions:
 // bottom[k] -> lower neighbour's ghost_hi, top[k] -> upper neighbour's ghost_lo   (same message order as above).
 // async: on the comm stream (second communicator) after ev_ready, which the caller recorded behind the producer of the
-// buffers; nothing waits for it here -- the caller joins (records ev_halo on the comm stream, lets the compute stream wait)
+// buffers; nothing waits for it here -- the caller joins (devjoin_signal on the comm stream, devjoin_wait on the compute stream)
 // before the first kernel that reads the ghosts.
 int comm_faces_exchange(qexhip_ctx *c, int nbuf, double *const bottom[], double *const top[], double *const ghost_hi[],
                         double *const ghost_lo[], size_t ndoubles, int async) {

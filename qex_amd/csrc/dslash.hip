@@ -461,8 +461,11 @@ static int fused_ctl(qexhip_ctx *c, int nbnd, FusedCtl *F) {
   F->dec = c->fz_buf; F->ndef = c->fz_buf + 32; F->cl_done = c->fz_buf + 64; F->late = c->fz_buf + 96;
   F->list = c->fz_buf + 256;
   // the cleanup workgroups hold their slots through the LONG wait when the faces are late: few, so that a neighbour that shares the chip
-  // always finds room; enough to take a whole face's parked blocks in ~100 us when it comes to that
-  F->ncl = std::max(1, std::min(nbnd, 64));
+  // always finds room; enough to take a whole face's parked blocks in ~100 us when it comes to that.  Measured (48^3 x 12 / 32^3 x 4
+  // slabs, profiles/r06_fused_ab.log): 8 | 16 | 32 | 64 of them cost 91 | 92.5 | 95 | 97.6 us per iteration on the thin slab's normal
+  // path (they poll while the whole launch is resident) and 663 | 513 | 450 | 438 us with EVERY block parked on the 48^3 one
+  F->ncl = std::max(1, std::min(nbnd, 32));
+  if (const char *e = getenv("QEXHIP_TUNE_FUSED_NCL")) { const int v = atoi(e); if (v > 0) F->ncl = std::min(nbnd, v); }     // (A/B hook of scratch/fused_ab.sh)
   const double tick_per_us = (double)c->dj.ticks / (c->dj.timeout_s * 1e6);
   if (c->opt_fused_spin_us == -2) F->spin_ticks = -1;
   else {

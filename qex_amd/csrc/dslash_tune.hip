@@ -384,7 +384,9 @@ extern "C" int qexhip_tune_fma64(qexhip_handle c, int kind, int chains, int wps,
 // from U), gathered by NW wavefronts per workgroup into REGISTERS, D matrices in flight per wavefront, nothing else: no LDS,
 // no barrier, 18 integer ops per matrix to keep the loads alive.  Persistent workgroups walk tile_order_table.
 #include "gauge_index.h"
-template <int D>
+// R = 9: whole matrices; R = 6: rows 0,1 only (round 6: would gathering 2/3 of every link -- and rebuilding row 2 of an SU(3) link in
+// registers -- shorten the stream?  profiles/r06_notes.md section 4)
+template <int D, int R = 9>
 __global__ void __launch_bounds__(512) k_gather_test(Geom g, const double2 *__restrict__ U, const int *__restrict__ order, int chunk,
                                                        unsigned long long *out) {
   const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -422,14 +424,18 @@ __global__ void __launch_bounds__(512) k_gather_test(Geom g, const double2 *__re
     return U + fs_link_off(g, lex, par, mu);
   };
   if (nunit == 0) return;
+  auto gload = [&](M3 &m, const double2 *p) __attribute__((always_inline)) {
 #pragma unroll
-  for (int d = 0; d < D; d++) { st[d] = m3_load(src(d), 64); __builtin_amdgcn_sched_barrier(0); }
+    for (int k = 0; k < R; k++) m.e[k] = p[(size_t)k * 64];
+  };
+#pragma unroll
+  for (int d = 0; d < D; d++) { gload(st[d], src(d)); __builtin_amdgcn_sched_barrier(0); }
   for (int u0 = 0; u0 < nunit; u0 += D) {
 #pragma unroll
     for (int d = 0; d < D; d++) {
 #pragma unroll
-      for (int k = 0; k < 9; k++) acc ^= (unsigned long long)__double_as_longlong(st[d].e[k].x) + (unsigned long long)__double_as_longlong(st[d].e[k].y);
-      st[d] = m3_load(src(u0 + d + D), 64);
+      for (int k = 0; k < R; k++) acc ^= (unsigned long long)__double_as_longlong(st[d].e[k].x) + (unsigned long long)__double_as_longlong(st[d].e[k].y);
+      gload(st[d], src(u0 + d + D));
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -437,8 +443,13 @@ __global__ void __launch_bounds__(512) k_gather_test(Geom g, const double2 *__re
 }
 // nw wavefronts per workgroup (divides 48), wgpc workgroups per CU, depth matrices in flight per wavefront (2, 4, 6, 8);
 // returns the average launch time; the lattice's resident links (qexhip_gauge_set) are the table
+extern "C" int qexhip_tune_gather_rows(qexhip_handle c, int nw, int wgpc, int depth, int rows, int nrep, double *avg_us);
 extern "C" int qexhip_tune_gather(qexhip_handle c, int nw, int wgpc, int depth, int nrep, double *avg_us) {
-  if (!c || !avg_us || nw < 1 || nw > 8 || 48 % nw || wgpc < 1) return -1;
+  return qexhip_tune_gather_rows(c, nw, wgpc, depth, 3, nrep, avg_us);
+}
+// rows = 3: whole matrices, 2: rows 0,1 only
+extern "C" int qexhip_tune_gather_rows(qexhip_handle c, int nw, int wgpc, int depth, int rows, int nrep, double *avg_us) {
+  if (!c || !avg_us || nw < 1 || nw > 8 || 48 % nw || wgpc < 1 || rows < 2 || rows > 3) return -1;
   const double2 *U = gauge_links_dev(c);
   if (!U) { qexhip_set_error("tune_gather: qexhip_gauge_set first"); return -3; }
   const int *order = nullptr; int chunk = 0;
@@ -450,7 +461,12 @@ extern "C" int qexhip_tune_gather(qexhip_handle c, int nw, int wgpc, int depth, 
   HIPCHK(hipEventCreate(&e1));
   const int nb = 256 * wgpc;
   auto run = [&]() {
-    if (depth == 2) k_gather_test<2><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
+    if (rows == 2) {
+      if (depth == 2) k_gather_test<2, 6><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
+      else if (depth == 4) k_gather_test<4, 6><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
+      else if (depth == 6) k_gather_test<6, 6><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
+      else k_gather_test<1, 6><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
+    } else if (depth == 2) k_gather_test<2><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
     else if (depth == 4) k_gather_test<4><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
     else if (depth == 6) k_gather_test<6><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);
     else k_gather_test<1><<<nb, 64 * nw, 0, c->stream>>>(c->g, U, order, chunk, out);

@@ -74,7 +74,23 @@ __global__ void __launch_bounds__(256) k_gauge_from_tiles(Geom g, double2 *__res
 // S4: instead of the six plane sums, the eight sums of `s4_gauge` (stagg_pv_hmc/staghmc_spv_meas.nim:25-65, the S4 order
 // parameter of arXiv:1111.2317): the plaquette of plane (mu, nu) at x is added to peo[mu][x_mu mod 2] and to peo[nu][x_nu mod 2];
 // partial k = 2 d + (x_d mod 2).
-template <bool HALO, bool S4 = false>
+// SU3 (round-6 experiment, option "gauge_su3", profiles/r06_notes.md section 4): gather rows 0,1 of every link (6 of 9 sixteen-byte
+// requests per lane) and rebuild row 2 = conj(row 0 x row 1) in registers -- the kernel is bound by L2->L1 requests, not by flops.
+__device__ __forceinline__ M3 m3_load_su3(const double2 *p, int stride) {
+  M3 r;
+#pragma unroll
+  for (int k = 0; k < 6; k++) r.e[k] = p[(size_t)k * stride];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int a = (k + 1) % 3, b = (k + 2) % 3;
+    const double2 u = r.e[a], v = r.e[3 + b], w = r.e[b], z = r.e[3 + a];
+    const double re = (u.x * v.x - u.y * v.y) - (w.x * z.x - w.y * z.y);
+    const double im = (u.x * v.y + u.y * v.x) - (w.x * z.y + w.y * z.x);
+    r.e[6 + k] = make_double2(re, -im);
+  }
+  return r;
+}
+template <bool HALO, bool S4 = false, bool SU3 = false>
 __global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict__ G, double *partials, const int *order, int chunk) {
   double pl[S4 ? 8 : 6] = {0, 0, 0, 0, 0, 0};
   const int slot = 4 * (blockIdx.x >> 3) + (threadIdx.x >> 6);
@@ -85,15 +101,15 @@ __global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict_
     coords_of(g, c, p, x);
     M3 U[4];
 #pragma unroll
-    for (int mu = 0; mu < 4; mu++) U[mu] = m3_load(G + link_off_t<HALO>(g, x, mu), 64);
+    for (int mu = 0; mu < 4; mu++) U[mu] = SU3 ? m3_load_su3(G + link_off_t<HALO>(g, x, mu), 64) : m3_load(G + link_off_t<HALO>(g, x, mu), 64);
 #pragma unroll
     for (int mu = 1; mu < 4; mu++) {
 #pragma unroll
       for (int nu = 0; nu < mu; nu++) {
         shifted_t<HALO>(g, x, nu, 1, y);
-        M3 unumu = m3_mul(U[nu], m3_load(G + link_off_t<HALO>(g, y, mu), 64));
+        M3 unumu = m3_mul(U[nu], SU3 ? m3_load_su3(G + link_off_t<HALO>(g, y, mu), 64) : m3_load(G + link_off_t<HALO>(g, y, mu), 64));
         shifted_t<HALO>(g, x, mu, 1, y);
-        M3 umunu = m3_mul(U[mu], m3_load(G + link_off_t<HALO>(g, y, nu), 64));
+        M3 umunu = m3_mul(U[mu], SU3 ? m3_load_su3(G + link_off_t<HALO>(g, y, nu), 64) : m3_load(G + link_off_t<HALO>(g, y, nu), 64));
         const double ps = m3_redot(umunu, unumu);
         if (S4) {
           const bool om = x[mu] & 1, on = x[nu] & 1;     // (a t-sharded slab starts at an even global t: local parity = global)
@@ -1086,7 +1102,8 @@ int gauge_plaq(qexhip_ctx *c, double out[6]) {
   CHK(ordered_sites(c, &order, &chunk, &nb, &part));
   {
     ScopedTimer tm(c, "plaq", c->stream);
-    if (c->g.halo) k_plaq<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+    if (c->opt_gauge_su3 == 1 && !c->g.halo) k_plaq<false, false, true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+    else if (c->g.halo) k_plaq<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
     else k_plaq<false><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
     HIPCHK(hipGetLastError());
   }

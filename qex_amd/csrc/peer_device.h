@@ -186,11 +186,13 @@ struct FusedCtl {
   long long spin_ticks;                          // the short wait's bound; < 0: park unconditionally (test hook: the cleanup path on every block)
   int ncl;                                       // cleanup workgroups at the end of the grid (>= 1)
 };
+// (coarse on purpose, ~1 us between looks: up to 64 cleanup workgroups poll ONE word for as long as the sweep runs when the whole
+// launch is resident at once, and every look is an L2 atomic on the channel the boundary workgroups' counts go through)
 __device__ inline bool peer_poll_u32(const unsigned int *p, unsigned int want, u64 *err, long long ticks, u64 code) {
   if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
   const long long t0 = wall_clock64();
   for (unsigned it = 1;; it++) {
-    __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_s_sleep(32);
     if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
     if ((it & 255) == 0) {
       if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return false;

@@ -90,7 +90,7 @@ struct qexhip_ctx {
   Geom g{};
   int rankGeom[4]{1, 1, 1, 1}, rankCoord[4]{0, 0, 0, 0};
   hipStream_t stream = nullptr, cstream = nullptr;
-  hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
+  hipEvent_t ev_ready = nullptr;      // compute -> comm stream: "the producer of the faces is done" (the way back is a device-side join: DevJoin)
   // communicator
   void *comm = nullptr;  // ncclComm_t: everything posted on the compute stream (all-reduces, ghost refreshes, non-overlapped faces)
   void *comm2 = nullptr; // ncclComm_t split off comm: the face exchanges posted on cstream beside the interior sweep
@@ -146,6 +146,8 @@ struct qexhip_ctx {
   unsigned int *fz_buf = nullptr; int fz_cap = 0;   // FusedCtl words + parked-block list of the fused sweep (dslash.hip)
   double xchg_us[2]{0, 0};      // measured at set_links (collective, max over ranks): one face exchange of the 8- / 16-link operator, us (0: not measured)
   int form_auto[2]{-1, -1};     // measured at set_links: 2 fused / 0 by sites for 8- and 16-link operators (-1: not measured)
+  int opt_gauge_su3 = 0;  // option "gauge_su3" (round-6 experiment hook, profiles/r06_notes.md section 4): 1 = k_plaq gathers rows 0,1 of every link and rebuilds
+                          // row 2 (valid on SU(3) links only: the caller's responsibility); 0 = all 18 reals (the product path)
   int opt_chain_overlap = 1; // option "chain_overlap" (A/B, test hook): 1 = the nHYP force chain's staple derivatives of a t-sharded field run in two passes,
                           // the ghost-free slices beside the exchange of the level's chain fields, the boundary slices behind it
   int opt_smear_ca = 1;   // option "smear_ca" (A/B, test hook): 1 = the nHYP levels of a t-sharded field are computed on shrinking ghost slices from

@@ -677,8 +677,8 @@ struct Smear {
   int ghosts_f_async(const double2 *f) { return ghosts_many(&f, 1, 576, 1, 1); }
   int ghosts_join() {
     if (!g.halo) return 0;
-    HIPCHK(hipEventRecord(c->ev_halo, c->cstream));
-    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    CHK(devjoin_signal(c, c->cstream));               // device-side join (peer.hip), as the sweeps: no cross-queue event dependency
+    CHK(devjoin_wait(c, c->stream, c->cstream));
     return 0;
   }
   int ghosts_f(const double2 *f, int depth = 1) { return ghosts(f, 576, depth); }

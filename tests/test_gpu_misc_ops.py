@@ -183,9 +183,13 @@ def test_bench_two_ranks_share_one_gpu():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", QEX_BENCH_FORCE_CANARY="1")
+    # QEXHIP_OVERLAP=1 QEXHIP_HOP_SPLIT=2 (left to itself set_links finds that overlapping does not pay between two processes on ONE
+    # chip and posts the exchange first): the fused self-pushing sweep -- what 8 GPUs run -- on BOTH legs, the 48^3 x 96 one included (its HISQ Naik
+    # multi-shift self-check has 1 296 boundary workgroups per sweep: the case that ran round 5's build into the wait bound,
+    # profiles/r06_notes.md section 1)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", QEX_BENCH_FORCE_CANARY="1", QEXHIP_HOP_SPLIT="2", QEXHIP_OVERLAP="1", QEXHIP_PEER_TIMEOUT="20")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-48x96"]
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=root, env=env)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2000:])
     lines = [json.loads(x) for x in p.stdout.splitlines() if x.startswith("{")]
@@ -201,6 +205,14 @@ def test_bench_two_ranks_share_one_gpu():
     # the peer-transport canary that precedes the RCCL measurement on a multi-GPU node (forced here): verified like every sharded leg
     can = ln["cg_32x4_peer_transport"]
     assert "error" not in can and can["transport"] == "peer" and can["shard_check"]["ok"] is True and can["value"] > 0, can
+    assert ln["multi_gpu"]["sweep"]["form"] == "fused", ln["multi_gpu"]["sweep"]
+    # BASELINE configs[3] over the same two real ranks, fused sweeps: every quantity of the oracle-pinned fixture, Naik 10-shift included
+    big = ln["cg_48x48x48x96"]
+    assert "error" not in big and big["transport"] == "peer" and big["value"] > 0, big
+    assert big["shard_check"]["ok"] is True and big["shard_check"]["fixture_pinned_to_oracle"]["ok"] is True, big["shard_check"]
+    assert big["multi_gpu"]["sweep"]["form"] == "fused", big["multi_gpu"]["sweep"]
+    nk = ln["naik_multishift_48x48x48x96"]
+    assert "error" not in nk and nk["links_per_site"] == 16 and nk["value"] > 0, nk
 
 
 @pytest.mark.parametrize("comm2", ["1", "0"])
