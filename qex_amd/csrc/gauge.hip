@@ -240,12 +240,12 @@ __device__ __forceinline__ int site_cidx(const Geom &g, const int x[4]) {
 }
 // U_a(gs) from global memory, unless the site s (parity q = the other one) lies in this tile position: then from the
 // workgroup's LDS copy, slot 0 = U_a(s), slot 1 = U_a(s - a)
-template <bool HALO>
+template <bool HALO, bool SU3 = false>
 __device__ __forceinline__ M3 link_lds_or_global(const Geom &g, const double2 *__restrict__ G, const double2 *smq, int tile,
                                                  const int s[4], int a, int slot, const int gs[4]) {
   const int cs = site_cidx<HALO>(g, s);
   if ((cs >> 6) == tile) return m3_load(smq + (size_t)(2 * a + slot) * 576 + (cs & 63), 64);
-  return m3_load(G + link_off_t<HALO>(g, gs, a), 64);
+  return SU3 ? m3_load_su3(G + link_off_t<HALO>(g, gs, a), 64) : m3_load(G + link_off_t<HALO>(g, gs, a), 64);
 }
 // the same choice as an ADDRESS (generic pointer: the flat load that follows serves either aperture): one load sequence per
 // operand instead of a divergent branch around two, which is what keeps k_flow_obs_clover2 inside its register budget
@@ -257,7 +257,9 @@ __device__ __forceinline__ const double2 *link_ptr_lds_or_global(const Geom &g, 
   const double2 *pg = G + link_off_t<HALO>(g, gs, a);
   return (cs >> 6) == tile ? pl : pg;
 }
-template <bool CLOSED, bool HALO>
+// SU3 (round-6 experiment, option "gauge_su3" = 1): every GLOBAL matrix gather fetches rows 0,1 only and rebuilds row 2 in registers
+// (m3_load_su3); the LDS copies are whole matrices (rebuilt once by the wavefront that owns them).
+template <bool CLOSED, bool HALO, bool SU3 = false>
 __global__ void __launch_bounds__(512) k_force_lds2(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
                                                     double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk) {
   extern __shared__ double2 smU[];                    // [parity][2 nu + (0: U_nu(x) | 1: U_nu(x-nu))][9][64]
@@ -277,7 +279,8 @@ __global__ void __launch_bounds__(512) k_force_lds2(Geom g, const double2 *__res
   const double2 *smq = smU + (size_t)(1 - p) * 8 * 576;   // the other parity's: every one-hop neighbour
   {
     shifted_t<HALO>(g, x, mu, -1, y);
-    const M3 a = m3_load(G + o, 64), b = m3_load(G + link_off_t<HALO>(g, y, mu), 64);
+    const M3 a = SU3 ? m3_load_su3(G + o, 64) : m3_load(G + o, 64);
+    const M3 b = SU3 ? m3_load_su3(G + link_off_t<HALO>(g, y, mu), 64) : m3_load(G + link_off_t<HALO>(g, y, mu), 64);
     double2 *s0 = smp + (size_t)(2 * mu) * 576 + lane;
 #pragma unroll
     for (int k = 0; k < 9; k++) { s0[k * 64] = a.e[k]; s0[576 + k * 64] = b.e[k]; }
@@ -290,13 +293,13 @@ __global__ void __launch_bounds__(512) k_force_lds2(Geom g, const double2 *__res
     const double2 *sn = smp + (size_t)(2 * nu) * 576 + lane;
     // forward: U_nu(x) U_mu(x+nu) U_nu(x+mu)^+          (stf[mu,nu], staples.nim:181-183)
     shifted_t<HALO>(g, x, nu, 1, y);
-    M3 t = m3_mul_na(link_lds_or_global<HALO>(g, G, smq, tile, y, mu, 0, y), link_lds_or_global<HALO>(g, G, smq, tile, xpm, nu, 0, xpm));
+    M3 t = m3_mul_na(link_lds_or_global<HALO, SU3>(g, G, smq, tile, y, mu, 0, y), link_lds_or_global<HALO, SU3>(g, G, smq, tile, xpm, nu, 0, xpm));
     m3_mac(acc, m3_load(sn, 64), t);
     // backward: U_nu(x-nu)^+ U_mu(x-nu) U_nu(x-nu+mu)   (stu[mu,nu] shifted down, staples.nim:184-186)
     shifted_t<HALO>(g, x, nu, -1, y);
     shifted_t<HALO>(g, y, mu, 1, z);
-    t = m3_mul_an(m3_load(sn + 576, 64), link_lds_or_global<HALO>(g, G, smq, tile, y, mu, 0, y));
-    m3_mac(acc, t, link_lds_or_global<HALO>(g, G, smq, tile, xpm, nu, 1, z));     // U_nu(x+mu-nu) = slot 1 of site x+mu
+    t = m3_mul_an(m3_load(sn + 576, 64), link_lds_or_global<HALO, SU3>(g, G, smq, tile, y, mu, 0, y));
+    m3_mac(acc, t, link_lds_or_global<HALO, SU3>(g, G, smq, tile, xpm, nu, 1, z));     // U_nu(x+mu-nu) = slot 1 of site x+mu
   }
   const M3 U = m3_load(smp + (size_t)(2 * mu) * 576 + lane, 64);
   force_finish<CLOSED>(U, acc, live, o, F, cp, Pm, cf, cpm, Uout, 1);
@@ -1178,7 +1181,13 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
         c->lds_attr_done |= 8;
       }
 #define QX_FLDS2(CL, HL) k_force_lds2<CL, HL><<<nb / 2, 512, 2 * shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk)
-      if (closed) { if (c->g.halo) QX_FLDS2(true, true); else QX_FLDS2(true, false); }
+      if (closed && !c->g.halo && c->opt_gauge_su3 == 1) {
+        if (!(c->lds_attr_done & 32)) {
+          HIPCHK(hipFuncSetAttribute((const void *)k_force_lds2<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * shb)));
+          c->lds_attr_done |= 32;
+        }
+        k_force_lds2<true, false, true><<<nb / 2, 512, 2 * shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk);
+      } else if (closed) { if (c->g.halo) QX_FLDS2(true, true); else QX_FLDS2(true, false); }
       else { if (c->g.halo) QX_FLDS2(false, true); else QX_FLDS2(false, false); }
 #undef QX_FLDS2
     } else {

@@ -11,6 +11,11 @@ ctx = q.Context(lat)
 if halo:
     ctx.comm_init(q.Context.unique_id(), 1, 0); ctx.force_halo(True); ctx.set_option("batch_multi", 1)
     if len(sys.argv) > 3: ctx.set_option("overlap", int(sys.argv[3]))
+    import os
+    if os.environ.get("QEX_EMU"):          # "exchange_us,link_gbs,allreduce_us": emulated transport (round 6)
+        e = [int(v) for v in os.environ["QEX_EMU"].split(",")]
+        ctx.set_option("emu_exchange_us", e[0]); ctx.set_option("emu_link_gbs", e[1]); ctx.set_option("emu_allreduce_us", e[2])
+    print("transport", ctx.comm_transport()[0], flush=True)
 s = q.newStag(ctx, g)
 ms = [0.1, 0.2, 0.4, 0.05]
 bs = [rf.gaussian_vector() for _ in range(4)]
