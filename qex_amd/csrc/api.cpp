@@ -692,7 +692,6 @@ extern "C" int qexhip_set_option(qexhip_handle c, const char *name, int value) {
     c->opt_hop_split = value;
   }
   else if (n == "fused_spin_us") c->opt_fused_spin_us = value;
-  else if (n == "gauge_su3") c->opt_gauge_su3 = value;
   else if (n == "emu_exchange_us") c->emu_exchange_us = value;
   else if (n == "emu_allreduce_us") c->emu_allreduce_us = value;
   else if (n == "emu_link_gbs") c->emu_link_gbs = value;

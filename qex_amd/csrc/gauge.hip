@@ -74,23 +74,7 @@ __global__ void __launch_bounds__(256) k_gauge_from_tiles(Geom g, double2 *__res
 // S4: instead of the six plane sums, the eight sums of `s4_gauge` (stagg_pv_hmc/staghmc_spv_meas.nim:25-65, the S4 order
 // parameter of arXiv:1111.2317): the plaquette of plane (mu, nu) at x is added to peo[mu][x_mu mod 2] and to peo[nu][x_nu mod 2];
 // partial k = 2 d + (x_d mod 2).
-// SU3 (round-6 experiment, option "gauge_su3", profiles/r06_notes.md section 4): gather rows 0,1 of every link (6 of 9 sixteen-byte
-// requests per lane) and rebuild row 2 = conj(row 0 x row 1) in registers -- the kernel is bound by L2->L1 requests, not by flops.
-__device__ __forceinline__ M3 m3_load_su3(const double2 *p, int stride) {
-  M3 r;
-#pragma unroll
-  for (int k = 0; k < 6; k++) r.e[k] = p[(size_t)k * stride];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const int a = (k + 1) % 3, b = (k + 2) % 3;
-    const double2 u = r.e[a], v = r.e[3 + b], w = r.e[b], z = r.e[3 + a];
-    const double re = (u.x * v.x - u.y * v.y) - (w.x * z.x - w.y * z.y);
-    const double im = (u.x * v.y + u.y * v.x) - (w.x * z.y + w.y * z.x);
-    r.e[6 + k] = make_double2(re, -im);
-  }
-  return r;
-}
-template <bool HALO, bool S4 = false, bool SU3 = false>
+template <bool HALO, bool S4 = false>
 __global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict__ G, double *partials, const int *order, int chunk) {
   double pl[S4 ? 8 : 6] = {0, 0, 0, 0, 0, 0};
   const int slot = 4 * (blockIdx.x >> 3) + (threadIdx.x >> 6);
@@ -101,15 +85,15 @@ __global__ void __launch_bounds__(256) k_plaq(Geom g, const double2 *__restrict_
     coords_of(g, c, p, x);
     M3 U[4];
 #pragma unroll
-    for (int mu = 0; mu < 4; mu++) U[mu] = SU3 ? m3_load_su3(G + link_off_t<HALO>(g, x, mu), 64) : m3_load(G + link_off_t<HALO>(g, x, mu), 64);
+    for (int mu = 0; mu < 4; mu++) U[mu] = m3_load(G + link_off_t<HALO>(g, x, mu), 64);
 #pragma unroll
     for (int mu = 1; mu < 4; mu++) {
 #pragma unroll
       for (int nu = 0; nu < mu; nu++) {
         shifted_t<HALO>(g, x, nu, 1, y);
-        M3 unumu = m3_mul(U[nu], SU3 ? m3_load_su3(G + link_off_t<HALO>(g, y, mu), 64) : m3_load(G + link_off_t<HALO>(g, y, mu), 64));
+        M3 unumu = m3_mul(U[nu], m3_load(G + link_off_t<HALO>(g, y, mu), 64));
         shifted_t<HALO>(g, x, mu, 1, y);
-        M3 umunu = m3_mul(U[mu], SU3 ? m3_load_su3(G + link_off_t<HALO>(g, y, nu), 64) : m3_load(G + link_off_t<HALO>(g, y, nu), 64));
+        M3 umunu = m3_mul(U[mu], m3_load(G + link_off_t<HALO>(g, y, nu), 64));
         const double ps = m3_redot(umunu, unumu);
         if (S4) {
           const bool om = x[mu] & 1, on = x[nu] & 1;     // (a t-sharded slab starts at an even global t: local parity = global)
@@ -240,12 +224,12 @@ __device__ __forceinline__ int site_cidx(const Geom &g, const int x[4]) {
 }
 // U_a(gs) from global memory, unless the site s (parity q = the other one) lies in this tile position: then from the
 // workgroup's LDS copy, slot 0 = U_a(s), slot 1 = U_a(s - a)
-template <bool HALO, bool SU3 = false>
+template <bool HALO>
 __device__ __forceinline__ M3 link_lds_or_global(const Geom &g, const double2 *__restrict__ G, const double2 *smq, int tile,
                                                  const int s[4], int a, int slot, const int gs[4]) {
   const int cs = site_cidx<HALO>(g, s);
   if ((cs >> 6) == tile) return m3_load(smq + (size_t)(2 * a + slot) * 576 + (cs & 63), 64);
-  return SU3 ? m3_load_su3(G + link_off_t<HALO>(g, gs, a), 64) : m3_load(G + link_off_t<HALO>(g, gs, a), 64);
+  return m3_load(G + link_off_t<HALO>(g, gs, a), 64);
 }
 // the same choice as an ADDRESS (generic pointer: the flat load that follows serves either aperture): one load sequence per
 // operand instead of a divergent branch around two, which is what keeps k_flow_obs_clover2 inside its register budget
@@ -257,9 +241,10 @@ __device__ __forceinline__ const double2 *link_ptr_lds_or_global(const Geom &g, 
   const double2 *pg = G + link_off_t<HALO>(g, gs, a);
   return (cs >> 6) == tile ? pl : pg;
 }
-// SU3 (round-6 experiment, option "gauge_su3" = 1): every GLOBAL matrix gather fetches rows 0,1 only and rebuilds row 2 in registers
-// (m3_load_su3); the LDS copies are whole matrices (rebuilt once by the wavefront that owns them).
-template <bool CLOSED, bool HALO, bool SU3 = false>
+// (Round 6 tried fetching only rows 0,1 of every globally gathered SU(3) link and rebuilding row 2 in registers: the gather stream alone
+// runs 527 -> 291 us that way, this kernel 687 -> 948 us -- 104 B/lane of spills and 44 % more fp64 work on a pipe that is already at
+// its power limit; profiles/r06_notes.md section 4.  Not in the library.)
+template <bool CLOSED, bool HALO>
 __global__ void __launch_bounds__(512) k_force_lds2(Geom g, const double2 *__restrict__ G, double2 *F, double cp,
                                                     double2 *Pm, double cf, double cpm, double2 *Uout, const int *order, int chunk) {
   extern __shared__ double2 smU[];                    // [parity][2 nu + (0: U_nu(x) | 1: U_nu(x-nu))][9][64]
@@ -279,8 +264,7 @@ __global__ void __launch_bounds__(512) k_force_lds2(Geom g, const double2 *__res
   const double2 *smq = smU + (size_t)(1 - p) * 8 * 576;   // the other parity's: every one-hop neighbour
   {
     shifted_t<HALO>(g, x, mu, -1, y);
-    const M3 a = SU3 ? m3_load_su3(G + o, 64) : m3_load(G + o, 64);
-    const M3 b = SU3 ? m3_load_su3(G + link_off_t<HALO>(g, y, mu), 64) : m3_load(G + link_off_t<HALO>(g, y, mu), 64);
+    const M3 a = m3_load(G + o, 64), b = m3_load(G + link_off_t<HALO>(g, y, mu), 64);
     double2 *s0 = smp + (size_t)(2 * mu) * 576 + lane;
 #pragma unroll
     for (int k = 0; k < 9; k++) { s0[k * 64] = a.e[k]; s0[576 + k * 64] = b.e[k]; }
@@ -293,13 +277,13 @@ __global__ void __launch_bounds__(512) k_force_lds2(Geom g, const double2 *__res
     const double2 *sn = smp + (size_t)(2 * nu) * 576 + lane;
     // forward: U_nu(x) U_mu(x+nu) U_nu(x+mu)^+          (stf[mu,nu], staples.nim:181-183)
     shifted_t<HALO>(g, x, nu, 1, y);
-    M3 t = m3_mul_na(link_lds_or_global<HALO, SU3>(g, G, smq, tile, y, mu, 0, y), link_lds_or_global<HALO, SU3>(g, G, smq, tile, xpm, nu, 0, xpm));
+    M3 t = m3_mul_na(link_lds_or_global<HALO>(g, G, smq, tile, y, mu, 0, y), link_lds_or_global<HALO>(g, G, smq, tile, xpm, nu, 0, xpm));
     m3_mac(acc, m3_load(sn, 64), t);
     // backward: U_nu(x-nu)^+ U_mu(x-nu) U_nu(x-nu+mu)   (stu[mu,nu] shifted down, staples.nim:184-186)
     shifted_t<HALO>(g, x, nu, -1, y);
     shifted_t<HALO>(g, y, mu, 1, z);
-    t = m3_mul_an(m3_load(sn + 576, 64), link_lds_or_global<HALO, SU3>(g, G, smq, tile, y, mu, 0, y));
-    m3_mac(acc, t, link_lds_or_global<HALO, SU3>(g, G, smq, tile, xpm, nu, 1, z));     // U_nu(x+mu-nu) = slot 1 of site x+mu
+    t = m3_mul_an(m3_load(sn + 576, 64), link_lds_or_global<HALO>(g, G, smq, tile, y, mu, 0, y));
+    m3_mac(acc, t, link_lds_or_global<HALO>(g, G, smq, tile, xpm, nu, 1, z));     // U_nu(x+mu-nu) = slot 1 of site x+mu
   }
   const M3 U = m3_load(smp + (size_t)(2 * mu) * 576 + lane, 64);
   force_finish<CLOSED>(U, acc, live, o, F, cp, Pm, cf, cpm, Uout, 1);
@@ -1105,8 +1089,7 @@ int gauge_plaq(qexhip_ctx *c, double out[6]) {
   CHK(ordered_sites(c, &order, &chunk, &nb, &part));
   {
     ScopedTimer tm(c, "plaq", c->stream);
-    if (c->opt_gauge_su3 == 1 && !c->g.halo) k_plaq<false, false, true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
-    else if (c->g.halo) k_plaq<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
+    if (c->g.halo) k_plaq<true><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
     else k_plaq<false><<<nb, 256, 0, c->stream>>>(c->g, c->gn->U, part, order, chunk);
     HIPCHK(hipGetLastError());
   }
@@ -1181,13 +1164,7 @@ static int force_dev(qexhip_ctx *c, double cplaq, int flow = 0, double cf = 0, d
         c->lds_attr_done |= 8;
       }
 #define QX_FLDS2(CL, HL) k_force_lds2<CL, HL><<<nb / 2, 512, 2 * shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk)
-      if (closed && !c->g.halo && c->opt_gauge_su3 == 1) {
-        if (!(c->lds_attr_done & 32)) {
-          HIPCHK(hipFuncSetAttribute((const void *)k_force_lds2<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * shb)));
-          c->lds_attr_done |= 32;
-        }
-        k_force_lds2<true, false, true><<<nb / 2, 512, 2 * shb, c->stream>>>(c->g, c->gn->U, c->gn->F, cplaq / 3.0, Pf, cf, cpm, Uout, order, chunk);
-      } else if (closed) { if (c->g.halo) QX_FLDS2(true, true); else QX_FLDS2(true, false); }
+      if (closed) { if (c->g.halo) QX_FLDS2(true, true); else QX_FLDS2(true, false); }
       else { if (c->g.halo) QX_FLDS2(false, true); else QX_FLDS2(false, false); }
 #undef QX_FLDS2
     } else {

@@ -138,26 +138,30 @@ struct PeerGhost {
 };
 int peer_ghost_args(qexhip_ctx *c, PeerGhost *G);   // for the push-only exchange just prepared on the comm stream class: takes over the owed credits; peer.hip
 
-__device__ inline bool peer_ghost_ready(const PeerGhost &G) {
-  if (__hip_atomic_load(G.flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < G.flagval[0]) return false;
-  if (__hip_atomic_load(G.flag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < G.flagval[1]) return false;
-  if (G.emu_ticks > 0) {       // rehearsal: nothing arrives earlier than the transfer would take between two GPUs
-    const long long t0 = __hip_atomic_load(G.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wall_clock64() - t0 < G.emu_ticks) return false;
+// one look: the flags; once they are in (remembered in `seen`), under emulation only the clock -- the transfer between two GPUs would
+// take emu_ticks from the push's start -- so that a rehearsal's waiting lanes do not keep hammering the flags' memory channel
+__device__ inline bool peer_ghost_ready(const PeerGhost &G, bool &seen, long long &t0e) {
+  if (!seen) {
+    if (__hip_atomic_load(G.flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < G.flagval[0]) return false;
+    if (__hip_atomic_load(G.flag[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < G.flagval[1]) return false;
+    seen = true;
+    if (G.emu_ticks > 0) t0e = __hip_atomic_load(G.t_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  return true;
+  return G.emu_ticks <= 0 || wall_clock64() - t0e >= G.emu_ticks;
 }
 // The SHORT wait of a boundary workgroup between its local and its slab-leaving hops, one lane: true when the faces are in.  False
 // after `spin_ticks` (about the estimated transfer time), or at once when another workgroup of this launch has already waited that
 // long in vain (`late`): the caller then parks its accumulator and leaves the slot to others -- on a chip shared with the neighbour's
 // process, to the very kernel it is waiting for.  Never an error: a lost peer is found by the cleanup workgroups' long wait.
 __device__ inline bool peer_ghost_try(const PeerGhost &G, long long spin_ticks, unsigned int *late) {
-  if (peer_ghost_ready(G)) return true;
+  bool seen = false;
+  long long t0e = 0;
+  if (peer_ghost_ready(G, seen, t0e)) return true;
   if (spin_ticks <= 0 || __hip_atomic_load(late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
   const long long t0 = wall_clock64();
   for (unsigned it = 1;; it++) {
     __builtin_amdgcn_s_sleep(4);
-    if (peer_ghost_ready(G)) return true;
+    if (peer_ghost_ready(G, seen, t0e)) return true;
     if ((it & 15) == 0) {
       if (__hip_atomic_load(late, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
       if (wall_clock64() - t0 > spin_ticks) {

@@ -146,8 +146,6 @@ struct qexhip_ctx {
   unsigned int *fz_buf = nullptr; int fz_cap = 0;   // FusedCtl words + parked-block list of the fused sweep (dslash.hip)
   double xchg_us[2]{0, 0};      // measured at set_links (collective, max over ranks): one face exchange of the 8- / 16-link operator, us (0: not measured)
   int form_auto[2]{-1, -1};     // measured at set_links: 2 fused / 0 by sites for 8- and 16-link operators (-1: not measured)
-  int opt_gauge_su3 = 0;  // option "gauge_su3" (round-6 experiment hook, profiles/r06_notes.md section 4): 1 = k_plaq gathers rows 0,1 of every link and rebuilds
-                          // row 2 (valid on SU(3) links only: the caller's responsibility); 0 = all 18 reals (the product path)
   int opt_chain_overlap = 1; // option "chain_overlap" (A/B, test hook): 1 = the nHYP force chain's staple derivatives of a t-sharded field run in two passes,
                           // the ghost-free slices beside the exchange of the level's chain fields, the boundary slices behind it
   int opt_smear_ca = 1;   // option "smear_ca" (A/B, test hook): 1 = the nHYP levels of a t-sharded field are computed on shrinking ghost slices from
