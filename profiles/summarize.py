@@ -126,9 +126,9 @@ if rd and cp_w:
             "the dispatches of profiles/pmc_workload.py; corrections from the 1 GiB k_read16 / k_copy16 kernels of the same passes; "
             "kernels matched by exact function name and template arguments")
     tj = {"source": "profiles/collect.sh " + tag, "fetch_correction": fcorr, "write_correction": wcorr, "note": note}
-    for fn, targs, key in (("k_dslash", "<8, false, false, false, 0, false, 0>", "dslash8_sweep1_18real"), ("k_dslash", "<8, false, true, true, 0, false, 0>", "dslash8_sweep2_18real"),
-                           ("k_dslash", "<8, false, false, false, 1, false, 0>", "dslash8_sweep1_recon12"), ("k_dslash", "<8, false, true, true, 1, false, 0>", "dslash8_sweep2_recon12"),
-                           ("k_dslash", "<16, false, false, false, 0, false, 0>", "dslash16_sweep1_18real"), ("k_dslash", "<16, false, true, true, 0, false, 0>", "dslash16_sweep2_18real")):
+    for fn, targs, key in (("k_dslash", "<8, false, false, false, 0>", "dslash8_sweep1_18real"), ("k_dslash", "<8, false, true, true, 0>", "dslash8_sweep2_18real"),
+                           ("k_dslash", "<8, false, false, false, 1>", "dslash8_sweep1_recon12"), ("k_dslash", "<8, false, true, true, 1>", "dslash8_sweep2_recon12"),
+                           ("k_dslash", "<16, false, false, false, 0>", "dslash16_sweep1_18real"), ("k_dslash", "<16, false, true, true, 0>", "dslash16_sweep2_18real")):
         fe, _ = mean(fn, targs, "FETCH_SIZE")
         wr, _ = mean(fn, targs, "WRITE_SIZE")
         if fe is not None and wr is not None:
@@ -144,10 +144,10 @@ if rd and cp_w:
     M = 144                                        # bytes of one 3x3 complex fp64 matrix
     # (function, template args or None = all instantiations that ran, algorithmic bytes per launch, what they are)
     priced = [
-        ("k_dslash", "<8, false, false, false, 0, false, 0>", (8 * M + 48 + 48) * Vh, "8 links + vector in + vector out per output site (SURVEY 8d: 1248 B)"),
-        ("k_dslash", "<8, false, true, true, 0, false, 0>", (8 * M + 48 + 48 + 48) * Vh, "the same + the 4 m^2 x term (1296 B)"),
-        ("k_dslash", "<16, false, false, false, 0, false, 0>", (16 * M + 48 + 48) * Vh, "16 links + vector in + out (2400 B)"),
-        ("k_dslash", "<16, false, true, true, 0, false, 0>", (16 * M + 48 + 48 + 48) * Vh, "the same + the 4 m^2 x term"),
+        ("k_dslash", "<8, false, false, false, 0>", (8 * M + 48 + 48) * Vh, "8 links + vector in + vector out per output site (SURVEY 8d: 1248 B)"),
+        ("k_dslash", "<8, false, true, true, 0>", (8 * M + 48 + 48 + 48) * Vh, "the same + the 4 m^2 x term (1296 B)"),
+        ("k_dslash", "<16, false, false, false, 0>", (16 * M + 48 + 48) * Vh, "16 links + vector in + out (2400 B)"),
+        ("k_dslash", "<16, false, true, true, 0>", (16 * M + 48 + 48 + 48) * Vh, "the same + the 4 m^2 x term"),
         ("k_cg_xpay", None, 144 * Vh, "p = r + beta p: 2 reads + 1 write of 48 B"),
         ("k_cg_update", None, 288 * Vh, "x, r updates: 4 reads + 2 writes of 48 B"),
         ("k_cgm_update", None, (48 + 96 + 9 * 192) * Vh, "r in, ps[0] in/out, 9 x (xs, ps in/out), 10 shifts"),

@@ -15,6 +15,7 @@
 #include "site_index.h"
 #include "reduce.h"
 #include "dslash_core.h"
+#include "peer_device.h"
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -138,6 +139,254 @@ __global__ void __launch_bounds__(256) k_dslash_mrhs(MrhsArgs A) {
       double r = block_sum_256(dotv[j]);
       if (threadIdx.x == 0) A.partials[j][A.part_off + blockIdx.x] = r;
     }
+  }
+}
+
+// The lock-step sweep of a t-sharded slab on the peer transport as ONE launch on ONE stream -- k_dslash_fused (dslash.hip) for up to four
+// systems: push workgroups (the faces of all systems, one piece each) | interior | boundary (hops inside the slab, SHORT wait, hops from
+// the receive arena or park) | cleanup (parked blocks behind the one long wait).  A system's arithmetic is k_dslash_fused's: same hop
+// order (local first), same partial slots; parked or not a block gives the same bits.
+struct MrhsFusedArgs {
+  MrhsArgs a;                       // c0..c1 interior, d0..d1 low face (workgroups >= nb1), e0..e1 below
+  int e0, e1, nb2, nbA;
+  const double2 *gh_hi[QX_MAXRHS], *gh_lo[QX_MAXRHS];
+  PeerGhost pg;
+  PeerPush push;
+  FusedCtl fz;
+};
+template <int NDIR, int RECON, bool SECOND>
+__global__ void __launch_bounds__(256) k_dslash_mrhs_fused(MrhsFusedArgs F) {
+  const MrhsArgs &A = F.a;
+  bool act[QX_MAXRHS];
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < QX_MAXRHS; j++) { act[j] = j < A.nrhs && !A.st[j].done; any = any || act[j]; }
+  const bool skip = !any;              // every system has converged: nothing is pushed, the credits still go back
+  __shared__ int sh_n;
+  int bid = blockIdx.x;
+  if (bid < F.push.nblocks) {
+    if (!skip) peer_push_block(F.push, (unsigned)bid);
+    return;
+  }
+  bid -= F.push.nblocks;
+  const int ngrid = (int)gridDim.x - F.push.nblocks - F.fz.ncl;
+  const int nbnd = ngrid - A.nb1;
+  const bool cleanup = bid >= ngrid;
+  int npark = 0, jpark = 0;
+  if (cleanup) {
+    if (threadIdx.x == 0) {
+      int n = 0;
+      if (peer_poll_u32(F.fz.dec, (unsigned)nbnd, F.pg.err, F.pg.ticks, 0x520)) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        n = (int)__hip_atomic_load(F.fz.ndef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n > 0) {
+          if (!peer_ghost_wait(F.pg)) n = -1;
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      } else n = -1;
+      sh_n = n;
+    }
+    __syncthreads();
+    npark = sh_n;
+    jpark = bid - ngrid;
+  }
+  bool parked = false, bnd = false;
+  for (;;) {
+    int lb = bid;
+    if (cleanup) {
+      if (jpark >= npark) break;
+      lb = (int)F.fz.list[jpark];
+      jpark += F.fz.ncl;
+      bnd = true;
+    } else {
+      bnd = bid >= F.nbA && bid < F.nbA + nbnd;
+      lb = bnd ? A.nb1 + (bid - F.nbA) : (bid < F.nbA ? bid : bid - nbnd);
+    }
+    int c = A.c0 + lb * 256 + threadIdx.x, clim = A.c1;
+    if (bnd) {
+      c = A.d0 + (lb - A.nb1) * 256 + threadIdx.x; clim = A.d1;
+      if (lb >= F.nb2) { c = F.e0 + (lb - F.nb2) * 256 + threadIdx.x; clim = F.e1; }
+    }
+    double dotv[QX_MAXRHS] = {0, 0, 0, 0};
+    const bool active = c < clim && !skip;
+    const Geom &g = A.g;
+    const SiteXYZT s = site_coord(g, c, A.parity);
+    const int tu = __builtin_amdgcn_readfirstlane(s.t);
+    const bool hi1 = tu + 1 >= g.X[3], lo1 = tu - 1 < 0, hi3 = tu + 3 >= g.X[3], lo3 = tu - 3 < 0;
+    double2 acc[QX_MAXRHS][3], xsv[QX_MAXRHS][3];
+    const double sgn = SECOND ? -1.0 : 1.0;
+    constexpr int NLOAD = RECON == 1 ? 6 : (RECON == 2 ? 7 : 9);
+    constexpr int LROW = NLOAD * 64;
+    const double2 *w = A.W + (size_t)(c >> 6) * (NDIR * LROW) + (c & 63);
+    const unsigned long long *sm = RECON == 1 ? A.S + (size_t)(c >> 6) * NDIR : nullptr;
+    auto pair = [&](const int pr, const bool do_f, const bool do_b) __attribute__((always_inline)) {
+      const int mu = pr & 3;
+      const int hop = pr >= 4 ? 3 : 1;
+      const int pf = nbr_pos<true>(g, c, s, mu, hop);
+      const int pb = nbr_pos<true>(g, c, s, mu, -hop);
+      const double2 *wp = w + (size_t)pr * (2 * LROW);
+      double2 U[9], Wm[9];
+      if (do_f) {
+#pragma unroll
+        for (int k = 0; k < NLOAD; k++) {
+          d2v t = __builtin_nontemporal_load((const d2v *)&wp[k * 64]);
+          U[k] = make_double2(t.x, t.y);
+        }
+      }
+      if (do_b) {
+#pragma unroll
+        for (int k = 0; k < NLOAD; k++) {
+          d2v t = __builtin_nontemporal_load((const d2v *)&wp[LROW + k * 64]);
+          Wm[k] = make_double2(t.x, t.y);
+        }
+      }
+      if (RECON == 1) {
+        const int lane = c & 63;
+        if (do_f) recon_row2<1>(U, (sm[2 * pr] >> lane) & 1ull);
+        if (do_b) recon_row2<1>(Wm, (sm[2 * pr + 1] >> lane) & 1ull);
+      } else if (RECON == 2) {
+        if (do_f) recon_row2<2>(U, false);
+        if (do_b) recon_row2<2>(Wm, false);
+      }
+      const bool xf = mu == 3 && (hop == 3 ? hi3 : hi1), xb = mu == 3 && (hop == 3 ? lo3 : lo1);     // this hop leaves the slab (wavefront-uniform)
+#pragma unroll
+      for (int j = 0; j < QX_MAXRHS; j++) {
+        if (!act[j]) continue;
+        double2 vf[3], vb[3];
+        if (do_f) {
+          const double2 *src = xf ? F.gh_hi[j] : A.in[j];
+#pragma unroll
+          for (int k = 0; k < 3; k++) vf[k] = src[vec_off(pf, k)];
+          mv3<false>(acc[j], U, vf);
+        }
+        if (do_b) {
+          const double2 *src = xb ? F.gh_lo[j] : A.in[j];
+#pragma unroll
+          for (int k = 0; k < 3; k++) vb[k] = src[vec_off(pb, k)];
+          mv3<true>(acc[j], Wm, vb);
+        }
+      }
+    };
+    auto edge_pairs = [&](const bool crossing) __attribute__((always_inline)) {
+      if (!crossing) {
+        constexpr int NSP = NDIR / 2 - NDIR / 8;
+#pragma unroll 1
+        for (int q = 0; q < NSP; q++) pair(q + q / 3, true, true);
+      }
+#pragma unroll 1
+      for (int pr = 3; pr < NDIR / 2; pr += 4) {
+        const int hop = pr >= 4 ? 3 : 1;
+        const bool xf = tu + hop >= g.X[3], xb = tu - hop < 0;
+        pair(pr, crossing ? xf : !xf, crossing ? xb : !xb);
+      }
+    };
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < QX_MAXRHS; j++) {
+        if (!act[j]) continue;
+        if (SECOND) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) xsv[j][k] = A.xs[j][vec_off(c, k)];
+        }
+        if (cleanup) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) acc[j][k] = A.out[j][vec_off(c, k)];
+        } else if (SECOND) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            acc[j][k].x = (sgn * A.cb[j]) * xsv[j][k].x;
+            acc[j][k].y = (sgn * A.cb[j]) * xsv[j][k].y;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; k++) acc[j][k] = make_double2(0.0, 0.0);
+        }
+      }
+      if (!bnd) {
+#pragma unroll 1
+        for (int pr = 0; pr < NDIR / 2; pr++) pair(pr, true, true);
+      } else if (!cleanup) {
+        edge_pairs(false);
+      }
+    }
+    if (bnd && !skip) {
+      if (!cleanup) {
+        if (threadIdx.x == 0) {
+          const bool in = F.fz.spin_ticks >= 0 && peer_ghost_try(F.pg, F.fz.spin_ticks, F.fz.late);
+          if (in) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          sh_n = in ? 1 : 0;
+        }
+        __syncthreads();
+        parked = sh_n == 0;
+      }
+      if (active && !parked) edge_pairs(true);
+    }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < QX_MAXRHS; j++) {
+        if (!act[j]) continue;
+        if (parked) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) A.out[j][vec_off(c, k)] = acc[j][k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            acc[j][k].x *= sgn; acc[j][k].y *= sgn;
+            d2v t; t.x = acc[j][k].x; t.y = acc[j][k].y;
+            __builtin_nontemporal_store(t, (d2v *)&A.out[j][vec_off(c, k)]);
+          }
+          if (SECOND) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) dotv[j] = fma(xsv[j][k].x, acc[j][k].x, fma(xsv[j][k].y, acc[j][k].y, dotv[j]));
+          }
+        }
+      }
+    }
+    if (SECOND && !skip && !parked) {
+      const int pidx = cleanup ? F.nbA + (lb - A.nb1) : bid;
+#pragma unroll
+      for (int j = 0; j < QX_MAXRHS; j++) {
+        if (!act[j]) continue;             // uniform over the grid
+        double r = block_sum_256(dotv[j]);
+        if (threadIdx.x == 0) A.partials[j][A.part_off + pidx] = r;
+      }
+    }
+    if (!cleanup) break;
+  }
+  if (!(bnd || cleanup)) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  bool credits = false;
+  if (!cleanup) {
+    if (parked) {
+      const unsigned idx = __hip_atomic_fetch_add(F.fz.ndef, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&F.fz.list[idx], (unsigned)(A.nb1 + (bid - F.nbA)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned a = __hip_atomic_fetch_add(F.fz.dec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a == (unsigned)nbnd - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      credits = __hip_atomic_load(F.fz.ndef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+    }
+  } else {
+    const unsigned a = __hip_atomic_fetch_add(F.fz.cl_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a == (unsigned)F.fz.ncl - 1) {
+      credits = npark > 0;
+      __hip_atomic_store(F.fz.ndef, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(F.fz.dec, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(F.fz.late, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(F.fz.cl_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (credits) {
+    __hip_atomic_store(F.pg.credit[0], F.pg.credit_val[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(F.pg.credit[1], F.pg.credit_val[1], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -296,6 +545,33 @@ static int sweep_mrhs(qexhip_ctx *c, MrhsArgs &A, bool second, int *ndot, DevFie
   // -- unless the single-system form was MEASURED at set_links and lost: a measurement outranks the rule (round-4 advice)
   if (g.halo && !overlap && c->opt_overlap < 0 && c->nranks > 1 && hi_beg > lo_end && c->overlap_auto[c->ndir == 16] < 0 &&
       (size_t)A.nrhs * g.depth * g.F * 48 >= ((size_t)1 << 20)) overlap = 1;
+  if (g.halo && overlap && sweep_form(c, overlap) == 2) {
+    // the fused lock-step sweep (peer transport): the launch pushes all systems' faces itself and reads what arrives in the arena
+    MrhsFusedArgs Fz;
+    memset(&Fz, 0, sizeof Fz);
+    CHK(devjoin_flush(c));
+    CHK(comm_halo_push_only_multi(c, A.nrhs, infield, inpar, Fz.gh_hi, Fz.gh_lo, &Fz.push));
+    CHK(peer_ghost_args(c, &Fz.pg));
+    const int nb_int = (hi_beg - lo_end + 255) / 256, nb_lo = (lo_end + 255) / 256, nb_hi = (g.Vh - hi_beg + 255) / 256;
+    CHK(sweep_fused_ctl(c, nb_lo + nb_hi, &Fz.fz, A.nrhs));
+    A.c0 = lo_end; A.c1 = hi_beg; A.d0 = 0; A.d1 = lo_end; A.nb1 = nb_int; A.part_off = 0; A.swz = 0; A.ntstore = 1;
+    Fz.a = A;
+    Fz.e0 = hi_beg; Fz.e1 = g.Vh; Fz.nb2 = nb_int + nb_lo;
+    Fz.nbA = (int)(sweep_push_fraction(c, hi_beg - lo_end, A.nrhs) * nb_int);
+    const int grid = Fz.push.nblocks + nb_int + nb_lo + nb_hi + Fz.fz.ncl;
+    ScopedTimer tm(c, "dslash_batch", c->stream);
+#define QX_MF(ND, RC) \
+    do { \
+      if (second) hipLaunchKernelGGL((k_dslash_mrhs_fused<ND, RC, true>), dim3(grid), dim3(256), 0, c->stream, Fz); \
+      else hipLaunchKernelGGL((k_dslash_mrhs_fused<ND, RC, false>), dim3(grid), dim3(256), 0, c->stream, Fz); \
+    } while (0)
+    if (c->ndir == 8) { if (c->recon == 1) QX_MF(8, 1); else if (c->recon == 2) QX_MF(8, 2); else QX_MF(8, 0); }
+    else { if (c->recon == 1) QX_MF(16, 1); else if (c->recon == 2) QX_MF(16, 2); else QX_MF(16, 0); }
+#undef QX_MF
+    HIPCHK(hipGetLastError());
+    *ndot = nb_int + nb_lo + nb_hi;
+    return 0;
+  }
   if (g.halo && overlap) HIPCHK(hipEventRecord(c->ev_ready, c->stream));
   if (g.halo) CHK(comm_halo_exchange_multi(c, A.nrhs, infield, inpar, overlap));
   ScopedTimer tm(c, "dslash_batch", c->stream);

@@ -283,24 +283,35 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
   return 0;
 }
 
-// Peer transport, the fused sweep: the faces of one parity half of f will be pushed by the caller's OWN kernel (`push` is filled for its
-// first workgroups) and what arrives STAYS in the receive arena.  gh_hi / gh_lo come back pre-offset so that gh[vec_off(pos, colour)]
-// addresses the ghost POSITION pos of the field (ghost_hi: pos in [Vh, Vh + depth F), ghost_lo: the depth F positions behind it) -- the
-// kernel reads them instead of the field's ghost tiles and returns the credits (peer_ghost_args).  Nothing is launched here.
-int comm_halo_push_only(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, PeerPush *push) {
+// Peer transport, the fused sweeps: the faces of one parity half of n fields (n = 1: dslash.hip; up to 4: the lock-step batch) will be
+// pushed by the caller's OWN kernel (`push` is filled for its first workgroups) and what arrives STAYS in the receive arena.
+// gh_hi[j] / gh_lo[j] come back pre-offset so that gh[vec_off(pos, colour)] addresses the ghost POSITION pos of field j (ghost_hi: pos in
+// [Vh, Vh + depth F), ghost_lo: the depth F positions behind it) -- the kernel reads them instead of the fields' ghost tiles and returns
+// the credits (peer_ghost_args).  Nothing is launched here.
+int comm_halo_push_only_multi(qexhip_ctx *c, int n, DevField *const *f, int parity, const double2 **gh_hi, const double2 **gh_lo, PeerPush *push) {
   CHK(need_comm(c));
   if (!peer_faces(c)) { qexhip_set_error("internal: fused sweep without the peer transport's arenas"); return QEXHIP_ERR_STATE; }
+  if (n < 1 || n > 4) { qexhip_set_error("internal: fused sweep over %d fields", n); return QEXHIP_ERR_ARG; }
   const Geom &g = c->g;
   const size_t face2 = (size_t)g.depth * g.F * 3;
   const size_t nd = face2 * 2;
-  double2 *base = f.par(parity);
-  const void *dn = base, *up = base + (size_t)(g.ntile) * 192 - face2;
+  const void *dn[4], *up[4];
+  for (int j = 0; j < n; j++) {
+    double2 *base = f[j]->par(parity);
+    dn[j] = base; up[j] = base + (size_t)(g.ntile) * 192 - face2;
+  }
   const void *from_up = nullptr, *from_dn = nullptr;
-  CHK(peer_exchange(c, c->cstream, 1, &dn, 1, &up, nullptr, nullptr, nd * sizeof(double), emu_exchange_time(c, nd * sizeof(double)), &from_up, &from_dn, push));
+  CHK(peer_exchange(c, c->cstream, n, dn, n, up, nullptr, nullptr, nd * sizeof(double), emu_exchange_time(c, (size_t)n * nd * sizeof(double)), &from_up, &from_dn, push));
   // tile-aligned zones (64 | F): vec_off(pos, k) - vec_off(zone start, 0) = vec_off(pos - zone start, k)
-  *gh_hi = (const double2 *)from_up - (size_t)(g.Vh >> 6) * 192;
-  *gh_lo = (const double2 *)from_dn - (size_t)((g.Vh + g.depth * g.F) >> 6) * 192;
+  for (int j = 0; j < n; j++) {
+    gh_hi[j] = (const double2 *)from_up + (size_t)j * face2 - (size_t)(g.Vh >> 6) * 192;
+    gh_lo[j] = (const double2 *)from_dn + (size_t)j * face2 - (size_t)((g.Vh + g.depth * g.F) >> 6) * 192;
+  }
   return 0;
+}
+int comm_halo_push_only(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, PeerPush *push) {
+  DevField *fp = &f;
+  return comm_halo_push_only_multi(c, 1, &fp, parity, gh_hi, gh_lo, push);
 }
 
 // The same for the input fields of the n systems of a lock-step batch in ONE RCCL group (one kernel instead of n): per field

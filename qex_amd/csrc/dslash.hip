@@ -441,14 +441,15 @@ static double exchange_estimate_us(const qexhip_ctx *c) {
 // over estimated interior time (its bytes at 5.5 TB/s); never before 65 % (their rolled edge loops should not be the tail either),
 // last of all when the exchange is the longer of the two.  A wrong guess costs little since round 6 (a boundary workgroup waits
 // about one exchange time, then parks), but the waiting ones do hold slots meanwhile.
-double sweep_push_fraction(const qexhip_ctx *c, int interior_sites) {
-  const double bsite = c->ndir * (c->recon == 1 ? 96.0 : (c->recon == 2 ? 112.0 : 144.0)) + 120.0;
+// nrhs > 1 (the lock-step batch): the links once, the vectors and the faces nrhs times.
+double sweep_push_fraction(const qexhip_ctx *c, int interior_sites, int nrhs) {
+  const double bsite = c->ndir * (c->recon == 1 ? 96.0 : (c->recon == 2 ? 112.0 : 144.0)) + 120.0 * nrhs;
   const double t_int = (double)interior_sites * bsite / 5.5e6;       // us
-  return t_int > 0 ? std::min(1.0, std::max(0.65, exchange_estimate_us(c) / t_int)) : 1.0;
+  return t_int > 0 ? std::min(1.0, std::max(0.65, nrhs * exchange_estimate_us(c) / t_int)) : 1.0;
 }
 
 // FusedCtl of the next fused launch: five words on lines of their own + the parked-block list
-static int fused_ctl(qexhip_ctx *c, int nbnd, FusedCtl *F) {
+int sweep_fused_ctl(qexhip_ctx *c, int nbnd, FusedCtl *F, int nrhs) {
   if (c->fz_cap < nbnd) {
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->fz_buf) HIPCHK(hipFree(c->fz_buf));
@@ -469,7 +470,7 @@ static int fused_ctl(qexhip_ctx *c, int nbnd, FusedCtl *F) {
   const double tick_per_us = (double)c->dj.ticks / (c->dj.timeout_s * 1e6);
   if (c->opt_fused_spin_us == -2) F->spin_ticks = -1;
   else {
-    const double us = c->opt_fused_spin_us >= 0 ? (double)c->opt_fused_spin_us : std::max(25.0, exchange_estimate_us(c));
+    const double us = c->opt_fused_spin_us >= 0 ? (double)c->opt_fused_spin_us : std::max(25.0, nrhs * exchange_estimate_us(c));
     F->spin_ticks = (long long)(us * tick_per_us);
   }
   return 0;
@@ -607,7 +608,7 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
       // data words, park when those are late, its last workgroups clean up -- and neither the comm stream nor an event is involved.
       CHK(comm_halo_push_only(c, in, 1 - parity, &A.gh_hi, &A.gh_lo, &A.push));
       CHK(peer_ghost_args(c, &A.pg));
-      CHK(fused_ctl(c, nb_lo + nb_hi, &A.fz));
+      CHK(sweep_fused_ctl(c, nb_lo + nb_hi, &A.fz));
       if (c->ndir == 8) CHK((launch<8, true>(c, A, lo_end, hi_beg, init, o.dot, 0, 0, lo_end, "dslash", nullptr, true, hi_beg, g.Vh)));
       else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0, 0, lo_end, "dslash", nullptr, true, hi_beg, g.Vh)));
       nparts = nb_int + nb_lo + nb_hi;

@@ -420,15 +420,19 @@ static int peer_ensure_arena(qexhip_ctx *c, int s, size_t bytes) {
 // One exchange on stream st: ns_dn pieces to the lower neighbour (they arrive in ITS from-upper half), ns_up pieces to the upper
 // one; by symmetry ns_up pieces arrive from the lower neighbour (-> dst_from_dn) and ns_dn from the upper one (-> dst_from_up).
 // Every piece is `bytes` long (a multiple of 16).
-// push_only (one piece per direction, comm stream class): NOTHING is launched -- the caller's own kernel pushes (its first
-// push_only->nblocks workgroups run peer_push_block) and reads what arrives in the receive arena itself: zc_from_up / zc_from_dn return
-// where the faces from the upper / lower neighbour lie there, and the credits stay owed until that kernel returns them (peer_ghost_args).
+// push_only (1..4 pieces per direction, as many up as down; comm stream class): NOTHING is launched -- the caller's own kernel pushes (its
+// first push_only->nblocks workgroups run peer_push_block) and reads what arrives in the receive arena itself: zc_from_up / zc_from_dn
+// return where the faces from the upper / lower neighbour lie there (piece k at k * bytes), and the credits stay owed until that kernel
+// returns them (peer_ghost_args).
 int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *src_dn, int ns_up, const void *const *src_up,
                   void *const *dst_from_up, void *const *dst_from_dn, size_t bytes, double emu_us, const void **zc_from_up,
                   const void **zc_from_dn, PeerPush *push_only) {
   PeerComm *p = c->peer;
   const bool zc = push_only != nullptr;
-  if (zc && (ns_dn != 1 || ns_up != 1 || !zc_from_up || !zc_from_dn)) { qexhip_set_error("peer transport: a push-only exchange takes one piece per direction"); return QEXHIP_ERR_ARG; }
+  if (zc && (ns_dn != ns_up || ns_dn < 1 || ns_dn > PEER_PUSH_MAXPIECE || !zc_from_up || !zc_from_dn)) {
+    qexhip_set_error("peer transport: a push-only exchange takes 1..%d pieces, as many up as down", (int)PEER_PUSH_MAXPIECE);
+    return QEXHIP_ERR_ARG;
+  }
   if (bytes % 16 != 0) { qexhip_set_error("peer transport: message of %zu bytes is not a multiple of 16", bytes); return QEXHIP_ERR_ARG; }
   if (ns_dn < 0 || ns_up < 0 || (ns_dn == 0 && ns_up == 0) || bytes == 0) return 0;
   const int s = (st == c->cstream) ? 1 : 0;
@@ -479,8 +483,10 @@ int peer_exchange(qexhip_ctx *c, hipStream_t st, int ns_dn, const void *const *s
     if (push_only) {
       PeerPush &P = *push_only;
       for (int d = 0; d < 2; d++) {
-        P.src[d] = X.src[d][0]; P.out_arena[d] = X.out_arena[d]; P.out_flag[d] = X.out_flag[d]; P.credit[d] = X.credit[d]; P.seq_out[d] = X.seq_out[d];
+        for (int k = 0; k < PEER_PUSH_MAXPIECE; k++) P.src[d][k] = X.src[d][k < nd ? k : 0];
+        P.out_arena[d] = X.out_arena[d]; P.out_flag[d] = X.out_flag[d]; P.credit[d] = X.credit[d]; P.seq_out[d] = X.seq_out[d];
       }
+      P.npiece = nd;
       P.n16 = X.n16; P.done = X.done; P.t_start_out = (long long *)(c->dj.ready + 56); P.err = X.err; P.ticks = X.ticks; P.nblocks = grid;
       p->zc.live = 1;
       for (int d = 0; d < 2; d++) { p->zc.credit_out[d] = X.credit_out[d]; p->zc.seq_in[d] = X.seq_in[d]; p->zc.in_flag[d] = X.in_flag[d]; }

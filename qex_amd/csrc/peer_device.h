@@ -82,15 +82,18 @@ __device__ inline void peer_copy_chunk(uint4 *__restrict__ d4, const uint4 *__re
   }
 }
 
-// The push half of a face exchange as workgroups of SOMEBODY ELSE's launch (the fused hop-split sweep: dslash.hip): one piece per
-// direction; workgroup blk of nblocks copies its chunks into the neighbours' arenas, the last one through raises the data words.
+// The push half of a face exchange as workgroups of SOMEBODY ELSE's launch (the fused sweeps: dslash.hip, batch.hip): npiece pieces per
+// direction (one per system of a lock-step batch), piece k at k * n16 of the neighbour's arena half; workgroup blk of nblocks copies
+// its chunks, the last one through raises the data words.
+enum { PEER_PUSH_MAXPIECE = 4 };
 struct PeerPush {
-  const uint4 *src[2];                // my faces: [to lower | to upper]
+  const uint4 *src[2][PEER_PUSH_MAXPIECE];   // my faces: [to lower | to upper][piece]
   uint4 *out_arena[2];                // peer-mapped halves they go to
   u64 *out_flag[2];                   // peer-mapped data words
   const u64 *credit[2];               // my credit words of the two outbound channels
   u64 seq_out[2];
   unsigned n16;                       // 16-byte units per piece
+  int npiece;
   unsigned int *done;                 // completion counter of the pushing workgroups
   long long *t_start_out;             // when the push started (emulated transport time counts from here)
   u64 *err; long long ticks;
@@ -108,11 +111,16 @@ __device__ inline void peer_push_block(const PeerPush &P, const unsigned blk) {
   __syncthreads();
   if (!push_ok) return;
   const unsigned cpp = (P.n16 + PEER_CHUNK - 1) / PEER_CHUNK;       // 32-bit chunk arithmetic on purpose: see k_peer_exchange
-  for (unsigned ch = blk; ch < 2 * cpp; ch += (unsigned)P.nblocks) {
-    const int dir = ch >= cpp;
-    const unsigned off = (dir ? ch - cpp : ch) * PEER_CHUNK;
+  const unsigned per_dir = (unsigned)P.npiece * cpp;
+  for (unsigned ch = blk; ch < 2 * per_dir; ch += (unsigned)P.nblocks) {
+    const int dir = ch >= per_dir;
+    const unsigned q = dir ? ch - per_dir : ch;
+    const unsigned k = q / cpp, off = (q - k * cpp) * PEER_CHUNK;
     const unsigned n = min(P.n16 - off, (unsigned)PEER_CHUNK);
-    peer_copy_chunk(P.out_arena[dir] + off, P.src[dir] + off, n);
+    const uint4 *sp = P.src[dir][0];
+#pragma unroll
+    for (int j = 1; j < PEER_PUSH_MAXPIECE; j++) sp = (unsigned)j == k ? P.src[dir][j] : sp;     // (selects, not an indexed read of the kernel arguments)
+    peer_copy_chunk(P.out_arena[dir] + (u64)k * P.n16 + off, sp + off, n);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: its stores have reached L2 / the fabric
   __syncthreads();

@@ -228,6 +228,7 @@ inline bool multi_rank(const qexhip_ctx *c) { return c->nranks > 1 || c->opt_mul
 // ---- comm.cpp ----
 int comm_halo_push_only(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, struct PeerPush *push);   // peer faces: the fused sweep
                                                                               // pushes the faces of f itself and reads what arrives in the receive arena
+int comm_halo_push_only_multi(qexhip_ctx *c, int n, DevField *const *f, int parity, const double2 **gh_hi, const double2 **gh_lo, struct PeerPush *push);   // n <= 4 fields (lock-step batch)
 int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready; the caller joins behind what it posts next
 int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parity, int overlap);   // n fields, one RCCL group
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
@@ -286,7 +287,9 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
 int sweep_autotune(qexhip_ctx *c);      // measure the sweep's forms once per operator shape (collective)
 void sweep_plan(const qexhip_ctx *c, int *lo_end, int *hi_beg, int *overlap);   // boundary / interior ranges and the overlap decision
 int sweep_form(const qexhip_ctx *c, int overlap);                              // 2 fused / 0 by sites: what an overlapped sweep runs as
-double sweep_push_fraction(const qexhip_ctx *c, int interior_sites);           // where in the dispatch order the fused sweep's boundary workgroups go
+double sweep_push_fraction(const qexhip_ctx *c, int interior_sites, int nrhs = 1);   // where in the dispatch order the fused sweep's boundary workgroups go
+struct FusedCtl;
+int sweep_fused_ctl(qexhip_ctx *c, int nbnd, FusedCtl *F, int nrhs = 1);               // the bookkeeping words + short wait of the next fused launch
 
 // ---- blas.hip ----
 int blas_zero(qexhip_ctx *c, DevField &f, int parity);

@@ -104,3 +104,65 @@ def test_batch_on_the_sharded_path(oracle, kind, multi):
         s.D(r, xs[j], ms[j])
         assert ((r - bs[j]) ** 2).sum() / (bs[j] ** 2).sum() <= 1e-18
     s.ctx.set_option("batch_multi", 0)
+
+
+@pytest.mark.parametrize("kind", ["random", "warm", "naik"])
+def test_batch_fused_sweep_on_the_peer_transport(oracle, kind):
+    """The lock-step sweep of a t-sharded slab as ONE launch (k_dslash_mrhs_fused: push of all systems' faces | interior | boundary
+    with a short wait | cleanup), one rank on the peer transport (its own neighbour through the receive arena): against the split
+    by sites, with every boundary block parked (same bits as unparked: local hops first either way, partial in the block's own slot),
+    and against single-system solves on the periodic kernels.  staghmc_sh.nim:339-364 (the Hasenbusch solves) is what runs on it."""
+    import qex_amd as q
+
+    lat = [8, 8, 8, 16]
+    o = oracle
+    lo = o.Layout(lat)
+    rf = o.RngField(lo, o.RNG_MILC6, 4711)
+    if kind == "naik":
+        g = o.gauge_warm(lo, 0.5, rf); o.rephase(lo, g)
+        g3 = 0.3 * o.gauge_warm(lo, 0.6, rf); o.rephase(lo, g3)
+    else:
+        g = (o.gauge_random if kind == "random" else lambda l, r: o.gauge_warm(l, 0.5, r))(lo, rf); o.rephase(lo, g)
+        g3 = None
+    ms = [0.1, 0.2, 0.4]
+    bs = [o.vector_gaussian(lo, rf) for _ in ms]
+    ref_ctx = q.Context(lat)
+    sref = q.newStag3(ref_ctx, g, g3) if g3 is not None else q.newStag(ref_ctx, g)
+    ref = []
+    for j in range(3):
+        sp = q.SolverParams(r2req=1e-14, maxits=5000, verbosity=0)
+        x1 = np.zeros_like(bs[j])
+        sref.solveXX(x1, bs[j], ms[j], sp, True)
+        ref.append((sp.iterations, x1))
+    keep = {}
+    for name, opts in (("by_sites", dict(hop_split=0)), ("fused", dict(hop_split=2)), ("fused_parked", dict(hop_split=2, fused_spin_us=-2)),
+                       ("fused_spin0", dict(hop_split=2, fused_spin_us=0))):
+        ctx = q.Context(lat)
+        ctx.set_option("transport", 2)
+        ctx.comm_init(q.Context.unique_id(), 1, 0)
+        ctx.force_halo(True)
+        ctx.set_option("batch_multi", 1)
+        ctx.set_option("overlap", 1)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        s = q.newStag3(ctx, g, g3) if g3 is not None else q.newStag(ctx, g)
+        xs = [np.zeros_like(b) for b in bs]
+        its, _ = s.solveXX_batch(xs, bs, ms, 1e-14, 5000, True)
+        ctx.sync()
+        for j in range(3):
+            assert abs(its[j] - ref[j][0]) <= 1, (name, j, its, ref[j][0])
+            assert relerr(xs[j], ref[j][1]) < 1e-7, (name, j)
+        # a shared iteration cap with one system switched off early (a zero source is done at once): the credits still go back
+        xz = [np.zeros_like(b) for b in bs]
+        bz = [bs[0], np.zeros_like(bs[1]), bs[2]]
+        itz, _ = s.solveXX_batch(xz, bz, ms, 0.0, 9, True)
+        assert itz[0] == 9 and itz[2] == 9 and itz[1] == 0, itz
+        keep[name] = ([x.copy() for x in xs], list(its), [x.copy() for x in xz])
+        st = ctx.comm_transport()[1]
+        assert st["exchanges"] > 20, st
+        del s
+        ctx.close()
+    for name in ("fused_parked", "fused_spin0"):
+        assert keep[name][1] == keep["fused"][1], name
+        for a, b in zip(keep[name][0] + keep[name][2], keep["fused"][0] + keep["fused"][2]):
+            assert np.array_equal(a, b), name
