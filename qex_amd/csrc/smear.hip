@@ -645,11 +645,29 @@ struct Smear {
       slab_used += n16;
       return 0;
     }
+    // scratch of a long-lived closure (scratch_keep): the k-th allocation of a call takes the k-th buffer of the previous call again
+    // instead of a hipMalloc / hipFree pair per field and call -- milliseconds each, and after a large free (the nHYP closure's 14 GB
+    // slab) ONE such call was seen to stall for 0.95 s in the runtime (profiles/r06_notes.md section 6)
+    if (scratch_keep && scratch_next < scratch.size() && scratch[scratch_next].second >= n) {
+      *p = scratch[scratch_next++].first;
+      HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(double2), c->stream));
+      return 0;
+    }
     HIPCHK(hipMalloc((void **)p, n * sizeof(double2)));
     HIPCHK(hipMemsetAsync(*p, 0, n * sizeof(double2), c->stream));
     owned.push_back(*p);
+    if (scratch_keep) {
+      if (scratch_next < scratch.size()) scratch[scratch_next] = {*p, n};      // (a larger request than last time: the old buffer stays owned, unused)
+      else scratch.push_back({*p, n});
+      scratch_next++;
+    }
     return 0;
   }
+  // per-call scratch kept between calls: scratch_begin() before the first per-call alloc of a call (everything allocated earlier is state)
+  bool scratch_keep = false;
+  std::vector<std::pair<double2 *, size_t>> scratch;
+  size_t scratch_next = 0;
+  void scratch_begin() { scratch_keep = true; scratch_next = 0; }
   int nb() const { return (g.V + 255) / 256; }
   // t-sharded: refresh the ghost slices of a field (tstride 576: one matrix field, 2304: gauge-shaped) to `depth`;
   // the caller does this for every field that is about to be read at shifted sites.  No-op on one GPU without ghosts.
@@ -1159,6 +1177,7 @@ int hisq_prepare(qexhip_ctx *c, const double *g_host, double *fl_host, double *l
     for (double2 **p : {&st->G, &st->V, &st->W, &st->FL, &st->LL, &st->CF, &st->CL, &st->F}) CHK(S.alloc(p, S.gsz));
   }
   Smear &S = st->S;
+  S.scratch_begin();                   // the scratch of the two fat7 passes is kept from call to call (qexhip_hisq_release / finalize free it)
   const double naik = 1.0, f2 = 2.0;
   const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
   CHK(S.upload(st->G, g_host));
@@ -1167,18 +1186,16 @@ int hisq_prepare(qexhip_ctx *c, const double *g_host, double *fl_host, double *l
   if (fl_host) CHK(S.download(fl_host, st->FL));
   if (ll_host) CHK(S.download(ll_host, st->LL));
   HIPCHK(hipStreamSynchronize(c->stream));
-  while (S.owned.size() > 8) { (void)hipFree(S.owned.back()); S.owned.pop_back(); }     // scratch of the two fat7 passes
   return 0;
 }
 int hisq_closure_force(qexhip_ctx *c, const double *dfl_host, const double *dll_host, double *f_host) {
   HisqState *st = (HisqState *)c->hisq;
   if (!st) { qexhip_set_error("hisq force: call qexhip_hisq_prepare first (smearGetForce)"); return -1; }
   Smear &S = st->S;
+  S.scratch_begin();                   // the reverse pass's scratch: the buffers of the previous call again
   CHK(S.upload(st->CF, dfl_host)); CHK(S.upload(st->CL, dll_host));
   CHK(S.hisq_reverse(st->G, st->V, st->W, st->CF, st->CL, st->F));
   CHK(S.download(f_host, st->F));
-  // the reverse pass parks its scratch in the closure's Smear: release what it allocated beyond the 8 fields
-  while (S.owned.size() > 8) { (void)hipFree(S.owned.back()); S.owned.pop_back(); }
   return 0;
 }
 // fermionForce of the HISQ HMC (src/examples/hisqhmc.nim:496-541) on the closure's fields: f1 = sum_k s_k p_k(x) (x) p_k(x+mu)^+,
@@ -1188,6 +1205,7 @@ int hisq_fermion_force(qexhip_ctx *c, double *f_host, const double *const *psi, 
   if (!st) { qexhip_set_error("hisq fermion force: call qexhip_hisq_prepare first (smearGetForce)"); return -1; }
   if (n < 1) { qexhip_set_error("hisq fermion force: n < 1"); return -1; }
   Smear &S = st->S;
+  S.scratch_begin();
   DevField *fx;
   CHK(get_work(c, WK_IN, &fx));
   for (int k = 0; k < n; k++) {
@@ -1200,7 +1218,6 @@ int hisq_fermion_force(qexhip_ctx *c, double *f_host, const double *const *psi, 
   k_force_projtah<<<(unsigned)((ltiles * 64 + 255) / 256), 256, 0, c->stream>>>(ltiles, st->F, st->G, 0);
   HIPCHK(hipGetLastError());
   CHK(S.download(f_host, st->F));
-  while (S.owned.size() > 8) { (void)hipFree(S.owned.back()); S.owned.pop_back(); }
   return 0;
 }
 int hisq_set_links_from_closure(qexhip_ctx *c) {

@@ -3,10 +3,14 @@ nHYP smear (smearGetForce), the smeared gauge force chain, the fermion force (2 
   periodic          the slab as a periodic lattice: the kernels alone, nothing exchanged
   halo              ghost zones through the one-rank exchange path (launch / event structure of the sharded job, no transport time)
   halo + emulation  every exchange preceded (RCCL arm) / stretched (peer arm) by 3 us + bytes / 45 GB/s
-usage: QEXHIP_TRANSPORT=rccl|peer python scratch/config4_emulated.py [XxYxZxT]"""
+usage: QEXHIP_TRANSPORT=rccl|mbox|peer python scratch/config4_emulated.py [XxYxZxT] [mode]
+Round 6: give ONE mode per process (periodic | halo | halo+emu).  With the three contexts in one process the third one paid ~11 ms per
+call that had nothing to do with the emulation (gforce alone in its own process: 32.7 ms halo, 36.8 ms halo + emulation; as the third
+context of one process 48.5) -- round 5's "+19 ms exposed" was mostly that."""
 import sys, time; sys.path.insert(0, '.')
 import numpy as np, qex_amd as q
 lat = [int(v) for v in (sys.argv[1].split('x') if len(sys.argv) > 1 else [48, 48, 48, 12])]
+only = sys.argv[2] if len(sys.argv) > 2 else None
 lo = q.Layout(lat)
 g = q.RngField(lat, q.RngMilc6, 987654321).warm(0.5)
 psis = [q.synthetic_gaussian_vector(lo, seed=5 + k) for k in range(2)]
@@ -28,6 +32,8 @@ def timed(fn, ctx, n=3):
 
 rows = []
 for mode in ("periodic", "halo", "halo+emu"):
+    if only and mode != only:
+        continue
     ctx = q.Context(lat)
     if mode != "periodic":
         ctx.comm_init(q.Context.unique_id(), 1, 0)
@@ -50,5 +56,5 @@ for mode in ("periodic", "halo", "halo+emu"):
           % (mode, tr[0], t_smear, t_gf, t_ff, t_hisq, tr[1] if tr[0] == "peer" else ""), flush=True)
     ctx.close()
 p = rows[0]
-for r in rows[1:]:
+for r in (rows[1:] if not only else []):
     print("%-10s / periodic:  smear %.2fx  gauge force %.2fx  fermion force %.2fx  HISQ %.2fx" % (r[0], r[1] / p[1], r[2] / p[2], r[3] / p[3], r[4] / p[4]))
