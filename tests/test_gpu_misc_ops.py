@@ -215,7 +215,7 @@ def test_bench_two_ranks_share_one_gpu():
     assert "error" not in nk and nk["links_per_site"] == 16 and nk["value"] > 0, nk
 
 
-@pytest.mark.parametrize("comm2", ["1", "0"])
+@pytest.mark.parametrize("comm2", ["1", "0", "mbox"])
 def test_bench_self_verification_on_the_sharded_code_path(comm2):
     """bench.py --halo on one GPU: ghost zones, faces through a one-rank RCCL communicator on the second stream (its own
     communicator, split off the first: QEXHIP_COMM2 = 1, the default; 0 = the single communicator), the multi-rank reduction
@@ -229,6 +229,8 @@ def test_bench_self_verification_on_the_sharded_code_path(comm2):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", QEXHIP_COMM2=comm2)
+    if comm2 == "mbox":          # the transport `auto` picks between distinct devices of one node: RCCL faces, mailbox rank sums
+        env.update(QEXHIP_COMM2="1", QEXHIP_TRANSPORT="mbox")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--halo", "--steps", "20", "--warmup", "3", "--repeats", "2", "--no-cpu", "--no-48x96"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=root, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -237,6 +239,7 @@ def test_bench_self_verification_on_the_sharded_code_path(comm2):
     assert sc["ok"] is True and not sc["failed"], sc
     assert sc["max_rel"]["operator"] <= 1e-10 and sc["max_rel"]["history"] <= 1e-6 and sc["max_rel"]["solution"] <= 1e-8
     assert ln["rccl_nranks"] == 1 and "error" not in ln
+    assert ln["transport"] == ("rccl+mbox" if comm2 == "mbox" else "rccl")
 
 
 def test_bench_self_verification_fails_loudly(tmp_path):

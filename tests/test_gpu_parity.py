@@ -737,18 +737,23 @@ def test_largest_single_gpu_lattice_48x96(oracle):
     assert relerr(D0, Dx) < 1e-15
 
 
+@pytest.mark.parametrize("transport", ["rccl", "rccl+mbox"])
 @pytest.mark.parametrize("naik", [False, True])
-def test_multi_rank_code_path_on_one_rank(oracle, naik):
+def test_multi_rank_code_path_on_one_rank(oracle, naik, transport):
     """Everything a rank of a t-sharded job executes, on one GPU: ghost zones, the exchange through a ONE-RANK RCCL
     communicator (ncclSend/ncclRecv to self on the second stream), and -- option "multi_reduce" -- the multi-rank
-    reduction branches of the CG, the multi-shift CG and the norms (partial sums -> one-block sum -> ncclAllReduce ->
-    bookkeeping kernel), which a single rank otherwise never takes.  Must reproduce the periodic single-rank results."""
+    reduction branches of the CG, the multi-shift CG and the norms (partial sums -> one-block sum -> ncclAllReduce, or with
+    `rccl+mbox` -- what `auto` picks between distinct devices of one node -- the mailbox all-reduce with the deferred join in its
+    prologue -> bookkeeping kernel), which a single rank otherwise never takes.  Must reproduce the periodic single-rank results."""
     import qex_amd as q
 
     A = Setup(oracle, [8, 8, 8, 8], naik=naik)
     lat = [8, 8, 8, 8]
     ctx = q.Context(lat)
+    if transport == "rccl+mbox":
+        ctx.set_option("transport", 3)
     ctx.comm_init(q.Context.unique_id(), 1, 0)
+    assert ctx.comm_transport()[0] == transport
     assert ctx.comm_info()[:2] == (1, 0)                       # what RCCL itself reports
     ctx.force_halo(True)
     ctx.set_option("overlap", 1)
