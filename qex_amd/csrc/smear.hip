@@ -1092,11 +1092,14 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
     QX_PB_LAUNCH;
     HIPCHK(hipGetLastError());
     {
+      // The chain fields of the level in ONE group -- those the next level reads across the t boundary.  A staple derivative gathers in
+      // its (mu, a) plane only (k_staple_deriv_pair: x +- mu, x +- a and the two corners), and fl2[m][n] enters the calls whose plane
+      // contains m and not n: fl2[m][3] (m != 3) is never read at a t-shifted site.  9 of 12 fields travel (round 6).
       const double2 *fs[12]; int nf = 0;
       for (int mu = 0; mu < 4; mu++)
         for (int nu = 0; nu < 4; nu++)
-          if (nu != mu) fs[nf++] = st->fl2[mu][nu];
-      CHK(refresh(fs, nf, 576));                  // the twelve chain fields of the level in ONE group
+          if (nu != mu && !(nu == 3 && mu != 3)) fs[nf++] = st->fl2[mu][nu];
+      CHK(refresh(fs, nf, 576));
     }
   }
   HIPCHK(hipGetLastError());
@@ -1129,10 +1132,12 @@ static int nhyp_backward_dev(qexhip_ctx *c, NhypState *st) {
     QX_PB_LAUNCH;
     HIPCHK(hipGetLastError());
     {
+      // ... and here fl1[m][n] is read by the ONE call whose plane is (m, n): only fl1[m][3] and fl1[3][m] cross the t boundary --
+      // 6 of 12 fields, 2.1 instead of 4.25 ms at 45 GB/s on a 48^3 face, beside 1.9 ms of interior kernels (profiles/r06_notes.md section 6)
       const double2 *fs[12]; int nf = 0;
       for (int mu = 0; mu < 4; mu++)
         for (int nu = 0; nu < 4; nu++)
-          if (nu != mu) fs[nf++] = st->fl1[mu][nu];
+          if (nu != mu && (mu == 3 || nu == 3)) fs[nf++] = st->fl1[mu][nu];
       CHK(refresh(fs, nf, 576));
     }
   }
