@@ -725,8 +725,9 @@ struct Smear {
   // ext > 0 (t-sharded only): also on the `ext` ghost slices either side of the slab -- the operands must be valid `ext + 1`
   // slices out (communication-avoiding smearing levels: nhyp() below)
   // ext_acc = false: on the ghost slices only the staple field `st` is wanted (fat7: the accumulator is read on the slab only)
+  // part: 0 = the body launch and (ext > 0) the two ghost-slice launches; 1 = the body launch only; 2 = the ghost-slice launches only
   int staple(MView A, MView B, int mu, int nu, MViewW st, MViewW acc, double coef, MView init = MView{nullptr, 0}, double cinit = 0.0,
-             MViewW proj = MViewW{nullptr, 0}, int ext = 0, bool ext_acc = true) {
+             MViewW proj = MViewW{nullptr, 0}, int ext = 0, bool ext_acc = true, int part = 0) {
     ScopedTimer tm(c, "smear", c->stream);
     constexpr int swz = 1;     // XCD-aware block remap of the gather kernels (measured winner, profiles/r02_pmc_staple_kernels_order.log)
     const int *order; int chunk, nblk;
@@ -737,9 +738,11 @@ struct Smear {
     // (45 KB: 7.14, 100 KB = one workgroup per CU: 7.41; none: 7.27).
     constexpr int ldsb = 60000;
     constexpr int gnt = 1;     // non-temporal stores of the staple / accumulator (written once, read by a later kernel)
-    if (g.halo) k_gen_staple<true><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk, gnt);
-    else k_gen_staple<false><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk, gnt);
-    if (g.halo && ext > 0) {
+    if (part != 2) {
+      if (g.halo) k_gen_staple<true><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk, gnt);
+      else k_gen_staple<false><<<nblk, 256, ldsb, c->stream>>>(g, A, B, mu, nu, st, acc, coef, swz, init, cinit, proj, order, chunk, gnt);
+    }
+    if (g.halo && ext > 0 && part != 1) {
       // ghost_hi holds the virtual slices Xt .. Xt+2 at [Vh, Vh + 3F), ghost_lo the slices -3 .. -1 at [Vh + 3F, Vh + 6F)
       const int F = g.F, hi0 = g.Vh, lo1 = g.Vh + 6 * F;
       const int nb = (2 * ext * F + 255) / 256;
@@ -928,14 +931,34 @@ struct Smear {
     // i.e. 382 -> 191 MB per direction, and no exchange left inside the levels; profiles/r05_notes.md).  Extra arithmetic:
     // 4 / T of level 1 and 2 / T of level 2.
     const bool ca = g.halo && c->opt_smear_ca;      // option "smear_ca" = 0: the per-field refreshes of rounds 1-4 (A/B, test hook)
-    CHK(ghosts_g(G, ca ? 3 : 1));
-    for (int mu = 0; mu < 4; mu++)
-      for (int nu = 0; nu < 4; nu++) {
-        if (nu == mu) continue;
-        CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(K.l1x[mu][nu]), alp1, gv(G, mu), 1 - a1, fvw(K.l1[mu][nu]), ca ? 2 : 0));
-        if (g.halo && !ca) CHK(ghosts_f_async(K.l1[mu][nu]));                  // travels while the next (mu, nu) is computed
+    if (ca) {
+      // Round 6: the one exchange travels beside what does not need it.  A level-1 staple gathers in its (mu, nu) plane only, so the BODY
+      // launches of the six purely spatial planes read no ghost slice: they run while the thin links' three ghost slices are on the
+      // way; behind the join come the body launches of the six planes that contain t and every plane's launches ON the ghost slices.
+      // Same launches, another order: bit-identical.  (+4.2 -> +2.7 ms exposed per smear at 48^3 x 12, 45 GB/s; profiles/r06_notes.md section 6)
+      const double2 *gp = G;
+      CHK(ghosts_many(&gp, 1, 4 * 576, 3, 1));
+      for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) CHK(ghosts_join());
+        for (int mu = 0; mu < 4; mu++)
+          for (int nu = 0; nu < 4; nu++) {
+            if (nu == mu) continue;
+            const bool spatial = mu != 3 && nu != 3;
+            const int part = pass == 0 ? (spatial ? 1 : -1) : (spatial ? 2 : 0);
+            if (part < 0) continue;
+            CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(K.l1x[mu][nu]), alp1, gv(G, mu), 1 - a1, fvw(K.l1[mu][nu]), 2, true, part));
+          }
       }
-    if (g.halo && !ca) CHK(ghosts_join());
+    } else {
+      CHK(ghosts_g(G, 1));
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < 4; nu++) {
+          if (nu == mu) continue;
+          CHK(staple(gv(G, nu), gv(G, mu), mu, nu, none, fvw(K.l1x[mu][nu]), alp1, gv(G, mu), 1 - a1, fvw(K.l1[mu][nu]), 0));
+          if (g.halo) CHK(ghosts_f_async(K.l1[mu][nu]));                  // travels while the next (mu, nu) is computed
+        }
+      if (g.halo) CHK(ghosts_join());
+    }
     for (int mu = 0; mu < 4; mu++)
       for (int nu = 0; nu < 4; nu++) {
         if (nu == mu) continue;

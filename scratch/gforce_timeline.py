@@ -14,8 +14,13 @@ if sys.argv[1] == "run":
     if os.environ.get("QEX_EMU", "1") != "0":
         ctx.set_option("emu_exchange_us", 3); ctx.set_option("emu_link_gbs", 45); ctx.set_option("emu_allreduce_us", 3)
     fl, f = np.zeros_like(g), np.zeros_like(g)
-    sf = q.HypCoefs(0.4, 0.5, 0.5).smearGetForce(ctx, g, fl)
     import time
+    sf = q.HypCoefs(0.4, 0.5, 0.5).smearGetForce(ctx, g, fl)
+    for _ in range(3):
+        t = time.perf_counter()
+        sf = q.HypCoefs(0.4, 0.5, 0.5).smearGetForce(ctx, g, fl)
+        ctx.sync()
+        print("smear wall %.2f ms" % (1e3 * (time.perf_counter() - t)), flush=True)
     for _ in range(4):
         t = time.perf_counter()
         sf.gforce(f, plaq=1.0)
