@@ -108,12 +108,13 @@ int qexhip_comm_transport(qexhip_handle h, char *name, int len, long stats[4]);
  * channels are independent by construction). */
 int qexhip_comm_count(qexhip_handle h, int *ncomms);
 /* How a one-parity sweep runs on this context's (t-sharded) field: out[0] = 1 if t-hops across the slab boundary go through
- * ghost zones, out[1] = 1 if the face exchange is posted on the second stream beside an interior launch, out[2] = interior
+ * ghost zones, out[1] = 1 if the face exchange runs beside interior work (second stream, or inside the fused launch), out[2] = interior
  * sites of one parity, out[3] = bytes of one face message, out[4] = 1 if out[1] was MEASURED: with a communicator of more
- * than one rank, set_links times a few sweeps in either form (collective; the slowest rank decides, so all ranks agree) --
- * out[5], out[6] = microseconds per sweep it saw exchange-first / overlapped; otherwise out[1] follows option "overlap" or,
- * at -1, the rule of the one-rank rehearsals (overlap when the interior is >= 131072 sites and a face >= 1 MiB);
- * out[7] = the option's value.  bench.py prints it so that a scaling run explains its own launch structure. */
+ * than one rank, set_links times a few sweeps in every form (collective; the slowest rank decides, so all ranks agree) --
+ * out[5], out[6] = microseconds per sweep it saw exchange-first / overlapped and split by sites (0: that form was not timed;
+ * qexhip_stag_sweep_tuning has all three forms); otherwise out[1] follows option "overlap" or, at -1, the rule of the one-rank
+ * rehearsals (overlap when the interior is >= 131072 sites and a face >= 1 MiB); out[7] = the option's value.  bench.py prints it
+ * so that a scaling run explains its own launch structure. */
 int qexhip_stag_sweep_info(qexhip_handle h, int out[8]);
 /* ... and what set_links MEASURED for them (collective, max over ranks; qexhip_device_info prints the same):
  *   out[0] one face exchange of this operator, microseconds (measured where the communicator has more than one rank or option
