@@ -70,7 +70,9 @@ __global__ void __launch_bounds__(256) k_gauge_from_tiles(Geom g, double2 *__res
 // (24 loads, 8 of them L1 hits, 132 VGPR = 3 waves/SIMD instead of 1) measured 383 us against 277 us at 32^4: the
 // kernel is bound by the number of L2->L1 requests, not by occupancy.  (Round 2: a workgroup per tile with six
 // wavefronts, one per plane, and the four site links through LDS -- the same 16 loads at three wavefronts per SIMD -- measured
-// 285-291 us against 230: rejected as well.)
+// 285-291 us against 230: rejected as well.  Round 6: gathering rows 0,1 of SU(3) links and rebuilding row 2: 227 -> 227 us, no change --
+// the kernel is latency-bound at one wavefront per SIMD, 256 VGPRs + 35 AGPRs; __launch_bounds__(256, 2): two wavefronts per SIMD with
+// 136-192 B/lane of scratch, 277-286 us.  profiles/r06_notes.md section 4.)
 // S4: instead of the six plane sums, the eight sums of `s4_gauge` (stagg_pv_hmc/staghmc_spv_meas.nim:25-65, the S4 order
 // parameter of arXiv:1111.2317): the plaquette of plane (mu, nu) at x is added to peo[mu][x_mu mod 2] and to peo[nu][x_nu mod 2];
 // partial k = 2 d + (x_d mod 2).
