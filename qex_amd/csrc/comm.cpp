@@ -244,7 +244,7 @@ static inline int lower(const qexhip_ctx *c) { return (c->rank - 1 + c->nranks) 
 // producer of f on the compute stream); the caller joins (devjoin_signal / devjoin_wait) behind whatever it posts after the exchange.  Message order is the same on every
 // rank -- sends {bottom->lower, top->upper}, receives {ghost_hi<-upper, ghost_lo<-lower} -- so
 // that with two ranks (upper == lower) or one rank (self) the k-th send pairs with the k-th recv.
-int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
+int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap, bool wait_ready) {
   // overlap == 0: post the exchange on the compute stream itself (no cross-stream events).  Used
   // when the interior sweep is too short to hide the exchange: two cross-stream dependencies
   // cost more than they buy there.
@@ -258,7 +258,7 @@ int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap) {
   double2 *top = base + (size_t)(g.ntile) * 192 - face2;        // t = Xt-depth .. Xt-1
   double2 *ghost_hi = base + (size_t)g.ntile * 192;
   double2 *ghost_lo = ghost_hi + face2;
-  if (overlap) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
+  if (overlap && wait_ready) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));     // (not when the comm stream produced the faces itself)
   ScopedTimer tm(c, "exchange", cs);            // on the stream the group is posted on: transport + waiting for the neighbours
   CHK(emu_exchange(c, cs, nd * sizeof(double)));
   if (peer_faces(c)) {

@@ -594,6 +594,7 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
   if ((init || o.dot) && !A.xs) { qexhip_set_error("dslash_sweep: b-term/dot needs xs"); return -1; }
   if (o.ca != 0.0 && !A.rin) { qexhip_set_error("dslash_sweep: a-term needs rin"); return -1; }
   int nparts = 0;
+  const double2 *faces_on_cstream = nullptr;
   if (!g.halo) {
     if (c->ndir == 8) CHK((launch<8, false>(c, A, 0, g.Vh, init, o.dot, 0)));
     else CHK((launch<16, false>(c, A, 0, g.Vh, init, o.dot, 0)));
@@ -627,8 +628,15 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
       // one-lane signal kernel behind the boundary launch, a one-wave wait on the compute stream -- or, with o.defer_join, in the
       // prologue of the mailbox all-reduce that comes next): the runtime's cross-queue event dependency was ~28 us of dead time per
       // sweep (profiles/r05_timeline_*.txt).
+      // Second sweep of a pair (op_xx) behind a first one of this form: the faces it sends ARE the output of the first sweep's boundary
+      // launch, the comm stream's own previous kernel -- the exchange is posted at once (~28 us earlier: it no longer waits for the first
+      // sweep's interior launch and the join), and only the boundary launch, which also reads the slices next to the faces, waits for
+      // ev_ready.  (Round 5's "chained pair" did this and more -- it also dropped the join by narrowing the second interior -- and never
+      // won; this keeps every launch as it is.)
+      const bool early = o.pair2 && c->bnd_out_on_cstream == in.par(1 - parity);
       HIPCHK(hipEventRecord(c->ev_ready, c->stream));
-      CHK(comm_halo_exchange(c, in, 1 - parity, 1));
+      CHK(comm_halo_exchange(c, in, 1 - parity, 1, !early));
+      if (early) HIPCHK(hipStreamWaitEvent(c->cstream, c->ev_ready, 0));
       if (c->ndir == 8) CHK((launch<8, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
       else CHK((launch<16, true>(c, A, lo_end, hi_beg, init, o.dot, 0)));
       if (c->ndir == 8) CHK((launch<8, true>(c, A, 0, lo_end, init, o.dot, nb_int, hi_beg, g.Vh, "dslash_bnd", c->cstream)));
@@ -637,8 +645,10 @@ int dslash_sweep(qexhip_ctx *c, DevField &out, DevField &in, int parity, const D
       if (o.defer_join && c->peer) CHK(devjoin_defer(c));
       else CHK(devjoin_wait(c, c->stream, c->cstream));
       nparts = nb_int + nb_lo + nb_hi;
+      faces_on_cstream = out.par(parity);
     }
   }
+  c->bnd_out_on_cstream = faces_on_cstream;
   if (o.dot) {
     if (nparts > c->part2_off) { qexhip_set_error("internal: partial buffer too small"); return -3; }
     // deferred final sum (inside k_cg_update) only while every workgroup can afford to re-sum the

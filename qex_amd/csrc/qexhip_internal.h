@@ -144,6 +144,7 @@ struct qexhip_ctx {
                                 // dozen slots while it waits for another rank any more)
   int hybrid_sums = 0;          // RCCL carries the faces, the mailboxes of the peer control block the CG's rank sums (comm.cpp: comm_init)
   unsigned int *fz_buf = nullptr; int fz_cap = 0;   // FusedCtl words + parked-block list of the fused sweep (dslash.hip)
+  const double2 *bnd_out_on_cstream = nullptr;      // the parity half whose t-faces the LAST sweep's boundary launch wrote on the comm stream (split by sites), else null
   double xchg_us[2]{0, 0};      // measured at set_links (collective, max over ranks): one face exchange of the 8- / 16-link operator, us (0: not measured)
   int form_auto[2]{-1, -1};     // measured at set_links: 2 fused / 0 by sites for 8- and 16-link operators (-1: not measured)
   int opt_chain_overlap = 1; // option "chain_overlap" (A/B, test hook): 1 = the nHYP force chain's staple derivatives of a t-sharded field run in two passes,
@@ -229,7 +230,8 @@ inline bool multi_rank(const qexhip_ctx *c) { return c->nranks > 1 || c->opt_mul
 int comm_halo_push_only(qexhip_ctx *c, DevField &f, int parity, const double2 **gh_hi, const double2 **gh_lo, struct PeerPush *push);   // peer faces: the fused sweep
                                                                               // pushes the faces of f itself and reads what arrives in the receive arena
 int comm_halo_push_only_multi(qexhip_ctx *c, int n, DevField *const *f, int parity, const double2 **gh_hi, const double2 **gh_lo, struct PeerPush *push);   // n <= 4 fields (lock-step batch)
-int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap);  // overlap: on cstream after ev_ready; the caller joins behind what it posts next
+int comm_halo_exchange(qexhip_ctx *c, DevField &f, int parity, int overlap, bool wait_ready = true);  // overlap: on cstream after ev_ready (wait_ready);
+                                                                              // the caller joins behind what it posts next
 int comm_halo_exchange_multi(qexhip_ctx *c, int n, DevField *const *f, int parity, int overlap);   // n fields, one RCCL group
 int comm_allreduce(qexhip_ctx *c, double *dptr, int n);          // on stream
 int comm_allreduce_parts(qexhip_ctx *c, double *parts, int n, int *n_out);   // workgroup partials -> *n_out values whose sum is the rank-global dot product
@@ -280,6 +282,9 @@ struct DslashOpts {
   int *nparts_out = nullptr;
   double *dot_out = nullptr;       // device scalar
   const int *done = nullptr;       // device flag: skip when set
+  int pair2 = 0;                   // second sweep of a back-to-back pair out2 = D (D in) (op_xx): its input is the first sweep's output and nothing came
+                                   // between -- where the first sweep's boundary launch ran on the comm stream, the faces this sweep sends were
+                                   // produced THERE: its exchange is posted at once, only its boundary launch waits for the first sweep's interior
   int defer_join = 0;              // the caller's next operation on the compute stream is comm_allreduce_parts (or devjoin_flush): a sweep split by
                                    // sites leaves its join from the comm stream to that kernel's prologue where the mailboxes carry the sum
 };

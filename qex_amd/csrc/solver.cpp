@@ -44,6 +44,7 @@ int op_xx(qexhip_ctx *c, DevField &r, DevField &x, double m2, int par_even, int 
   o2.dot_out = &c->cg->pAp;
   o2.done = done;
   o2.defer_join = (dot && ndot) ? 1 : 0;
+  o2.pair2 = (t->d != x.d && t->d != r.d) ? 1 : 0;
   if (o2.cb == 0.0 && dot) { qexhip_set_error("op_xx: dot with m2 == 0 unsupported"); return -1; }
   CHK(dslash_sweep(c, *t, x, py, o1));
   CHK(dslash_sweep(c, r, *t, px, o2));
