@@ -425,6 +425,9 @@ int qexhip_stag_links_info(qexhip_handle h, int *nlinks, int *compressed, double
  * Environment (read once, at qexhip_init / qexhip_comm_init) -- the complete list:
  *   QEXHIP_RECON, QEXHIP_OVERLAP, QEXHIP_HOP_SPLIT, QEXHIP_FLOW_EXP   initial values of the options of the same (lower-case) name
  *   QEXHIP_TRANSPORT=auto|rccl|peer|mbox, QEXHIP_RENDEZVOUS_TIMEOUT, QEXHIP_PEER_TIMEOUT, QEXHIP_LOCAL_RANKS   see "communicator"
+ *   QEXHIP_TEST_FAIL_INIT, QEXHIP_TEST_FAIL_MBOX   test hooks: inject a late failure into qexhip_init / into comm_init's mailbox self-test
+ *                    (1: it fails; 2: and an explicit `mbox` wish falls back to rccl like `auto`), so that the clean-up and fall-back
+ *                    paths run on a one-GPU box (tests/test_gpu_misc_ops.py)
  *   QEXHIP_COMM2=0   keep ONE RCCL communicator for both streams (default: the overlapped face exchange gets a communicator
  *                    of its own); the ranks agree on this by a min-all-reduce, any rank's 0 wins
  * Every other choice the kernels make (visiting orders, non-temporal accesses, LDS staging, launch shapes) is fixed to the

@@ -466,7 +466,6 @@ int sweep_fused_ctl(qexhip_ctx *c, int nbnd, FusedCtl *F, int nrhs) {
   // slabs, profiles/r06_fused_ab.log): 8 | 16 | 32 | 64 of them cost 91 | 92.5 | 95 | 97.6 us per iteration on the thin slab's normal
   // path (they poll while the whole launch is resident) and 663 | 513 | 450 | 438 us with EVERY block parked on the 48^3 one
   F->ncl = std::max(1, std::min(nbnd, 32));
-  if (const char *e = getenv("QEXHIP_TUNE_FUSED_NCL")) { const int v = atoi(e); if (v > 0) F->ncl = std::min(nbnd, v); }     // (A/B hook of scratch/fused_ab.sh)
   const double tick_per_us = (double)c->dj.ticks / (c->dj.timeout_s * 1e6);
   if (c->opt_fused_spin_us == -2) F->spin_ticks = -1;
   else {

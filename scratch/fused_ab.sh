@@ -18,7 +18,7 @@ for rep in 1 2; do
     run QEXHIP_TRANSPORT=peer $lib --halo --lat 48 48 48 12 --emulate-transport 6 6 --set-option emu_link_gbs=22 --set-option overlap=1 --set-option hop_split=2
   done
 done
-for ncl in 8 16 32; do
+for ncl in; do   # (the QEXHIP_TUNE_FUSED_NCL hook of this A/B left the library with the decision: 32; profiles/r06_fused_ab.log)
   export QEXHIP_TUNE_FUSED_NCL=$ncl
   echo "ncl $ncl"
   run QEXHIP_TRANSPORT=peer $NEW --halo --lat 32 32 32 4 --emulate-transport 3 3 --set-option emu_link_gbs=45 --set-option overlap=1 --set-option hop_split=2

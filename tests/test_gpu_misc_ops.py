@@ -1,4 +1,6 @@
 """Remaining pieces of SURVEY.md 8 rows a3 / a9: Staggered.peqDdag and sp.usePrevSoln."""
+import os
+
 import numpy as np
 import pytest
 
@@ -345,6 +347,45 @@ def test_resident_field_entry_points_against_the_oracle(oracle):
     assert n1 == n2 and all(np.array_equal(u, ctx.field_download(i)) for u, i in zip(a, xids[:2]))
     ctx.comm_init(q.Context.unique_id(), 1, 0)
     assert ctx.comm_count() in (1, 2)
+
+
+def test_mailbox_selftest_failure_falls_back_to_rccl(oracle):
+    """`auto` between distinct devices of one node takes RCCL for the faces and the mailboxes for the rank sums only if a self-test of
+    the mailbox all-reduce passes on every rank (comm.cpp); if not, every rank drops the control block and RCCL carries the sums too -- a
+    working communicator, not an error; an explicit `mbox` wish turns the same failure into QEXHIP_ERR_COMM.  No one-GPU box reaches
+    either branch by itself, so the failure is injected (QEXHIP_TEST_FAIL_MBOX); run in child processes because the hook is read from the
+    environment.  commsUtils.nim:195-204 (threadRankSum) is what the sums restate on either transport."""
+    import subprocess
+    import sys
+
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import qex_amd as q
+ctx = q.Context([8, 8, 8, 8])
+ctx.set_option("transport", 3)
+try:
+    ctx.comm_init(q.Context.unique_id(), 1, 0)
+except q.QexHipError as e:
+    print("COMM_INIT_ERROR", str(e)[:200]); sys.exit(0)
+ctx.force_halo(True); ctx.set_option("multi_reduce", 1); ctx.set_option("overlap", 1)
+rng = np.random.default_rng(1)
+g = 0.3 * rng.standard_normal((4096, 4, 3, 3, 2)); b = rng.standard_normal((4096, 3, 2)); b[2048:] = 0
+s = q.newStag(ctx, g)
+sp = q.SolverParams(r2req=1e-10, maxits=500, verbosity=0)
+x = np.zeros_like(b); s.solveEE(x, b, 0.5, sp); ctx.sync()
+print("TRANSPORT", ctx.comm_transport()[0], "ITS", sp.iterations)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for hook in ("0", "1", "2"):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", QEXHIP_TEST_FAIL_MBOX=hook)
+        p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=200, env=env)
+        assert p.returncode == 0, (hook, p.stdout[-500:], p.stderr[-1500:])
+        out[hook] = [ln for ln in p.stdout.splitlines() if ln.startswith(("TRANSPORT", "COMM_INIT_ERROR"))][-1]
+    assert out["0"].startswith("TRANSPORT rccl+mbox"), out
+    assert out["1"].startswith("COMM_INIT_ERROR") and "self-test" in out["1"], out
+    assert out["2"].startswith("TRANSPORT rccl ITS"), out
+    assert out["2"].split()[-1] == out["0"].split()[-1], out          # the same solve on either transport
 
 
 def test_fused_sweep_placement_follows_the_measured_exchange():
