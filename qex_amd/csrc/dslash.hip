@@ -456,7 +456,7 @@ int sweep_fused_ctl(qexhip_ctx *c, int nbnd, FusedCtl *F, int nrhs) {
     c->fz_buf = nullptr; c->fz_cap = 0;
     const int cap = std::max(2 * nbnd, 4096);
     HIPCHK(hipMalloc((void **)&c->fz_buf, (size_t)(256 + cap) * sizeof(unsigned int)));
-    HIPCHK(hipMemset(c->fz_buf, 0, (size_t)(256 + cap) * sizeof(unsigned int)));
+    HIPCHK(hipMemsetAsync(c->fz_buf, 0, (size_t)(256 + cap) * sizeof(unsigned int), c->stream));     // (ordered before the launch that uses it)
     c->fz_cap = cap;
   }
   F->dec = c->fz_buf; F->ndef = c->fz_buf + 32; F->cl_done = c->fz_buf + 64; F->late = c->fz_buf + 96;

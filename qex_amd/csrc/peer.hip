@@ -284,6 +284,7 @@ int devjoin_init(qexhip_ctx *c) {
   HIPCHK(hipMemset(J.ready, 0, 512));
   HIPCHK(hipHostMalloc((void **)&J.err, 64, hipHostMallocDefault));
   *J.err = 0;
+  HIPCHK(hipDeviceSynchronize());          // (the context's streams are non-blocking: nothing orders them behind the memset by itself)
   return 0;
 }
 void devjoin_destroy(qexhip_ctx *c) {
