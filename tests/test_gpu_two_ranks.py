@@ -116,6 +116,21 @@ def test_two_ranks_against_the_global_oracle(lat, overlap):
 
 
 @needs2
+@pytest.mark.parametrize("transport", ["rccl", "mbox", "peer"])
+def test_two_ranks_on_each_transport(transport):
+    """Two distinct devices, every transport by name (auto picks `mbox` there if its self-test passes): RCCL alone, RCCL faces + mailbox
+    rank sums, and the peer-memory transport with its fused self-pushing sweep -- each rank's slab of every result against the global
+    oracle (the same rungs scratch/first_contact.sh walks)."""
+    p = _launch(2, [os.path.join(ROOT, "tests", "two_rank_worker.py"), "16", "16", "16", "32", "--overlap", "1"],
+                extra_env={"QEXHIP_TRANSPORT": transport, "QEXHIP_PEER_TIMEOUT": "60"})
+    ok = [ln for ln in p.stdout.splitlines() if ln.startswith("TWO_RANK_OK")]
+    assert p.returncode == 0 and len(ok) == 2, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    res = [json.loads(ln.split(" ", 3)[3]) for ln in ok]
+    assert {r["transport"] for r in res} == {{"rccl": "rccl", "mbox": "rccl+mbox", "peer": "peer"}[transport]}
+    assert len({r["pci_bus"] for r in res}) == 2
+
+
+@needs2
 def test_four_ranks_against_the_global_oracle():
     if _ngpu() < 4:
         pytest.skip("needs four GPUs")
