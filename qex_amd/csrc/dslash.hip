@@ -464,8 +464,9 @@ int sweep_fused_ctl(qexhip_ctx *c, int nbnd, FusedCtl *F, int nrhs) {
   // the cleanup workgroups hold their slots through the LONG wait when the faces are late: few, so that a neighbour that shares the chip
   // always finds room; enough to take a whole face's parked blocks in ~100 us when it comes to that.  Measured (48^3 x 12 / 32^3 x 4
   // slabs, profiles/r06_fused_ab.log): 8 | 16 | 32 | 64 of them cost 91 | 92.5 | 95 | 97.6 us per iteration on the thin slab's normal
-  // path (they poll while the whole launch is resident) and 663 | 513 | 450 | 438 us with EVERY block parked on the 48^3 one
-  F->ncl = std::max(1, std::min(nbnd, 32));
+  // path (they poll while the whole launch is resident) and 663 | 513 | 450 | 438 us with EVERY block parked on the 48^3 one:
+  // one per eight boundary workgroups (a parked face then costs each of them the same ~8-14 blocks whatever the face), at most 32
+  F->ncl = std::max(std::min(nbnd, 4), std::min(nbnd / 8, 32));       // one per eight boundary workgroups, 4 .. 32
   const double tick_per_us = (double)c->dj.ticks / (c->dj.timeout_s * 1e6);
   if (c->opt_fused_spin_us == -2) F->spin_ticks = -1;
   else {
