@@ -174,8 +174,9 @@ def test_gpu_action_and_plaquette_repeat_exactly():
     assert abs(a0 + 6.0 * 6.0 * lo.vol * p0.sum()) <= 1e-12 * abs(a0)
 
 
-def test_bench_two_ranks_share_one_gpu():
-    """The driver's N = 2 launch line on a ONE-GPU box: two ranks under torch.distributed.run share GPU 0, the communicator takes
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_bench_two_ranks_share_one_gpu(nranks):
+    """The driver's N = 2 (and N = 4) launch line on a ONE-GPU box: the ranks under torch.distributed.run share GPU 0, the communicator takes
     the peer-memory transport by itself (RCCL refuses duplicate devices), and the faces / reductions are REAL exchanges with the
     other process: the self-verification against the committed single-GPU numbers must pass (round 4 could only rehearse the
     control flow here, each rank wrapping its own slab).  One parsable line that carries both ranks."""
@@ -190,17 +191,17 @@ def test_bench_two_ranks_share_one_gpu():
     # multi-shift self-check has 1 296 boundary workgroups per sweep: the case that ran round 5's build into the wait bound,
     # profiles/r06_notes.md section 1)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", QEX_BENCH_FORCE_CANARY="1", QEXHIP_HOP_SPLIT="2", QEXHIP_OVERLAP="1", QEXHIP_PEER_TIMEOUT="20")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(29531 + nranks), os.path.join(root, "bench.py"), "--gpus", str(nranks), "--steps", "20", "--warmup", "5"]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=root, env=env)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2000:])
     lines = [json.loads(x) for x in p.stdout.splitlines() if x.startswith("{")]
     assert len(lines) == 1
     ln = lines[0]
-    assert "error" not in ln and ln["n_gpus"] == 2 and ln["value"] > 0 and ln["scaling"] == "strong"
-    assert sorted(r["rank"] for r in ln["ranks"]) == [0, 1]
+    assert "error" not in ln and ln["n_gpus"] == nranks and ln["value"] > 0 and ln["scaling"] == "strong"
+    assert sorted(r["rank"] for r in ln["ranks"]) == list(range(nranks))
     assert 0 < ln["roofline"]["frac"] <= 1
-    assert ln["transport"] == "peer" and ln["shared_device"] is True and ln["rccl_nranks"] == 2
+    assert ln["transport"] == "peer" and ln["shared_device"] is True and ln["rccl_nranks"] == nranks
     assert ln["shard_check"]["ok"] is True and ln["repeats"]["n"] >= 1, ln["shard_check"]
     for k in ("interior_us", "boundary_us", "exchange_us", "allreduce_us", "comm_count", "overlap", "per_rank"):
         assert k in ln["multi_gpu"], k
