@@ -198,7 +198,7 @@ struct FusedCtl {
   long long spin_ticks;                          // the short wait's bound; < 0: park unconditionally (test hook: the cleanup path on every block)
   int ncl;                                       // cleanup workgroups at the end of the grid (>= 1)
 };
-// (coarse on purpose, ~1 us between looks: up to 64 cleanup workgroups poll ONE word for as long as the sweep runs when the whole
+// (coarse on purpose, ~1 us between looks: up to 32 cleanup workgroups poll ONE word for as long as the sweep runs when the whole
 // launch is resident at once, and every look is an L2 atomic on the channel the boundary workgroups' counts go through)
 __device__ inline bool peer_poll_u32(const unsigned int *p, unsigned int want, u64 *err, long long ticks, u64 code) {
   if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
