@@ -616,6 +616,16 @@ namespace {
 struct NhypKeep {
   double2 *l1x[4][4], *l1[4][4], *l2x[4][4], *l2[4][4], *flx = nullptr;
 };
+// k_links_from_nat (layout.hip) reads ONE thing below the slab: U_t on the lower neighbour's top `depth` slices, for the backward t-links
+// of the first slices.  Copy the direction-3 sub-blocks of `ntf` whole tiles per parity between a gauge-shaped field and a packed buffer.
+__global__ void __launch_bounds__(256) k_tlink_tiles(double2 *G, double2 *buf, size_t etile, size_t tile0, size_t ntf, int to_field) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;        // (parity, tile, element)
+  if (i >= 2 * ntf * 576) return;
+  const size_t p = i / (ntf * 576), r = i - p * ntf * 576, j = r / 576, e = r - j * 576;
+  double2 *f = G + ((p * etile + tile0 + j) * 4 + 3) * 576 + e;
+  if (to_field) *f = buf[i]; else buf[i] = *f;
+}
+
 struct Smear {
   qexhip_ctx *c;
   Geom g;
@@ -701,6 +711,23 @@ struct Smear {
   }
   int ghosts_f(const double2 *f, int depth = 1) { return ghosts(f, 576, depth); }
   int ghosts_g(const double2 *G, int depth = 1) { return ghosts(G, 4 * 576, depth); }
+  // What links_from_natural needs of a gauge field's ghost slices and no more: the t-links of the lower neighbour's top `depth` slices in
+  // MY ghost_lo slices (k_links_from_nat: the backward t-links of the first slices are U_t(x - hop t)^+).  One direction of four, one way:
+  // a quarter of the bytes of ghosts_g (48^3 x 12: 48 instead of 191 MB for the Naik links' three slices).  Packed through the staging buffer.
+  int ghosts_tlinks_lo(double2 *G, int depth) {
+    if (!g.halo) return 0;
+    const size_t ft = (size_t)g.F / 64, ntf = (size_t)depth * ft, n2 = 2 * ntf * 576;
+    CHK(ensure_stage(c, 2 * n2 * sizeof(double2)));
+    double2 *snd = (double2 *)c->stage, *rcv = snd + n2;
+    const unsigned nb = (unsigned)((n2 + 255) / 256);
+    ScopedTimer tm(c, "smear_halo", c->stream);
+    k_tlink_tiles<<<nb, 256, 0, c->stream>>>(G, snd, (size_t)g.etile, (size_t)g.ntile - ntf, ntf, 0);
+    HIPCHK(hipGetLastError());
+    CHK(comm_exchange_raw(c, snd, rcv, n2 * sizeof(double2), c->stream));       // my top slices -> the upper neighbour; the lower one's -> me
+    k_tlink_tiles<<<nb, 256, 0, c->stream>>>(G, rcv, (size_t)g.etile, (size_t)g.ntile + 3 * ft + (3 - depth) * ft, ntf, 1);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   MView gv(const double2 *G, int mu) const { return MView{G + (size_t)mu * 576, 4 * 576}; }
   MViewW gvw(double2 *G, int mu) const { return MViewW{G + (size_t)mu * 576, 4 * 576}; }
   MView fv(const double2 *F) const { return MView{F, 576}; }
@@ -864,14 +891,17 @@ struct Smear {
     return hisq_reverse(G, V, W, CF, CL, F);
   }
   // first half of the smearing, the part the reverse pass needs: V = fat7_1(G), W = projectU(V) (ghosts of G, W refreshed)
-  int hisq_first(const double2 *G, double2 *V, double2 *W) {
+  int hisq_first(const double2 *G, double2 *V, double2 *W, bool refresh_w = true) {
     const double f7lf = 0.0;
     const double c_first[5] = {(1.0 + 3.0 * f7lf + 0.0) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f7lf / 16.0};
     if (!(g.halo && c->opt_smear_ca)) CHK(ghosts_g(G));    // (communication-avoiding: fat7 fetches its input three slices deep itself)
     CHK(fat7(V, G, c_first, nullptr, G, 0.0));
     for (int mu = 0; mu < 4; mu++) k_projectU<<<nb(), 256, 0, c->stream>>>(g, gvw(W, mu), gv(V, mu));
     HIPCHK(hipGetLastError());
-    return ghosts_g(W, 2);
+    // refresh_w = false: the caller's next step is the communication-avoiding second fat7 pass, which fetches W three slices deep itself
+    // (and with it what a later reverse pass needs): the two-slice refresh here would be a second exchange of the same field
+    // (2.85 ms at 45 GB/s on a 48^3 face; round 6).  hisq_force, which goes straight into the reverse pass, keeps it.
+    return refresh_w ? ghosts_g(W, 2) : 0;
   }
   int hisq_reverse(const double2 *G, const double2 *V, const double2 *W, const double2 *CF, const double2 *CL, double2 *F) {
     const double f7lf = 0.0, naik = 1.0, f2 = 2.0 - f7lf;
@@ -1209,7 +1239,7 @@ int hisq_prepare(qexhip_ctx *c, const double *g_host, double *fl_host, double *l
   const double naik = 1.0, f2 = 2.0;
   const double c_second[5] = {(1.0 + 3.0 * f2 + naik) / 8.0, -1.0 / 16.0, 1.0 / 64.0, -1.0 / 384.0, -f2 / 16.0};
   CHK(S.upload(st->G, g_host));
-  CHK(S.hisq_first(st->G, st->V, st->W));
+  CHK(S.hisq_first(st->G, st->V, st->W, !(c->g.halo && c->opt_smear_ca)));
   CHK(S.fat7(st->FL, st->W, c_second, st->LL, st->W, -naik / 24.0));
   if (fl_host) CHK(S.download(fl_host, st->FL));
   if (ll_host) CHK(S.download(ll_host, st->LL));
@@ -1251,7 +1281,7 @@ int hisq_fermion_force(qexhip_ctx *c, double *f_host, const double *const *psi, 
 int hisq_set_links_from_closure(qexhip_ctx *c) {
   HisqState *st = (HisqState *)c->hisq;
   if (!st) { qexhip_set_error("set_links_hisq(g = NULL) needs qexhip_hisq_prepare first"); return -1; }
-  CHK(st->S.ghosts_g(st->FL, 1)); CHK(st->S.ghosts_g(st->LL, 3));
+  CHK(st->S.ghosts_tlinks_lo(st->FL, 1)); CHK(st->S.ghosts_tlinks_lo(st->LL, 3));
   return links_from_natural(c, st->FL, st->LL);
 }
 
@@ -1352,7 +1382,7 @@ int smear_set_links_hisq(qexhip_ctx *c, const double *g_host) {
   CHK(S.alloc(&G, S.gsz)); CHK(S.alloc(&FL, S.gsz)); CHK(S.alloc(&LL, S.gsz));
   CHK(S.upload(G, g_host));
   CHK(S.hisq(G, FL, LL));
-  CHK(S.ghosts_g(FL, 1)); CHK(S.ghosts_g(LL, 3));      // backward links x - mu, x - 3 mu below the slab
+  CHK(S.ghosts_tlinks_lo(FL, 1)); CHK(S.ghosts_tlinks_lo(LL, 3));      // backward t-links x - t, x - 3 t below the slab
   return links_from_natural(c, FL, LL);
 }
 int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double a2, double a3, int bcmask, const int ph[4]) {
@@ -1364,7 +1394,7 @@ int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double 
     HIPCHK(hipMemcpyAsync(st->F, st->FL, st->S.gsz * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
     k_rephase<<<st->S.nb(), 256, 0, c->stream>>>(st->S.g, st->F, bcmask, ph[0], ph[1], ph[2], ph[3], c->rankCoord[3] == c->rankGeom[3] - 1);
     HIPCHK(hipGetLastError());
-    CHK(st->S.ghosts_g(st->F, 1));
+    CHK(st->S.ghosts_tlinks_lo(st->F, 1));
     return links_from_natural(c, st->F, nullptr);
   }
   Smear S(c);
@@ -1374,7 +1404,7 @@ int smear_set_links_nhyp(qexhip_ctx *c, const double *g_host, double a1, double 
   CHK(S.nhyp(G, FL, a1, a2, a3));
   k_rephase<<<S.nb(), 256, 0, c->stream>>>(S.g, FL, bcmask, ph[0], ph[1], ph[2], ph[3], c->rankCoord[3] == c->rankGeom[3] - 1);
   HIPCHK(hipGetLastError());
-  CHK(S.ghosts_g(FL, 1));
+  CHK(S.ghosts_tlinks_lo(FL, 1));
   return links_from_natural(c, FL, nullptr);
 }
 
